@@ -1,0 +1,151 @@
+/* pda_hip.h -- C ABI of libpda_hip.so: the MI355X (gfx950) implementation of the PDA BPR-MF hot path.
+ *
+ * This is the drop-in boundary.  The reference (zyang1580/PDA) has no plugin registry: the path is a
+ * TensorFlow-1.14 graph driven through `sess.run` from Python, plus two native helpers with a plain
+ * C-style signature (caller-owned contiguous row-major buffers, blocking, void):
+ *     void arg_top_k_2d(float*, int rating_len, int rows_num, int top_k, int thread_num, int* results)
+ *                                                         util/cython/include/arg_topk.h:29
+ *     void cpp_evaluate_matrix(float*, int, vector<unordered_set<int>>&, vector<int>, int, int, float*)
+ *                                                         evaluator/backend/cpp/include/evaluate.h:53-54
+ * The entry points below keep that shape (plain pointers + sizes, caller-owned buffers) and replace
+ * the `sess.run([...])` fetches named next to each one.  Differences, by design:
+ *   - pointers are DEVICE pointers (HBM) unless the name says `host`;
+ *   - every call takes a hipStream_t (passed as void*) and is stream-ordered / asynchronous;
+ *   - every call returns int: 0 = ok, <0 = PDA_ERR_* ; no exceptions cross the ABI;
+ *   - no global mutable state: re-entrant across streams and threads.
+ * Python binds this with ctypes (pda_amd/_lib.py); INTEGRATION.md shows the stub a reference
+ * maintainer would add to MF/.
+ */
+#ifndef PDA_HIP_H
+#define PDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDA_ABI_VERSION 1
+
+#define PDA_OK 0
+#define PDA_ERR_ARG (-1)         /* null pointer, negative size, K out of range ...            */
+#define PDA_ERR_UNSUPPORTED (-2) /* embed dim / K / mode combination without a compiled kernel */
+#define PDA_ERR_LAUNCH (-3)      /* hipLaunch / hipGetLastError failure                        */
+#define PDA_ERR_WORKSPACE (-4)   /* caller-provided workspace too small                        */
+
+/* Recommendation heads of DatasetApi_Model.Create_Recommendation (MF/train_new_api.py:594-612). */
+#define PDA_HEAD_RAW 0 /* 'main_branch': top_k(R + M)                              :597-598      */
+#define PDA_HEAD_POP 1 /* 'main_with_pop' / 'condition': top_k((elu(R)+1)*pop + M) :601-604,608-609 */
+
+/* How hist_indptr is indexed. */
+#define PDA_HIST_BY_BLOCK_ROW 0 /* row r of this call's user block (the reference's COO rows, :736) */
+#define PDA_HIST_BY_USER_ID 1   /* global user id users[r] (one resident CSR for all users)         */
+
+/* Update modes of the fused triplet step. */
+#define PDA_UPD_NONE 0       /* loss + per-occurrence gradients only (parity harness)                        */
+#define PDA_UPD_SGD_FUSED 1  /* north_star: in-kernel row update, atomics on item rows                       */
+#define PDA_UPD_DENSE_GRAD 2 /* atomically sum gradients into dense gU/gI (feeds pda_adam_dense_sweep_f32)  */
+
+#define PDA_MAX_K 64
+#define PDA_TOPK_CAP 60 /* per-user on-chip candidate slots (>= K) */
+
+int pda_abi_version(void);
+const char* pda_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------------
+ * Full-catalogue score + history mask + top-K   (A6; replaces sess.run(main_brach_topk_idx |
+ * main_with_pop_topk_idx | condition_topk_idx), MF/train_new_api.py:632-637, i.e. the graph
+ * Gather -> MatMul[Bu,I] -> Elu,+1,*pop -> SparseTensorDenseAdd(-inf) -> TopKV2 of :594-612
+ * and MF/model_api.py:62,113).
+ *
+ *   U          f32 [n_users_total, d]      user table (replicated on every rank)
+ *   I_shard    f32 [n_items_local, d]      this rank's item rows; local row j is global item item_offset+j
+ *   pop_shard  f32 [n_items_local] or NULL popularity^gamma for the same rows (required for PDA_HEAD_POP)
+ *   users      i32 [n_users_blk]           user ids of the block
+ *   hist_*     CSR of train items to mask: indptr i64 [rows+1], indices i32 (GLOBAL item ids) which MUST
+ *              be sorted ascending within each row (duplicates allowed); NULL indptr = no mask
+ *   K          1..PDA_MAX_K (reference: 50), K <= n_items_local * is not required * (short lists are
+ *              padded with empty keys and resolved by the merge)
+ *   n_splits   item-range splits per user tile (>=1; 0 = choose automatically).  Each split yields a
+ *              partial list; out_keys holds [n_splits, n_users_blk, K] packed keys, best first.
+ * Packed key: (orderable_bits(score) << 32) | (0xFFFFFFFF - global_item); 0 = empty slot; larger = better,
+ * so that ties on the score resolve to the lower item index exactly like tf.nn.top_k.
+ * Scores are exact fp32: a k-ordered fmaf chain in the order documented in oracle/pda_oracle.c.
+ * ------------------------------------------------------------------------------------------------ */
+int pda_score_topk_auto_splits(int n_users_blk, int n_items_local);
+
+int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_shard, const int32_t* users,
+                       int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                       const int32_t* hist_indices, int hist_row_mode, int K, int head, int n_splits,
+                       uint64_t* out_keys, void* stream);
+
+/* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
+ *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0
+ *   out_keys u64 [n_users_blk, K] or NULL;  out_idx i32 / out_val f32 [n_users_blk, K] or NULL.
+ * When out_idx is given, slots still empty after the merge (a user with fewer than K unmasked items)
+ * are filled like tf.nn.top_k would: score -inf, lowest masked item ids first, taken from the
+ * user's (sorted) history row when hist_indptr != NULL (else idx = -1).
+ * No reference counterpart (single device there); see SURVEY 8(e). */
+int pda_topk_merge(const uint64_t* in_keys, int R, int n_users_blk, int K, uint64_t* out_keys, int32_t* out_idx,
+                   float* out_val, const int32_t* users, const int64_t* hist_indptr, const int32_t* hist_indices,
+                   int hist_row_mode, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused BPR triplet step (A1-A5; replaces sess.run([opt*, loss*, mf_loss*, reg_loss*]),
+ * MF/train_new_api.py:1080-1090 over the graph of MF/model_api.py:51-53,102-121 / :449-451,695-706).
+ *
+ *   U, I         f32 tables, updated in place for PDA_UPD_SGD_FUSED
+ *   users,pos,neg i32 [B];  pos_pop,neg_pop f32 [B] or both NULL (NULL = plain BPRMF, no ELU/pop)
+ *   regs         --regs;  reg_div = the --batch_size flag constant (MF/model_api.py:118)
+ *   lr           SGD learning rate (PDA_UPD_SGD_FUSED only)
+ *   g_user/g_pos/g_neg  f32 [B,d] per-occurrence gradient out (PDA_UPD_NONE), may be NULL otherwise
+ *   gU, gI       dense f32 gradient accumulators (PDA_UPD_DENSE_GRAD), same shape as the tables
+ *   loss_acc     f32 [3]: (loss, mf_loss, reg_loss) are ADDED to it (zero it to fetch one step)
+ * ------------------------------------------------------------------------------------------------ */
+int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                     const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
+                     int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU, float* gI,
+                     float* loss_acc, void* stream);
+
+/* TF-1.14 AdamOptimizer `_apply_sparse_shared`: decay m,v on EVERY row, add the (pre-summed) sparse
+ * gradient, update EVERY row (MF/model_api.py:83,:470-471 [TF-ext]).  `g` is the dense accumulator
+ * filled by PDA_UPD_DENSE_GRAD; it is reset to zero by this sweep.  n = rows*d.  lr_t is the
+ * bias-corrected rate lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
+int pda_adam_dense_sweep_f32(float* var, float* m, float* v, float* g, size_t n, float lr_t, float beta1,
+                             float beta2, float eps, void* stream);
+
+/* Lazy/sparse Adam on the touched rows only (declared deviation).  rows i32 [n_rows]
+ * must be unique; g is the dense accumulator (reset on the touched rows). */
+int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const int32_t* rows, int n_rows, int d, float lr_t,
+                      float beta1, float beta2, float eps, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Ranking metrics (A8; replaces get_performance + the Pool(5) reduction, MF/used_metric.py:4-80,
+ * MF/train_new_api.py:741-778).   topk i32 [n_rows, k_cols]; targets as CSR by block row;
+ * Ks i32 [n_ks] (device);  sums f64 [4, n_ks] = precision, recall, ndcg, hit -- ADDED to (not divided).
+ * ------------------------------------------------------------------------------------------------ */
+int pda_metrics(const int32_t* topk, int n_rows, int k_cols, const int64_t* tgt_indptr, const int32_t* tgt_indices,
+                const int32_t* Ks, int n_ks, double* sums, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Device-side triplet sampler (N1; replaces generator_n_batch / generator_n_batch_with_pop,
+ * MF/train_new_api.py:260-288, 366-412).  One batch: users[r] given (unique, as rd.sample),
+ * pos uniform over the user's train items (0 when empty, :387-389), neg uniform over the catalogue
+ * minus the user's train items by rejection (:397-401), pops = pop_matrix[item, slot_of_pos] (:402-403).
+ *   users      i32 [B]: read when gen_users == 0; WRITTEN when gen_users != 0 (B distinct users drawn
+ *              from user_pool[0..n_pool) -- or from 0..n_pool-1 when user_pool is NULL -- by a keyed
+ *              Feistel permutation; with replacement when B > n_pool, :383)
+ *   train CSR indexed by user id, indices sorted ascending; train_slots i32 parallel to indices or NULL
+ *   negatives are drawn from [neg_lo, neg_hi) (the whole catalogue, or a rank's item shard)
+ *   pop_matrix f32 [n_items, n_slots] or NULL.   Counter-based RNG: (seed, step, row) -> draws.
+ * ------------------------------------------------------------------------------------------------ */
+int pda_sample_triplets(int32_t* users, int gen_users, const int32_t* user_pool, int n_pool, int B,
+                        const int64_t* train_indptr, const int32_t* train_indices, const int32_t* train_slots,
+                        int neg_lo, int neg_hi, const float* pop_matrix, int n_slots, uint64_t seed, uint64_t step,
+                        int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDA_HIP_H */

@@ -1,0 +1,82 @@
+"""ctypes binding of libpda_hip.so (the C ABI declared in include/pda_hip.h).
+
+There is NO CPU fallback: if the shared object is missing or a symbol is absent this module raises.
+Device pointers come from torch ROCm tensors (``tensor.data_ptr()``); the launch stream is torch's
+current HIP stream, so torch.cuda.Event / torch.cuda.graph see every kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpda_hip.so")
+
+# Constants mirrored from include/pda_hip.h
+ABI_VERSION = 1
+HEAD_RAW, HEAD_POP = 0, 1
+HIST_BY_BLOCK_ROW, HIST_BY_USER_ID = 0, 1
+UPD_NONE, UPD_SGD_FUSED, UPD_DENSE_GRAD = 0, 1, 2
+MAX_K = 64
+TOPK_CAP = 60
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+
+# name -> (restype, argtypes); exactly the declarations of include/pda_hip.h
+SIGNATURES = {
+    "pda_abi_version": (_i, []),
+    "pda_error_string": (C.c_char_p, [_i]),
+    "pda_score_topk_auto_splits": (_i, [_i, _i]),
+    "pda_score_topk_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pda_adam_dense_sweep_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
+    "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
+    "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "pda_sample_triplets": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class PdaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and type every entry point.  Raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PdaHipError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C pda_amd/csrc`.  pda_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise PdaHipError(f"libpda_hip.so does not export {name}") from e
+        fn.restype, fn.argtypes = res, args
+    got = lib.pda_abi_version()
+    if got != ABI_VERSION:
+        raise PdaHipError(f"libpda_hip.so ABI {got} != binding ABI {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        msg = load().pda_error_string(code).decode()
+        raise PdaHipError(f"{what}: {msg} ({code})")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,240 @@
+// Fused BPR triplet step for MI355X (gfx950): gather -> dots -> (ELU+1)*pop -> log-sigmoid loss + L2 ->
+// closed-form gradients -> update, in one launch.
+//
+// Replaces the per-step TF graph of MF/model_api.py:51-53 (gather), :102-110 / :695-697 (scores),
+// :112-121 / :699-705 (loss), the implicit gradient of `minimize` (:83, :471) and -- in the SGD mode
+// the north_star asks for -- the parameter update.  The reference optimiser is Adam with dense decay
+// [TF-ext]; that mode is PDA_UPD_DENSE_GRAD followed by pda_adam_dense_sweep_f32 on both tables.
+//
+// This path is HBM/latency bound (about 6*d*4 B per triplet, ~10*d flop): no MFMA.  Layout: d/4 lanes
+// per triplet, each lane owns one float4 of the three gathered rows (a 4*d-byte row is one fully
+// coalesced segment), dots by xor-shuffle inside the lane group, per-block loss reduction -> 3 atomics.
+#include "pda_common.h"
+
+namespace {
+
+struct StepArgs {
+    float* U;
+    float* I;
+    const int32_t* users;
+    const int32_t* pos;
+    const int32_t* neg;
+    const float* pos_pop;
+    const float* neg_pop;
+    float* g_user;
+    float* g_pos;
+    float* g_neg;
+    float* gU;
+    float* gI;
+    float* loss_acc;
+    int B;
+    float inv_B;
+    float reg_c;  // regs / reg_div
+    float lr;
+    int mode;
+};
+
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+__device__ __forceinline__ void atomic_add4(float* p, f32x4 v) {
+    unsafeAtomicAdd(p + 0, v[0]);
+    unsafeAtomicAdd(p + 1, v[1]);
+    unsafeAtomicAdd(p + 2, v[2]);
+    unsafeAtomicAdd(p + 3, v[3]);
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) bpr_step_kernel(StepArgs a) {
+    constexpr int L = D / 4;        // lanes per triplet
+    constexpr int TPB = 256 / L;    // triplets per block
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x, g = tid / L, e = tid % L;
+    const int t = blockIdx.x * TPB + g;
+    const bool active = t < a.B;
+    const bool with_pop = a.pos_pop != nullptr;
+
+    float maxi = 0.f, sq = 0.f;
+    if (active) {
+        const int u = a.users[t], p = a.pos[t], n = a.neg[t];
+        float* up = a.U + (size_t)u * D + 4 * e;
+        float* pp = a.I + (size_t)p * D + 4 * e;
+        float* np_ = a.I + (size_t)n * D + 4 * e;
+        const f32x4 ue = *reinterpret_cast<const f32x4*>(up);
+        const f32x4 pe = *reinterpret_cast<const f32x4*>(pp);
+        const f32x4 ne = *reinterpret_cast<const f32x4*>(np_);
+        float ps = dot4(ue, pe), ns = dot4(ue, ne);
+        sq = dot4(ue, ue) + dot4(pe, pe) + dot4(ne, ne);
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) {
+            ps += __shfl_xor(ps, o, 64);
+            ns += __shfl_xor(ns, o, 64);
+        }
+        float ap = 1.f, an = 1.f, psw = ps, nsw = ns;
+        if (with_pop) {
+            const float qp = a.pos_pop[t], qn = a.neg_pop[t];
+            const float ep = ps > 0.f ? 1.f : expf(ps);   // d(elu+1)/dx  [TF-ext EluGrad]
+            const float en = ns > 0.f ? 1.f : expf(ns);
+            psw = (ps > 0.f ? ps + 1.f : ep) * qp;        // (elu(ps)+1)*pos_pop   MF/model_api.py:107,109
+            nsw = (ns > 0.f ? ns + 1.f : en) * qn;        // :108,110
+            ap = qp * ep;
+            an = qn * en;
+        }
+        const float x = psw - nsw;
+        const float s = 1.f / (1.f + expf(-x));
+        if (e == 0) maxi = logf(s + 1e-10f);              // :112 / :702
+        const float gg = -a.inv_B * s * (1.f - s) / (s + 1e-10f);
+        const float gp = gg * ap, gn = gg * an, c = a.reg_c;
+        f32x4 due, dpe, dne;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            due[k] = gp * pe[k] - gn * ne[k] + c * ue[k];
+            dpe[k] = gp * ue[k] + c * pe[k];
+            dne[k] = -gn * ue[k] + c * ne[k];
+        }
+        if (a.mode == PDA_UPD_SGD_FUSED) {
+            const float nlr = -a.lr;
+            atomic_add4(up, due * nlr);   // users are unique per batch (rd.sample) but atomics keep B > n_users safe
+            atomic_add4(pp, dpe * nlr);   // items repeat inside a batch: wavefront atomics sum the occurrences
+            atomic_add4(np_, dne * nlr);
+        } else if (a.mode == PDA_UPD_DENSE_GRAD) {
+            atomic_add4(a.gU + (size_t)u * D + 4 * e, due);
+            atomic_add4(a.gI + (size_t)p * D + 4 * e, dpe);
+            atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
+        }
+        if (a.g_user) {
+            *reinterpret_cast<f32x4*>(a.g_user + (size_t)t * D + 4 * e) = due;
+            *reinterpret_cast<f32x4*>(a.g_pos + (size_t)t * D + 4 * e) = dpe;
+            *reinterpret_cast<f32x4*>(a.g_neg + (size_t)t * D + 4 * e) = dne;
+        }
+    }
+    // block reduction of sum(log(.)) and sum of squares -> (loss, mf, reg)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        maxi += __shfl_xor(maxi, o, 64);
+        sq += __shfl_xor(sq, o, 64);
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+    if (lane == 0) {
+        red[0][wave] = maxi;
+        red[1][wave] = sq;
+    }
+    __syncthreads();
+    if (tid == 0 && a.loss_acc) {
+        const float sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        const float ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float mf = -sm * a.inv_B;             // -mean(maxi)          :114 / :704
+        const float rg = a.reg_c * 0.5f * ss;       // regs * l2 / batch    :117-120
+        unsafeAtomicAdd(a.loss_acc + 0, mf + rg);
+        unsafeAtomicAdd(a.loss_acc + 1, mf);
+        unsafeAtomicAdd(a.loss_acc + 2, rg);
+    }
+}
+
+// TF-1.14 Adam with dense decay: one streaming pass over a whole table (4 reads + 4 writes of n floats).
+__global__ void __launch_bounds__(256) adam_dense_sweep_kernel(float* __restrict__ var, float* __restrict__ m,
+                                                               float* __restrict__ v, float* __restrict__ g, size_t n4,
+                                                               float lr_t, float b1, float b2, float eps) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 gg = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 xx = reinterpret_cast<f32x4*>(var)[i];
+        bool touched = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            touched |= gg[k] != 0.f;
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+            xx[k] = xx[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        }
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        reinterpret_cast<f32x4*>(var)[i] = xx;
+        if (touched) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, float* v, float* g, const int32_t* rows,
+                                                        int n_rows, float lr_t, float b1, float b2, float eps) {
+    constexpr int L = D / 4, RPB = 256 / L;
+    const int r = blockIdx.x * RPB + threadIdx.x / L, e = threadIdx.x % L;
+    if (r >= n_rows) return;
+    const size_t off = (size_t)rows[r] * D + 4 * e;
+    f32x4 gg = *reinterpret_cast<f32x4*>(g + off), mm = *reinterpret_cast<f32x4*>(m + off);
+    f32x4 vv = *reinterpret_cast<f32x4*>(v + off), xx = *reinterpret_cast<f32x4*>(var + off);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+        vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+        xx[k] = xx[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+    }
+    *reinterpret_cast<f32x4*>(m + off) = mm;
+    *reinterpret_cast<f32x4*>(v + off) = vv;
+    *reinterpret_cast<f32x4*>(var + off) = xx;
+    *reinterpret_cast<f32x4*>(g + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int D>
+int launch_step(const StepArgs& a, hipStream_t s) {
+    constexpr int TPB = 256 / (D / 4);
+    hipLaunchKernelGGL(bpr_step_kernel<D>, dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(256), 0, s, a);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+}  // namespace
+
+extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                                const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div,
+                                float lr, int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU,
+                                float* gI, float* loss_acc, void* stream) {
+    if (!U || !I || !users || !pos || !neg || B <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    if (update_mode < PDA_UPD_NONE || update_mode > PDA_UPD_DENSE_GRAD) return PDA_ERR_ARG;
+    if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
+    if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
+    StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (d) {
+        case 32: return launch_step<32>(a, s);
+        case 64: return launch_step<64>(a, s);
+        case 128: return launch_step<128>(a, s);
+        case 256: return launch_step<256>(a, s);
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int pda_adam_dense_sweep_f32(float* var, float* m, float* v, float* g, size_t n, float lr_t, float beta1,
+                                        float beta2, float eps, void* stream) {
+    if (!var || !m || !v || !g || n == 0 || (n & 3)) return PDA_ERR_ARG;
+    const size_t n4 = n / 4;
+    const size_t want = (n4 + 255) / 256;
+    const unsigned blocks = (unsigned)(want < 256u * 8u ? want : 256u * 8u);  // 8 blocks/CU, grid-stride
+    hipLaunchKernelGGL(adam_dense_sweep_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), var, m,
+                       v, g, n4, lr_t, beta1, beta2, eps);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const int32_t* rows, int n_rows, int d,
+                                 float lr_t, float beta1, float beta2, float eps, void* stream) {
+    if (!var || !m || !v || !g || !rows || n_rows <= 0) return PDA_ERR_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define PDA_ROWS(DD)                                                                                              \
+    case DD: {                                                                                                    \
+        constexpr int RPB = 256 / (DD / 4);                                                                       \
+        hipLaunchKernelGGL(adam_rows_kernel<DD>, dim3((unsigned)((n_rows + RPB - 1) / RPB)), dim3(256), 0, s, var, m, v, \
+                           g, rows, n_rows, lr_t, beta1, beta2, eps);                                             \
+        break;                                                                                                    \
+    }
+    switch (d) {
+        PDA_ROWS(32) PDA_ROWS(64) PDA_ROWS(128) PDA_ROWS(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_ROWS
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}

@@ -1,0 +1,216 @@
+"""Thin, typed front-ends over the C ABI (include/pda_hip.h).  Tensors in, tensors out; every call is
+stream-ordered on torch's current HIP stream.  No arithmetic happens here."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import (HEAD_POP, HEAD_RAW, HIST_BY_BLOCK_ROW, HIST_BY_USER_ID, UPD_DENSE_GRAD, UPD_NONE,  # noqa: F401
+                   UPD_SGD_FUSED, check, ptr, stream_ptr)
+
+ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults (MF/model_api.py:83)
+
+
+def _need(t: Optional[torch.Tensor], dtype, name: str, optional=False):
+    if t is None:
+        if optional:
+            return None
+        raise ValueError(f"{name} is required")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live in HBM (cuda tensor); pda_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous (row-major)")
+    return t
+
+
+class HistoryCSR:
+    """Train-item mask in the layout the kernel wants: CSR, int64 indptr, int32 GLOBAL item ids sorted
+    ascending inside each row.  ``by_user`` tells whether rows are user ids or block rows
+    (the reference builds block-row COO per 2048-user block, MF/train_new_api.py:730-739)."""
+
+    def __init__(self, indptr: torch.Tensor, indices: torch.Tensor, by_user: bool):
+        self.indptr = _need(indptr, torch.int64, "hist indptr")
+        self.indices = _need(indices, torch.int32, "hist indices")
+        self.mode = HIST_BY_USER_ID if by_user else HIST_BY_BLOCK_ROW
+
+    @staticmethod
+    def from_lists(rows, device, by_user: bool) -> "HistoryCSR":
+        """rows: iterable of per-row item lists (any order, duplicates allowed) -> sorted CSR on device."""
+        import numpy as np
+        lens = np.fromiter((len(r) for r in rows), dtype=np.int64)
+        indptr = np.zeros(len(lens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=indptr[1:])
+        flat = np.empty(int(indptr[-1]), dtype=np.int32)
+        for r, items in enumerate(rows):
+            flat[indptr[r]:indptr[r + 1]] = np.sort(np.asarray(items, dtype=np.int32))
+        return HistoryCSR(torch.from_numpy(indptr).to(device), torch.from_numpy(flat).to(device), by_user)
+
+    @staticmethod
+    def from_coo(index, n_rows: int, device) -> "HistoryCSR":
+        """The reference's sparse mask triple index int64[nnz,2] = (row, item) (MF/train_new_api.py:736)."""
+        import numpy as np
+        index = np.asarray(index, dtype=np.int64).reshape(-1, 2)
+        order = np.lexsort((index[:, 1], index[:, 0]))
+        rows, items = index[order, 0], index[order, 1].astype(np.int32)
+        indptr = np.zeros(n_rows + 1, dtype=np.int64)
+        np.add.at(indptr, rows + 1, 1)
+        np.cumsum(indptr, out=indptr)
+        return HistoryCSR(torch.from_numpy(indptr).to(device), torch.from_numpy(items).to(device), by_user=False)
+
+
+def auto_splits(n_users_blk: int, n_items_local: int) -> int:
+    return _lib.load().pda_score_topk_auto_splits(n_users_blk, n_items_local)
+
+
+def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
+                    item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pda_score_topk_f32 -> packed keys int64[n_splits, Bu, K] (uint64 bit patterns), best first."""
+    lib = _lib.load()
+    U = _need(U, torch.float32, "U")
+    I_shard = _need(I_shard, torch.float32, "I_shard")
+    users = _need(users, torch.int32, "users")
+    pop_shard = _need(pop_shard, torch.float32, "pop_shard", optional=True)
+    nu, nloc, d = users.numel(), I_shard.shape[0], I_shard.shape[1]
+    if U.shape[1] != d:
+        raise ValueError("U and I_shard disagree on embed dim")
+    if pop_shard is not None and pop_shard.numel() != nloc:
+        raise ValueError("pop_shard must have one entry per local item row")
+    if n_splits <= 0:
+        n_splits = lib.pda_score_topk_auto_splits(nu, nloc)
+    if out is None:
+        out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
+    elif out.shape != (n_splits, nu, K) or out.dtype != torch.int64:
+        raise ValueError("out must be int64 [n_splits, Bu, K]")
+    check(lib.pda_score_topk_f32(ptr(U), ptr(I_shard), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+                                 ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None,
+                                 hist.mode if hist else 0, K, head, n_splits, ptr(out), stream_ptr()),
+          "pda_score_topk_f32")
+    return out
+
+
+def topk_merge(keys: torch.Tensor, users=None, hist: Optional[HistoryCSR] = None, want="idx_val"):
+    """pda_topk_merge.  keys int64[R, Bu, K].  want: 'keys' -> int64[Bu,K];  'idx_val' -> (int32, float32)."""
+    lib = _lib.load()
+    keys = _need(keys, torch.int64, "keys")
+    R, nu, K = keys.shape
+    dev = keys.device
+    out_keys = out_idx = out_val = None
+    if want == "keys":
+        out_keys = torch.empty((nu, K), dtype=torch.int64, device=dev)
+    else:
+        out_idx = torch.empty((nu, K), dtype=torch.int32, device=dev)
+        out_val = torch.empty((nu, K), dtype=torch.float32, device=dev)
+    if users is not None:
+        users = _need(users, torch.int32, "users")
+    check(lib.pda_topk_merge(ptr(keys), R, nu, K, ptr(out_keys), ptr(out_idx), ptr(out_val), ptr(users),
+                             ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None,
+                             hist.mode if hist else 0, stream_ptr()), "pda_topk_merge")
+    return out_keys if want == "keys" else (out_idx, out_val)
+
+
+def recommend_topk(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist=None, item_offset=0,
+                   n_splits=0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Single-GPU convenience: score + mask + top-K + split merge -> (idx int32[Bu,K], val f32[Bu,K])."""
+    keys = score_topk_keys(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits)
+    return topk_merge(keys, users, hist, want="idx_val")
+
+
+def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float = 0.0,
+             mode: int = UPD_NONE, grads_out=None, gU=None, gI=None, loss_acc: Optional[torch.Tensor] = None):
+    """pda_bpr_step_f32.  grads_out = (g_user, g_pos, g_neg) float32 [B,d] or None."""
+    lib = _lib.load()
+    U = _need(U, torch.float32, "U")
+    I = _need(I, torch.float32, "I")
+    users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
+    pos_pop = _need(pos_pop, torch.float32, "pos_pop", optional=True)
+    neg_pop = _need(neg_pop, torch.float32, "neg_pop", optional=True)
+    B, d = users.numel(), U.shape[1]
+    if pos.numel() != B or neg.numel() != B:
+        raise ValueError("users/pos/neg must have the same length")
+    gu = gp = gn = None
+    if grads_out is not None:
+        gu, gp, gn = (_need(t, torch.float32, "grads_out") for t in grads_out)
+    gU = _need(gU, torch.float32, "gU", optional=True)
+    gI = _need(gI, torch.float32, "gI", optional=True)
+    loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
+    check(lib.pda_bpr_step_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), B, d,
+                               float(regs), float(reg_div), float(lr), mode, ptr(gu), ptr(gp), ptr(gn), ptr(gU),
+                               ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_f32")
+
+
+def adam_lr_t(lr: float, t: int, beta1=ADAM_BETA1, beta2=ADAM_BETA2) -> float:
+    """lr * sqrt(1-beta2^t) / (1-beta1^t)  [TF-ext AdamOptimizer._apply_sparse_shared]."""
+    return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+
+
+def adam_dense_sweep(var, m, v, g, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+    lib = _lib.load()
+    for t, n in ((var, "var"), (m, "m"), (v, "v"), (g, "g")):
+        _need(t, torch.float32, n)
+    check(lib.pda_adam_dense_sweep_f32(ptr(var), ptr(m), ptr(v), ptr(g), var.numel(), lr_t, beta1, beta2, eps,
+                                       stream_ptr()), "pda_adam_dense_sweep_f32")
+
+
+def adam_rows(var, m, v, g, rows, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+    lib = _lib.load()
+    rows = _need(rows, torch.int32, "rows")
+    check(lib.pda_adam_rows_f32(ptr(var), ptr(m), ptr(v), ptr(g), ptr(rows), rows.numel(), var.shape[1], lr_t, beta1,
+                                beta2, eps, stream_ptr()), "pda_adam_rows_f32")
+
+
+def metrics_sums(topk, tgt_indptr, tgt_indices, Ks, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pda_metrics: float64 [4, len(Ks)] sums of precision, recall, ndcg, hit over the rows (added to `sums`)."""
+    lib = _lib.load()
+    topk = _need(topk, torch.int32, "topk")
+    tgt_indptr = _need(tgt_indptr, torch.int64, "tgt_indptr")
+    tgt_indices = _need(tgt_indices, torch.int32, "tgt_indices")
+    Ks = _need(Ks, torch.int32, "Ks")
+    if sums is None:
+        sums = torch.zeros((4, Ks.numel()), dtype=torch.float64, device=topk.device)
+    check(lib.pda_metrics(ptr(topk), topk.shape[0], topk.shape[1], ptr(tgt_indptr), ptr(tgt_indices), ptr(Ks),
+                          Ks.numel(), ptr(sums), stream_ptr()), "pda_metrics")
+    return sums
+
+
+def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int, users=None, user_pool=None,
+                    n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None):
+    """pda_sample_triplets -> (users, pos, neg, pos_pop|None, neg_pop|None), all on device."""
+    lib = _lib.load()
+    dev = train_indptr.device
+    gen = users is None
+    if gen:
+        users = torch.empty(B, dtype=torch.int32, device=dev)
+    pos = torch.empty(B, dtype=torch.int32, device=dev)
+    neg = torch.empty(B, dtype=torch.int32, device=dev)
+    pp = pn = None
+    n_slots = 0
+    if pop_matrix is not None:
+        pop_matrix = _need(pop_matrix, torch.float32, "pop_matrix")
+        n_slots = pop_matrix.shape[1]
+        pp = torch.empty(B, dtype=torch.float32, device=dev)
+        pn = torch.empty(B, dtype=torch.float32, device=dev)
+    check(lib.pda_sample_triplets(ptr(users), int(gen), ptr(user_pool), int(n_pool), B, ptr(train_indptr),
+                                  ptr(train_indices), ptr(train_slots), int(neg_range[0]), int(neg_range[1]),
+                                  ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), step, ptr(pos), ptr(neg), ptr(pp),
+                                  ptr(pn), stream_ptr()), "pda_sample_triplets")
+    return users, pos, neg, pp, pn
+
+
+def unpack_keys(keys: torch.Tensor):
+    """Host-side helper for tests: packed int64 keys -> (idx int64, val float32); empty (0) -> (-1, -inf)."""
+    k = keys.cpu().numpy().view("uint64")
+    import numpy as np
+    hi = (k >> np.uint64(32)).astype(np.uint32)
+    lo = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    bits = np.where(hi & np.uint32(0x80000000), hi ^ np.uint32(0x80000000), ~hi).astype(np.uint32)
+    val = bits.view(np.float32).copy()
+    idx = (np.uint32(0xFFFFFFFF) - lo).astype(np.int64)
+    empty = k == 0
+    idx[empty] = -1
+    val[empty] = -np.inf
+    return idx, val

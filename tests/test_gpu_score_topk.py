@@ -1,0 +1,273 @@
+"""GPU parity: full-catalogue score + mask + top-K (pda_score_topk_f32 / pda_topk_merge) vs the CPU oracle.
+
+Bar: bit-exact fp32 scores and exact top-K lists for the raw head (the kernel's fmaf chain is restated
+by oracle order=1); for the popularity head the kernel uses the hardware exp, so scores must agree to
+1e-5 (the north_star tolerance) and any list disagreement must be a near-tie within that tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import pda_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
+
+
+def make_case(rng, nU, nI, d, max_hist=30, scale=0.1):
+    U = (rng.standard_normal((nU, d)) * scale).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * scale).astype(np.float32)
+    pop = (rng.uniform(0, 1, nI) ** 0.22).astype(np.float32)
+    pop[rng.integers(0, nI, max(1, nI // 50))] = 0.0         # pop_pre.py min-max gives exact zeros per slot
+    hist = [rng.integers(0, nI, rng.integers(0, max_hist + 1)).astype(np.int32) for _ in range(nU)]
+    return U, I, pop, hist
+
+
+def csr(hist_rows):
+    indptr = np.zeros(len(hist_rows) + 1, dtype=np.int64)
+    indptr[1:] = np.cumsum([len(h) for h in hist_rows])
+    idx = np.concatenate([np.sort(h) for h in hist_rows]).astype(np.int32) if len(hist_rows) else np.zeros(0, np.int32)
+    return indptr, idx
+
+
+def run_gpu(dev, U, I, users, K, head, pop, hist_rows, by_user, n_splits=0, item_offset=0, n_local=None):
+    from pda_amd import ops
+    n_local = I.shape[0] - item_offset if n_local is None else n_local
+    Ish = torch.from_numpy(I[item_offset:item_offset + n_local].copy()).to(dev)
+    popsh = None if pop is None else torch.from_numpy(pop[item_offset:item_offset + n_local].copy()).to(dev)
+    h = None
+    if hist_rows is not None:
+        ip, ix = csr(hist_rows)
+        h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=by_user)
+    ut = torch.from_numpy(users).to(dev)
+    keys = ops.score_topk_keys(torch.from_numpy(U).to(dev), Ish, ut, K, head, popsh, h, item_offset, n_splits)
+    idx, val = ops.topk_merge(keys, ut, h)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), val.cpu().numpy(), keys
+
+
+def check_against_oracle(idx, val, U, I, users, K, head, pop, hist_block_rows, exact):
+    ip, ix = csr(hist_block_rows) if hist_block_rows is not None else (None, None)
+    ridx, rval, sc = c_oracle.score_topk(U, I, users, K, head, pop, ip, ix, order=1, want_scores=True)
+    if exact:
+        np.testing.assert_array_equal(val, rval)
+        np.testing.assert_array_equal(idx, ridx)
+        return
+    np.testing.assert_allclose(val, rval, rtol=TOL, atol=TOL)
+    bad = np.argwhere(idx != ridx)
+    for r, k in bad:   # any disagreement must be a near-tie between the two items
+        a, b = idx[r, k], ridx[r, k]
+        assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b, sc[r, a], sc[r, b])
+    for r in np.unique(bad[:, 0]) if len(bad) else []:
+        assert len(set(idx[r])) == K
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("head", [0, 1])
+def test_block_row_hist_all_dims(dev, d, head):
+    rng = np.random.default_rng(100 + d + head)
+    nU, nI, K = 300, 1999, 50
+    U, I, pop, hist = make_case(rng, nU, nI, d)
+    users = rng.permutation(nU)[:173].astype(np.int32)          # ragged: not a multiple of 32 or 128
+    rows = [hist[u] for u in users]
+    idx, val, _ = run_gpu(dev, U, I, users, K, head, pop if head else None, rows, by_user=False)
+    check_against_oracle(idx, val, U, I, users, K, head, pop, rows, exact=(head == 0))
+
+
+@pytest.mark.parametrize("n_splits", [1, 2, 3, 8])
+@pytest.mark.parametrize("K", [1, 20, 50, 59])
+def test_splits_and_k(dev, n_splits, K):
+    rng = np.random.default_rng(7 * n_splits + K)
+    nU, nI, d = 140, 2500, 64
+    U, I, pop, hist = make_case(rng, nU, nI, d)
+    users = np.arange(nU, dtype=np.int32)
+    idx, val, keys = run_gpu(dev, U, I, users, K, 0, None, hist, by_user=True, n_splits=n_splits)
+    assert keys.shape == (n_splits, nU, K)
+    check_against_oracle(idx, val, U, I, users, K, 0, None, hist, exact=True)
+
+
+def test_history_by_user_unsorted_with_duplicates(dev):
+    from pda_amd import ops
+    rng = np.random.default_rng(5)
+    nU, nI, d, K = 90, 777, 64, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d)
+    hist = [np.concatenate([rng.integers(0, nI, 25), rng.integers(0, nI, 5).repeat(2)]).astype(np.int32) for _ in range(nU)]
+    h = ops.HistoryCSR.from_lists(hist, dev, by_user=True)      # sorts rows; duplicates stay
+    users = rng.permutation(nU).astype(np.int32)
+    ut = torch.from_numpy(users).to(dev)
+    idx, val = ops.recommend_topk(torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), ut, K, 1,
+                                  torch.from_numpy(pop).to(dev), h)
+    rows = [hist[u] for u in users]
+    check_against_oracle(idx.cpu().numpy(), val.cpu().numpy(), U, I, users, K, 1, pop, rows, exact=False)
+    for r, u in enumerate(users):                                # no train item may ever be recommended
+        assert not set(idx[r].cpu().numpy()) & set(hist[u].tolist())
+
+
+def test_reference_coo_mask_triple(dev):
+    """The reference passes (index int64[nnz,2], [-inf]*nnz, shape): MF/train_new_api.py:736,791."""
+    from pda_amd import ops
+    rng = np.random.default_rng(11)
+    nU, nI, d, K = 64, 512, 64, 50
+    U, I, pop, hist = make_case(rng, nU, nI, d)
+    users = np.arange(nU, dtype=np.int32)
+    train = {u: hist[u].tolist() for u in users}
+    blocks = po.build_eval_blocks({u: [0] for u in users}, train, block=2048)
+    bu, index, rows, nnz = blocks[0]
+    h = ops.HistoryCSR.from_coo(index, rows, dev)
+    idx, val = ops.recommend_topk(torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev),
+                                  torch.tensor(bu, dtype=torch.int32, device=dev), K, 0, None, h)
+    check_against_oracle(idx.cpu().numpy(), val.cpu().numpy(), U, I, users, K, 0, None, hist, exact=True)
+
+
+def test_exact_ties_resolve_to_lower_index(dev):
+    rng = np.random.default_rng(3)
+    nU, nI, d, K = 40, 640, 64, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d, max_hist=0)
+    I[100:400] = I[50]                  # 301 items with bit-identical scores for every user
+    I[500:520] = 0.0                    # exact zeros (+ -0.0 products)
+    users = np.arange(nU, dtype=np.int32)
+    for head, p in ((0, None), (1, pop)):
+        idx, val, _ = run_gpu(dev, U, I, users, K, head, p, None, by_user=False, n_splits=4)
+        ridx, rval = c_oracle.score_topk(U, I, users, K, head, p, order=1)
+        if head == 0:
+            np.testing.assert_array_equal(idx, ridx)
+        # ties inside every returned list are in ascending index order
+        for r in range(nU):
+            same = val[r][1:] == val[r][:-1]
+            assert np.all(idx[r][1:][same] > idx[r][:-1][same])
+    # popularity exactly 0 => score exactly 0 for those items (SURVEY 'hard parts'): all-zero pop vector
+    zpop = np.zeros(nI, dtype=np.float32)
+    idx, val, _ = run_gpu(dev, U, I, users, K, 1, zpop, None, by_user=False)
+    np.testing.assert_array_equal(idx, np.tile(np.arange(K, dtype=np.int32), (nU, 1)))
+    np.testing.assert_array_equal(val, np.zeros_like(val))
+
+
+def test_fewer_than_k_unmasked_items(dev):
+    """tf.nn.top_k then returns the -inf (masked) entries, lowest index first."""
+    rng = np.random.default_rng(9)
+    nU, nI, d, K = 33, 96, 64, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d, max_hist=0)
+    hist = [rng.permutation(nI)[:rng.integers(40, nI + 1)].astype(np.int32) for _ in range(nU)]
+    hist[0] = np.arange(nI, dtype=np.int32)                    # everything masked
+    users = np.arange(nU, dtype=np.int32)
+    idx, val, _ = run_gpu(dev, U, I, users, K, 0, None, hist, by_user=True, n_splits=2)
+    ridx, rval = po.recommend_topk(U, I, users, *csr(hist), k=K, dtype=np.float32)
+    np.testing.assert_array_equal(idx, ridx)
+    assert np.all(np.isneginf(val) == np.isneginf(rval))
+
+
+def test_item_shards_merge_equals_single_device(dev):
+    """Item-parallel layout of SURVEY 8(e): R shards -> partial lists -> merge == unsharded result."""
+    from pda_amd import ops
+    rng = np.random.default_rng(21)
+    nU, nI, d, K, R = 150, 4001, 128, 50, 8
+    U, I, pop, hist = make_case(rng, nU, nI, d)
+    users = np.arange(nU, dtype=np.int32)
+    ip, ix = csr(hist)
+    h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    ut = torch.from_numpy(users).to(dev)
+    Ut = torch.from_numpy(U).to(dev)
+    per = (nI + R - 1) // R
+    parts = []
+    for r in range(R):
+        lo, hi = r * per, min(nI, (r + 1) * per)
+        keys = ops.score_topk_keys(Ut, torch.from_numpy(I[lo:hi].copy()).to(dev), ut, K, 1,
+                                   torch.from_numpy(pop[lo:hi].copy()).to(dev), h, item_offset=lo)
+        parts.append(ops.topk_merge(keys, ut, h, want="keys"))
+    idx, val = ops.topk_merge(torch.stack(parts), ut, h)
+    idx1, val1, _ = run_gpu(dev, U, I, users, K, 1, pop, hist, by_user=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), idx1)
+    np.testing.assert_array_equal(val.cpu().numpy(), val1)
+    check_against_oracle(idx1, val1, U, I, users, K, 1, pop, hist, exact=False)
+
+
+def test_merge_matches_numpy_oracle(dev):
+    from pda_amd import ops
+    rng = np.random.default_rng(2)
+    R, nU, K = 5, 70, 50
+    vals = -np.sort(-rng.standard_normal((R, nU, K)).astype(np.float32), axis=2)
+    vals[:, :, 40:] = np.round(vals[:, :, 40:], 1)            # force cross-list ties
+    vals = -np.sort(-vals, axis=2) + np.float32(0.0)          # canonical +0.0 like the kernel's pack
+    idxs = rng.permutation(100000)[:R * nU * K].reshape(R, nU, K).astype(np.int32)   # unique items
+    # within a list, ties must already be (val desc, idx asc): sort idx inside equal-value runs
+    for r in range(R):
+        for u in range(nU):
+            o = np.lexsort((idxs[r, u], -vals[r, u]))
+            vals[r, u], idxs[r, u] = vals[r, u][o], idxs[r, u][o]
+    hi = (vals.view(np.uint32).astype(np.uint64))
+    ordb = np.where(hi & np.uint64(0x80000000), (~hi) & np.uint64(0xFFFFFFFF), hi | np.uint64(0x80000000))
+    keys = ((ordb << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - idxs.astype(np.uint64))).view(np.int64)
+    gi, gv = ops.topk_merge(torch.from_numpy(keys).to(dev))
+    ri, rv = po.merge_partial_topk(vals, idxs, K)
+    np.testing.assert_array_equal(gi.cpu().numpy(), ri)
+    np.testing.assert_array_equal(gv.cpu().numpy(), rv)
+
+
+def test_c2_shape_sample_against_oracle(dev):
+    """BASELINE config 2 shape (50k x 20k, d=64, PDA head): a 4096-user sample, whole catalogue."""
+    from pda_amd import ops
+    rng = np.random.default_rng(2020)
+    nU, nI, d, K = 50000, 20000, 64, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d, max_hist=0)
+    users = rng.permutation(nU)[:4096].astype(np.int32)
+    lens = np.clip(rng.lognormal(4.5, 0.8, len(users)).astype(np.int64), 1, 2000)
+    rows = [np.sort(rng.integers(0, nI, n)).astype(np.int32) for n in lens]
+    idx, val, _ = run_gpu(dev, U, I, users, K, 1, pop, rows, by_user=False)
+    check_against_oracle(idx, val, U, I, users, K, 1, pop, rows, exact=False)
+    idx0, val0, _ = run_gpu(dev, U, I, users, K, 0, None, rows, by_user=False)
+    check_against_oracle(idx0, val0, U, I, users, K, 0, None, rows, exact=True)
+
+
+def test_c3_shape_properties(dev):
+    """BASELINE config 3 shape (1M x 200k, d=128) is too big for the oracle: check size-independent
+    properties on one 8192-user block -- sortedness, no masked item, threshold consistency against
+    exact chain scores of the returned + 2000 random other items, split-invariance (bit-identical lists)."""
+    from pda_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(2021)
+    nU, nI, d, K, Bu = 1_000_000, 200_000, 128, 50, 8192
+    U = (torch.randn(nU, d, generator=g) * 0.1).to(dev)
+    I = (torch.randn(nI, d, generator=g) * 0.1).to(dev)
+    pop = (torch.rand(nI, generator=g) ** 0.22).to(dev)
+    rng = np.random.default_rng(1)
+    users = rng.permutation(nU)[:Bu].astype(np.int32)
+    rows = [np.unique(rng.integers(0, nI, 50)).astype(np.int32) for _ in range(Bu)]
+    ip, ix = csr(rows)
+    h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=False)
+    ut = torch.from_numpy(users).to(dev)
+    idx_a, val_a = ops.recommend_topk(U, I, ut, K, 1, pop, h, n_splits=1)
+    idx_b, val_b = ops.recommend_topk(U, I, ut, K, 1, pop, h, n_splits=16)
+    assert torch.equal(idx_a, idx_b) and torch.equal(val_a, val_b)
+    idx, val = idx_a.cpu().numpy(), val_a.cpu().numpy()
+    assert np.all(val[:, 1:] <= val[:, :-1])
+    for r in range(0, Bu, 97):
+        assert not set(idx[r]) & set(rows[r].tolist())
+        assert len(set(idx[r])) == K
+    # threshold consistency on 64 users with exact recomputation on the CPU
+    Uh, Ih, ph = U.cpu().numpy(), I.cpu().numpy(), pop.cpu().numpy()
+    for r in range(0, Bu, Bu // 64):
+        others = np.setdiff1d(rng.integers(0, nI, 2000), np.concatenate([idx[r], rows[r]]))
+        cand = np.concatenate([idx[r], others]).astype(np.int64)
+        s = c_oracle.scores_chain(Uh, Ih[cand], users[r:r + 1])[0]
+        t = np.where(s > 0, s + 1, np.exp(np.minimum(s, 0))).astype(np.float32) * ph[cand]
+        np.testing.assert_allclose(val[r], t[:K], rtol=TOL, atol=TOL)
+        assert t[K:].max() <= val[r, -1] + TOL
+
+
+def test_argument_errors(dev):
+    from pda_amd import ops
+    from pda_amd._lib import PdaHipError
+    U = torch.zeros(10, 48, device=dev)
+    I = torch.zeros(100, 48, device=dev)
+    users = torch.arange(10, dtype=torch.int32, device=dev)
+    with pytest.raises(PdaHipError):              # embed dim without a compiled kernel
+        ops.score_topk_keys(U, I, users, 50)
+    U = torch.zeros(10, 64, device=dev)
+    I = torch.zeros(100, 64, device=dev)
+    with pytest.raises(PdaHipError):              # K beyond the on-chip list
+        ops.score_topk_keys(U, I, users, 64)
+    with pytest.raises(PdaHipError):              # popularity head without popularity
+        ops.score_topk_keys(U, I, users, 50, head=1)
+    with pytest.raises(ValueError):               # host tensors are refused: no CPU path
+        ops.score_topk_keys(U.cpu(), I, users, 50)
