@@ -1,0 +1,276 @@
+#!/usr/bin/env python
+"""bench.py -- PDA BPR-MF hot path on MI355X: full-catalogue score + mask + top-K@50 users/s (headline `value`)
+and BPR triplets/s (reported beside it), on synthetic Douban-shaped data (pda_amd/synthetic.py).
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one pass of the evaluation hot path over one block of `--eval-block` users against the WHOLE item
+catalogue: score (fp32 MFMA) + history mask + top-K on every rank's item shard, one RCCL all-gather of the
+packed partial lists, merge.  Inputs are resident in HBM before the timed region.  Scaling is STRONG: the
+catalogue and the users per step are fixed while N grows (item-parallel sharding of BASELINE config 3 -> 4).
+
+The JSON line also carries: `roofline` (dominant kernel = score_topk_kernel, bound = fp32 MFMA; achieved from the
+algorithmic flops 2*Bu*I_local*d per launch and the kernel's HIP-event duration), `cpu_baseline` (torch-CPU
+restatement of the reference op sequence, oracle/cpu_baseline.py, bounded sample, rank 0, N=1 only) and `train`
+(fused BPR step throughput on BASELINE config 2, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (guides/MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--workload", default="c3", choices=["c2", "c3", "tiny"])
+    p.add_argument("--eval-block", type=int, default=65536, help="users per step")
+    p.add_argument("--head", default="condition", choices=["main_branch", "condition"])
+    p.add_argument("--K", type=int, default=50)
+    p.add_argument("--no-train", action="store_true")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--train-steps", type=int, default=2048)
+    p.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
+    return p.parse_args()
+
+
+class TimedScore:
+    """Wraps ops.score_topk_keys with HIP events on the launch stream (torch's current stream)."""
+
+    def __init__(self):
+        from pda_amd import ops
+        self.fn = ops.score_topk_keys
+        self.events = []
+        self.enabled = False
+
+    def __call__(self, *a, **k):
+        if not self.enabled:
+            return self.fn(*a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = self.fn(*a, **k)
+        e.record()
+        self.events.append((s, e))
+        return out
+
+    def mean_ms(self):
+        return sum(s.elapsed_time(e) for s, e in self.events) / max(1, len(self.events))
+
+
+def bench_eval(args, rank, world, dev):
+    import torch.distributed as dist
+    from pda_amd import ops, synthetic
+    from pda_amd.dist import ItemShardedTopK
+    W = synthetic.make_workload(args.workload, dev)
+    head = ops.HEAD_POP if args.head == "condition" else ops.HEAD_RAW
+    timed = TimedScore()
+    ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, rank, world, score_fn=timed)
+    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+    Bu = min(args.eval_block, W.n_users)
+    n_blocks = args.warmup + args.steps
+    starts = [(b * Bu) % max(1, W.n_users - Bu + 1) for b in range(n_blocks)]
+    blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in starts]
+    if world > 1:
+        del W.I                                           # every rank keeps only its shard of the item table
+    sink = []
+
+    def run(bl):
+        for idx, val in ev.topk_blocks(bl, args.K, head, hist):
+            sink.append(idx[0, 0])                        # keep the result alive without a sync
+    run(blocks[:args.warmup])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timed.enabled = True
+    t0 = time.perf_counter()
+    run(blocks[args.warmup:])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    n_local = ev.I_shard.shape[0]
+    k_ms = timed.mean_ms()
+    flops = 2.0 * Bu * n_local * W.d
+    nnz_blk = float(W.n_train) * Bu / W.n_users
+    abytes = n_local * W.d * 4 + n_local * 4 + Bu * W.d * 4 + nnz_blk * 4 + (Bu + 1) * 8 + Bu * args.K * 8
+    roof = {"kernel": "score_topk_kernel<%d,%s>" % (W.d, "POP" if head else "RAW"), "bound": "mfma",
+            "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "kernel_ms": k_ms, "flops_per_launch": flops,
+            "hbm": {"algorithmic_bytes_per_launch": abytes, "achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
+                    "peak_GBs": PEAK_HBM_GBS, "frac": abytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    res = {"users_per_s": Bu * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "Bu": Bu, "W": W,
+           "roofline": roof, "hist": hist}
+    return res
+
+
+def bench_train(args, dev):
+    """Fused BPR step on BASELINE config 2 (50k x 20k, d=64, B=2048, PD/PDA s_condition), batches pre-staged in HBM
+    by the device sampler; steps captured into HIP graphs of 64 launches (launch-bound regime)."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("c2" if args.workload != "tiny" else "tiny", dev)
+    B, regs, lr, NB, G = 2048, 1e-2, 1e-2, 64, 64
+    batches = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2020, step=s, n_pool=W.n_users,
+                                   train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+               for s in range(NB)]
+    out = {"workload": "C2: synthetic %d users x %d items, d=%d, B=%d, PD/PDA (s_condition, gamma=%.2f)" %
+                       (W.n_users, W.n_items, W.d, B, W.gamma), "graph_launches": G}
+
+    def timed_graph(body, n_steps):
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for i in range(3):
+                body(i)
+        torch.cuda.current_stream().wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for i in range(G):
+                body(i)
+        reps = max(1, n_steps // G)
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"triplets_per_s": reps * G * B / dt, "us_per_step": dt / (reps * G) * 1e6, "steps": reps * G}
+
+    U, I = W.U.clone(), W.I.clone()
+    loss = torch.zeros(3, device=dev)
+    out["sgd_fused"] = timed_graph(lambda i: ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, lr=lr,
+                                                          mode=ops.UPD_SGD_FUSED, loss_acc=loss), args.train_steps)
+    out["sgd_fused"]["bytes_per_triplet"] = 6 * W.d * 4 + 20
+    out["sgd_fused"]["hbm_frac"] = out["sgd_fused"]["triplets_per_s"] * (6 * W.d * 4 + 20) / 1e9 / PEAK_HBM_GBS
+
+    U, I = W.U.clone(), W.I.clone()
+    st = [torch.zeros_like(t) for t in (U, U, U, I, I, I)]   # mU vU gU mI vI gI
+    tcount = [0]
+
+    def adam_body(i):
+        tcount[0] += 1
+        lr_t = ops.adam_lr_t(lr, min(tcount[0], 1000))       # host scalar frozen in the graph: fine for timing
+        ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=st[2], gI=st[5], loss_acc=loss)
+        ops.adam_dense_sweep(U, st[0], st[1], st[2], lr_t)
+        ops.adam_dense_sweep(I, st[3], st[4], st[5], lr_t)
+    out["adam_dense_reference_faithful"] = timed_graph(adam_body, max(256, args.train_steps // 4))
+    sweep_bytes = 6 * (W.n_users + W.n_items) * W.d * 4
+    r = out["adam_dense_reference_faithful"]
+    r["algorithmic_bytes_per_step"] = sweep_bytes
+    r["hbm_frac"] = sweep_bytes / (r["us_per_step"] * 1e-6) / 1e9 / PEAK_HBM_GBS
+
+    U, I = W.U.clone(), W.I.clone()
+    stepc = [0]
+
+    def sampled_body(i):
+        stepc[0] += 1
+        b = ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=7, step=stepc[0], n_pool=W.n_users,
+                                train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+        ops.bpr_step(U, I, *b, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
+    torch.cuda.synchronize()
+    for i in range(8):
+        sampled_body(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = max(256, args.train_steps // 4)
+    for i in range(n):
+        sampled_body(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["sgd_fused_with_device_sampler_eager"] = {"triplets_per_s": n * B / dt, "us_per_step": dt / n * 1e6, "steps": n}
+    return out, W, batches
+
+
+def cpu_baseline(args, ev_res, train_pack):
+    """Reference op sequence on the host cores (torch CPU fp32), bounded sample.  kind = "port"."""
+    from oracle import cpu_baseline as cb
+    W = ev_res["W"]
+    cores = torch.get_num_threads()
+    U, pop = W.U.cpu(), W.pop_last.cpu()
+    I = W.I.cpu()
+    indptr, indices = W.hist_indptr.cpu(), W.hist_indices.cpu()
+    blocks, coos = [], []
+    for b in range(64):
+        s = (b * 2048) % max(1, W.n_users - 2048)
+        users = torch.arange(s, min(s + 2048, W.n_users))
+        lo, hi = int(indptr[users[0]]), int(indptr[users[-1] + 1])
+        lens = (indptr[users + 1] - indptr[users])
+        rows = torch.repeat_interleave(torch.arange(users.numel()), lens)
+        blocks.append(users)
+        coos.append((rows, indices[lo:hi].long()))
+    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, "condition" if args.head == "condition" else "main_branch",
+                           budget_s=args.cpu_budget)
+    out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port",
+           "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d (torch-CPU restatement of "
+                     "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk)" % (n, W.n_items, W.d)}
+    if train_pack is not None:
+        _, W2, batches = train_pack
+        cpu_batches = [tuple(t.cpu().long() if t.dtype == torch.int32 else t.cpu() for t in b) for b in batches[:16]]
+        r, steps = cb.time_train(W2.U.cpu(), W2.I.cpu(), cpu_batches, 1e-2, 2048, 1e-2, budget_s=min(8.0, args.cpu_budget))
+        out["train"] = {"value": r, "unit": "triplets/s", "steps": steps,
+                        "sample": "C2 tables, B=2048, dense-decay Adam over both full tables (reference-faithful)"}
+    return out
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
+        sys.exit(2)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
+    ev = bench_eval(args, rank, world, dev)
+    train_pack = None
+    if world == 1 and not args.no_train:
+        train_pack = bench_train(args, dev)
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, ev, train_pack)
+    if rank == 0:
+        W = ev["W"]
+        line = {
+            "metric": "users/sec full-catalogue top-K@%d (eval)" % args.K, "value": ev["users_per_s"], "unit": "users/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ev["ms_per_step"],
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: synthetic %d users x %d items, embed_dim=%d, %s head, history-masked top-K@%d"
+                                   % (args.workload.upper(), W.n_users, W.n_items, W.d,
+                                      "PDA condition ((elu+1)*pop^%.2f)" % W.gamma if args.head == "condition" else "raw",
+                                      args.K),
+                       "users_per_step": ev["Bu"], "sharding": "item-parallel x%d, RCCL all-gather of partial top-K" % world,
+                       "train_nnz": W.n_train},
+            "roofline": ev["roofline"], "cpu_baseline": cpu, "train": train_pack[0] if train_pack else None,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

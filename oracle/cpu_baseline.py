@@ -1,0 +1,84 @@
+"""CPU baseline = torch-CPU fp32 restatement of the *exact reference op sequence* (BASELINE.md section 3).
+
+TEST/BENCH INFRASTRUCTURE ONLY (see oracle/pda_oracle.py header): used by bench.py's `cpu_baseline` leg and by
+tests; never imported by pda_amd.  The literal TF-1.14 CPU path cannot run here or on the GPU box, so every
+number produced by this file is labelled kind="port".
+
+eval  (MF/model_api.py:62,113; MF/train_new_api.py:594-612, 780-794), per 2048-user block:
+      R = U[u] @ I.T  (materialised [Bu, I])  ->  elu  ->  +1  ->  * pop  ->  scatter -inf at history  ->  topk(50)
+train (MF/model_api.py:51-53,102-121,83): index_select x3 -> dots -> (ELU+1)*pop -> -mean(log(sigmoid+1e-10))
+      + regs*sum(l2)/B -> autograd -> Adam with dense decay over both full tables [TF-ext].
+"""
+from __future__ import annotations
+
+import time
+
+import torch
+import torch.nn.functional as F
+
+
+def eval_block(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition"):
+    R = U.index_select(0, users) @ I.t()                         # tf.matmul, model_api.py:62
+    if rec_type != "main_branch":
+        R = (F.elu(R) + 1.0) * pop.unsqueeze(0)                  # model_api.py:113 / train_new_api.py:601-602
+    R[coo_rows, coo_cols] = float("-inf")                        # tf.sparse.add(-inf), :597,603,608
+    return torch.topk(R, K, dim=1, sorted=True).indices          # tf.nn.top_k, :598,604,609
+
+
+def time_eval(U, I, pop, users_blocks, coo_blocks, K=50, rec_type="condition", budget_s=20.0):
+    """Runs whole 2048-user reference blocks until `budget_s` of CPU time is used.  Returns (users/s, n_users)."""
+    done, t0 = 0, time.perf_counter()
+    for users, (rows, cols) in zip(users_blocks, coo_blocks):
+        eval_block(U, I, pop, users, rows, cols, K, rec_type)
+        done += users.numel()
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return done / dt, done
+
+
+class AdamDenseDecay:
+    """TF-1.14 AdamOptimizer sparse apply: decay m,v and update var on EVERY row each step [TF-ext]."""
+
+    def __init__(self, params, lr, b1=0.9, b2=0.999, eps=1e-8):
+        self.params, self.lr, self.b1, self.b2, self.eps, self.t = params, lr, b1, b2, eps, 0
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+
+    @torch.no_grad()
+    def step(self):
+        self.t += 1
+        lr_t = self.lr * (1 - self.b2 ** self.t) ** 0.5 / (1 - self.b1 ** self.t)
+        for p, m, v in zip(self.params, self.m, self.v):
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            m.mul_(self.b1).add_(g, alpha=1 - self.b1)
+            v.mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
+            p.sub_(lr_t * m / (v.sqrt() + self.eps))
+            p.grad = None
+
+
+def train_step(U, I, opt, users, pos, neg, pos_pop, neg_pop, regs, batch_size):
+    ue, pe, ne = U.index_select(0, users), I.index_select(0, pos), I.index_select(0, neg)
+    ps, ns = (ue * pe).sum(1), (ue * ne).sum(1)
+    if pos_pop is not None:
+        ps, ns = (F.elu(ps) + 1) * pos_pop, (F.elu(ns) + 1) * neg_pop
+    mf = -torch.log(torch.sigmoid(ps - ns) + 1e-10).mean()
+    reg = regs * 0.5 * ((ue ** 2).sum() + (pe ** 2).sum() + (ne ** 2).sum()) / batch_size
+    (mf + reg).backward()
+    opt.step()
+    return float(mf + reg), float(mf), float(reg)
+
+
+def time_train(U, I, batches, regs, batch_size, lr, budget_s=10.0):
+    """`batches`: list of (users, pos, neg, pos_pop, neg_pop) CPU tensors.  Returns (triplets/s, n_steps)."""
+    U = U.clone().requires_grad_(True)
+    I = I.clone().requires_grad_(True)
+    opt = AdamDenseDecay([U, I], lr)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for b in batches:
+            train_step(U, I, opt, *b, regs, batch_size)
+            n += 1
+            if time.perf_counter() - t0 > budget_s:
+                dt = time.perf_counter() - t0
+                return n * batch_size / dt, n

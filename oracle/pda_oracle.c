@@ -16,11 +16,11 @@
  *
  * Two accumulation orders are offered for the fp32 dot:
  *   order 0: float64 accumulate, rounded once           (the "truth" used with a tolerance)
- *   order 1: the HIP kernel's exact fp32 fmaf chain     (bit-exact comparison of scores):
- *            for c in 0..d/8: for s in 0..3: acc=fmaf(u[8c+s],i[8c+s],acc);
- *                                            acc=fmaf(u[8c+4+s],i[8c+4+s],acc)
- *            which is what v_mfma_f32_32x32x2_f32 computes when lane-half h supplies
- *            k = 8c+4h+s (see pda_amd/csrc/pda_score_topk.hip).
+ *   order 1: the HIP kernel's exact fp32 arithmetic       (bit-exact comparison of scores):
+ *            two fmaf chains, chain c&1 over the k-chunks c = 0..d/8-1:
+ *              for s in 0..3: acc=fmaf(u[8c+s],i[8c+s],acc); acc=fmaf(u[8c+4+s],i[8c+4+s],acc)
+ *            (what v_mfma_f32_32x32x2_f32 computes when lane-half h supplies k = 8c+4h+s),
+ *            then score = chain0 + chain1 (see pda_amd/csrc/pda_score_topk.hip).
  */
 #include <math.h>
 #include <stdint.h>
@@ -28,13 +28,13 @@
 #include <string.h>
 
 static inline float dot_chain(const float* u, const float* v, int d) {
-    float acc = 0.0f;
+    float acc[2] = {0.0f, 0.0f};                 /* even / odd k-chunks: two independent chains */
     for (int c = 0; c < d / 8; ++c)
         for (int s = 0; s < 4; ++s) {
-            acc = fmaf(u[8 * c + s], v[8 * c + s], acc);
-            acc = fmaf(u[8 * c + 4 + s], v[8 * c + 4 + s], acc);
+            acc[c & 1] = fmaf(u[8 * c + s], v[8 * c + s], acc[c & 1]);
+            acc[c & 1] = fmaf(u[8 * c + 4 + s], v[8 * c + 4 + s], acc[c & 1]);
         }
-    return acc;
+    return acc[0] + acc[1];
 }
 
 static inline float dot_f64(const float* u, const float* v, int d) {

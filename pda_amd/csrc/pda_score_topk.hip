@@ -17,7 +17,8 @@
 //                four 16-lane groups are bank-conflict free; next tile prefetched into registers
 //                while the MFMAs of the current one run.
 //   k order    = lane-half h supplies k = 8c+4h+s for MFMA (c, s): both operands become one
-//                16-byte load per 8 k's, and the result is a fixed fmaf chain (oracle order 1).
+//                16-byte load per 8 k's.  Even and odd k-chunks accumulate in two independent fmaf
+//                chains that are added once at the end (oracle order 1 restates exactly this).
 //   epilogue   = per accumulator register: head transform ((elu+1)*pop), one v_cmp against the
 //                per-user running threshold, wave ballot.  Only when some lane passes (rare after
 //                warm-up: ~K/i of the scores at item i) does the wave enter the slow path, which
@@ -26,6 +27,7 @@
 //   mask       = history CSR rows sorted by item id; each user row keeps a cursor, producing a
 //                32-bit mask per (user, tile) that is consulted only on the slow path.
 #include "pda_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -58,36 +60,62 @@ __device__ __forceinline__ int swz(int row) {
     else return (row >> 1) & 7;  // D == 32: 8 chunks per 128-B row, two rows per 256-B bank line
 }
 
-// In-register rank sort of one user's candidate list (<= 60 keys, one per lane), keeping the best K
-// at buf[0..K) in descending order.  Returns the new count and threshold.
-__device__ __forceinline__ void compact_list(uint64_t* buf, int& c, float& tau, int K, int lane) {
+// Compaction of one user's candidate list (<= 60 keys, one per lane): keep the best K at buf[0..K) in
+// descending order, update the row's LDS count and threshold.  Whole-wave call.
+// After the first compaction buf[0..K) is already sorted, so only the (<= kCap-K) appended keys need ranking:
+// rank(old i) = i + #new greater; rank(new) = #old greater (one ballot) + #new greater.  ~4x cheaper than the
+// generic all-pairs rank sort, which remains for the first compaction and the final sort.
+__device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane) {
     pda_wave_sync();
+    const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), kCap);   // failed appends may have pushed it past kCap
+    const bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
     uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);  // fillers: unique, below any real key
-    int rank = 0;
-    for (int jj = 0; jj < c; ++jj) {
-        uint64_t kj = pda_readlane_u64(key, jj);
-        rank += (kj > key) ? 1 : 0;
+    int rank;
+    if (sorted_prefix) {
+        rank = lane < K ? lane : 0;
+        const uint64_t oldmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+        for (int jj = K; jj < c; ++jj) {
+            const uint64_t kj = pda_readlane_u64(key, jj);
+            rank += (kj > key) ? 1 : 0;
+            const int olds_above = __popcll(__ballot(key > kj) & oldmask);
+            rank += (lane == jj) ? olds_above : 0;
+        }
+    } else {
+        rank = 0;
+        for (int jj = 0; jj < c; ++jj) {
+            const uint64_t kj = pda_readlane_u64(key, jj);
+            rank += (kj > key) ? 1 : 0;
+        }
     }
     pda_wave_sync();
     if (lane < c && rank < K) buf[rank] = key;
     if (c >= K) {
         uint64_t mk = __ballot(lane < c && rank == K - 1);
         int src = __builtin_ctzll(mk);
-        tau = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src));
-        c = K;
+        const float tau = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src));
+        if (lane == 0) {
+            *tau_slot = tau;
+            *cnt_slot = K;
+        }
+    } else if (lane == 0) {
+        *cnt_slot = c;
     }
     pda_wave_sync();
 }
 
-template <int D, int HEAD>
+// ABL: profiling-only ablation bits (0 in the shipped instantiations): 1 skip slow path, 2 skip threshold test,
+// 4 skip history cursor, 8 skip item-tile global loads.  Enabled by building with -DPDA_ABLATION.
+template <int D, int HEAD, int ABL = 0>
 __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Bt = reinterpret_cast<float*>(smem);                                   // [32][D] swizzled
     uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 32 * D * sizeof(float));  // [128][kCap]
 
     constexpr int CPR = D / 4;            // 16-B chunks per item row
-    constexpr int NLD = (32 * CPR) / kThreads > 0 ? (32 * CPR) / kThreads : 1;  // float4 loads / thread / tile
-    constexpr int NC = D / 8;             // k-chunks of 8
+    constexpr int NLD = (32 * CPR) / kThreads;  // float4 loads / thread / tile (D >= 32)
+    static_assert(NLD >= 1, "embed dim too small for the 256-thread staging pattern");
+    constexpr int NC = D / 8;             // k-chunks of 8 (even: two accumulator chains)
+    static_assert(NC % 2 == 0, "embed dim must be a multiple of 16");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -115,10 +143,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
         }
     }
 
-    // ---- history cursor ---------------------------------------------------------------------
+    // ---- history cursor: head `nxt`, look-ahead `nxt2`, and one refill load in flight (`pend_v`).  All loads of
+    // the steady-state loop are unconditional and straight-line so the compiler's vmcnt counting stays exact ---
     int64_t hp = 0, he = 0;
-    int nxt = 0x7fffffff;
-    if (a.hist_indptr != nullptr && row_ok) {
+    int nxt = 0x7fffffff, nxt2 = 0x7fffffff, pend_v = 0x7fffffff;
+    bool pend_flag = false, pend_ok = false;
+    const bool hist_on = (a.hist_indptr != nullptr) && !(ABL & 4);
+    if (hist_on && row_ok) {
         const int64_t hr = a.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)row_blk;
         hp = a.hist_indptr[hr];
         he = a.hist_indptr[hr + 1];
@@ -130,26 +161,38 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
         }
         hp = lo;
         if (hp < he) nxt = a.hist_indices[hp];
+        if (hp + 1 < he) nxt2 = a.hist_indices[hp + 1];
     }
 
-    // ---- per-row running state: count + threshold (lane l <-> row l&31) ------------------------
-    int cnt = 0;
-    float tau = row_ok ? -INFINITY : INFINITY;  // rows past the end never accept anything
+    // ---- per-row running state in LDS: candidate count + threshold (rows are private to their wave) ------
+    int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap);   // [128]
+    float* taul = reinterpret_cast<float*>(cntl + kUserTile);               // [128]
+    if (lane < 32) {
+        cntl[wave * 32 + lane] = 0;
+        taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;  // rows past the end never accept anything
+    }
+    pda_wave_sync();
     f32x16 thr;
+    auto refresh_thr = [&]() {
+        int hv = h;
+        asm volatile("" : "+v"(hv));   // opaque: keeps the 16 LDS addresses from being hoisted into live registers
 #pragma unroll
-    for (int r = 0; r < 16; ++r) thr[r] = __shfl(tau, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+        for (int r = 0; r < 16; ++r) thr[r] = taul[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv];
+    };
+    refresh_thr();
 
     // ---- item tile staging -------------------------------------------------------------------
     f32x4 pre[NLD];
+    // Unconditional loads (row index clamped, never predicated): a load hidden behind a branch cannot be counted
+    // by the compiler's vmcnt bookkeeping and turns every later wait into a full drain.  Rows past the end of the
+    // shard produce garbage scores that `vmask` discards.
     auto tile_load = [&](int t) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
-            const int it = t * 32 + jj;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (jj < 32 && it < a.n_items_local) v = *reinterpret_cast<const f32x4*>(a.I + (size_t)it * D + 4 * ch);
-            pre[q] = v;
+            const int it = min(t * 32 + jj, a.n_items_local - 1);
+            pre[q] = *reinterpret_cast<const f32x4*>(a.I + (size_t)it * D + 4 * ch);
         }
     };
     auto tile_store = [&]() {
@@ -157,122 +200,210 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
-            if (jj < 32) *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pre[q];
+            *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pre[q];
         }
     };
-
-    if (t0 < t1) {
-        tile_load(t0);
-        tile_store();
-    }
-    __syncthreads();
+    auto pop_load = [&](int t) -> float {
+        if constexpr (HEAD == PDA_HEAD_POP) return a.pop[min(t * 32 + j, a.n_items_local - 1)];
+        return 1.0f;
+    };
+    // History bits of tile t for my row.  Branch-free for the common case (at most one train item of the row
+    // inside the tile): commit the refill issued by the previous call, advance once, issue the next refill.
+    auto hist_bits = [&](int t) -> uint32_t {
+        if (!hist_on) return 0u;                                   // wave-uniform
+        const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
+        nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2; // value loaded one tile ago: no stall
+        const bool adv = nxt < jg1;
+        uint32_t hb = adv ? (1u << ((nxt - jg0) & 31)) : 0u;
+        hp += adv ? 1 : 0;
+        nxt = adv ? nxt2 : nxt;
+        const int64_t idx = hp + 1;
+        pend_ok = idx < he;
+        pend_flag = adv;
+        const int64_t idc = max((int64_t)0, min(idx, he - 1));     // clamped: the load is never predicated
+        pend_v = a.hist_indices[idc];
+        if (__builtin_expect(__any(nxt < jg1), 0)) {               // rare: several train items in one tile
+            do {
+                if (nxt < jg1) {
+                    const int nn2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
+                    hb |= 1u << ((nxt - jg0) & 31);
+                    ++hp;
+                    nxt = nn2;
+                    nxt2 = (hp + 1 < he) ? a.hist_indices[hp + 1] : 0x7fffffff;
+                    pend_flag = false;
+                }
+            } while (__any(nxt < jg1));
+        }
+        return hb;
+    };
+    auto valid_mask = [&](int t) -> uint64_t {
+        const int nvalid = min(32, a.n_items_local - t * 32);
+        return nvalid >= 32 ? ~0ull : (((1ull << nvalid) - 1ull) * 0x100000001ull);
+    };
 
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap;
     const float* brow = Bt + j * D;
     const int bswz = swz<D>(j);
 
+    // Slow path for one finished tile.  `regmask`: accumulator registers in which some lane beat its threshold.
+    // Every passing lane appends its own candidate with an LDS atomic on the row's counter -- no serialisation
+    // over lanes or rows; a full list is compacted lazily and only the failed lanes retry.  The loop over
+    // registers is a run-time loop (dynamic VGPR index) on purpose: unrolled 16x it costs ~70 live registers.
+    auto slow_path = [&](uint32_t regmask, const f32x16& accv, float popv, uint64_t vmask, uint32_t hb, int jg0) {
+        const uint32_t my_item = (uint32_t)(jg0 + j);
+        const bool lane_ok = (vmask >> lane) & 1ull;
+        const bool any_hb = __any(hb != 0);   // some row of this wave has train items inside the tile
+        uint32_t still = 0xFFFFu;             // per-lane: registers this lane may (still) append
+        uint32_t rm = regmask;
+        for (;;) {
+            uint32_t ovf_regs = 0, next_still = 0;
+#pragma nounroll
+            while (rm) {
+                const int r = __builtin_ctz(rm);
+                rm &= rm - 1u;
+                float tt = accv[r];   // exact head value (the fast test only saw an upper bound)
+                if constexpr (HEAD == PDA_HEAD_POP) tt = (tt > 0.0f ? tt + 1.0f : __expf(tt)) * popv;
+                bool p = lane_ok && ((still >> r) & 1u) && (tt > thr[r]);
+                const int rowb = (r & 3) + 8 * (r >> 2);
+                if (any_hb) {   // train items never enter
+                    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hb, rowb);
+                    const uint32_t h1 = (uint32_t)__builtin_amdgcn_readlane((int)hb, rowb + 4);
+                    if (((h ? h1 : h0) >> j) & 1u) p = false;
+                }
+                bool ov = false;
+                if (p) {
+                    const int row = wave * 32 + rowb + 4 * h;
+                    const int slot = atomicAdd(&cntl[row], 1);   // ds_add_rtn_u32: distinct slots for concurrent lanes
+                    if (slot < kCap) lists[(size_t)row * kCap + slot] = pda_pack_key(tt, my_item);
+                    else ov = true;
+                }
+                if (ov) next_still |= 1u << r;
+                if (__any(ov)) ovf_regs |= 1u << r;
+            }
+            if (!ovf_regs) break;
+            // some list overflowed: compact every full list of this wave, then retry what is still above threshold
+            pda_wave_sync();
+            uint64_t full = __ballot(lane < 32 && cntl[wave * 32 + (lane & 31)] >= kCap);
+            while (full) {
+                const int row = __builtin_ctzll(full);
+                full &= full - 1ull;
+                compact_list(my_lists + row * kCap, &cntl[wave * 32 + row], &taul[wave * 32 + row], K, lane);
+            }
+            refresh_thr();
+            still = next_still;
+            rm = ovf_regs;
+        }
+    };
+
+    // Threshold test on an UPPER BOUND of the head: ub = (max(s,0)+1)*pop equals the exact (elu(s)+1)*pop for
+    // s > 0 (bitwise) and is >= it for s <= 0, so no candidate is missed and the exp is only paid on the slow path.
+    auto head_ub = [&](float sc, float popv) -> float {
+        if constexpr (HEAD == PDA_HEAD_POP) return (fmaxf(sc, 0.0f) + 1.0f) * popv;
+        return sc;
+    };
+    auto fast_test = [&](const f32x16& accv, float popv, uint64_t vmask) -> uint32_t {
+        uint32_t regmask = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            regmask |= (__ballot(head_ub(accv[r], popv) > thr[r]) & vmask) ? (1u << r) : 0u;
+        return regmask;
+    };
+
+    // Software pipeline.  Iteration t:  issue the global loads of tile t+1;  MFMA chain of tile t with the
+    // threshold test of tile t-1 interleaved in the matrix instructions' shadow;  barrier;  stage tile t+1 into
+    // LDS (the only vmcnt wait of the iteration);  advance the history cursor to tile t+1;  slow path of t-1.
+    f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint64_t vmask_prev = 0, vmask_cur = 0;
+    uint32_t hb_prev = 0, hb_cur = 0;
+    float popj_prev = 0.f, popj_cur = 0.f;
+
+    if (t0 < t1) {
+        tile_load(t0);
+        popj_cur = pop_load(t0);
+        tile_store();
+        hb_cur = hist_bits(t0);
+        vmask_cur = valid_mask(t0);
+    }
+    __syncthreads();
+
     for (int t = t0; t < t1; ++t) {
-        const int j0 = t * 32;
         const bool has_next = (t + 1) < t1;
-        if (has_next) tile_load(t + 1);
+        const int tn = has_next ? t + 1 : t;          // last iteration re-loads its own tile: keeps the loads unconditional
+        float popj_next = 0.f;
+        if constexpr (!(ABL & 8)) {
+            tile_load(tn);
+            popj_next = pop_load(tn);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // pin the prefetch ahead of the MFMA chain (the scheduler otherwise sinks it)
 
-        float popj = 1.0f;
-        if constexpr (HEAD == PDA_HEAD_POP) popj = (j0 + j < a.n_items_local) ? a.pop[j0 + j] : 0.0f;
-
-        // history bits of this tile for my row
-        const int jg0 = a.item_offset + j0, jg1 = jg0 + 32;
-        uint32_t hb = 0;
-        while (__any(nxt < jg1)) {
-            if (nxt < jg1) {
-                hb |= 1u << (nxt - jg0);
-                ++hp;
-                nxt = hp < he ? a.hist_indices[hp] : 0x7fffffff;
+        // ---- contraction of tile t on the matrix cores  ||  threshold test of tile t-1 ------------
+        // Two accumulator chains (even / odd k-chunks): a dependent v_mfma chain loses its SrcC forwarding (+43
+        // cycles) as soon as anything is issued between two links, while instructions between MFMAs on DIFFERENT
+        // accumulators are nearly free -- so the test of the previous tile is interleaved here.
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc1 = acc0;
+        uint32_t regmask = 0;
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + h) ^ bswz));
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + 2 + h) ^ bswz));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][q], b0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c + 1][q], b1[q], acc1, 0, 0, 0);
+            }
+            if constexpr (!(ABL & 2)) {
+#pragma unroll
+                for (int r = (16 * c) / NC; r < (16 * (c + 2)) / NC; ++r)
+                    regmask |= (__ballot(head_ub(acc_prev[r], popj_prev) > thr[r]) & vmask_prev) ? (1u << r) : 0u;
             }
         }
-
-        // ---- contraction: 32 users x 32 items x D on the matrix cores -------------------------
-        f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if constexpr (ABL & 2) asm volatile("" ::"v"(acc_prev[0]), "v"(acc_prev[7]), "v"(acc_prev[15]));
+        // Scheduling recipe for the block above: B fragments ahead of their MFMAs, the test spread over the gaps.
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + h) ^ bswz));
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][0], b[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][1], b[1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][2], b[2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][3], b[3], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (HEAD == PDA_HEAD_POP ? 64 : 16) / (4 * NC) + 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
+        const f32x16 acc = acc0 + acc1;
 
         __syncthreads();  // every wave is done reading Bt
-        if (has_next) tile_store();
-
-        // ---- epilogue: head transform + threshold test (fast path) ----------------------------
-        const int nvalid = min(32, a.n_items_local - j0);
-        const uint64_t vmask = nvalid >= 32 ? ~0ull : (((1ull << nvalid) - 1ull) * 0x100000001ull);
-        f32x16 tv;
-        uint64_t any = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = acc[r];
-            if constexpr (HEAD == PDA_HEAD_POP) s = (s > 0.0f ? s + 1.0f : __expf(s)) * popj;
-            tv[r] = s;
-            any |= __ballot(s > thr[r]);
+        uint32_t hb_next = 0;
+        if (has_next) {
+            tile_store();
+            hb_next = hist_bits(t + 1);
         }
-        any &= vmask;
-
-        if (any) {
-            // ---- slow path: some (user, item) beats the user's current threshold ---------------
-            const uint32_t my_item = (uint32_t)(jg0 + j);
-#pragma nounroll
-            for (int r = 0; r < 16; ++r) {
-                const float tt = tv[r];
-                const uint64_t m = __ballot(tt > thr[r]) & vmask;
-                if (!m) continue;
-                const uint64_t key = pda_pack_key(tt, my_item);
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    uint32_t mh = (uint32_t)(m >> (32 * half));
-                    if (!mh) continue;
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    mh &= ~(uint32_t)__builtin_amdgcn_readlane((int)hb, row);  // train items never enter
-                    if (!mh) continue;
-                    int c = __builtin_amdgcn_readlane(cnt, row);
-                    float ta = pda_readlane_f32(tau, row);
-                    uint64_t* buf = my_lists + row * kCap;
-                    const bool mine = (h == half);
-                    for (;;) {
-                        const int n = __popc(mh);
-                        const int room = kCap - c;
-                        if (n > room && c > K) {
-                            compact_list(buf, c, ta, K, lane);
-                            mh &= (uint32_t)(__ballot(tt > ta) >> (32 * half));  // re-filter with the new threshold
-                            if (!mh) break;
-                            continue;
-                        }
-                        const int take = min(n, room);
-                        const int rank = __popc(mh & ((1u << j) - 1u));
-                        const bool doit = mine && ((mh >> j) & 1u) && rank < take;
-                        if (doit) buf[c + rank] = key;
-                        c += take;
-                        if (take == n) break;
-                        // list full (c == kCap > K): drop the lanes just stored, compact on the next turn
-                        mh &= ~(uint32_t)(__ballot(doit) >> (32 * half));
-                    }
-                    if (j == row) {
-                        cnt = c;
-                        tau = ta;
-                    }
-                    thr[r] = mine ? ta : thr[r];
-                }
-            }
+        if constexpr (ABL & 1) {
+            asm volatile("" ::"s"(regmask));
+        } else {
+            if (regmask) slow_path(regmask, acc_prev, popj_prev, vmask_prev, hb_prev, a.item_offset + (t - 1) * 32);
         }
         __syncthreads();  // next tile visible in Bt
+
+        acc_prev = acc;
+        vmask_prev = vmask_cur;
+        hb_prev = hb_cur;
+        popj_prev = popj_cur;
+        vmask_cur = has_next ? valid_mask(t + 1) : 0ull;
+        hb_cur = hb_next;
+        popj_cur = popj_next;
+    }
+    if (t0 < t1) {   // drain: threshold test + slow path of the last tile
+        const uint32_t regmask = fast_test(acc_prev, popj_prev, vmask_prev);
+        if (!(ABL & 1) && regmask) slow_path(regmask, acc_prev, popj_prev, vmask_prev, hb_prev, a.item_offset + (t1 - 1) * 32);
     }
 
     // ---- finalise: sort every row's list, emit K packed keys (0 = empty) -------------------------
     for (int rr = 0; rr < 32; ++rr) {
-        int c = __builtin_amdgcn_readlane(cnt, rr);
-        float ta = 0.f;
         uint64_t* buf = my_lists + rr * kCap;
-        compact_list(buf, c, ta, K, lane);  // c <- min(c, K), buf sorted best-first
+        compact_list(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);  // count <- min(count, K), buf sorted
+        const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
         if (rb < a.n_users_blk && lane < K) {
             const uint64_t k = lane < c ? buf[lane] : 0ull;
@@ -281,19 +412,19 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
     }
 }
 
-template <int D, int HEAD>
+template <int D, int HEAD, int ABL = 0>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
-    const size_t smem = 32 * D * sizeof(float) + (size_t)kUserTile * kCap * sizeof(uint64_t);
+    const size_t smem = 32 * D * sizeof(float) + (size_t)kUserTile * (kCap * sizeof(uint64_t) + 8);
     static int attr_set = 0;  // idempotent attribute; benign if raced
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_kernel<D, HEAD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_kernel<D, HEAD, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (a.n_users_blk + kUserTile - 1) / kUserTile;
     dim3 grid((unsigned)(utiles * a.n_splits));
-    hipLaunchKernelGGL((score_topk_kernel<D, HEAD>), grid, dim3(kThreads), smem, stream, a);
+    hipLaunchKernelGGL((score_topk_kernel<D, HEAD, ABL>), grid, dim3(kThreads), smem, stream, a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -394,6 +525,18 @@ extern "C" int pda_score_topk_f32(const float* U, const float* I_shard, const fl
     ScoreArgs a{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys,
                 n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef PDA_ABLATION
+    if (const char* e = getenv("PDA_ABLATE")) {
+        if (d == 128 && head == PDA_HEAD_POP) switch (atoi(e)) {
+            case 1: return launch_score<128, PDA_HEAD_POP, 1>(a, s);
+            case 3: return launch_score<128, PDA_HEAD_POP, 3>(a, s);
+            case 7: return launch_score<128, PDA_HEAD_POP, 7>(a, s);
+            case 15: return launch_score<128, PDA_HEAD_POP, 15>(a, s);
+            case 4: return launch_score<128, PDA_HEAD_POP, 4>(a, s);
+            default: break;
+        }
+    }
+#endif
 #define PDA_DISPATCH(DD)                                                  \
     case DD:                                                              \
         return head == PDA_HEAD_POP ? launch_score<DD, PDA_HEAD_POP>(a, s) \

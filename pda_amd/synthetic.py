@@ -1,0 +1,90 @@
+"""Douban-shaped synthetic workloads: the processed Douban data is absent from the reference
+tree (data/douban/douban.zip is a missing blob), so every benchmark and scale test uses this generator.
+
+Everything is produced directly in HBM with torch (plumbing, not product): N(0, 0.1^2) embeddings (Xavier
+at 1M users gives |w| < 0.0025 and degenerate rankings), Zipf(1.0) item popularity over a random item
+permutation, clipped log-normal history lengths, ten time slots of which the first nine are train slots,
+per-slot popularity by the pop_pre.py:31-42 recipe raised to gamma.  Seeds follow the reference's habit
+(MF/train_new_api.py:934-936): 2020 for data, 2021 for weights.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import torch
+
+CONFIGS = {
+    # name: (n_users, n_items, embed, mean_hist)      BASELINE.json configs[1..3]
+    "c2": (50_000, 20_000, 64, 150),
+    "c3": (1_000_000, 200_000, 128, 50),
+    "tiny": (4_000, 3_000, 64, 30),
+}
+
+
+@dataclasses.dataclass
+class Workload:
+    name: str
+    n_users: int
+    n_items: int
+    d: int
+    gamma: float
+    U: torch.Tensor                 # f32 [n_users, d]
+    I: torch.Tensor                 # f32 [n_items, d]
+    hist_indptr: torch.Tensor       # i64 [n_users+1]   train CSR by user id, items sorted ascending
+    hist_indices: torch.Tensor      # i32 [nnz]
+    hist_slots: torch.Tensor        # i32 [nnz]         time slot (0..T-2) of each train interaction
+    pop_train: torch.Tensor         # f32 [n_items, T-1]  pop^gamma per train slot  (train_new_api.py:988-990)
+    pop_last: torch.Tensor          # f32 [n_items]       last-stage pop^gamma       (:954-955)
+    n_train: int
+
+
+def _gen(seed: int, device) -> torch.Generator:
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return g
+
+
+def make_workload(name: str = "c2", device="cuda", gamma: float = 0.22, n_slots: int = 10,
+                  n_users: Optional[int] = None, n_items: Optional[int] = None, d: Optional[int] = None,
+                  mean_hist: Optional[int] = None) -> Workload:
+    cu, ci, cd, ch = CONFIGS[name]
+    n_users, n_items, d, mean_hist = n_users or cu, n_items or ci, d or cd, mean_hist or ch
+    dev = torch.device(device)
+    gd, gw = _gen(2020, dev), _gen(2021, dev)
+
+    U = torch.randn(n_users, d, generator=gw, device=dev) * 0.1
+    I = torch.randn(n_items, d, generator=gw, device=dev) * 0.1
+
+    # history lengths: clipped log-normal with the requested mean (sigma 0.8)
+    sigma = 0.8
+    mu = math.log(mean_hist) - 0.5 * sigma * sigma
+    lens = torch.exp(torch.randn(n_users, generator=gd, device=dev) * sigma + mu).clamp_(1, min(4 * mean_hist + 200, n_items // 2)).long()
+    indptr = torch.zeros(n_users + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(lens, 0, out=indptr[1:])
+    nnz = int(indptr[-1])
+
+    # item draw: Zipf(1.0) over a random permutation, by inverse CDF
+    w = 1.0 / torch.arange(1, n_items + 1, device=dev, dtype=torch.float64)
+    cdf = torch.cumsum(w / w.sum(), 0).float()
+    perm = torch.randperm(n_items, generator=gd, device=dev)
+    draws = torch.searchsorted(cdf, torch.rand(nnz, generator=gd, device=dev)).clamp_(max=n_items - 1)
+    items = perm[draws]
+    rows = torch.repeat_interleave(torch.arange(n_users, device=dev), lens)
+    slots = torch.randint(0, n_slots - 1, (nnz,), generator=gd, device=dev, dtype=torch.int32)
+    order = torch.argsort(rows * n_items + items)              # sort items inside each row (kernel contract)
+    items, slots = items[order].int().contiguous(), slots[order].contiguous()
+    del rows, order, draws
+
+    # per-slot popularity, pop_pre.py:31-42: (cnt+1)/(total+n_item), min-max per slot, then ^gamma
+    cnt = torch.zeros(n_slots, n_items, dtype=torch.float64, device=dev)
+    cnt.view(-1).index_add_(0, slots.long() * n_items + items.long(), torch.ones(nnz, dtype=torch.float64, device=dev))
+    cnt[n_slots - 1] = cnt[n_slots - 2] * 0.9 + cnt[n_slots - 3] * 0.1   # a test-stage slot, shaped like its neighbours
+    tot = cnt.sum(1, keepdim=True)
+    pop = (cnt + 1.0) / (tot + n_items)
+    pop = (pop - pop.min(1, keepdim=True).values) / (pop.max(1, keepdim=True).values - pop.min(1, keepdim=True).values)
+    pop_all = pop.t().contiguous()                              # [I, T] like item_pop_seq_ori2.txt
+    pop_train = pop_all[:, :-1].pow(gamma).float().contiguous()
+    pop_last = pop_all[:, -2].pow(gamma).float().contiguous()
+    return Workload(name, n_users, n_items, d, gamma, U, I, indptr, items, slots, pop_train, pop_last, nnz)
