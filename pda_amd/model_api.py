@@ -1,0 +1,154 @@
+"""Model objects with the reference's names and constructor arguments (MF/model_api.py), backed by HIP kernels.
+
+    ConditionalBPRMF   PD / PDA            MF/model_api.py:14-185
+    BPRMF              plain BPR-MF        MF/model_api.py:419-757   (only :419-471, :521-536, :695-706 are live)
+
+A TF-1 graph exposes *fetchables* (`opt`, `loss`, `mf_loss`, `reg_loss`, `batch_ratings`, ...) that the
+trainer passes to `sess.run`.  Here they are light handle objects understood by `pda_amd.train_new_api.Session`,
+so the reference's loop `sess.run([model.Recommender.opt, model.Recommender.loss, ...])` keeps its shape;
+the direct API is `train_step(users, pos, neg[, pos_pop, neg_pop]) -> float32[3] device tensor`.
+
+Optimisers (`args.optimizer`):
+    adam       TF-1.14 AdamOptimizer semantics: m, v decayed and EVERY row updated each step [TF-ext]
+               (= pda_bpr_step_f32(DENSE_GRAD) + pda_adam_dense_sweep_f32 on both tables).  Reference-faithful.
+    lazy_adam  the same update restricted to the rows touched by the batch (declared deviation).
+    sgd        the north_star's fused in-kernel scatter update (declared deviation from MF/model_api.py:83).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import ops
+
+
+class Fetch:
+    """Stand-in for a TF tensor/op handle: `Session.run` dispatches on (owner, name)."""
+
+    def __init__(self, owner, name):
+        self.owner, self.name = owner, name
+
+    def __repr__(self):
+        return "<pda_amd fetch %s.%s>" % (type(self.owner).__name__, self.name)
+
+
+def xavier_uniform_(t: torch.Tensor, gen: torch.Generator):
+    """tf.contrib.layers.xavier_initializer(): U(-l, l), l = sqrt(6/(fan_in+fan_out)) [TF-ext]; :88-92, :523-527."""
+    lim = math.sqrt(6.0 / (t.shape[0] + t.shape[1]))
+    return t.uniform_(-lim, lim, generator=gen)
+
+
+class _MFBase:
+    with_pop = False
+
+    def __init__(self, args, data_config, use_dataset_api=False, users_api=None, pos_items_api=None,
+                 neg_items_api=None, pos_pop_api=None, neg_pop_api=None, device=None, seed=2021):
+        self.n_users = data_config["n_users"]
+        self.n_items = data_config["n_items"]
+        self.decay = args.regs                       # MF/model_api.py:23
+        self.emb_dim = args.embed_size
+        self.lr = args.lr
+        self.batch_size = args.batch_size            # the flag constant that divides the regulariser (:118)
+        self.verbose = args.verbose
+        self.optimizer = getattr(args, "optimizer", "adam")
+        if self.optimizer not in ("adam", "lazy_adam", "sgd"):
+            raise NotImplementedError("optimizer must be adam | lazy_adam | sgd")
+        self.device = torch.device(device if device is not None else "cuda")
+        gen = torch.Generator(device=self.device)
+        gen.manual_seed(seed)                        # tf.set_random_seed(2021), MF/train_new_api.py:936
+        self.weights = self.init_weights(gen)
+        self._t = 0
+        self._state = None
+        self._loss = torch.zeros(3, dtype=torch.float32, device=self.device)
+        self._statistics_params()
+
+    # ---- parameters -----------------------------------------------------------------------------------
+    def init_weights(self, gen):
+        w = {}
+        w["user_embedding"] = xavier_uniform_(torch.empty(self.n_users, self.emb_dim, device=self.device), gen)
+        w["item_embedding"] = xavier_uniform_(torch.empty(self.n_items, self.emb_dim, device=self.device), gen)
+        return w
+
+    def _statistics_params(self):
+        total = sum(int(v.numel()) for v in self.weights.values())
+        if self.verbose > 0:
+            print("#params: %d" % total)
+
+    def _opt_state(self):
+        if self._state is None:
+            U, I = self.weights["user_embedding"], self.weights["item_embedding"]
+            z = torch.zeros_like
+            self._state = {"mU": z(U), "vU": z(U), "gU": z(U), "mI": z(I), "vI": z(I), "gI": z(I)}
+        return self._state
+
+    # ---- one training step (A1-A5) --------------------------------------------------------------------
+    def train_step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
+        """Forward + loss + gradient + update on one batch of device tensors (int32 / float32).
+        Returns the float32[3] device tensor (loss, mf_loss, reg_loss) of THIS step (no host sync)."""
+        U, I = self.weights["user_embedding"], self.weights["item_embedding"]
+        if not self.with_pop:
+            pos_pop = neg_pop = None
+        elif pos_pop is None or neg_pop is None:
+            raise ValueError("PD/PDA needs pos_pop and neg_pop")
+        self._loss.zero_()
+        if self.optimizer == "sgd":
+            ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr,
+                         mode=ops.UPD_SGD_FUSED, loss_acc=self._loss)
+            return self._loss
+        st = self._opt_state()
+        self._t += 1
+        lr_t = ops.adam_lr_t(self.lr, self._t)
+        ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
+                     mode=ops.UPD_DENSE_GRAD, gU=st["gU"], gI=st["gI"], loss_acc=self._loss)
+        if self.optimizer == "adam":
+            ops.adam_dense_sweep(U, st["mU"], st["vU"], st["gU"], lr_t)
+            ops.adam_dense_sweep(I, st["mI"], st["vI"], st["gI"], lr_t)
+        else:
+            ops.adam_rows(U, st["mU"], st["vU"], st["gU"], torch.unique(users).int(), lr_t)
+            ops.adam_rows(I, st["mI"], st["vI"], st["gI"], torch.unique(torch.cat([pos, neg])).int(), lr_t)
+        return self._loss
+
+    # ---- checkpoint (tf.train.Saver stand-in, MF/train_new_api.py:1014,1218-1228) ---------------------
+    def state_dict(self):
+        sd = {"user_embedding": self.weights["user_embedding"], "item_embedding": self.weights["item_embedding"],
+              "adam_t": self._t}
+        if self._state is not None:
+            sd.update({k: v for k, v in self._state.items() if k[0] in "mv"})
+        return sd
+
+    def load_state_dict(self, sd):
+        self.weights["user_embedding"].copy_(sd["user_embedding"])
+        self.weights["item_embedding"].copy_(sd["item_embedding"])
+        self._t = int(sd.get("adam_t", 0))
+        if "mU" in sd:
+            st = self._opt_state()
+            for k in ("mU", "vU", "mI", "vI"):
+                st[k].copy_(sd[k])
+
+
+class BPRMF(_MFBase):
+    """BPRMF.  Fetchables: opt, loss, mf_loss, reg_loss, batch_ratings  (MF/model_api.py:459-471)."""
+    with_pop = False
+
+    def __init__(self, args, data_config, use_dataset_api=False, users_api=None, pos_items_api=None,
+                 neg_items_api=None, **kw):
+        super().__init__(args, data_config, use_dataset_api, users_api, pos_items_api, neg_items_api, **kw)
+        self.opt, self.loss = Fetch(self, "opt"), Fetch(self, "loss")
+        self.mf_loss, self.reg_loss = Fetch(self, "mf_loss"), Fetch(self, "reg_loss")
+        self.batch_ratings = Fetch(self, "batch_ratings")
+
+
+class ConditionalBPRMF(_MFBase):
+    """PD/PDA.  Fetchables: opt_pop_global, loss_pop_global, mf_loss_pop_global, reg_loss_pop_global,
+    batch_ratings, condition_ratings  (MF/model_api.py:62,81-83,113)."""
+    with_pop = True
+
+    def __init__(self, args, data_config, use_dataset_api=False, users_api=None, pos_items_api=None,
+                 neg_items_api=None, pos_pop_api=None, neg_pop_api=None, **kw):
+        super().__init__(args, data_config, use_dataset_api, users_api, pos_items_api, neg_items_api,
+                         pos_pop_api, neg_pop_api, **kw)
+        self.opt_pop_global, self.loss_pop_global = Fetch(self, "opt"), Fetch(self, "loss")
+        self.mf_loss_pop_global, self.reg_loss_pop_global = Fetch(self, "mf_loss"), Fetch(self, "reg_loss")
+        self.batch_ratings = Fetch(self, "batch_ratings")
+        self.condition_ratings = Fetch(self, "condition_ratings")

@@ -80,6 +80,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         raise ValueError("U and I_shard disagree on embed dim")
     if pop_shard is not None and pop_shard.numel() != nloc:
         raise ValueError("pop_shard must have one entry per local item row")
+    if hist is not None and hist.indices.numel() == 0:
+        hist = None                       # an all-empty mask: the kernel must never dereference a 0-length buffer
     if n_splits <= 0:
         n_splits = lib.pda_score_topk_auto_splits(nu, nloc)
     if out is None:
@@ -107,6 +109,8 @@ def topk_merge(keys: torch.Tensor, users=None, hist: Optional[HistoryCSR] = None
         out_val = torch.empty((nu, K), dtype=torch.float32, device=dev)
     if users is not None:
         users = _need(users, torch.int32, "users")
+    if hist is not None and hist.indices.numel() == 0:
+        hist = None
     check(lib.pda_topk_merge(ptr(keys), R, nu, K, ptr(out_keys), ptr(out_idx), ptr(out_val), ptr(users),
                              ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None,
                              hist.mode if hist else 0, stream_ptr()), "pda_topk_merge")

@@ -88,3 +88,58 @@ def make_workload(name: str = "c2", device="cuda", gamma: float = 0.22, n_slots:
     pop_train = pop_all[:, :-1].pow(gamma).float().contiguous()
     pop_last = pop_all[:, -2].pow(gamma).float().contiguous()
     return Workload(name, n_users, n_items, d, gamma, U, I, indptr, items, slots, pop_train, pop_last, nnz)
+
+
+def write_dataset(root: str, n_users=600, n_items=400, n_slots=10, mean_hist=25, seed=2020):
+    """Write a small Douban-shaped dataset in the reference's on-disk formats (host numpy; for tests and
+    for trying the CLI):  train.txt, train_with_time.txt, valid.txt, test.txt, t_0..t_{T-1}.txt  and, through the
+    pop_pre restatement, item_pop_seq_ori2.txt.  Slots 0..T-2 are train, slot T-1 is split 70/30 by user into
+    test/valid (data/douban/douban_split.ipynb, cells 16 and 26).  Returns the directory."""
+    import os
+
+    import numpy as np
+
+    from . import pop_pre
+    os.makedirs(root, exist_ok=True)
+    rng = np.random.default_rng(seed)
+    w = 1.0 / np.arange(1, n_items + 1)
+    perm = rng.permutation(n_items)
+    p = np.empty(n_items)
+    p[perm] = w / w.sum()
+    rows = []   # (u, i, t)
+    for u in range(n_users):
+        n = int(np.clip(rng.lognormal(np.log(mean_hist) - 0.32, 0.8), 3, n_items // 2))
+        items = rng.choice(n_items, size=n, replace=False, p=p)
+        slots = rng.integers(0, n_slots, n)
+        slots[:2] = [0, n_slots - 2]                         # every user has train rows in >= 2 slots
+        rows += [(u, int(i), int(t)) for i, t in zip(items, slots)]
+    rows = np.array(rows)
+    rows[:n_items, 1] = np.arange(n_items)                   # every item id occurs (pop_pre counts distinct ids)
+    train = rows[rows[:, 2] < n_slots - 1]
+    last = rows[rows[:, 2] == n_slots - 1]
+    is_test = rng.random(n_users) < 0.7
+
+    def write_lists(name, triples):
+        by = {}
+        for u, i, _ in triples:
+            by.setdefault(int(u), []).append(int(i))
+        with open(os.path.join(root, name), "w") as f:
+            for u, items in by.items():
+                f.write(" ".join(str(x) for x in [u] + items) + "\n")
+
+    write_lists("train.txt", train)
+    write_lists("test.txt", last[is_test[last[:, 0]]])
+    write_lists("valid.txt", last[~is_test[last[:, 0]]])
+    with open(os.path.join(root, "train_with_time.txt"), "w") as f:
+        for u, i, t in train:
+            f.write("%d %d %d 5\n" % (u, i, t))
+    for t in range(n_slots):
+        by = {}
+        for u, i, _ in rows[rows[:, 2] == t]:
+            by.setdefault(int(i), []).append(int(u))
+        with open(os.path.join(root, "t_%d.txt" % t), "w") as f:
+            for i, us in by.items():
+                f.write(" ".join(str(x) for x in [i] + us) + "\n")
+    pop = pop_pre.compute_popularity(pop_pre.read_stage_counts(root, n_slots), n_item=n_items)
+    pop_pre.write_popularity(root, pop)
+    return root

@@ -1,0 +1,119 @@
+"""GPU: the drop-in trainer end to end on a dataset written in the reference's on-disk formats -- CLI, loaders,
+device sampler / host generator, fused step + Adam, evaluation driver + device metrics, checkpoints, log lines."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import pda_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def toy(tmp_path_factory):
+    from pda_amd import synthetic
+    root = tmp_path_factory.mktemp("data")
+    synthetic.write_dataset(str(root / "toy"), n_users=400, n_items=300, mean_hist=20)
+    return str(root) + "/"
+
+
+def _argv(toy, save, train, extra=()):
+    return ["--data_path", toy, "--dataset", "toy", "--train", train, "--test", train, "--epoch", "3", "--log_interval", "2",
+            "--batch_size", "256", "--lr", "1e-2", "--regs", "1e-2", "--valid_set", "valid", "--pop_exp", "0.22",
+            "--save_dir", save, "--Ks", "[20,50]", "--save_flag", "0", "--saveID", "t", "--cuda", "0", "--eval_block", "128"] + list(extra)
+
+
+@pytest.mark.parametrize("train,extra", [("s_condition", ()), ("normal", ("--sampler", "host")),
+                                         ("s_condition", ("--optimizer", "sgd", "--lr", "0.05")),
+                                         ("s_condition", ("--optimizer", "lazy_adam"))])
+def test_main_runs_like_the_reference_script(dev, toy, tmp_path, capsys, train, extra):
+    from pda_amd import train_new_api as t
+    cfg, cfg_main = t.main(_argv(toy, str(tmp_path) + "/", train, extra))
+    out = capsys.readouterr().out
+    assert "Epoch 0 [" in out and "train==[" in out and "recall=[" in out and "training and testing end!!!!" in out
+    assert ("injecting last stage popularity" in out) == (train == "s_condition")
+    assert ("best expo" in out) == (train == "normal")
+    ck = [f for _, _, fs in os.walk(tmp_path) for f in fs]
+    assert "best_ckpt.ckpt" in ck and "best_main_ckpt.ckpt" in ck
+    assert 0.0 <= cfg["best_recall"] <= 1.0 and cfg_main["best_recall"] >= 0.0
+
+
+def test_training_reduces_the_loss_and_beats_random_ranking(dev, toy, tmp_path):
+    from pda_amd import train_new_api as t
+    from pda_amd.sampler import DeviceSampler
+    t.configure(_argv(toy, str(tmp_path) + "/", "s_condition"))
+    a, d = t.args, t.data
+    pop_all = t.load_popularity(a)
+    d.add_expo_popularity(np.power(t.get_popularity_from_load(pop_all), a.pop_exp))
+    model = t.DatasetApi_Model(a, {"n_users": d.n_users, "n_items": d.n_items}, 256, DeviceSampler(d, dev, True), dev)
+    sess = t.Session(model)
+    rec = model.Recommender
+    fetches = [rec.opt_pop_global, rec.loss_pop_global, rec.mf_loss_pop_global, rec.reg_loss_pop_global]
+    ev = t.evaluation(d, [20, 50], dev, block=128)
+    ev.set_evaluate_obj_pre("valid")
+    ev.set_testing_popularity(None)
+    before = ev.eval(model, sess, "main_branch")
+    losses = []
+    for epoch in range(30):
+        model.switch_to_training_or_reinitsampler(sess)
+        tot, n = 0.0, 0
+        try:
+            while True:
+                _, loss, mf, reg = sess.run(fetches)          # the reference's per-step fetch (one sync per step)
+                assert abs(loss - (mf + reg)) < 1e-5
+                tot, n = tot + loss, n + 1
+        except t.OutOfRangeError:
+            pass
+        assert n == d.n_train // a.batch_size + 1
+        losses.append(tot / n)
+    assert losses[-1] < losses[0] - 0.02
+    after = ev.eval(model, sess, "main_branch")
+    assert after["recall"][1] > before["recall"][1] + 0.02      # popularity-skewed data: BPR learns it quickly
+
+    # evaluation driver == oracle on the trained weights (device metrics + fused top-K vs numpy float64)
+    U = rec.weights["user_embedding"].cpu().numpy()
+    I = rec.weights["item_embedding"].cpu().numpy()
+    users = list(d.valid_user_list.keys())
+    hist = [sorted(d.train_user_list[u]) for u in users]
+    ip = np.zeros(len(users) + 1, np.int64)
+    ip[1:] = np.cumsum([len(h) for h in hist])
+    pop_last = np.power(pop_all[:, -2], a.pop_exp)
+    for rec_type, pop in (("main_branch", None), ("condition", pop_last)):
+        ev.set_testing_popularity(pop)
+        got = ev.eval(model, sess, rec_type)
+        ridx, _ = po.recommend_topk(U, I, np.asarray(users), ip, np.concatenate(hist), 50, rec_type, pop)
+        ref = po.evaluate_topk(ridx, users, d.valid_user_list, [20, 50])
+        for k in ref:
+            np.testing.assert_allclose(got[k], ref[k], atol=2e-3, err_msg=rec_type + " " + k)   # fp32 near-tie swaps only
+
+    # reference-style call: python lists + the (index, [-inf]*nnz, shape) mask triple
+    blocks = po.build_eval_blocks(d.valid_user_list, d.train_user_list, block=2048)
+    bu, index, rows, nnz = blocks[0]
+    mask = (index, np.array([-np.inf] * nnz, dtype=np.float32), np.array([rows, d.n_items], dtype=np.int64))
+    topk = model.do_recommendation(sess, bu, list(range(d.n_items)), "condition", pos_pop=pop_last, sparse_cliked_matrix=mask)
+    assert topk.shape == (len(bu), 50) and topk.dtype == np.int32
+    agree = (topk == ridx[:len(bu)]).mean()
+    assert agree > 0.99
+    with pytest.raises(NotImplementedError):
+        model.do_recommendation(sess, bu, None, "bogus")
+    # dense compatibility surface
+    sc = model.testing(sess, bu[:4], list(range(d.n_items)), "condition", pos_pop=pop_last)
+    ref_sc = po.score_matrix(U, I, np.asarray(bu[:4]), "condition", pop_last)
+    np.testing.assert_allclose(sc, ref_sc, rtol=1e-4, atol=1e-5)
+
+    # checkpoint round trip
+    sd = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in rec.state_dict().items()}
+    rec.weights["user_embedding"].zero_()
+    rec.load_state_dict(sd)
+    assert torch.equal(rec.weights["user_embedding"], sd["user_embedding"])
+
+
+def test_eval_user_without_train_rows_raises_keyerror_under_data2(dev, toy, tmp_path):
+    from pda_amd import train_new_api as t
+    t.configure(_argv(toy, str(tmp_path) + "/", "s_condition"))
+    t.data.valid_user_list[10 ** 6] = [1]
+    ev = t.evaluation(t.data, [20], dev)
+    with pytest.raises(KeyError):
+        ev.set_evaluate_obj_pre("valid")

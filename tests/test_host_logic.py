@@ -1,0 +1,88 @@
+"""CPU suite, part 3: host-side logic of the drop-in (no kernels): sharding arithmetic, samplers, dataset writer +
+loaders round trip, early stopping, the Session/fetch protocol."""
+import os
+import random
+
+import numpy as np
+import pytest
+
+from pda_amd import dist, load_data, parse, sampler, synthetic
+
+
+def test_shard_ranges_cover_and_balance():
+    for n in (1, 31, 32, 33, 20000, 200000, 2_000_001):
+        for w in (1, 2, 3, 4, 8):
+            rs = [dist.shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(rs, rs[1:]))
+            sizes = [hi - lo for lo, hi in rs]
+            assert all(lo % 32 == 0 for lo, _ in rs)
+            assert max(sizes) - min(s for s in sizes[:-1] or sizes) <= 32 or sizes[-1] <= sizes[0]
+
+
+@pytest.fixture(scope="module")
+def toy(tmp_path_factory):
+    root = tmp_path_factory.mktemp("data")
+    synthetic.write_dataset(str(root / "toy"), n_users=120, n_items=90, mean_hist=12)
+    return str(root) + "/"
+
+
+def test_written_dataset_round_trips_through_both_loaders(toy):
+    a = parse.parse_args(["--data_path", toy, "--dataset", "toy", "--batch_size", "32", "--train", "s_condition"])
+    d2, d1 = load_data.Data2(a), load_data.Data(a)
+    assert d1.n_train == d2.n_train and d1.n_users == d2.n_users == 120 and d1.n_items == d2.n_items == 90
+    for u, items in d1.train_user_list.items():
+        assert sorted(items) == sorted(d2.train_user_list[u])
+        assert len(d2.train_user_list_time[u]) == len(items)
+    assert len(d2.unique_times) == 9 and set(d2.unique_times) == set(range(9))
+    pop = load_data.load_popularity(a)
+    assert pop.shape == (90, 10) and pop.min() == 0.0 and pop.max() == 1.0
+    ip, ix, sl = d2.train_csr("cpu")
+    assert int(ip[-1]) == d2.n_train
+    for u in (0, 7, 119):
+        row = ix[ip[u]:ip[u + 1]].numpy()
+        assert np.all(np.diff(row) >= 0) and sorted(d2.train_user_list[u]) == row.tolist()
+        # slots stay attached to their items through the sort
+        pairs = sorted(zip(d2.train_user_list[u], d2.train_user_list_time[u]))
+        assert sorted(zip(row.tolist(), sl[ip[u]:ip[u + 1]].tolist())) == pairs
+
+
+def test_host_generator_follows_the_sampler_protocol(toy):
+    a = parse.parse_args(["--data_path", toy, "--dataset", "toy", "--batch_size", "32", "--train", "s_condition"])
+    d = load_data.Data2(a)
+    pop = np.power(load_data.get_popularity_from_load(load_data.load_popularity(a)), 0.22)
+    d.add_expo_popularity(pop)
+    random.seed(2020)
+    np.random.seed(2020)
+    batches = list(sampler.host_generator(d, with_pop=True))
+    assert len(batches) == d.n_train // 32 + 1                       # MF/train_new_api.py:190
+    for users, pos, neg, pp, pn in batches[:5]:
+        assert len(users) == len(pos) == len(neg) == len(pp) == len(pn) == 32
+        assert len(set(users)) == 32                                 # rd.sample: unique users
+        for u, p, n, a_, b_ in zip(users, pos, neg, pp, pn):
+            assert p in d.train_user_list[u] and n not in d.train_user_list[u]
+            ts = [t for i, t in zip(d.train_user_list[u], d.train_user_list_time[u]) if i == p]
+            assert any(a_ == pop[p, t] and b_ == pop[n, t] for t in ts)
+    plain = next(iter(sampler.host_generator(d, with_pop=False)))
+    assert len(plain) == 3
+
+
+def test_early_stop_matches_reference_logic():
+    from pda_amd.train_new_api import early_stop
+    cfg = dict(best_hr=0, best_ndcg=0, best_recall=0, best_pre=0, best_epoch=0)
+    step = 0
+    cfg, step, stop = early_stop(0.3, 0.2, 0.1, 0.05, 0, cfg, step, flag_step=2)
+    assert (step, stop, cfg["best_recall"], cfg["best_epoch"]) == (0, False, 0.1, 0)
+    cfg, step, stop = early_stop(0.3, 0.2, 0.1, 0.05, 5, cfg, step, flag_step=2)     # ties count as improvement (>=)
+    assert (step, cfg["best_epoch"]) == (0, 5)
+    cfg, step, stop = early_stop(0.1, 0.1, 0.05, 0.01, 10, cfg, step, flag_step=2)
+    assert (step, stop) == (1, False)
+    cfg, step, stop = early_stop(0.1, 0.1, 0.05, 0.01, 15, cfg, step, flag_step=2)
+    assert (step, stop, cfg["best_epoch"]) == (2, True, 5)
+
+
+def test_unknown_modes_raise_like_the_reference():
+    from pda_amd import train_new_api as t
+    a = parse.parse_args(["--train", "temp_pop"])
+    with pytest.raises(NotImplementedError):
+        t.DatasetApi_Model(a, {"n_users": 4, "n_items": 4}, 16, lambda: iter(()), device="cpu")
