@@ -78,8 +78,7 @@ def make_workload(name: str = "c2", device="cuda", gamma: float = 0.22, n_slots:
     del rows, order, draws
 
     # per-slot popularity, pop_pre.py:31-42: (cnt+1)/(total+n_item), min-max per slot, then ^gamma
-    cnt = torch.zeros(n_slots, n_items, dtype=torch.float64, device=dev)
-    cnt.view(-1).index_add_(0, slots.long() * n_items + items.long(), torch.ones(nnz, dtype=torch.float64, device=dev))
+    cnt = torch.bincount(slots.long() * n_items + items.long(), minlength=n_slots * n_items).double().view(n_slots, n_items)
     cnt[n_slots - 1] = cnt[n_slots - 2] * 0.9 + cnt[n_slots - 3] * 0.1   # a test-stage slot, shaped like its neighbours
     tot = cnt.sum(1, keepdim=True)
     pop = (cnt + 1.0) / (tot + n_items)
