@@ -80,6 +80,20 @@ int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_sh
                        const int32_t* hist_indices, int hist_row_mode, int K, int head, int n_splits,
                        uint64_t* out_keys, void* stream);
 
+/* Generation-2 path: bf16x3 MFMA pre-filter + exact fp32 rescoring; returns exactly the keys of pda_score_topk_f32
+ * (see pda_amd/csrc/pda_score_topk_v2.hip for the error bound).  The item shard is pre-split once per weight
+ * version into bf16 hi / lo planes + padded row norms:
+ *   pda_item_prep_bytes(n, d)  -> size of the caller-owned `prep` buffer (device)
+ *   pda_item_prep_f32(I_shard, n, d, prep, stream)
+ *   pda_score_topk_prepped_f32(..same arguments as pda_score_topk_f32 plus `prep` after I_shard..)
+ * d in {64,128,256}; item ids must be < 2^27; K <= PDA_TOPK_CAP-2. */
+size_t pda_item_prep_bytes(int n_items_local, int d);
+int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream);
+int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
+                               const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                               const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
+                               int head, int n_splits, uint64_t* out_keys, void* stream);
+
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0
  *   out_keys u64 [n_users_blk, K] or NULL;  out_idx i32 / out_val f32 [n_users_blk, K] or NULL.

@@ -1,0 +1,511 @@
+// score + mask + top-K, generation 2: bf16x3 MFMA pre-filter + exact fp32 rescoring (same results as v1, bit for bit).
+//
+// v1 (pda_score_topk.hip) is bound by the fp32 matrix pipe: d/2 v_mfma_f32_32x32x2_f32 of 64 cycles per 32x32 tile,
+// and every non-MFMA instruction steals pipe time.  The top-K only needs EXACT scores for the few (user, item) pairs
+// that can beat the user's running threshold (~K*ln(I/K) of I).  v2 therefore
+//   1. scores every pair approximately with bf16 MFMAs on a hi/lo split of both operands,
+//        s~ = uh.ih + uh.il + ul.ih                       (3 x d/16 v_mfma_f32_32x32x16_bf16 of 32 cycles: 5.3x less pipe time)
+//   2. bounds the error rigorously:  |s~ - s_exact| <= eps(u,i) = 2^-13 * ||u||_2 * ||i||_2   (derivation below)
+//   3. tests the UPPER BOUND  head_ub(s~ + eps) > threshold  in the MFMA shadow,
+//   4. pushes the rare survivors (row, item) into a per-wave LDS ring (a few instructions, no serialisation), and
+//   5. when the ring fills, rescoring happens lane-parallel: each lane recomputes ONE candidate's score with the
+//      exact fp32 fmaf chain of v1 (two chains over even/odd k-chunks -- bitwise what v_mfma_f32_32x32x2_f32 gives),
+//      applies the exact head, compares with the exact threshold and appends to the user's LDS list (v1 machinery).
+// Because step 5 is exact and step 3 never rejects a pair whose exact head beats the threshold, v2 returns the
+// same packed keys as v1 (tests/test_gpu_score_topk.py checks equality with v1 and with the oracle).
+//
+// Error bound.  bf16 keeps 8 significant bits (RNE): x = xh + xl + xr with |x-xh| <= 2^-8|x|, |xr| <= 2^-16|x|.
+//   u.i - (uh.ih + uh.il + ul.ih) = ul.il + ur.i + (uh+ul).ir   =>  |.| <= (2^-16 + 2^-16 + 2^-16(1+2^-8)) sum|u_k i_k|
+//   the bf16 products are exact in fp32; their fp32 accumulation (3d/16*16 adds, any order) errs by <= 3d*2^-24 sum|.|
+//   the exact chain itself differs from the real dot by <= d*2^-24 sum|u_k i_k|.
+//   With d <= 256: total <= (3.1*2^-16 + 1024*2^-24) sum|u_k i_k| < 2^-13.6 ||u|| ||i||  (Cauchy-Schwarz); we use 2^-13 and
+//   norms rounded up by (1+2^-10).  The fp32 evaluation of s~+eps and of the head bound is covered by comparing against
+//   threshold*(1 -/+ 2^-20).
+#include "pda_topk_common.h"
+
+using namespace pda_topk;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kCap2 = PDA_TOPK_CAP - 1;  // 59 slots per user list (leaves LDS room for the rings)
+constexpr int kRing = 192;               // ring entries per wave (u32 each); processed when > kRing-64
+constexpr float kEpsScale = 1.220703125e-4f;  // 2^-13
+
+struct ScoreArgs2 {
+    ScoreArgs a;
+    const uint16_t* I_hi;   // bf16 [n_items_local, d]
+    const uint16_t* I_lo;   // bf16 [n_items_local, d]
+    const float* I_norm;    // f32  [n_items_local]   ||i||_2 * (1+2^-10)
+};
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// split 8 floats into packed bf16 hi / lo words
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h[k] = bf16_rne(v[k]);
+        l[k] = bf16_rne(v[k] - __uint_as_float(h[k] << 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        hi[k] = h[2 * k] | (h[2 * k + 1] << 16);
+        lo[k] = l[2 * k] | (l[2 * k + 1] << 16);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ int swzb(int row) {   // bf16 tile: D/8 16-byte chunks per row
+    constexpr int CPR = D / 8;
+    if constexpr (CPR >= 16) return row & 15;
+    else if constexpr (CPR == 8) return (row >> 1) & 7;
+    else return (row >> 2) & 3;
+}
+
+// one row per D/8 threads: fp32 -> bf16 hi, bf16 lo, padded norm
+template <int D>
+__global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict__ I, int n, uint16_t* __restrict__ hi,
+                                                        uint16_t* __restrict__ lo, float* __restrict__ nrm) {
+    constexpr int TPR = D / 8;
+    const int row = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
+    float ss = 0.f;
+    if (row < n) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(I + (size_t)row * D + 8 * e);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(I + (size_t)row * D + 8 * e + 4);
+        u32x4 h, l;
+        split8(a, b, h, l);
+        *reinterpret_cast<u32x4*>(hi + (size_t)row * D + 8 * e) = h;
+        *reinterpret_cast<u32x4*>(lo + (size_t)row * D + 8 * e) = l;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ss += a[k] * a[k] + b[k] * b[k];
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (row < n && e == 0) nrm[row] = sqrtf(ss) * 1.0009765625f * 1.0001f;
+}
+
+template <int D, int HEAD>
+__global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 aa) {
+    const ScoreArgs& a = aa.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int CPR = D / 8;                 // 16-byte chunks per bf16 row
+    constexpr int NM = D / 16;                 // MFMA k-steps
+    constexpr int NLD = (32 * CPR) / kThreads; // 16-byte loads per thread per tile, per plane (hi / lo)
+    static_assert(NLD >= 1, "v2 needs embed dim >= 64");
+    uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);              // [32][D] bf16 hi, swizzled
+    uint16_t* Bl = Bh + 32 * D;                                    // [32][D] bf16 lo
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 2 * 32 * D * sizeof(uint16_t));   // [128][kCap2]
+    int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap2);                 // [128]
+    float* taul = reinterpret_cast<float*>(cntl + kUserTile);                              // [128]
+    uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                       // [4][kRing]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x % a.n_splits, utile = blockIdx.x / a.n_splits;
+    const int K = a.K;
+    const int tiles_total = (a.n_items_local + 31) >> 5;
+    const int tiles_per = (tiles_total + a.n_splits - 1) / a.n_splits;
+    const int t0 = split * tiles_per;
+    const int t1 = min(t0 + tiles_per, tiles_total);
+
+    const int row_blk = utile * kUserTile + wave * 32 + j;
+    const bool row_ok = row_blk < a.n_users_blk;
+    const int uid = row_ok ? a.users[row_blk] : 0;
+
+    // ---- A operand: this lane's user row (k = 16m + 8h .. +7), split into bf16 hi / lo; padded row norm ----------
+    u32x4 ah[NM], al[NM];
+    float nu_row;
+    {
+        const float* up = a.U + (size_t)uid * D + 8 * h;
+        float ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+            if (row_ok) {
+                x = *reinterpret_cast<const f32x4*>(up + 16 * m);
+                y = *reinterpret_cast<const f32x4*>(up + 16 * m + 4);
+            }
+            split8(x, y, ah[m], al[m]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        nu_row = sqrtf(ss) * 1.0009765625f * 1.0001f * kEpsScale;   // eps(u,i) = nu_row * I_norm[i]
+    }
+
+    // ---- history cursor (as v1) ------------------------------------------------------------------------------
+    int64_t hp = 0, he = 0;
+    int nxt = 0x7fffffff, nxt2 = 0x7fffffff, pend_v = 0x7fffffff;
+    bool pend_flag = false, pend_ok = false;
+    const bool hist_on = a.hist_indptr != nullptr;
+    if (hist_on && row_ok) {
+        const int64_t hr = a.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)row_blk;
+        hp = a.hist_indptr[hr];
+        he = a.hist_indptr[hr + 1];
+        const int lo_item = a.item_offset + t0 * 32;
+        int64_t lo = hp, hi = he;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (a.hist_indices[mid] < lo_item) lo = mid + 1; else hi = mid;
+        }
+        hp = lo;
+        if (hp < he) nxt = a.hist_indices[hp];
+        if (hp + 1 < he) nxt2 = a.hist_indices[hp + 1];
+    }
+    auto hist_bits = [&](int t) -> uint32_t {
+        if (!hist_on) return 0u;
+        const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
+        nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
+        const bool adv = nxt < jg1;
+        uint32_t hb = adv ? (1u << ((nxt - jg0) & 31)) : 0u;
+        hp += adv ? 1 : 0;
+        nxt = adv ? nxt2 : nxt;
+        const int64_t idx = hp + 1;
+        pend_ok = idx < he;
+        pend_flag = adv;
+        const int64_t idc = max((int64_t)0, min(idx, he - 1));
+        pend_v = a.hist_indices[idc];
+        if (__builtin_expect(__any(nxt < jg1), 0)) {
+            do {
+                if (nxt < jg1) {
+                    const int nn2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
+                    hb |= 1u << ((nxt - jg0) & 31);
+                    ++hp;
+                    nxt = nn2;
+                    nxt2 = (hp + 1 < he) ? a.hist_indices[hp + 1] : 0x7fffffff;
+                    pend_flag = false;
+                }
+            } while (__any(nxt < jg1));
+        }
+        return hb;
+    };
+
+    // ---- per-row state in LDS -------------------------------------------------------------------------------
+    if (lane < 32) {
+        cntl[wave * 32 + lane] = 0;
+        taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
+    }
+    pda_wave_sync();
+    f32x16 thr;    // thresholds lowered by a 2^-20 relative margin (covers the fp32 evaluation of the bound)
+    f32x16 nu;     // eps scale of the row behind each accumulator register
+    auto refresh_thr = [&]() {
+        int hv = h;
+        asm volatile("" : "+v"(hv));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float tq = taul[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv];
+            thr[r] = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f;
+        }
+    };
+    refresh_thr();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) nu[r] = __shfl(nu_row, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+
+    uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap2;
+    uint32_t* ring = rings + wave * kRing;
+    int ring_cnt = 0;   // wave-uniform
+
+    // ---- item tile staging (register prefetch, unconditional clamped loads) ------------------------------------
+    u32x4 preh[NLD], prel[NLD];
+    auto tile_load = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int id = tid + kThreads * q;
+            const int jj = id / CPR, ch = id % CPR;
+            const int it = min(t * 32 + jj, a.n_items_local - 1);
+            preh[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (size_t)it * D + 8 * ch);
+            prel[q] = *reinterpret_cast<const u32x4*>(aa.I_lo + (size_t)it * D + 8 * ch);
+        }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int id = tid + kThreads * q;
+            const int jj = id / CPR, ch = id % CPR;
+            const int off = jj * D + 8 * (ch ^ swzb<D>(jj));
+            *reinterpret_cast<u32x4*>(Bh + off) = preh[q];
+            *reinterpret_cast<u32x4*>(Bl + off) = prel[q];
+        }
+    };
+    auto lane_consts = [&](int t, float& popv, float& niv) {
+        const int it = min(t * 32 + j, a.n_items_local - 1);
+        niv = aa.I_norm[it];
+        popv = 1.0f;
+        if constexpr (HEAD == PDA_HEAD_POP) popv = a.pop[it];
+    };
+
+    // ---- exact head of one candidate; appends with the v1 list machinery ------------------------------------------
+    auto process_ring = [&]() {
+        for (int base = 0; base < ring_cnt; base += 64) {
+            const int e = base + lane;
+            const bool valid = e < ring_cnt;
+            const uint32_t word = valid ? ring[e] : 0u;
+            const int row = (int)(word >> 27);
+            const int item = (int)(word & 0x7FFFFFFu);            // global item id
+            const int urow = __shfl(uid, row, 64);
+            float tt = -INFINITY;
+            {
+                const float* up = a.U + (size_t)urow * D;
+                const float* ip = a.I + (size_t)(valid ? item - a.item_offset : 0) * D;
+                float c0 = 0.f, c1 = 0.f;   // the two fmaf chains of v1 (even / odd k-chunks)
+#pragma unroll 4
+                for (int c = 0; c < D / 8; c += 2) {
+                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + 8 * c), u1 = *reinterpret_cast<const f32x4*>(up + 8 * c + 4);
+                    const f32x4 i0 = *reinterpret_cast<const f32x4*>(ip + 8 * c), i1 = *reinterpret_cast<const f32x4*>(ip + 8 * c + 4);
+                    const f32x4 u2 = *reinterpret_cast<const f32x4*>(up + 8 * c + 8), u3 = *reinterpret_cast<const f32x4*>(up + 8 * c + 12);
+                    const f32x4 i2 = *reinterpret_cast<const f32x4*>(ip + 8 * c + 8), i3 = *reinterpret_cast<const f32x4*>(ip + 8 * c + 12);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        c0 = __builtin_fmaf(u0[s], i0[s], c0);
+                        c0 = __builtin_fmaf(u1[s], i1[s], c0);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        c1 = __builtin_fmaf(u2[s], i2[s], c1);
+                        c1 = __builtin_fmaf(u3[s], i3[s], c1);
+                    }
+                }
+                float sc = c0 + c1;
+                if constexpr (HEAD == PDA_HEAD_POP) {
+                    const float pv = a.pop[valid ? item - a.item_offset : 0];
+                    sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+                }
+                if (valid) tt = sc;
+            }
+            const int lrow = wave * 32 + row;
+            bool p = valid && (tt > taul[lrow]);
+            const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+            for (;;) {
+                bool ov = false;
+                if (p) {
+                    const int slot = atomicAdd(&cntl[lrow], 1);
+                    if (slot < kCap2) lists[(size_t)lrow * kCap2 + slot] = key;
+                    else ov = true;
+                }
+                if (!__any(ov)) break;
+                pda_wave_sync();
+                uint64_t full = __ballot(lane < 32 && cntl[wave * 32 + (lane & 31)] >= kCap2);
+                while (full) {
+                    const int rr = __builtin_ctzll(full);
+                    full &= full - 1ull;
+                    compact_list<kCap2>(my_lists + rr * kCap2, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+                }
+                p = ov && (tt > taul[lrow]);
+            }
+        }
+        ring_cnt = 0;
+        pda_wave_sync();
+        refresh_thr();
+    };
+
+    // ---- push the lanes flagged in `m` (bit 15-r <-> accumulator register r) into the ring ------------------------
+    auto push_flagged = [&](uint32_t m, uint32_t hb, int jg0) {
+        const bool any_hb = __any(hb != 0);
+        for (;;) {
+            const uint64_t who = __ballot(m != 0);
+            if (!who) break;
+            uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, __builtin_ctzll(who));   // registers flagged in one lane
+            while (mm) {
+                const int bit = 31 - __builtin_clz(mm);
+                mm &= ~(1u << bit);
+                const int r = 15 - bit;
+                const int rowb = (r & 3) + 8 * (r >> 2);
+                bool p = (m >> bit) & 1u;
+                m &= ~(1u << bit);                                                    // register handled for every lane
+                if (any_hb) {
+                    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hb, rowb);
+                    const uint32_t h1 = (uint32_t)__builtin_amdgcn_readlane((int)hb, rowb + 4);
+                    if (((h ? h1 : h0) >> j) & 1u) p = false;                          // train items never enter
+                }
+                const uint64_t pm = __ballot(p);
+                if (!pm) continue;
+                if (ring_cnt + 64 > kRing) process_ring();
+                const int slot = ring_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
+                if (p) ring[slot] = ((uint32_t)(rowb + 4 * h) << 27) | (uint32_t)(jg0 + j);
+                ring_cnt += __popcll(pm);
+            }
+        }
+    };
+
+    // ---- main loop (software pipeline as v1: test of tile t-1 in the shadow of the MFMAs of tile t) ----------------
+    f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t hb_prev = 0, hb_cur = 0;
+    float pop_prev = 0.f, pop_cur = 0.f, ni_prev = 0.f, ni_cur = 0.f;
+    bool ok_prev = false, ok_cur = false;   // lane's item exists
+
+    if (t0 < t1) {
+        tile_load(t0);
+        lane_consts(t0, pop_cur, ni_cur);
+        tile_store();
+        hb_cur = hist_bits(t0);
+        ok_cur = (t0 * 32 + j) < a.n_items_local;
+    }
+    __syncthreads();
+
+    const uint16_t* bhrow = Bh + j * D;
+    const uint16_t* blrow = Bl + j * D;
+    const int bsw = swzb<D>(j);
+
+    for (int t = t0; t < t1; ++t) {
+        const bool has_next = (t + 1) < t1;
+        const int tn = has_next ? t + 1 : t;
+        float pop_next, ni_next;
+        tile_load(tn);
+        lane_consts(tn, pop_next, ni_next);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc1 = acc0;
+        uint32_t m = 0;
+#pragma unroll
+        for (int mm = 0; mm < NM; ++mm) {
+            const int off = 8 * ((2 * mm + h) ^ bsw);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + off));
+            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(blrow + off));
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mm]);
+            const bf16x8 xl = __builtin_bit_cast(bf16x8, al[mm]);
+            if (mm & 1) {
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc1, 0, 0, 0);
+            } else {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc0, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc0, 0, 0, 0);
+            }
+            // upper-bound test of 16/NM registers of the previous tile
+#pragma unroll
+            for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) {
+                float x = __builtin_fmaf(nu[r], ni_prev, acc_prev[r]);                 // s~ + eps >= exact chain score
+                if constexpr (HEAD == PDA_HEAD_POP) x = __builtin_fmaf(fmaxf(x, 0.0f), pop_prev, pop_prev);
+                asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "v"(thr[r]) : "vcc");
+            }
+        }
+        m = ok_prev ? m : 0u;
+
+        __syncthreads();  // every wave is done reading the tile
+        uint32_t hb_next = 0;
+        if (has_next) {
+            tile_store();
+            hb_next = hist_bits(t + 1);
+        }
+        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t - 1) * 32);
+        __syncthreads();  // next tile visible
+
+        acc_prev = acc0 + acc1;
+        hb_prev = hb_cur;
+        pop_prev = pop_cur;
+        ni_prev = ni_cur;
+        ok_prev = ok_cur;
+        hb_cur = hb_next;
+        pop_cur = pop_next;
+        ni_cur = ni_next;
+        ok_cur = has_next && ((t + 1) * 32 + j) < a.n_items_local;
+    }
+    if (t0 < t1) {   // drain the last tile
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float x = __builtin_fmaf(nu[r], ni_prev, acc_prev[r]);
+            if constexpr (HEAD == PDA_HEAD_POP) x = __builtin_fmaf(fmaxf(x, 0.0f), pop_prev, pop_prev);
+            m = (m << 1) | ((x > thr[r]) ? 1u : 0u);
+        }
+        m = ok_prev ? m : 0u;
+        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t1 - 1) * 32);
+    }
+    if (ring_cnt > 0) process_ring();
+
+    // ---- finalise ------------------------------------------------------------------------------------------------
+    for (int rr = 0; rr < 32; ++rr) {
+        uint64_t* buf = my_lists + rr * kCap2;
+        compact_list<kCap2>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+        const int c = cntl[wave * 32 + rr];
+        const int rb = utile * kUserTile + wave * 32 + rr;
+        if (rb < a.n_users_blk && lane < K) {
+            const uint64_t k = lane < c ? buf[lane] : 0ull;
+            a.out_keys[((size_t)split * a.n_users_blk + rb) * K + lane] = k;
+        }
+    }
+}
+
+template <int D, int HEAD>
+int launch_v2(const ScoreArgs2& aa, hipStream_t stream) {
+    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t);
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return PDA_ERR_LAUNCH;
+        attr_set = 1;
+    }
+    const int utiles = (aa.a.n_users_blk + kUserTile - 1) / kUserTile;
+    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+}  // namespace
+
+extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) {
+    // [hi bf16 n*d][lo bf16 n*d][norm f32 n], each section 256-byte aligned
+    const size_t plane = (((size_t)n_items_local * d * 2) + 255) & ~(size_t)255;
+    return 2 * plane + (((size_t)n_items_local * 4 + 255) & ~(size_t)255);
+}
+
+extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream) {
+    if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    const size_t plane = (((size_t)n_items_local * d * 2) + 255) & ~(size_t)255;
+    uint16_t* hi = reinterpret_cast<uint16_t*>(prep);
+    uint16_t* lo = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(prep) + plane);
+    float* nrm = reinterpret_cast<float*>(reinterpret_cast<char*>(prep) + 2 * plane);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define PDA_PREP(DD)                                                                                         \
+    case DD: {                                                                                               \
+        constexpr int RPB = 256 / (DD / 8);                                                                  \
+        hipLaunchKernelGGL(item_prep_kernel<DD>, dim3((unsigned)((n_items_local + RPB - 1) / RPB)), dim3(256), 0, s, \
+                           I_shard, n_items_local, hi, lo, nrm);                                             \
+        break;                                                                                               \
+    }
+    switch (d) {
+        PDA_PREP(64) PDA_PREP(128) PDA_PREP(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_PREP
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
+                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                                          const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
+                                          int head, int n_splits, uint64_t* out_keys, void* stream) {
+    if (!U || !I_shard || !prep || !users || !out_keys) return PDA_ERR_ARG;
+    if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
+    if ((uint64_t)item_offset + (uint64_t)n_items_local > (1ull << 27)) return PDA_ERR_UNSUPPORTED;   // ring packs item ids in 27 bits
+    if (K < 1 || K > PDA_TOPK_CAP - 2) return PDA_ERR_ARG;
+    if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
+    if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
+    if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
+    if (n_splits <= 0) n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
+    const size_t plane = (((size_t)n_items_local * d * 2) + 255) & ~(size_t)255;
+    ScoreArgs2 aa{{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, n_users_blk, item_offset, n_items_local,
+                   hist_row_mode, K, n_splits},
+                  reinterpret_cast<const uint16_t*>(prep),
+                  reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(prep) + plane),
+                  reinterpret_cast<const float*>(reinterpret_cast<const char*>(prep) + 2 * plane)};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define PDA_V2(DD) \
+    case DD: return head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s);
+    switch (d) {
+        PDA_V2(64) PDA_V2(128) PDA_V2(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_V2
+}

@@ -1,0 +1,81 @@
+// Shared pieces of the score + top-K kernels (v1: exact fp32 MFMA; v2: bf16x3 MFMA pre-filter + exact fp32 rescoring).
+#pragma once
+#include "pda_common.h"
+
+namespace pda_topk {
+
+constexpr int kThreads = 256;
+constexpr int kWaves = 4;
+constexpr int kUserTile = 128;  // users per workgroup
+constexpr int kCap = PDA_TOPK_CAP;
+
+struct ScoreArgs {
+    const float* U;
+    const float* I;
+    const float* pop;
+    const int32_t* users;
+    const int64_t* hist_indptr;
+    const int32_t* hist_indices;
+    uint64_t* out_keys;
+    int n_users_blk;
+    int item_offset;
+    int n_items_local;
+    int hist_row_mode;
+    int K;
+    int n_splits;
+};
+
+template <int D>
+__device__ __forceinline__ int swz(int row) {
+    // chunks (16 B) per row = D/4.  The B read of one 16-lane group touches 16 different rows at the
+    // same logical chunk; XOR with a row-derived value spreads them over all sixteen 16-B bank slots.
+    if constexpr (D / 4 >= 16) return row & 15;
+    else return (row >> 1) & 7;  // D == 32: 8 chunks per 128-B row, two rows per 256-B bank line
+}
+
+// Compaction of one user's candidate list (<= 60 keys, one per lane): keep the best K at buf[0..K) in
+// descending order, update the row's LDS count and threshold.  Whole-wave call.
+// After the first compaction buf[0..K) is already sorted, so only the (<= kCap-K) appended keys need ranking:
+// rank(old i) = i + #new greater; rank(new) = #old greater (one ballot) + #new greater.  ~4x cheaper than the
+// generic all-pairs rank sort, which remains for the first compaction and the final sort.
+template <int CAP = kCap>
+__device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane) {
+    pda_wave_sync();
+    const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), CAP);   // failed appends may have pushed it past kCap
+    const bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
+    uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);  // fillers: unique, below any real key
+    int rank;
+    if (sorted_prefix) {
+        rank = lane < K ? lane : 0;
+        const uint64_t oldmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
+        for (int jj = K; jj < c; ++jj) {
+            const uint64_t kj = pda_readlane_u64(key, jj);
+            rank += (kj > key) ? 1 : 0;
+            const int olds_above = __popcll(__ballot(key > kj) & oldmask);
+            rank += (lane == jj) ? olds_above : 0;
+        }
+    } else {
+        rank = 0;
+        for (int jj = 0; jj < c; ++jj) {
+            const uint64_t kj = pda_readlane_u64(key, jj);
+            rank += (kj > key) ? 1 : 0;
+        }
+    }
+    pda_wave_sync();
+    if (lane < c && rank < K) buf[rank] = key;
+    if (c >= K) {
+        uint64_t mk = __ballot(lane < c && rank == K - 1);
+        int src = __builtin_ctzll(mk);
+        const float tau = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src));
+        if (lane == 0) {
+            *tau_slot = tau;
+            *cnt_slot = K;
+        }
+    } else if (lane == 0) {
+        *cnt_slot = c;
+    }
+    pda_wave_sync();
+}
+
+
+}  // namespace pda_topk

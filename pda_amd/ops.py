@@ -67,9 +67,50 @@ def auto_splits(n_users_blk: int, n_items_local: int) -> int:
     return _lib.load().pda_score_topk_auto_splits(n_users_blk, n_items_local)
 
 
+import weakref
+
+# id(tensor) -> (weakref(tensor), tensor._version, prep buffer).  Validated by OBJECT identity, never by address:
+# the caching allocator hands the same address to the next table of the same shape.
+_PREP_CACHE = {}
+
+
+def item_prep(I_shard: torch.Tensor) -> torch.Tensor:
+    """pda_item_prep_f32 (bf16 hi/lo planes + padded norms of an item shard), cached per weight version: any
+    in-place update of the table bumps tensor._version and triggers a re-split."""
+    lib = _lib.load()
+    key = id(I_shard)
+    hit = _PREP_CACHE.get(key)
+    if hit is not None and hit[0]() is I_shard:
+        if hit[1] == I_shard._version:
+            return hit[2]
+        buf = hit[2]
+    else:
+        n, d = I_shard.shape
+        buf = torch.empty(lib.pda_item_prep_bytes(n, d), dtype=torch.uint8, device=I_shard.device)
+    check(lib.pda_item_prep_f32(ptr(I_shard), I_shard.shape[0], I_shard.shape[1], ptr(buf), stream_ptr()), "pda_item_prep_f32")
+    for k in [k for k, v in _PREP_CACHE.items() if v[0]() is None]:
+        del _PREP_CACHE[k]                                   # drop entries whose table died
+    _PREP_CACHE[key] = (weakref.ref(I_shard), I_shard._version, buf)
+    return buf
+
+
+def score_impl(d: int, K: int, item_hi: int) -> str:
+    """'v2' (bf16x3 pre-filter + exact rescoring) where it applies, else 'v1' (exact fp32 MFMA).  Same results.
+    PDA_SCORE_IMPL=v1|v2 forces one (A/B measurements, cross-checks)."""
+    import os
+    forced = os.environ.get("PDA_SCORE_IMPL", "")
+    ok = d in (64, 128, 256) and K <= TOPK_CAP_V2 and item_hi <= (1 << 27)
+    if forced == "v1" or not ok:
+        return "v1"
+    return "v2"
+
+
+TOPK_CAP_V2 = _lib.TOPK_CAP - 2
+
+
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
-                    item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """pda_score_topk_f32 -> packed keys int64[n_splits, Bu, K] (uint64 bit patterns), best first."""
+                    item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None) -> torch.Tensor:
+    """pda_score_topk_f32 / pda_score_topk_prepped_f32 -> packed keys int64[n_splits, Bu, K] (uint64 bit patterns), best first."""
     lib = _lib.load()
     U = _need(U, torch.float32, "U")
     I_shard = _need(I_shard, torch.float32, "I_shard")
@@ -88,6 +129,14 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
     elif out.shape != (n_splits, nu, K) or out.dtype != torch.int64:
         raise ValueError("out must be int64 [n_splits, Bu, K]")
+    impl = impl or score_impl(d, K, item_offset + nloc)
+    if impl == "v2":
+        prep = item_prep(I_shard)
+        check(lib.pda_score_topk_prepped_f32(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
+                                             nloc, d, ptr(hist.indptr) if hist else None,
+                                             ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head,
+                                             n_splits, ptr(out), stream_ptr()), "pda_score_topk_prepped_f32")
+        return out
     check(lib.pda_score_topk_f32(ptr(U), ptr(I_shard), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None,
                                  hist.mode if hist else 0, K, head, n_splits, ptr(out), stream_ptr()),

@@ -16,6 +16,14 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
+@pytest.fixture(autouse=True, params=["v1", "v2"])
+def impl(request, monkeypatch):
+    """Every test runs against both kernel generations: v1 = exact fp32 MFMA, v2 = bf16x3 pre-filter + exact
+    rescoring (pda_score_topk_v2.hip).  They must be indistinguishable."""
+    monkeypatch.setenv("PDA_SCORE_IMPL", request.param)
+    return request.param
+
+
 def make_case(rng, nU, nI, d, max_hist=30, scale=0.1):
     U = (rng.standard_normal((nU, d)) * scale).astype(np.float32)
     I = (rng.standard_normal((nI, d)) * scale).astype(np.float32)
@@ -271,3 +279,37 @@ def test_argument_errors(dev):
         ops.score_topk_keys(U, I, users, 50, head=1)
     with pytest.raises(ValueError):               # host tensors are refused: no CPU path
         ops.score_topk_keys(U.cpu(), I, users, 50)
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("head", [0, 1])
+def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head):
+    """The bf16x3 pre-filter may only ever over-approximate: packed keys (scores AND order) identical to the exact
+    fp32-MFMA kernel, including adversarial magnitudes (large norms => large absolute error bound)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(900 + d + head)
+    nU, nI, K = 260, 5000, 50
+    for scale in (0.1, 3.0, 1e-3):
+        U, I, pop, hist = make_case(rng, nU, nI, d, scale=scale)
+        I[::7] *= 40.0                                   # wildly different item norms
+        U[::5] *= 0.01
+        users = np.arange(nU, dtype=np.int32)
+        ip, ix = csr(hist)
+        h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+        args = (torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.from_numpy(users).to(dev), K, head,
+                torch.from_numpy(pop).to(dev) if head else None, h, 0)
+        k1 = ops.score_topk_keys(*args, n_splits=2, impl="v1")
+        k2 = ops.score_topk_keys(*args, n_splits=2, impl="v2")
+        assert torch.equal(k1, k2), (d, head, scale, int((k1 != k2).sum()))
+
+
+def test_item_prep_cache_follows_weight_updates(dev):
+    from pda_amd import ops
+    rng = np.random.default_rng(77)
+    U, I, pop, _ = make_case(rng, 64, 640, 64, max_hist=0)
+    Ut, It, ut = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.arange(64, dtype=torch.int32, device=dev)
+    a = ops.score_topk_keys(Ut, It, ut, 50, impl="v2")
+    It.mul_(-1.0)                                        # in-place update => tensor._version changes => re-prep
+    b = ops.score_topk_keys(Ut, It, ut, 50, impl="v2")
+    c = ops.score_topk_keys(Ut, It, ut, 50, impl="v1")
+    assert torch.equal(b, c) and not torch.equal(a, b)
