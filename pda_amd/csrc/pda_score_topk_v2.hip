@@ -22,6 +22,7 @@
 //   norms rounded up by (1+2^-10).  The fp32 evaluation of s~+eps and of the head bound is covered by comparing against
 //   threshold*(1 -/+ 2^-20).
 #include "pda_topk_common.h"
+#include <cstdlib>
 
 using namespace pda_topk;
 
@@ -31,8 +32,18 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kCap2 = PDA_TOPK_CAP - 1;  // 59 slots per user list (leaves LDS room for the rings)
-constexpr int kRing = 192;               // ring entries per wave (u32 each); processed when > kRing-64
+constexpr int kRing = 192;               // ring entries per wave (u32 each); hard limit kRing-64 before a push
+constexpr int kRingTrig = 64;            // a wave above this asks the whole workgroup to drain
 constexpr float kEpsScale = 1.220703125e-4f;  // 2^-13
+
+#ifdef PDA_ABLATION
+__device__ unsigned long long pda_dbg[8];   // per-wave sums: 0 ring entries, 1 cycles in process_ring, 2 cycles in compactions, 3 cycles in push, 4 total cycles, 5 waves
+#define PDA_T0(v) const long long v = __builtin_readcyclecounter()
+#define PDA_T1(v, acc) acc += __builtin_readcyclecounter() - v
+#else
+#define PDA_T0(v) do {} while (0)
+#define PDA_T1(v, acc) do {} while (0)
+#endif
 
 struct ScoreArgs2 {
     ScoreArgs a;
@@ -91,7 +102,7 @@ __global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict_
     if (row < n && e == 0) nrm[row] = sqrtf(ss) * 1.0009765625f * 1.0001f;
 }
 
-template <int D, int HEAD>
+template <int D, int HEAD, int ABL = 0>   // ABL: profiling-only (-DPDA_ABLATION): 1 drop candidates, 2 skip the test, 4 no history
 __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 aa) {
     const ScoreArgs& a = aa.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,6 +116,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap2);                 // [128]
     float* taul = reinterpret_cast<float*>(cntl + kUserTile);                              // [128]
     uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                       // [4][kRing]
+    int* wgflag = reinterpret_cast<int*>(rings + 4 * kRing);                              // [2] "some wave wants to drain its ring"
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -144,7 +156,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     int64_t hp = 0, he = 0;
     int nxt = 0x7fffffff, nxt2 = 0x7fffffff, pend_v = 0x7fffffff;
     bool pend_flag = false, pend_ok = false;
-    const bool hist_on = a.hist_indptr != nullptr;
+    const bool hist_on = a.hist_indptr != nullptr && !(ABL & 4);
     if (hist_on && row_ok) {
         const int64_t hr = a.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)row_blk;
         hp = a.hist_indptr[hr];
@@ -192,6 +204,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         cntl[wave * 32 + lane] = 0;
         taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
     }
+    if (tid < 2) wgflag[tid] = 0;
     pda_wave_sync();
     f32x16 thr;    // thresholds lowered by a 2^-20 relative margin (covers the fp32 evaluation of the bound)
     f32x16 nu;     // eps scale of the row behind each accumulator register
@@ -211,27 +224,31 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap2;
     uint32_t* ring = rings + wave * kRing;
     int ring_cnt = 0;   // wave-uniform
+    long long dbg_entries = 0, dbg_proc = 0, dbg_comp = 0, dbg_push = 0;
+    PDA_T0(t_all);
+    (void)dbg_entries; (void)dbg_proc; (void)dbg_comp; (void)dbg_push;
 
     // ---- item tile staging (register prefetch, unconditional clamped loads) ------------------------------------
-    u32x4 preh[NLD], prel[NLD];
-    auto tile_load = [&](int t) {
+    // (a second register set, i.e. prefetching two tiles ahead, was measured: no gain -- the loads are not what waves wait for)
+    u32x4 pA_h[NLD], pA_l[NLD];
+    auto tile_load = [&](int t, u32x4 (&ph)[NLD], u32x4 (&pl)[NLD]) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
             const int it = min(t * 32 + jj, a.n_items_local - 1);
-            preh[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (size_t)it * D + 8 * ch);
-            prel[q] = *reinterpret_cast<const u32x4*>(aa.I_lo + (size_t)it * D + 8 * ch);
+            ph[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (size_t)it * D + 8 * ch);
+            pl[q] = *reinterpret_cast<const u32x4*>(aa.I_lo + (size_t)it * D + 8 * ch);
         }
     };
-    auto tile_store = [&]() {
+    auto tile_store = [&](const u32x4 (&ph)[NLD], const u32x4 (&pl)[NLD]) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
             const int off = jj * D + 8 * (ch ^ swzb<D>(jj));
-            *reinterpret_cast<u32x4*>(Bh + off) = preh[q];
-            *reinterpret_cast<u32x4*>(Bl + off) = prel[q];
+            *reinterpret_cast<u32x4*>(Bh + off) = ph[q];
+            *reinterpret_cast<u32x4*>(Bl + off) = pl[q];
         }
     };
     auto lane_consts = [&](int t, float& popv, float& niv) {
@@ -241,46 +258,68 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         if constexpr (HEAD == PDA_HEAD_POP) popv = a.pop[it];
     };
 
-    // ---- exact head of one candidate; appends with the v1 list machinery ------------------------------------------
+    // ---- exact rescoring of the ring, 16 candidates per pass, FOUR lanes per candidate ---------------------------
+    // Lane 4*ci+q loads the q-th quarter of candidate ci's user row and item row (64 contiguous bytes per 4 lanes, so an
+    // instruction touches 16 rows x 1 line instead of 64 rows), and the two fmaf chains of v1 (even / odd k-chunks,
+    // k ascending) are carried from quarter to quarter through the lanes: phase p completes quarter p and hands the
+    // accumulators to lane q = p+1.  Lane q = 3 ends up with the bit-exact v1 score and does the list append.
     auto process_ring = [&]() {
-        for (int base = 0; base < ring_cnt; base += 64) {
-            const int e = base + lane;
+        PDA_T0(tp);
+        dbg_entries += ring_cnt;
+        constexpr int NCH = D / 32;                 // 8-float chunks per lane (even)
+        const int q = lane & 3, ci = lane >> 2;
+        for (int base = 0; base < ring_cnt; base += 16) {
+            const int e = base + ci;
             const bool valid = e < ring_cnt;
             const uint32_t word = valid ? ring[e] : 0u;
             const int row = (int)(word >> 27);
             const int item = (int)(word & 0x7FFFFFFu);            // global item id
             const int urow = __shfl(uid, row, 64);
             float tt = -INFINITY;
-            {
-                const float* up = a.U + (size_t)urow * D;
-                const float* ip = a.I + (size_t)(valid ? item - a.item_offset : 0) * D;
-                float c0 = 0.f, c1 = 0.f;   // the two fmaf chains of v1 (even / odd k-chunks)
-#pragma unroll 4
-                for (int c = 0; c < D / 8; c += 2) {
-                    const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + 8 * c), u1 = *reinterpret_cast<const f32x4*>(up + 8 * c + 4);
-                    const f32x4 i0 = *reinterpret_cast<const f32x4*>(ip + 8 * c), i1 = *reinterpret_cast<const f32x4*>(ip + 8 * c + 4);
-                    const f32x4 u2 = *reinterpret_cast<const f32x4*>(up + 8 * c + 8), u3 = *reinterpret_cast<const f32x4*>(up + 8 * c + 12);
-                    const f32x4 i2 = *reinterpret_cast<const f32x4*>(ip + 8 * c + 8), i3 = *reinterpret_cast<const f32x4*>(ip + 8 * c + 12);
+            if constexpr (!(ABL & 8)) {
+                const float* up = a.U + (size_t)urow * D + q * (D / 4);
+                const float* ip = a.I + (size_t)(valid ? item - a.item_offset : 0) * D + q * (D / 4);
+                f32x4 uu[2 * NCH], ii[2 * NCH];
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        c0 = __builtin_fmaf(u0[s], i0[s], c0);
-                        c0 = __builtin_fmaf(u1[s], i1[s], c0);
+                for (int c = 0; c < 2 * NCH; ++c) {
+                    uu[c] = *reinterpret_cast<const f32x4*>(up + 4 * c);
+                    ii[c] = *reinterpret_cast<const f32x4*>(ip + 4 * c);
+                }
+                float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+                for (int ph = 0; ph < 4; ++ph) {
+                    o0 = c0;
+                    o1 = c1;
+#pragma unroll
+                    for (int cc = 0; cc < NCH; ++cc) {
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx) {
+                            if (cc & 1) {
+                                o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
+                                o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
+                            } else {
+                                o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
+                                o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
+                            }
+                        }
                     }
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        c1 = __builtin_fmaf(u2[s], i2[s], c1);
-                        c1 = __builtin_fmaf(u3[s], i3[s], c1);
+                    if (ph < 3) {
+                        const float r0 = __shfl_up(o0, 1, 64), r1 = __shfl_up(o1, 1, 64);
+                        if (q == ph + 1) {
+                            c0 = r0;
+                            c1 = r1;
+                        }
                     }
                 }
-                float sc = c0 + c1;
+                float sc = o0 + o1;                               // meaningful on q == 3
                 if constexpr (HEAD == PDA_HEAD_POP) {
                     const float pv = a.pop[valid ? item - a.item_offset : 0];
                     sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
                 }
-                if (valid) tt = sc;
+                if (valid && q == 3) tt = sc;
             }
             const int lrow = wave * 32 + row;
-            bool p = valid && (tt > taul[lrow]);
+            bool p = valid && q == 3 && (tt > taul[lrow]) && !(ABL & 16);
             const uint64_t key = pda_pack_key(tt, (uint32_t)item);
             for (;;) {
                 bool ov = false;
@@ -295,7 +334,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 while (full) {
                     const int rr = __builtin_ctzll(full);
                     full &= full - 1ull;
+                    PDA_T0(tc);
                     compact_list<kCap2>(my_lists + rr * kCap2, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+                    PDA_T1(tc, dbg_comp);
                 }
                 p = ov && (tt > taul[lrow]);
             }
@@ -303,35 +344,35 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         ring_cnt = 0;
         pda_wave_sync();
         refresh_thr();
+        PDA_T1(tp, dbg_proc);
     };
 
     // ---- push the lanes flagged in `m` (bit 15-r <-> accumulator register r) into the ring ------------------------
+    // Lane-parallel: every flagged lane pushes ITS OWN top flagged register per round (usually one round); the row
+    // behind (register, half) and its history bits are per-lane values (ds_bpermute), so there is no wave-uniform
+    // loop over registers and no SGPR dependency chain.
     auto push_flagged = [&](uint32_t m, uint32_t hb, int jg0) {
+        PDA_T0(tq);
         const bool any_hb = __any(hb != 0);
-        for (;;) {
-            const uint64_t who = __ballot(m != 0);
-            if (!who) break;
-            uint32_t mm = (uint32_t)__builtin_amdgcn_readlane((int)m, __builtin_ctzll(who));   // registers flagged in one lane
-            while (mm) {
-                const int bit = 31 - __builtin_clz(mm);
-                mm &= ~(1u << bit);
-                const int r = 15 - bit;
-                const int rowb = (r & 3) + 8 * (r >> 2);
-                bool p = (m >> bit) & 1u;
-                m &= ~(1u << bit);                                                    // register handled for every lane
-                if (any_hb) {
-                    const uint32_t h0 = (uint32_t)__builtin_amdgcn_readlane((int)hb, rowb);
-                    const uint32_t h1 = (uint32_t)__builtin_amdgcn_readlane((int)hb, rowb + 4);
-                    if (((h ? h1 : h0) >> j) & 1u) p = false;                          // train items never enter
-                }
-                const uint64_t pm = __ballot(p);
-                if (!pm) continue;
-                if (ring_cnt + 64 > kRing) process_ring();
-                const int slot = ring_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
-                if (p) ring[slot] = ((uint32_t)(rowb + 4 * h) << 27) | (uint32_t)(jg0 + j);
-                ring_cnt += __popcll(pm);
+        while (__any(m != 0)) {
+            const bool act = m != 0;
+            const int bit = 31 - __builtin_clz(m | 1u);
+            const int r = 15 - bit;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            m &= ~(1u << bit);
+            bool p = act;
+            if (any_hb) {
+                const uint32_t hbr = (uint32_t)__shfl((int)hb, row, 64);           // train items never enter
+                if ((hbr >> j) & 1u) p = false;
             }
+            const uint64_t pm = __ballot(p);
+            if (!pm) continue;
+            if (ring_cnt + 64 > kRing) process_ring();
+            const int slot = ring_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
+            if (p) ring[slot] = ((uint32_t)row << 27) | (uint32_t)(jg0 + j);
+            ring_cnt += __popcll(pm);
         }
+        PDA_T1(tq, dbg_push);
     };
 
     // ---- main loop (software pipeline as v1: test of tile t-1 in the shadow of the MFMAs of tile t) ----------------
@@ -341,9 +382,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     bool ok_prev = false, ok_cur = false;   // lane's item exists
 
     if (t0 < t1) {
-        tile_load(t0);
+        tile_load(t0, pA_h, pA_l);
         lane_consts(t0, pop_cur, ni_cur);
-        tile_store();
+        tile_store(pA_h, pA_l);
         hb_cur = hist_bits(t0);
         ok_cur = (t0 * 32 + j) < a.n_items_local;
     }
@@ -353,12 +394,13 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     const uint16_t* blrow = Bl + j * D;
     const int bsw = swzb<D>(j);
 
-    for (int t = t0; t < t1; ++t) {
+    // One iteration.  `cur` holds tile t+1 (loaded one iteration ago, stored at the end of this one);
+    // `nxt` receives tile t+2.
+    auto iteration = [&](int t, u32x4 (&cur_h)[NLD], u32x4 (&cur_l)[NLD]) {
         const bool has_next = (t + 1) < t1;
-        const int tn = has_next ? t + 1 : t;
         float pop_next, ni_next;
-        tile_load(tn);
-        lane_consts(tn, pop_next, ni_next);
+        tile_load(min(t + 1, t1 - 1), cur_h, cur_l);
+        lane_consts(min(t + 1, t1 - 1), pop_next, ni_next);
         __builtin_amdgcn_sched_barrier(0);
 
         f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -381,6 +423,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc0, 0, 0, 0);
             }
             // upper-bound test of 16/NM registers of the previous tile
+            if constexpr (!(ABL & 2))
 #pragma unroll
             for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) {
                 float x = __builtin_fmaf(nu[r], ni_prev, acc_prev[r]);                 // s~ + eps >= exact chain score
@@ -388,18 +431,27 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "v"(thr[r]) : "vcc");
             }
         }
+        const f32x16 acc_new = acc0 + acc1;   // summed here so that only 16 accumulator registers stay live across the slow path
         m = ok_prev ? m : 0u;
+        if constexpr (ABL & 2) asm volatile("" ::"v"(acc_prev[0]), "v"(acc_prev[5]), "v"(acc_prev[15]));
+        if constexpr (ABL & 1) { asm volatile("" ::"v"(m)); m = 0; }
 
+        // All four waves drain their rings in the SAME iteration (flag set by whichever wave is filling up): the
+        // latency-bound rescoring of the four waves then overlaps instead of stalling the workgroup four times.
+        if (ring_cnt > kRingTrig && lane == 0) wgflag[t & 1] = 1;
         __syncthreads();  // every wave is done reading the tile
+        const bool drain = wgflag[t & 1] != 0;
+        if (tid == 0) wgflag[(t + 1) & 1] = 0;   // flag of tile t-1: everyone has read it, nobody sets it before tile t+1
         uint32_t hb_next = 0;
         if (has_next) {
-            tile_store();
+            tile_store(cur_h, cur_l);
             hb_next = hist_bits(t + 1);
         }
         if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t - 1) * 32);
+        if (drain && ring_cnt > 0) process_ring();
         __syncthreads();  // next tile visible
 
-        acc_prev = acc0 + acc1;
+        acc_prev = acc_new;
         hb_prev = hb_cur;
         pop_prev = pop_cur;
         ni_prev = ni_cur;
@@ -408,7 +460,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         pop_cur = pop_next;
         ni_cur = ni_next;
         ok_cur = has_next && ((t + 1) * 32 + j) < a.n_items_local;
-    }
+    };
+    for (int t = t0; t < t1; ++t) iteration(t, pA_h, pA_l);
     if (t0 < t1) {   // drain the last tile
         uint32_t m = 0;
 #pragma unroll
@@ -433,25 +486,45 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             a.out_keys[((size_t)split * a.n_users_blk + rb) * K + lane] = k;
         }
     }
+#ifdef PDA_ABLATION
+    if (lane == 0) {
+        long long tot = 0;
+        PDA_T1(t_all, tot);
+        atomicAdd(&pda_dbg[0], (unsigned long long)dbg_entries);
+        atomicAdd(&pda_dbg[1], (unsigned long long)dbg_proc);
+        atomicAdd(&pda_dbg[2], (unsigned long long)dbg_comp);
+        atomicAdd(&pda_dbg[3], (unsigned long long)dbg_push);
+        atomicAdd(&pda_dbg[4], (unsigned long long)tot);
+        atomicAdd(&pda_dbg[5], 1ull);
+    }
+#endif
 }
 
-template <int D, int HEAD>
+template <int D, int HEAD, int ABL = 0>
 int launch_v2(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t);
+    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 16;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (aa.a.n_users_blk + kUserTile - 1) / kUserTile;
-    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
+    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD, ABL>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
 
 }  // namespace
+
+#ifdef PDA_ABLATION
+extern "C" int pda_debug_counters(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(pda_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pda_dbg), z, sizeof(z)) != hipSuccess) return PDA_ERR_LAUNCH; }
+    return PDA_OK;
+}
+#endif
 
 extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) {
     // [hi bf16 n*d][lo bf16 n*d][norm f32 n], each section 256-byte aligned
@@ -501,6 +574,19 @@ extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, 
                   reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(prep) + plane),
                   reinterpret_cast<const float*>(reinterpret_cast<const char*>(prep) + 2 * plane)};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef PDA_ABLATION
+    if (const char* e = getenv("PDA_ABLATE")) {
+        if (d == 128 && head == PDA_HEAD_POP) switch (atoi(e)) {
+            case 1: return launch_v2<128, PDA_HEAD_POP, 1>(aa, s);
+            case 3: return launch_v2<128, PDA_HEAD_POP, 3>(aa, s);
+            case 7: return launch_v2<128, PDA_HEAD_POP, 7>(aa, s);
+            case 4: return launch_v2<128, PDA_HEAD_POP, 4>(aa, s);
+            case 8: return launch_v2<128, PDA_HEAD_POP, 8>(aa, s);
+            case 16: return launch_v2<128, PDA_HEAD_POP, 16>(aa, s);
+            default: break;
+        }
+    }
+#endif
 #define PDA_V2(DD) \
     case DD: return head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s);
     switch (d) {
