@@ -122,6 +122,11 @@ int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* po
                      int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU, float* gI,
                      float* loss_acc, void* stream);
 
+/* Reorder one batch (all five arrays, in place) so that equal positives are adjacent: pda_bpr_step_f32 then sums each
+ * run on chip before touching HBM.  Purely a performance aid (order inside a batch has no meaning); B <= 4096. */
+int pda_sort_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
+                             void* stream);
+
 /* TF-1.14 AdamOptimizer `_apply_sparse_shared`: decay m,v on EVERY row, add the (pre-summed) sparse
  * gradient, update EVERY row (MF/model_api.py:83,:470-471 [TF-ext]).  `g` is the dense accumulator
  * filled by PDA_UPD_DENSE_GRAD; it is reset to zero by this sweep.  n = rows*d.  lr_t is the

@@ -33,6 +33,7 @@ SIGNATURES = {
     "pda_score_topk_prepped_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pda_sort_triplets_by_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_adam_dense_sweep_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -43,19 +43,30 @@ __device__ __forceinline__ void atomic_add4(float* p, f32x4 v) {
     unsafeAtomicAdd(p + 3, v[3]);
 }
 
+// 512 threads = 512/(D/4) triplets per block.  Positive items are popularity-skewed (the whole point of PDA): with Zipf
+// data one batch holds the hottest item ~170 times, and 170 x 64 float atomics on the same two cache lines serialise in
+// L2 (measured 25 us per 2048-triplet step).  The positives' contributions therefore go through LDS first: runs of
+// equal `pos` inside the block are summed by their first triplet and leave as ONE atomic per element.  Any batch order
+// is correct; a batch sorted by `pos` (pda_sort_triplets_by_pos, done by the device sampler) makes the runs long.
 template <int D>
-__global__ void __launch_bounds__(256) bpr_step_kernel(StepArgs a) {
+__global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
     constexpr int L = D / 4;        // lanes per triplet
-    constexpr int TPB = 256 / L;    // triplets per block
-    __shared__ float red[2][4];
+    constexpr int TPB = 512 / L;    // triplets per block
+    __shared__ float red[2][8];
+    __shared__ int s_pos[TPB];
+    __shared__ __attribute__((aligned(16))) float s_dpe[TPB * D];
     const int tid = threadIdx.x, g = tid / L, e = tid % L;
     const int t = blockIdx.x * TPB + g;
     const bool active = t < a.B;
     const bool with_pop = a.pos_pop != nullptr;
+    const bool scatter = a.mode == PDA_UPD_SGD_FUSED || a.mode == PDA_UPD_DENSE_GRAD;
 
     float maxi = 0.f, sq = 0.f;
+    int p = -1;
+    float* ptarget = nullptr;
     if (active) {
-        const int u = a.users[t], p = a.pos[t], n = a.neg[t];
+        const int u = a.users[t], n = a.neg[t];
+        p = a.pos[t];
         float* up = a.U + (size_t)u * D + 4 * e;
         float* pp = a.I + (size_t)p * D + 4 * e;
         float* np_ = a.I + (size_t)n * D + 4 * e;
@@ -80,9 +91,9 @@ __global__ void __launch_bounds__(256) bpr_step_kernel(StepArgs a) {
             an = qn * en;
         }
         const float x = psw - nsw;
-        const float s = 1.f / (1.f + expf(-x));
-        if (e == 0) maxi = logf(s + 1e-10f);              // :112 / :702
-        const float gg = -a.inv_B * s * (1.f - s) / (s + 1e-10f);
+        const float sg = 1.f / (1.f + expf(-x));
+        if (e == 0) maxi = logf(sg + 1e-10f);             // :112 / :702
+        const float gg = -a.inv_B * sg * (1.f - sg) / (sg + 1e-10f);
         const float gp = gg * ap, gn = gg * an, c = a.reg_c;
         f32x4 due, dpe, dne;
 #pragma unroll
@@ -91,21 +102,31 @@ __global__ void __launch_bounds__(256) bpr_step_kernel(StepArgs a) {
             dpe[k] = gp * ue[k] + c * pe[k];
             dne[k] = -gn * ue[k] + c * ne[k];
         }
+        const f32x4 dpe_raw = dpe;
         if (a.mode == PDA_UPD_SGD_FUSED) {
             const float nlr = -a.lr;
             atomic_add4(up, due * nlr);   // users are unique per batch (rd.sample) but atomics keep B > n_users safe
-            atomic_add4(pp, dpe * nlr);   // items repeat inside a batch: wavefront atomics sum the occurrences
-            atomic_add4(np_, dne * nlr);
+            atomic_add4(np_, dne * nlr);  // negatives are uniform over the catalogue: duplicates are rare
+            dpe = dpe * nlr;
+            ptarget = pp;
         } else if (a.mode == PDA_UPD_DENSE_GRAD) {
             atomic_add4(a.gU + (size_t)u * D + 4 * e, due);
-            atomic_add4(a.gI + (size_t)p * D + 4 * e, dpe);
             atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
+            ptarget = a.gI + (size_t)p * D + 4 * e;
         }
+        if (scatter) *reinterpret_cast<f32x4*>(s_dpe + g * D + 4 * e) = dpe;
         if (a.g_user) {
             *reinterpret_cast<f32x4*>(a.g_user + (size_t)t * D + 4 * e) = due;
-            *reinterpret_cast<f32x4*>(a.g_pos + (size_t)t * D + 4 * e) = dpe;
+            *reinterpret_cast<f32x4*>(a.g_pos + (size_t)t * D + 4 * e) = dpe_raw;
             *reinterpret_cast<f32x4*>(a.g_neg + (size_t)t * D + 4 * e) = dne;
         }
+    }
+    if (e == 0) s_pos[g] = p;
+    __syncthreads();
+    if (scatter && active && (g == 0 || s_pos[g - 1] != p)) {   // first triplet of a run of equal positives
+        f32x4 sum = *reinterpret_cast<const f32x4*>(s_dpe + g * D + 4 * e);
+        for (int k = g + 1; k < TPB && s_pos[k] == p; ++k) sum += *reinterpret_cast<const f32x4*>(s_dpe + k * D + 4 * e);
+        atomic_add4(ptarget, sum);
     }
     // block reduction of sum(log(.)) and sum of squares -> (loss, mf, reg)
 #pragma unroll
@@ -120,13 +141,53 @@ __global__ void __launch_bounds__(256) bpr_step_kernel(StepArgs a) {
     }
     __syncthreads();
     if (tid == 0 && a.loss_acc) {
-        const float sm = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        const float ss = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        float sm = 0.f, ss = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            sm += red[0][w];
+            ss += red[1][w];
+        }
         const float mf = -sm * a.inv_B;             // -mean(maxi)          :114 / :704
         const float rg = a.reg_c * 0.5f * ss;       // regs * l2 / batch    :117-120
         unsafeAtomicAdd(a.loss_acc + 0, mf + rg);
         unsafeAtomicAdd(a.loss_acc + 1, mf);
         unsafeAtomicAdd(a.loss_acc + 2, rg);
+    }
+}
+
+// Sort one batch by positive item inside a single workgroup (B <= 4096): bitonic sort of (pos, slot) in LDS, then all
+// five arrays are permuted through LDS.  Order inside a batch has no meaning for the loss or the update.
+__global__ void __launch_bounds__(1024) sort_by_pos_kernel(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop,
+                                                           float* neg_pop, int B, int n_pow2) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_sort[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem_sort);                  // [n_pow2]  (pos << 32) | slot
+    int32_t* buf = reinterpret_cast<int32_t*>(keys + n_pow2);                 // [B] staging for one array at a time
+    const int tid = threadIdx.x;
+    for (int i = tid; i < n_pow2; i += 1024) keys[i] = i < B ? (((uint64_t)(uint32_t)pos[i] << 32) | (uint32_t)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= n_pow2; k <<= 1)
+        for (int jj = k >> 1; jj > 0; jj >>= 1) {
+            for (int i = tid; i < n_pow2; i += 1024) {
+                const int ixj = i ^ jj;
+                if (ixj > i) {
+                    const uint64_t x = keys[i], y = keys[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) {
+                        keys[i] = y;
+                        keys[ixj] = x;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    int32_t* arrs[5] = {users, pos, neg, reinterpret_cast<int32_t*>(pos_pop), reinterpret_cast<int32_t*>(neg_pop)};
+    for (int q = 0; q < 5; ++q) {
+        int32_t* arr = arrs[q];
+        if (!arr) continue;
+        for (int i = tid; i < B; i += 1024) buf[i] = arr[i];
+        __syncthreads();
+        for (int i = tid; i < B; i += 1024) arr[i] = buf[(uint32_t)keys[i]];
+        __syncthreads();
     }
 }
 
@@ -178,8 +239,8 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, fl
 
 template <int D>
 int launch_step(const StepArgs& a, hipStream_t s) {
-    constexpr int TPB = 256 / (D / 4);
-    hipLaunchKernelGGL(bpr_step_kernel<D>, dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(256), 0, s, a);
+    constexpr int TPB = 512 / (D / 4);
+    hipLaunchKernelGGL(bpr_step_kernel<D>, dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -205,6 +266,20 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
         case 256: return launch_step<256>(a, s);
         default: return PDA_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int pda_sort_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
+                                        void* stream) {
+    if (!users || !pos || !neg || B <= 0) return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    if (B > 4096) return PDA_ERR_UNSUPPORTED;
+    int n2 = 1;
+    while (n2 < B) n2 <<= 1;
+    const size_t smem = (size_t)n2 * 8 + (size_t)B * 4;
+    hipLaunchKernelGGL(sort_by_pos_kernel, dim3(1), dim3(1024), smem, reinterpret_cast<hipStream_t>(stream), users, pos, neg,
+                       pos_pop, neg_pop, B, n2);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
 }
 
 extern "C" int pda_adam_dense_sweep_f32(float* var, float* m, float* v, float* g, size_t n, float lr_t, float beta1,

@@ -94,6 +94,14 @@ def item_prep(I_shard: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+def mark_modified(*tensors):
+    """Tell torch that a kernel wrote these tensors through raw pointers: bumps tensor._version, which is what keys
+    the item_prep cache (and autograd's in-place checks)."""
+    for t in tensors:
+        if t is not None:
+            torch.autograd.graph.increment_version(t)
+
+
 def score_impl(d: int, K: int, item_hi: int) -> str:
     """'v2' (bf16x3 pre-filter + exact rescoring) where it applies, else 'v1' (exact fp32 MFMA).  Same results.
     PDA_SCORE_IMPL=v1|v2 forces one (A/B measurements, cross-checks)."""
@@ -194,6 +202,8 @@ def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, 
     check(lib.pda_bpr_step_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), B, d,
                                float(regs), float(reg_div), float(lr), mode, ptr(gu), ptr(gp), ptr(gn), ptr(gU),
                                ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_f32")
+    if mode == UPD_SGD_FUSED:
+        mark_modified(U, I)
 
 
 def adam_lr_t(lr: float, t: int, beta1=ADAM_BETA1, beta2=ADAM_BETA2) -> float:
@@ -207,6 +217,7 @@ def adam_dense_sweep(var, m, v, g, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BET
         _need(t, torch.float32, n)
     check(lib.pda_adam_dense_sweep_f32(ptr(var), ptr(m), ptr(v), ptr(g), var.numel(), lr_t, beta1, beta2, eps,
                                        stream_ptr()), "pda_adam_dense_sweep_f32")
+    mark_modified(var)
 
 
 def adam_rows(var, m, v, g, rows, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
@@ -214,6 +225,7 @@ def adam_rows(var, m, v, g, rows, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA
     rows = _need(rows, torch.int32, "rows")
     check(lib.pda_adam_rows_f32(ptr(var), ptr(m), ptr(v), ptr(g), ptr(rows), rows.numel(), var.shape[1], lr_t, beta1,
                                 beta2, eps, stream_ptr()), "pda_adam_rows_f32")
+    mark_modified(var)
 
 
 def metrics_sums(topk, tgt_indptr, tgt_indices, Ks, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -231,7 +243,7 @@ def metrics_sums(topk, tgt_indptr, tgt_indices, Ks, sums: Optional[torch.Tensor]
 
 
 def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int, users=None, user_pool=None,
-                    n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None):
+                    n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = True):
     """pda_sample_triplets -> (users, pos, neg, pos_pop|None, neg_pop|None), all on device."""
     lib = _lib.load()
     dev = train_indptr.device
@@ -251,7 +263,18 @@ def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int
                                   ptr(train_indices), ptr(train_slots), int(neg_range[0]), int(neg_range[1]),
                                   ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), step, ptr(pos), ptr(neg), ptr(pp),
                                   ptr(pn), stream_ptr()), "pda_sample_triplets")
+    if sort_by_pos:
+        sort_triplets_by_pos(users, pos, neg, pp, pn)
     return users, pos, neg, pp, pn
+
+
+def sort_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):
+    """pda_sort_triplets_by_pos (in place).  Batches above 4096 triplets are left as they are."""
+    lib = _lib.load()
+    if users.numel() > 4096:
+        return
+    check(lib.pda_sort_triplets_by_pos(ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), users.numel(), stream_ptr()),
+          "pda_sort_triplets_by_pos")
 
 
 def unpack_keys(keys: torch.Tensor):

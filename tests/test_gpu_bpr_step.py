@@ -177,3 +177,39 @@ def test_sampler_semantics(dev):
     _, _, n3, _, _ = ops.sample_triplets(ip, ix, B, seed=1, step=0, n_pool=nU, neg_range=(100, 200))
     n3 = n3.cpu().numpy()
     assert n3.min() >= 100 and n3.max() < 200
+
+
+def test_hot_positive_runs_and_batch_sort(dev):
+    """Zipf-hot positives: the in-block run combining must give the same update for any batch order, and
+    pda_sort_triplets_by_pos must be a pure permutation of the batch (all five arrays together)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(41)
+    nU, nI, d, B, regs, lr = 6000, 300, 64, 2048, 1e-2, 0.05
+    U = (rng.standard_normal((nU, d)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.2).astype(np.float32)
+    users = rng.permutation(nU)[:B].astype(np.int32)
+    w = 1.0 / np.arange(1, nI + 1)
+    pos = rng.choice(nI, size=B, p=w / w.sum()).astype(np.int32)          # the hottest item ~330 times
+    neg = rng.integers(0, nI, B).astype(np.int32)
+    pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    assert np.bincount(pos).max() > 200
+    U1, I1, _, ref_loss = po.train_step(U, I, users, pos, neg, pp, pn, regs, B, lr, optimizer="sgd")
+    out = []
+    for sort in (False, True):
+        Ut, It, ut, pt, nt, ppt, pnt = to(dev, U, I, users, pos, neg, pp, pn)
+        if sort:
+            ops.sort_triplets_by_pos(ut, pt, nt, ppt, pnt)
+            got = np.stack([ut.cpu().numpy(), pt.cpu().numpy(), nt.cpu().numpy()], 1)
+            assert np.all(np.diff(got[:, 1]) >= 0)
+            ref_rows = {tuple(r) for r in np.stack([users, pos, neg], 1).tolist()}
+            assert {tuple(r) for r in got.tolist()} == ref_rows                  # a permutation of whole triplets
+            o = np.argsort(got[:, 0]); o2 = np.argsort(users)
+            np.testing.assert_array_equal(ppt.cpu().numpy()[o], pp[o2])            # pops moved with their triplets
+        loss = torch.zeros(3, device=dev)
+        ops.bpr_step(Ut, It, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
+        np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(Ut.cpu().numpy(), U1, atol=TOL)
+        np.testing.assert_allclose(It.cpu().numpy(), I1, atol=TOL)
+        out.append(It.cpu().numpy())
+    np.testing.assert_allclose(out[0], out[1], atol=2e-6)

@@ -313,3 +313,11 @@ def test_item_prep_cache_follows_weight_updates(dev):
     b = ops.score_topk_keys(Ut, It, ut, 50, impl="v2")
     c = ops.score_topk_keys(Ut, It, ut, 50, impl="v1")
     assert torch.equal(b, c) and not torch.equal(a, b)
+    # a table written by OUR kernels through raw pointers (training step) must invalidate the split as well
+    users = torch.arange(64, dtype=torch.int32, device=dev)
+    pos = torch.arange(64, dtype=torch.int32, device=dev)
+    neg = torch.arange(64, 128, dtype=torch.int32, device=dev)
+    ops.bpr_step(Ut, It, users, pos, neg, regs=1e-2, reg_div=64, lr=5.0, mode=ops.UPD_SGD_FUSED)
+    d2 = ops.score_topk_keys(Ut, It, ut, 50, impl="v2")
+    d1 = ops.score_topk_keys(Ut, It, ut, 50, impl="v1")
+    assert torch.equal(d1, d2) and not torch.equal(d2, b)
