@@ -85,14 +85,18 @@ int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_sh
  * version into bf16 hi / lo planes + padded row norms:
  *   pda_item_prep_bytes(n, d)  -> size of the caller-owned `prep` buffer (device)
  *   pda_item_prep_f32(I_shard, n, d, prep, stream)
- *   pda_score_topk_prepped_f32(..same arguments as pda_score_topk_f32 plus `prep` after I_shard..)
- * d in {64,128,256}; item ids must be < 2^27; K <= PDA_TOPK_CAP-2. */
+ *   pda_score_topk_workspace_bytes(n_users_blk) -> size of the per-call scratch `workspace` (device; the call
+ *                                 clears it itself, stream-ordered; one workspace per concurrent call)
+ *   pda_score_topk_prepped_f32(..arguments of pda_score_topk_f32 plus `prep` after I_shard and `workspace` before stream..)
+ * d in {64,128,256}; K <= PDA_TOPK_CAP-4.  User tiles whose near-tie band overflows the on-chip list are
+ * recomputed by the exact fp32 kernel inside the same call. */
 size_t pda_item_prep_bytes(int n_items_local, int d);
 int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream);
+size_t pda_score_topk_workspace_bytes(int n_users_blk);
 int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
                                const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                                const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
-                               int head, int n_splits, uint64_t* out_keys, void* stream);
+                               int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream);
 
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0

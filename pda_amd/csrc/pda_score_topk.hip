@@ -51,6 +51,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
     const int j = lane & 31, h = lane >> 5;
     const int split = blockIdx.x % a.n_splits, utile = blockIdx.x / a.n_splits;
     const int K = a.K;
+    if (a.tile_flags != nullptr && a.tile_flags[utile] == 0) return;   // v2 fallback mode: only flagged user tiles
 
     const int tiles_total = (a.n_items_local + 31) >> 5;
     const int tiles_per = (tiles_total + a.n_splits - 1) / a.n_splits;
@@ -432,32 +433,10 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(MergeArgs a) {
 
 }  // namespace
 
-extern "C" int pda_score_topk_auto_splits(int n_users_blk, int n_items_local) {
-    if (n_users_blk <= 0 || n_items_local <= 0) return 1;
-    const int utiles = (n_users_blk + kUserTile - 1) / kUserTile;
-    const int tiles = (n_items_local + 31) / 32;
-    int s = 1;
-    while (utiles * s < 512 && s < 64 && tiles / (2 * s) >= 16) s *= 2;
-    return s;
-}
-
-extern "C" int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_shard, const int32_t* users,
-                                  int n_users_blk, int item_offset, int n_items_local, int d,
-                                  const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
-                                  int head, int n_splits, uint64_t* out_keys, void* stream) {
-    if (!U || !I_shard || !users || !out_keys) return PDA_ERR_ARG;
-    if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
-    if (K < 1 || K > PDA_MAX_K || K > PDA_TOPK_CAP - 1) return PDA_ERR_ARG;
-    if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
-    if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
-    if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
-    if (n_splits <= 0) n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
-    ScoreArgs a{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys,
-                n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits};
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+int pda_topk::launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t s) {
 #ifdef PDA_ABLATION
     if (const char* e = getenv("PDA_ABLATE")) {
-        if (d == 128 && head == PDA_HEAD_POP) switch (atoi(e)) {
+        if (d == 128 && head == PDA_HEAD_POP && a.tile_flags == nullptr) switch (atoi(e)) {
             case 1: return launch_score<128, PDA_HEAD_POP, 1>(a, s);
             case 3: return launch_score<128, PDA_HEAD_POP, 3>(a, s);
             case 7: return launch_score<128, PDA_HEAD_POP, 7>(a, s);
@@ -480,6 +459,31 @@ extern "C" int pda_score_topk_f32(const float* U, const float* I_shard, const fl
             return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_DISPATCH
+}
+
+extern "C" int pda_score_topk_auto_splits(int n_users_blk, int n_items_local) {
+    if (n_users_blk <= 0 || n_items_local <= 0) return 1;
+    const int utiles = (n_users_blk + kUserTile - 1) / kUserTile;
+    const int tiles = (n_items_local + 31) / 32;
+    int s = 1;
+    while (utiles * s < 512 && s < 64 && tiles / (2 * s) >= 16) s *= 2;
+    return s;
+}
+
+extern "C" int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_shard, const int32_t* users,
+                                  int n_users_blk, int item_offset, int n_items_local, int d,
+                                  const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
+                                  int head, int n_splits, uint64_t* out_keys, void* stream) {
+    if (!U || !I_shard || !users || !out_keys) return PDA_ERR_ARG;
+    if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
+    if (K < 1 || K > PDA_MAX_K || K > PDA_TOPK_CAP - 1) return PDA_ERR_ARG;
+    if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
+    if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
+    if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
+    if (n_splits <= 0) n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
+    ScoreArgs a{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys,
+                n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, nullptr};
+    return pda_topk::launch_score_v1(a, d, head, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pda_topk_merge(const uint64_t* in_keys, int R, int n_users_blk, int K, uint64_t* out_keys,

@@ -14,6 +14,17 @@
 // Because step 5 is exact and step 3 never rejects a pair whose exact head beats the threshold, v2 returns the
 // same packed keys as v1 (tests/test_gpu_score_topk.py checks equality with v1 and with the oracle).
 //
+// Revision (approximate lists): measured, 35 % of v2's time was steps 4-5 -- ~550 exact rescorings per user, each a
+// 1 KB gather plus a 128-long dependent fmaf chain.  Only ~K of them matter at the end.  The sweep now keeps the
+// per-user lists keyed by the APPROXIMATE head h~ = head(s~) and a per-row half-width W >= |head(s_exact) - h~|
+// (head is pop-Lipschitz in s:  W = nu_row * max||i|| * max(pop), plus 2^-16 |h~| for the fp32 evaluation):
+//   * threshold of the fast test:  T = h~_(K) - W      (a lower bound of the exact K-th best so far)
+//   * a list entry is dropped at compaction only if   h~ < h~_(K) - 2W   (it can no longer reach the exact top K)
+//   * at the end of the sweep each row's <= 58 survivors are rescored exactly (the v1 fmaf chains) and sorted.
+// If more than 58-K entries ever sit inside a row's 2W band (massive near-ties), the row's user tile is flagged in
+// `workspace` and recomputed by the exact v1 kernel, launched right behind on the same stream (it exits immediately
+// for unflagged tiles).  The returned keys are therefore still exactly v1's.
+//
 // Error bound.  bf16 keeps 8 significant bits (RNE): x = xh + xl + xr with |x-xh| <= 2^-8|x|, |xr| <= 2^-16|x|.
 //   u.i - (uh.ih + uh.il + ul.ih) = ul.il + ur.i + (uh+ul).ir   =>  |.| <= (2^-16 + 2^-16 + 2^-16(1+2^-8)) sum|u_k i_k|
 //   the bf16 products are exact in fp32; their fp32 accumulation (3d/16*16 adds, any order) errs by <= 3d*2^-24 sum|.|
@@ -31,9 +42,7 @@ namespace {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kCap2 = PDA_TOPK_CAP - 1;  // 59 slots per user list (leaves LDS room for the rings)
-constexpr int kRing = 192;               // ring entries per wave (u32 each); hard limit kRing-64 before a push
-constexpr int kRingTrig = 64;            // a wave above this asks the whole workgroup to drain
+constexpr int kCap2 = PDA_TOPK_CAP - 2;  // 58 slots per user list
 constexpr float kEpsScale = 1.220703125e-4f;  // 2^-13
 
 #ifdef PDA_ABLATION
@@ -49,7 +58,10 @@ struct ScoreArgs2 {
     ScoreArgs a;
     const uint16_t* I_hi;   // bf16 [n_items_local, d]
     const uint16_t* I_lo;   // bf16 [n_items_local, d]
-    const float* I_norm;    // f32  [n_items_local]   ||i||_2 * (1+2^-10)
+    const float* I_norm;    // f32  [n_items_local]   ||i||_2 * (1+2^-10), followed (256-B aligned) by the max over the shard
+    const float* I_norm_max;
+    const float* pop_max;   // workspace: max |pop| over the shard (PDA_HEAD_POP)
+    int* tile_flags;        // workspace: [n_user_tiles], set when a row's near-tie band overflowed
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float x) {
@@ -83,7 +95,7 @@ __device__ __forceinline__ int swzb(int row) {   // bf16 tile: D/8 16-byte chunk
 // one row per D/8 threads: fp32 -> bf16 hi, bf16 lo, padded norm
 template <int D>
 __global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict__ I, int n, uint16_t* __restrict__ hi,
-                                                        uint16_t* __restrict__ lo, float* __restrict__ nrm) {
+                                                        uint16_t* __restrict__ lo, float* __restrict__ nrm, int* __restrict__ nrm_max_bits) {
     constexpr int TPR = D / 8;
     const int row = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
     float ss = 0.f;
@@ -99,7 +111,77 @@ __global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict_
     }
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if (row < n && e == 0) nrm[row] = sqrtf(ss) * 1.0009765625f * 1.0001f;
+    if (row < n && e == 0) {
+        const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
+        nrm[row] = v;
+        atomicMax(nrm_max_bits, __float_as_int(v));   // v >= 0: integer order == float order
+    }
+}
+
+__global__ void __launch_bounds__(256) pop_max_kernel(const float* __restrict__ pop, int n, int* __restrict__ out_bits) {
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) m = fmaxf(m, fabsf(pop[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_int(m));
+}
+
+// Compaction of one row's APPROXIMATE list: sort (sorted prefix + new tail), keep everything inside the 2W band under the
+// K-th entry, publish the lower-bound threshold T = h~_(K) - W.  Returns true if the band does not fit (tile must be redone).
+template <int CAP>
+__device__ __forceinline__ void compact_band(uint64_t* buf, int* cnt_slot, float* tau_slot, int* sorted_slot, float* drop_slot, float wabs, int K, int lane) {
+    pda_wave_sync();
+    const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), CAP);
+    const int n0 = min(__builtin_amdgcn_readfirstlane(*sorted_slot), c);
+    uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);
+    int rank;
+    if (n0 > 0) {
+        rank = lane < n0 ? lane : 0;
+        const uint64_t oldmask = n0 >= 64 ? ~0ull : ((1ull << n0) - 1ull);
+        for (int jj = n0; jj < c; ++jj) {
+            const uint64_t kj = pda_readlane_u64(key, jj);
+            rank += (kj > key) ? 1 : 0;
+            const int olds_above = __popcll(__ballot(key > kj) & oldmask);
+            rank += (lane == jj) ? olds_above : 0;
+        }
+    } else {
+        rank = 0;
+        for (int jj = 0; jj < c; ++jj) {
+            const uint64_t kj = pda_readlane_u64(key, jj);
+            rank += (kj > key) ? 1 : 0;
+        }
+    }
+    pda_wave_sync();
+    int keep = c;
+    if (c >= K) {
+        const uint64_t mk = __ballot(lane < c && rank == K - 1);
+#ifdef PDA_ABLATION
+        if (lane == 0 && __popcll(mk) != 1) atomicAdd(&pda_dbg[6], 1ull);
+#endif
+        const float vK = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), __builtin_ctzll(mk)));
+        const float w = (wabs + fabsf(vK) * 1.52587890625e-5f) * 1.001f;
+        const float band = vK - 2.0f * w;
+        keep = __popcll(__ballot(lane < c && pda_key_val(key) >= band));   // ranks 0..keep-1: the list is ordered by value
+        if (keep > CAP - 1) {
+            // The band does not fit: keep the best CAP-1 and remember how high the dropped ones could still reach.
+            // Whether that matters is decided at the END against the exact K-th value (early-sweep clusters, when the
+            // running threshold is still low, never do).
+#ifdef PDA_ABLATION
+            if (lane == 0) atomicAdd(&pda_dbg[7], 1ull);
+#endif
+            keep = CAP - 1;
+            const uint64_t md = __ballot(lane < c && rank == keep);          // best dropped entry
+            const float vd = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), __builtin_ctzll(md)));
+            if (lane == 0) *drop_slot = fmaxf(*drop_slot, vd + (wabs + fabsf(vd) * 1.52587890625e-5f) * 1.001f);
+        }
+        if (lane == 0) *tau_slot = vK - w;
+    }
+    if (lane < c && rank < keep) buf[rank] = key;
+    if (lane == 0) {
+        *cnt_slot = keep;
+        *sorted_slot = keep;
+    }
+    pda_wave_sync();
 }
 
 template <int D, int HEAD, int ABL = 0>   // ABL: profiling-only (-DPDA_ABLATION): 1 drop candidates, 2 skip the test, 4 no history
@@ -115,8 +197,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 2 * 32 * D * sizeof(uint16_t));   // [128][kCap2]
     int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap2);                 // [128]
     float* taul = reinterpret_cast<float*>(cntl + kUserTile);                              // [128]
-    uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                       // [4][kRing]
-    int* wgflag = reinterpret_cast<int*>(rings + 4 * kRing);                              // [2] "some wave wants to drain its ring"
+    int* sortl = reinterpret_cast<int*>(taul + kUserTile);                                 // [128] length of the sorted prefix
+    float* dropl = reinterpret_cast<float*>(sortl + kUserTile);                            // [128] highest reach of entries dropped by a band overflow
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -202,11 +284,16 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     // ---- per-row state in LDS -------------------------------------------------------------------------------
     if (lane < 32) {
         cntl[wave * 32 + lane] = 0;
+        sortl[wave * 32 + lane] = 0;
+        dropl[wave * 32 + lane] = -INFINITY;
         taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
     }
-    if (tid < 2) wgflag[tid] = 0;
     pda_wave_sync();
-    f32x16 thr;    // thresholds lowered by a 2^-20 relative margin (covers the fp32 evaluation of the bound)
+    // half-width of the head interval of this lane's row (absolute part):  |head(s_exact) - head(s~)| <= W
+    float w_abs = nu_row * aa.I_norm_max[0] * 1.004f;
+    if constexpr (HEAD == PDA_HEAD_POP) w_abs *= aa.pop_max[0];
+    bool ovf_tile = false;   // wave-uniform: some row's near-tie band overflowed -> tile recomputed by v1
+    f32x16 thr;    // lower-bound thresholds T, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
     f32x16 nu;     // eps scale of the row behind each accumulator register
     auto refresh_thr = [&]() {
         int hv = h;
@@ -222,8 +309,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     for (int r = 0; r < 16; ++r) nu[r] = __shfl(nu_row, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
 
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap2;
-    uint32_t* ring = rings + wave * kRing;
-    int ring_cnt = 0;   // wave-uniform
     long long dbg_entries = 0, dbg_proc = 0, dbg_comp = 0, dbg_push = 0;
     PDA_T0(t_all);
     (void)dbg_entries; (void)dbg_proc; (void)dbg_comp; (void)dbg_push;
@@ -258,69 +343,39 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         if constexpr (HEAD == PDA_HEAD_POP) popv = a.pop[it];
     };
 
-    // ---- exact rescoring of the ring, 16 candidates per pass, FOUR lanes per candidate ---------------------------
-    // Lane 4*ci+q loads the q-th quarter of candidate ci's user row and item row (64 contiguous bytes per 4 lanes, so an
-    // instruction touches 16 rows x 1 line instead of 64 rows), and the two fmaf chains of v1 (even / odd k-chunks,
-    // k ascending) are carried from quarter to quarter through the lanes: phase p completes quarter p and hands the
-    // accumulators to lane q = p+1.  Lane q = 3 ends up with the bit-exact v1 score and does the list append.
-    auto process_ring = [&]() {
-        PDA_T0(tp);
-        dbg_entries += ring_cnt;
-        constexpr int NCH = D / 32;                 // 8-float chunks per lane (even)
-        const int q = lane & 3, ci = lane >> 2;
-        for (int base = 0; base < ring_cnt; base += 16) {
-            const int e = base + ci;
-            const bool valid = e < ring_cnt;
-            const uint32_t word = valid ? ring[e] : 0u;
-            const int row = (int)(word >> 27);
-            const int item = (int)(word & 0x7FFFFFFu);            // global item id
-            const int urow = __shfl(uid, row, 64);
-            float tt = -INFINITY;
-            if constexpr (!(ABL & 8)) {
-                const float* up = a.U + (size_t)urow * D + q * (D / 4);
-                const float* ip = a.I + (size_t)(valid ? item - a.item_offset : 0) * D + q * (D / 4);
-                f32x4 uu[2 * NCH], ii[2 * NCH];
-#pragma unroll
-                for (int c = 0; c < 2 * NCH; ++c) {
-                    uu[c] = *reinterpret_cast<const f32x4*>(up + 4 * c);
-                    ii[c] = *reinterpret_cast<const f32x4*>(ip + 4 * c);
-                }
-                float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
-#pragma unroll
-                for (int ph = 0; ph < 4; ++ph) {
-                    o0 = c0;
-                    o1 = c1;
-#pragma unroll
-                    for (int cc = 0; cc < NCH; ++cc) {
-#pragma unroll
-                        for (int sidx = 0; sidx < 4; ++sidx) {
-                            if (cc & 1) {
-                                o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
-                                o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
-                            } else {
-                                o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
-                                o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
-                            }
-                        }
-                    }
-                    if (ph < 3) {
-                        const float r0 = __shfl_up(o0, 1, 64), r1 = __shfl_up(o1, 1, 64);
-                        if (q == ph + 1) {
-                            c0 = r0;
-                            c1 = r1;
-                        }
-                    }
-                }
-                float sc = o0 + o1;                               // meaningful on q == 3
-                if constexpr (HEAD == PDA_HEAD_POP) {
-                    const float pv = a.pop[valid ? item - a.item_offset : 0];
-                    sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
-                }
-                if (valid && q == 3) tt = sc;
+    // ---- slow path: flagged lanes append (h~, item) to their row's list, lane-parallel --------------------------------
+    // `m`: bit 15-r <-> accumulator register r of the previous tile.  Every flagged lane handles its own top flagged
+    // register per round (usually one round); row, history bits and s~ are per-lane values, so there is no
+    // wave-uniform loop over registers.
+    auto push_flagged = [&](uint32_t m, uint32_t hb, int jg0, float popv, const f32x16& accv) {
+        PDA_T0(tq);
+        const bool any_hb = __any(hb != 0);
+        bool compacted = false;
+        while (__any(m != 0)) {
+            const bool act = m != 0;
+            const int bit = 31 - __builtin_clz(m | 1u);
+            const int r = 15 - bit;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            m &= ~(1u << bit);
+            bool p = act;
+            if (any_hb) {
+                const uint32_t hbr = (uint32_t)__shfl((int)hb, row, 64);           // train items never enter
+                if ((hbr >> j) & 1u) p = false;
             }
+            // s~ of MY register r.  Common case: one flagged lane in the wave -> r is wave-uniform -> one indexed read.
+            float sv;
+            const uint64_t actm = __ballot(act);
+            if ((actm & (actm - 1ull)) == 0ull) {
+                sv = accv[__builtin_amdgcn_readlane(r, __builtin_ctzll(actm))];
+            } else {
+                sv = accv[0];
+#pragma unroll
+                for (int k = 1; k < 16; ++k) sv = (r == k) ? accv[k] : sv;
+            }
+            float hv = sv;
+            if constexpr (HEAD == PDA_HEAD_POP) hv = (sv > 0.0f ? sv + 1.0f : __expf(sv)) * popv;
             const int lrow = wave * 32 + row;
-            bool p = valid && q == 3 && (tt > taul[lrow]) && !(ABL & 16);
-            const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+            const uint64_t key = pda_pack_key(hv, (uint32_t)(jg0 + j));
             for (;;) {
                 bool ov = false;
                 if (p) {
@@ -335,43 +390,16 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                     const int rr = __builtin_ctzll(full);
                     full &= full - 1ull;
                     PDA_T0(tc);
-                    compact_list<kCap2>(my_lists + rr * kCap2, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+                    compact_band<kCap2>(my_lists + rr * kCap2, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], &sortl[wave * 32 + rr],
+                                        &dropl[wave * 32 + rr], pda_readlane_f32(w_abs, rr), K, lane);
                     PDA_T1(tc, dbg_comp);
                 }
-                p = ov && (tt > taul[lrow]);
+                compacted = true;
+                const float hv_hi = hv + __shfl(w_abs, row, 64) * 1.001f + fabsf(hv) * 1.52587890625e-5f;
+                p = ov && (hv_hi >= taul[lrow]);        // still able to reach the top K of its row?
             }
         }
-        ring_cnt = 0;
-        pda_wave_sync();
-        refresh_thr();
-        PDA_T1(tp, dbg_proc);
-    };
-
-    // ---- push the lanes flagged in `m` (bit 15-r <-> accumulator register r) into the ring ------------------------
-    // Lane-parallel: every flagged lane pushes ITS OWN top flagged register per round (usually one round); the row
-    // behind (register, half) and its history bits are per-lane values (ds_bpermute), so there is no wave-uniform
-    // loop over registers and no SGPR dependency chain.
-    auto push_flagged = [&](uint32_t m, uint32_t hb, int jg0) {
-        PDA_T0(tq);
-        const bool any_hb = __any(hb != 0);
-        while (__any(m != 0)) {
-            const bool act = m != 0;
-            const int bit = 31 - __builtin_clz(m | 1u);
-            const int r = 15 - bit;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            m &= ~(1u << bit);
-            bool p = act;
-            if (any_hb) {
-                const uint32_t hbr = (uint32_t)__shfl((int)hb, row, 64);           // train items never enter
-                if ((hbr >> j) & 1u) p = false;
-            }
-            const uint64_t pm = __ballot(p);
-            if (!pm) continue;
-            if (ring_cnt + 64 > kRing) process_ring();
-            const int slot = ring_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
-            if (p) ring[slot] = ((uint32_t)row << 27) | (uint32_t)(jg0 + j);
-            ring_cnt += __popcll(pm);
-        }
+        if (compacted) refresh_thr();
         PDA_T1(tq, dbg_push);
     };
 
@@ -436,19 +464,13 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         if constexpr (ABL & 2) asm volatile("" ::"v"(acc_prev[0]), "v"(acc_prev[5]), "v"(acc_prev[15]));
         if constexpr (ABL & 1) { asm volatile("" ::"v"(m)); m = 0; }
 
-        // All four waves drain their rings in the SAME iteration (flag set by whichever wave is filling up): the
-        // latency-bound rescoring of the four waves then overlaps instead of stalling the workgroup four times.
-        if (ring_cnt > kRingTrig && lane == 0) wgflag[t & 1] = 1;
         __syncthreads();  // every wave is done reading the tile
-        const bool drain = wgflag[t & 1] != 0;
-        if (tid == 0) wgflag[(t + 1) & 1] = 0;   // flag of tile t-1: everyone has read it, nobody sets it before tile t+1
         uint32_t hb_next = 0;
         if (has_next) {
             tile_store(cur_h, cur_l);
             hb_next = hist_bits(t + 1);
         }
-        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t - 1) * 32);
-        if (drain && ring_cnt > 0) process_ring();
+        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t - 1) * 32, pop_prev, acc_prev);
         __syncthreads();  // next tile visible
 
         acc_prev = acc_new;
@@ -471,21 +493,59 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             m = (m << 1) | ((x > thr[r]) ? 1u : 0u);
         }
         m = ok_prev ? m : 0u;
-        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t1 - 1) * 32);
+        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t1 - 1) * 32, pop_prev, acc_prev);
     }
-    if (ring_cnt > 0) process_ring();
 
-    // ---- finalise ------------------------------------------------------------------------------------------------
+    // ---- finalise: exact rescoring of each row's survivors (one lane per candidate, the fmaf chains of v1), exact
+    //      sort, K packed keys out.  ~58 candidates x 32 rows per wave: <1 % of the sweep.
+    PDA_T0(tp);
     for (int rr = 0; rr < 32; ++rr) {
-        uint64_t* buf = my_lists + rr * kCap2;
-        compact_list<kCap2>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
-        const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
-        if (rb < a.n_users_blk && lane < K) {
-            const uint64_t k = lane < c ? buf[lane] : 0ull;
-            a.out_keys[((size_t)split * a.n_users_blk + rb) * K + lane] = k;
+        if (rb >= a.n_users_blk) break;                       // wave-uniform
+        const uint64_t* buf = my_lists + rr * kCap2;
+        pda_wave_sync();
+        const int c = min(__builtin_amdgcn_readfirstlane(cntl[wave * 32 + rr]), kCap2);
+        const bool valid = lane < c;
+        const int item = valid ? pda_key_item(buf[lane]) : a.item_offset;
+        const int urow = __builtin_amdgcn_readlane(uid, rr);
+        const float* up = a.U + (size_t)urow * D;
+        const float* ip = a.I + (size_t)(item - a.item_offset) * D;
+        float c0 = 0.f, c1 = 0.f;
+#pragma unroll 2
+        for (int c8 = 0; c8 < D / 8; c8 += 2) {
+            const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + 8 * c8), u1 = *reinterpret_cast<const f32x4*>(up + 8 * c8 + 4);
+            const f32x4 i0 = *reinterpret_cast<const f32x4*>(ip + 8 * c8), i1 = *reinterpret_cast<const f32x4*>(ip + 8 * c8 + 4);
+            const f32x4 u2 = *reinterpret_cast<const f32x4*>(up + 8 * c8 + 8), u3 = *reinterpret_cast<const f32x4*>(up + 8 * c8 + 12);
+            const f32x4 i2 = *reinterpret_cast<const f32x4*>(ip + 8 * c8 + 8), i3 = *reinterpret_cast<const f32x4*>(ip + 8 * c8 + 12);
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                c0 = __builtin_fmaf(u0[sidx], i0[sidx], c0);
+                c0 = __builtin_fmaf(u1[sidx], i1[sidx], c0);
+            }
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                c1 = __builtin_fmaf(u2[sidx], i2[sidx], c1);
+                c1 = __builtin_fmaf(u3[sidx], i3[sidx], c1);
+            }
+        }
+        float sc = c0 + c1;
+        if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * a.pop[item - a.item_offset];
+        const uint64_t key = valid ? pda_pack_key(sc, (uint32_t)item) : (uint64_t)(63 - lane);
+        int rank = 0;
+        for (int jj = 0; jj < c; ++jj) rank += (pda_readlane_u64(key, jj) > key) ? 1 : 0;
+        uint64_t* out = a.out_keys + ((size_t)split * a.n_users_blk + rb) * K;
+        if (valid && rank < K) out[rank] = key;
+        if (lane >= c && lane < K) out[lane] = 0ull;
+        // entries dropped by a band overflow: harmless unless they could still have reached the exact K-th value
+        const float dmax = dropl[wave * 32 + rr];
+        if (dmax != -INFINITY) {
+            float kth = -INFINITY;
+            if (c >= K) kth = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), __builtin_ctzll(__ballot(valid && rank == K - 1))));
+            if (dmax >= kth) ovf_tile = true;
         }
     }
+    PDA_T1(tp, dbg_proc);
+    if (ovf_tile && lane == 0) aa.tile_flags[utile] = 1;
 #ifdef PDA_ABLATION
     if (lane == 0) {
         long long tot = 0;
@@ -502,7 +562,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 
 template <int D, int HEAD, int ABL = 0>
 int launch_v2(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 16;
+    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 16);
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD, ABL>),
@@ -526,24 +586,34 @@ extern "C" int pda_debug_counters(unsigned long long* out8, int reset) {
 }
 #endif
 
+static inline size_t prep_plane_bytes(int n, int d) { return (((size_t)n * d * 2) + 255) & ~(size_t)255; }
+static inline size_t prep_norm_bytes(int n) { return (((size_t)n * 4) + 255) & ~(size_t)255; }
+
 extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) {
-    // [hi bf16 n*d][lo bf16 n*d][norm f32 n], each section 256-byte aligned
-    const size_t plane = (((size_t)n_items_local * d * 2) + 255) & ~(size_t)255;
-    return 2 * plane + (((size_t)n_items_local * 4 + 255) & ~(size_t)255);
+    // [hi bf16 n*d][lo bf16 n*d][norm f32 n][max norm f32], each section 256-byte aligned
+    return 2 * prep_plane_bytes(n_items_local, d) + prep_norm_bytes(n_items_local) + 256;
+}
+
+extern "C" size_t pda_score_topk_workspace_bytes(int n_users_blk) {
+    // [max |pop| f32 (16 B slot)][tile_flags i32 per 128-user tile]
+    const size_t tiles = (size_t)(n_users_blk + kUserTile - 1) / kUserTile;
+    return (16 + tiles * 4 + 255) & ~(size_t)255;
 }
 
 extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream) {
     if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
-    const size_t plane = (((size_t)n_items_local * d * 2) + 255) & ~(size_t)255;
+    const size_t plane = prep_plane_bytes(n_items_local, d);
     uint16_t* hi = reinterpret_cast<uint16_t*>(prep);
     uint16_t* lo = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(prep) + plane);
     float* nrm = reinterpret_cast<float*>(reinterpret_cast<char*>(prep) + 2 * plane);
+    int* nmax = reinterpret_cast<int*>(reinterpret_cast<char*>(prep) + 2 * plane + prep_norm_bytes(n_items_local));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(nmax, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
 #define PDA_PREP(DD)                                                                                         \
     case DD: {                                                                                               \
         constexpr int RPB = 256 / (DD / 8);                                                                  \
         hipLaunchKernelGGL(item_prep_kernel<DD>, dim3((unsigned)((n_items_local + RPB - 1) / RPB)), dim3(256), 0, s, \
-                           I_shard, n_items_local, hi, lo, nrm);                                             \
+                           I_shard, n_items_local, hi, lo, nrm, nmax);                                       \
         break;                                                                                               \
     }
     switch (d) {
@@ -558,22 +628,30 @@ extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d,
 extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
                                           const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                                           const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
-                                          int head, int n_splits, uint64_t* out_keys, void* stream) {
-    if (!U || !I_shard || !prep || !users || !out_keys) return PDA_ERR_ARG;
+                                          int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream) {
+    if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
-    if ((uint64_t)item_offset + (uint64_t)n_items_local > (1ull << 27)) return PDA_ERR_UNSUPPORTED;   // ring packs item ids in 27 bits
-    if (K < 1 || K > PDA_TOPK_CAP - 2) return PDA_ERR_ARG;
+    if (K < 1 || K > PDA_TOPK_CAP - 4) return PDA_ERR_ARG;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
     if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
     if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
     if (n_splits <= 0) n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
-    const size_t plane = (((size_t)n_items_local * d * 2) + 255) & ~(size_t)255;
-    ScoreArgs2 aa{{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, n_users_blk, item_offset, n_items_local,
-                   hist_row_mode, K, n_splits},
-                  reinterpret_cast<const uint16_t*>(prep),
-                  reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(prep) + plane),
-                  reinterpret_cast<const float*>(reinterpret_cast<const char*>(prep) + 2 * plane)};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t plane = prep_plane_bytes(n_items_local, d);
+    const char* pb = reinterpret_cast<const char*>(prep);
+    int* ws = reinterpret_cast<int*>(workspace);
+    if (hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (head == PDA_HEAD_POP) {
+        hipLaunchKernelGGL(pop_max_kernel, dim3(64), dim3(256), 0, s, pop_shard, n_items_local, ws);
+        PDA_CHECK_LAUNCH();
+    }
+    ScoreArgs2 aa{{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, n_users_blk, item_offset, n_items_local,
+                   hist_row_mode, K, n_splits, nullptr},
+                  reinterpret_cast<const uint16_t*>(pb), reinterpret_cast<const uint16_t*>(pb + plane),
+                  reinterpret_cast<const float*>(pb + 2 * plane),
+                  reinterpret_cast<const float*>(pb + 2 * plane + prep_norm_bytes(n_items_local)),
+                  reinterpret_cast<const float*>(ws), ws + 4};
+    int rc = PDA_ERR_UNSUPPORTED;
 #ifdef PDA_ABLATION
     if (const char* e = getenv("PDA_ABLATE")) {
         if (d == 128 && head == PDA_HEAD_POP) switch (atoi(e)) {
@@ -581,17 +659,20 @@ extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, 
             case 3: return launch_v2<128, PDA_HEAD_POP, 3>(aa, s);
             case 7: return launch_v2<128, PDA_HEAD_POP, 7>(aa, s);
             case 4: return launch_v2<128, PDA_HEAD_POP, 4>(aa, s);
-            case 8: return launch_v2<128, PDA_HEAD_POP, 8>(aa, s);
-            case 16: return launch_v2<128, PDA_HEAD_POP, 16>(aa, s);
             default: break;
         }
     }
 #endif
 #define PDA_V2(DD) \
-    case DD: return head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s);
+    case DD: rc = head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s); break;
     switch (d) {
         PDA_V2(64) PDA_V2(128) PDA_V2(256)
         default: return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_V2
+    if (rc != PDA_OK) return rc;
+    // exact recomputation of the (normally zero) user tiles whose near-tie band overflowed
+    ScoreArgs v1 = aa.a;
+    v1.tile_flags = ws + 4;
+    return pda_topk::launch_score_v1(v1, d, head, s);
 }

@@ -23,7 +23,11 @@ struct ScoreArgs {
     int hist_row_mode;
     int K;
     int n_splits;
+    const int* tile_flags;   // optional [n_user_tiles]: only flagged tiles are computed (v2's exact fallback)
 };
+
+// defined in pda_score_topk.hip
+int launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t stream);
 
 template <int D>
 __device__ __forceinline__ int swz(int row) {

@@ -107,13 +107,13 @@ def score_impl(d: int, K: int, item_hi: int) -> str:
     PDA_SCORE_IMPL=v1|v2 forces one (A/B measurements, cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_IMPL", "")
-    ok = d in (64, 128, 256) and K <= TOPK_CAP_V2 and item_hi <= (1 << 27)
+    ok = d in (64, 128) and K <= TOPK_CAP_V2          # d=256 spills in v2 (two A planes of 128 VGPRs): v1 for now
     if forced == "v1" or not ok:
         return "v1"
     return "v2"
 
 
-TOPK_CAP_V2 = _lib.TOPK_CAP - 2
+TOPK_CAP_V2 = _lib.TOPK_CAP - 4
 
 
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
@@ -140,10 +140,11 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     impl = impl or score_impl(d, K, item_offset + nloc)
     if impl == "v2":
         prep = item_prep(I_shard)
+        ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)   # per call: re-entrant
         check(lib.pda_score_topk_prepped_f32(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
                                              nloc, d, ptr(hist.indptr) if hist else None,
                                              ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head,
-                                             n_splits, ptr(out), stream_ptr()), "pda_score_topk_prepped_f32")
+                                             n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk_prepped_f32")
         return out
     check(lib.pda_score_topk_f32(ptr(U), ptr(I_shard), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None,

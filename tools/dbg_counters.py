@@ -12,5 +12,5 @@ lib.pda_debug_counters(out, 1)
 ops.score_topk_keys(W.U, W.I, users, 50, 1, W.pop_last, hist, impl="v2"); torch.cuda.synchronize()
 lib.pda_debug_counters(out, 1)
 w = out[5]
-print("waves %d | per wave: entries %.0f  total cycles %.2fM  process_ring %.2fM (compaction inside %.2fM)  push %.2fM" %
-      (w, out[0] / w, out[4] / w / 1e6, out[1] / w / 1e6, out[2] / w / 1e6, out[3] / w / 1e6))
+print("waves %d | per wave: entries %.0f  total cycles %.2fM  finalize %.2fM  push(all) %.2fM of which compaction %.2fM | bad-rank %d overflows %d" %
+      (w, out[0] / w, out[4] / w / 1e6, out[1] / w / 1e6, out[3] / w / 1e6, out[2] / w / 1e6, out[6], out[7]))
