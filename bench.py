@@ -26,7 +26,8 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (guides/MI355X_MICROARCH.md)
+PEAK_F32_MFMA_TFLOPS = 157.3    # MI355X dense fp32 matrix peak (guides/MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 matrix peak (same guide; the 5 PF figure is 2:1 sparse)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -44,6 +45,24 @@ def parse():
     p.add_argument("--train-steps", type=int, default=2048)
     p.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
     return p.parse_args()
+
+
+def profile_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary of this round (rocprofv3 --pmc FETCH_SIZE
+    / WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in guides/MI355X_MICROARCH.md).  None when no
+    summary for this kernel is present -- PMC cannot be collected from inside the timed process."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.txt")), reverse=True):
+        txt = open(path).read()
+        if kernel_substr not in txt:
+            continue
+        f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
+        w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
+        if f and w:
+            return {"bytes_per_launch": (2.0 * float(f.group(1)) + float(w.group(1))) * 1024.0, "source": os.path.basename(path),
+                    "note": "FETCH_SIZE x2 (gfx950 under-count of wide coalesced reads) + WRITE_SIZE, KiB -> bytes"}
+    return None
 
 
 class TimedScore:
@@ -111,12 +130,24 @@ def bench_eval(args, rank, world, dev):
     flops = 2.0 * Bu * n_local * W.d
     nnz_blk = float(W.n_train) * Bu / W.n_users
     abytes = n_local * W.d * 4 + n_local * 4 + Bu * W.d * 4 + nnz_blk * 4 + (Bu + 1) * 8 + Bu * args.K * 8
-    roof = {"kernel": "score_topk_kernel<%d,%s>" % (W.d, "POP" if head else "RAW"), "bound": "mfma",
-            "achieved": flops / (k_ms * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": flops / (k_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-            "kernel_ms": k_ms, "flops_per_launch": flops,
-            "hbm": {"algorithmic_bytes_per_launch": abytes, "achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
-                    "peak_GBs": PEAK_HBM_GBS, "frac": abytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}}
+    impl = ops.score_impl(W.d, args.K, W.n_items)
+    hd = "POP" if head else "RAW"
+    alg_tf = flops / (k_ms * 1e-3) / 1e12
+    hbm = {"algorithmic_bytes_per_launch": abytes, "achieved_GBs": abytes / (k_ms * 1e-3) / 1e9,
+           "peak_GBs": PEAK_HBM_GBS, "frac": abytes / (k_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+    if impl == "v2":
+        # v2 = bf16x3 MFMA pre-filter (3 bf16 MFMAs per fp32 product) + exact fp32 rescoring of the survivors.
+        roof = {"kernel": "score_topk_v2_kernel<%d,%s>" % (W.d, hd), "bound": "mfma", "achieved": alg_tf,
+                "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_BF16_MFMA_TFLOPS,
+                "traffic": profile_traffic("score_topk_v2"), "kernel_ms": k_ms, "flops_per_launch": flops,
+                "executed": {"bf16_mfma_TFLOPs": 3 * alg_tf, "frac_of_bf16_peak": 3 * alg_tf / PEAK_BF16_MFMA_TFLOPS},
+                "fp32_equivalent": {"peak": PEAK_F32_MFMA_TFLOPS, "frac": alg_tf / PEAK_F32_MFMA_TFLOPS,
+                                    "note": "same bit-exact fp32 results as the fp32-MFMA kernel (v1), whose roof this is"},
+                "hbm": hbm}
+    else:
+        roof = {"kernel": "score_topk_kernel<%d,%s>" % (W.d, hd), "bound": "mfma", "achieved": alg_tf,
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_F32_MFMA_TFLOPS,
+                "traffic": profile_traffic("score_topk_kernel"), "kernel_ms": k_ms, "flops_per_launch": flops, "hbm": hbm}
     res = {"users_per_s": Bu * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "Bu": Bu, "W": W,
            "roofline": roof, "hist": hist}
     return res
@@ -256,7 +287,9 @@ def main():
         line = {
             "metric": "users/sec full-catalogue top-K@%d (eval)" % args.K, "value": ev["users_per_s"], "unit": "users/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ev["ms_per_step"],
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 results (bf16x3 MFMA pre-filter + exact f32 rescoring)" if ev["roofline"]["kernel"].startswith("score_topk_v2") else "f32",
+            "data": "synthetic",
             "config": {"workload": "%s: synthetic %d users x %d items, embed_dim=%d, %s head, history-masked top-K@%d"
                                    % (args.workload.upper(), W.n_users, W.n_items, W.d,
                                       "PDA condition ((elu+1)*pop^%.2f)" % W.gamma if args.head == "condition" else "raw",

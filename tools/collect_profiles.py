@@ -11,7 +11,8 @@ with open(os.path.join(dst, name + "_kernel_stats.csv"), "w", newline="") as f:
     for r in rows[1:13]:
         r[0] = r[0][:160]
         w.writerow(r)
-pm = subprocess.check_output([sys.executable, "tools/pmc_summary.py", src]).decode()
+pat = sys.argv[3] if len(sys.argv) > 3 else "score_topk"
+pm = "# kernel pattern: %s\n" % pat + subprocess.check_output([sys.executable, "tools/pmc_summary.py", src, pat]).decode()
 open(os.path.join(dst, name + "_pmc.txt"), "w").write(
     "# rocprofv3 --pmc passes (separate runs) of: python bench.py --steps 3 --warmup 1 --no-train --no-cpu-baseline\n"
     "# mean counter value per dispatch of score_topk_kernel, summed over the 8 XCDs; FETCH_SIZE/WRITE_SIZE in KiB\n"
