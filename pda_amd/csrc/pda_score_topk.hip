@@ -151,7 +151,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
         const int64_t idx = hp + 1;
         pend_ok = idx < he;
         pend_flag = adv;
-        const int64_t idc = max((int64_t)0, min(idx, he - 1));     // clamped: the load is never predicated
+        // never predicated (exact vmcnt bookkeeping), but lanes that did not advance all read element 0: one cache
+        // line for the wave instead of a 64-line gather on every tile
+        const int64_t idc = adv ? max((int64_t)0, min(idx, he - 1)) : (int64_t)0;
         pend_v = a.hist_indices[idc];
         if (__builtin_expect(__any(nxt < jg1), 0)) {               // rare: several train items in one tile
             do {
