@@ -270,11 +270,18 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
         sys.exit(2)
+    # PDA_BENCH_ONE_GPU=1 is a plumbing check only (tools/two_rank_smoke.sh): every rank on cuda:0 over gloo
+    one_gpu = os.environ.get("PDA_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # backend "nccl" IS RCCL on ROCm
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
     ev = bench_eval(args, rank, world, dev)
     train_pack = None
     if world == 1 and not args.no_train:

@@ -86,7 +86,9 @@ int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_sh
  *   pda_item_prep_bytes(n, d)  -> size of the caller-owned `prep` buffer (device)
  *   pda_item_prep_f32(I_shard, n, d, prep, stream)
  *   pda_score_topk_workspace_bytes(n_users_blk) -> size of the per-call scratch `workspace` (device; the call
- *                                 clears it itself, stream-ordered; one workspace per concurrent call)
+ *                                 clears it itself, stream-ordered; one workspace per concurrent call).  After the
+ *                                 call, the u64 at byte offset 8 holds the number of 32-item tiles scored, summed
+ *                                 over workgroups (statistics: (n_items/32) * ceil(n_users/128) when nothing was skipped)
  *   pda_score_topk_prepped_f32(..arguments of pda_score_topk_f32 plus `prep` after I_shard and `workspace` before stream..)
  * d in {64,128,256}; K <= PDA_TOPK_CAP-4.  User tiles whose near-tie band overflows the on-chip list are
  * recomputed by the exact fp32 kernel inside the same call. */
@@ -97,6 +99,34 @@ int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void*
                                const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                                const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
                                int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream);
+
+/* Ordered sweep with exact early termination (same keys again).  PDA's head is popularity-weighted:
+ *     head(s) = (elu(s)+1) pop  <=  pop + ||u|| (pop ||i||)          (PDA_HEAD_RAW:  s <= ||u|| ||i||)
+ * so when the catalogue is visited strongest-bound-first, a user block can stop as soon as the bound of everything
+ * not yet visited is below every user's running K-th value -- most of a popularity-skewed catalogue is never scored.
+ * The caller chooses the visiting `order` (i32 [n_items_local], a permutation of the local item ids; ANY permutation
+ * gives the exact result, `argsort(-pop * (1 + c ||i||))` makes the stop early); pop must be >= 0 for the bound to be
+ * tight (|pop| is used).  History rows have to be in visiting positions too:
+ *   pda_item_prep_ordered_bytes(n, d)
+ *   pda_item_prep_ordered_f32(I_shard, pop_shard|NULL, order, n, d, prep, stream)     per (weights, pop, order)
+ *   pda_item_prep_ordered_check(prep, n, d, stream)   optional, synchronises: PDA_ERR_ARG if `order` was not a permutation
+ *   pda_hist_reorder(prep, n, d, item_offset, hist_indptr, hist_indices, n_rows, out_indices, stream)
+ *        out_indices i32 [nnz]: in-shard ids replaced by item_offset + position, every row sorted again
+ *   pda_score_topk_ordered_f32(.. as pda_score_topk_prepped_f32, with hist_indices_ord after hist_indices ..)
+ *        hist_indices stays the ORIGINAL (item-id) history: the exact-kernel recomputation of overflowed tiles uses it.
+ * With n_splits > 1 the splits take interleaved tiles of the visiting order.
+ * No reference counterpart: the reference scores the full [Bu, I] matrix (MF/train_new_api.py:594-612). */
+size_t pda_item_prep_ordered_bytes(int n_items_local, int d);
+int pda_item_prep_ordered_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d,
+                              void* prep, void* stream);
+int pda_item_prep_ordered_check(const void* prep, int n_items_local, int d, void* stream);
+int pda_hist_reorder(const void* prep, int n_items_local, int d, int item_offset, const int64_t* hist_indptr,
+                     const int32_t* hist_indices, int n_rows, int32_t* out_indices, void* stream);
+int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
+                               const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                               const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
+                               int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
+                               void* stream);
 
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0

@@ -62,6 +62,12 @@ struct ScoreArgs2 {
     const float* I_norm_max;
     const float* pop_max;   // workspace: max |pop| over the shard (PDA_HEAD_POP)
     int* tile_flags;        // workspace: [n_user_tiles], set when a row's near-tie band overflowed
+    // ordered sweep (pda_score_topk_ordered_f32): the planes / norms above are stored in VISITING order
+    const int* order;       // [n_items_local] visiting position -> local item id
+    const float* pop_p;     // [n_items_local] pop in visiting order (PDA_HEAD_POP)
+    const float* sufA;      // [n_tiles] max over positions >= 32 t of |pop|            (1 for PDA_HEAD_RAW -> unused, 0)
+    const float* sufB;      // [n_tiles] max over positions >= 32 t of |pop| * ||i||    (||i|| for PDA_HEAD_RAW)
+    unsigned long long* visited;   // workspace: item tiles actually scored, summed over workgroups (statistics)
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float x) {
@@ -95,13 +101,24 @@ __device__ __forceinline__ int swzb(int row) {   // bf16 tile: D/8 16-byte chunk
 // one row per D/8 threads: fp32 -> bf16 hi, bf16 lo, padded norm
 template <int D>
 __global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict__ I, int n, uint16_t* __restrict__ hi,
-                                                        uint16_t* __restrict__ lo, float* __restrict__ nrm, int* __restrict__ nrm_max_bits) {
+                                                        uint16_t* __restrict__ lo, float* __restrict__ nrm, int* __restrict__ nrm_max_bits,
+                                                        const int* __restrict__ order, const float* __restrict__ pop,
+                                                        float* __restrict__ pop_p, int* __restrict__ pos_of, int* __restrict__ bad) {
     constexpr int TPR = D / 8;
     const int row = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
     float ss = 0.f;
     if (row < n) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(I + (size_t)row * D + 8 * e);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(I + (size_t)row * D + 8 * e + 4);
+        int src = row;
+        if (order) {                      // ordered prep: position `row` holds item order[row]
+            src = order[row];
+            if (src < 0 || src >= n) { if (e == 0) atomicOr(bad, 1); src = 0; }
+            else if (e == 0) {
+                if (atomicExch(&pos_of[src], row) != -1) atomicOr(bad, 1);   // not a permutation
+                if (pop) pop_p[row] = pop[src];
+            }
+        }
+        const f32x4 a = *reinterpret_cast<const f32x4*>(I + (size_t)src * D + 8 * e);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(I + (size_t)src * D + 8 * e + 4);
         u32x4 h, l;
         split8(a, b, h, l);
         *reinterpret_cast<u32x4*>(hi + (size_t)row * D + 8 * e) = h;
@@ -115,6 +132,85 @@ __global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict_
         const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
         nrm[row] = v;
         atomicMax(nrm_max_bits, __float_as_int(v));   // v >= 0: integer order == float order
+    }
+}
+
+// per-tile maxima of |pop| and |pop|*||i|| in visiting order, then their suffix maxima (single workgroup)
+__global__ void __launch_bounds__(256) tile_bound_kernel(const float* __restrict__ pop_p, const float* __restrict__ nrm, int n, int n_tiles,
+                                                         float* __restrict__ tA, float* __restrict__ tB) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    float ma = 0.f, mb = 0.f;
+    for (int q = 0; q < 32; ++q) {
+        const int i = t * 32 + q;
+        if (i < n) {
+            const float pa = pop_p ? fabsf(pop_p[i]) : 0.f, pb = pop_p ? pa * nrm[i] * 1.000001f : nrm[i];
+            ma = fmaxf(ma, pa);
+            mb = fmaxf(mb, pb);
+        }
+    }
+    tA[t] = ma;
+    tB[t] = mb;
+}
+__global__ void __launch_bounds__(1024) suffix_max_kernel(float* __restrict__ tA, float* __restrict__ tB, int n_tiles) {
+    __shared__ float sa[1024], sb[1024];
+    const int per = (n_tiles + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, n_tiles);
+    float ma = 0.f, mb = 0.f;
+    for (int t = lo; t < hi; ++t) { ma = fmaxf(ma, tA[t]); mb = fmaxf(mb, tB[t]); }
+    sa[threadIdx.x] = ma;
+    sb[threadIdx.x] = mb;
+    __syncthreads();
+    float ra = 0.f, rb = 0.f;                      // max over the chunks behind mine
+    for (int q = threadIdx.x + 1; q < 1024; ++q) { ra = fmaxf(ra, sa[q]); rb = fmaxf(rb, sb[q]); }
+    for (int t = hi - 1; t >= lo; --t) {
+        ra = fmaxf(ra, tA[t]);
+        rb = fmaxf(rb, tB[t]);
+        tA[t] = ra;
+        tB[t] = rb;
+    }
+}
+
+// History rows rewritten in visiting positions (in-shard item ids -> item_offset + pos_of[id - item_offset]) and sorted
+// again.  One wave per row: bitonic sort in LDS up to 2048 entries, rank sort in global memory beyond.
+__global__ void __launch_bounds__(64) hist_reorder_kernel(const int64_t* __restrict__ indptr, const int32_t* __restrict__ indices,
+                                                          const int* __restrict__ pos_of, int item_offset, int n_items_local,
+                                                          int32_t* __restrict__ out) {
+    __shared__ int buf[2048];
+    const int lane = threadIdx.x;
+    const int64_t b = indptr[blockIdx.x], e = indptr[blockIdx.x + 1];
+    const int64_t L = e - b;
+    if (L <= 0) return;
+    auto mapped = [&](int64_t i) {
+        const int v = indices[b + i];
+        const int loc = v - item_offset;
+        return (loc >= 0 && loc < n_items_local) ? item_offset + pos_of[loc] : v;
+    };
+    if (L <= 2048) {
+        int P = 64;
+        while (P < L) P <<= 1;
+        for (int i = lane; i < P; i += 64) buf[i] = i < L ? mapped(i) : 0x7fffffff;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1)
+            for (int jst = k >> 1; jst > 0; jst >>= 1) {
+                for (int q = lane; q < P / 2; q += 64) {
+                    const int i = ((q & ~(jst - 1)) << 1) | (q & (jst - 1)), p = i | jst;
+                    const int x = buf[i], y = buf[p];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { buf[i] = y; buf[p] = x; }
+                }
+                __syncthreads();
+            }
+        for (int i = lane; i < L; i += 64) out[b + i] = buf[i];
+    } else {
+        for (int64_t i = lane; i < L; i += 64) {
+            const int v = mapped(i);
+            int64_t rank = 0;
+            for (int64_t q = 0; q < L; ++q) {
+                const int w = mapped(q);
+                rank += (w < v || (w == v && q < i)) ? 1 : 0;
+            }
+            out[b + rank] = v;
+        }
     }
 }
 
@@ -184,7 +280,14 @@ __device__ __forceinline__ void compact_band(uint64_t* buf, int* cnt_slot, float
     pda_wave_sync();
 }
 
-template <int D, int HEAD, int ABL = 0>   // ABL: profiling-only (-DPDA_ABLATION): 1 drop candidates, 2 skip the test, 4 no history
+// ORD (ordered sweep with exact early termination): items are visited in the caller's `order` (planes, norms, pop and the
+// history CSR are all stored in visiting positions).  For a row with padded norm ||u|| every item at position >= 32 t has
+//     head(s) <= (1 + max(s,0)) |pop| <= |pop| + ||u|| (|pop| ||i||) <= sufA[t] + ||u|| sufB[t]        (Cauchy-Schwarz)
+// (PDA_HEAD_RAW: s <= ||u|| sufB[t]).  Once that bound is below the row's lower-bound threshold T for all 128 rows of
+// the workgroup, nothing behind t can enter any list and the sweep stops.  Any `order` is correct; popular-first makes
+// the suffix bounds fall quickly, which is how PDA's popularity-weighted head lets most of the catalogue go unscored.
+// Item splits take interleaved tiles (t = split, split + n_splits, ...) so that every split sees the strong items early.
+template <int D, int HEAD, bool ORD, int ABL = 0>   // ABL: profiling-only (-DPDA_ABLATION): 1 drop candidates, 2 skip the test, 4 no history
 __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 aa) {
     const ScoreArgs& a = aa.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -199,15 +302,26 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     float* taul = reinterpret_cast<float*>(cntl + kUserTile);                              // [128]
     int* sortl = reinterpret_cast<int*>(taul + kUserTile);                                 // [128] length of the sorted prefix
     float* dropl = reinterpret_cast<float*>(sortl + kUserTile);                            // [128] highest reach of entries dropped by a band overflow
+    int* votes = reinterpret_cast<int*>(dropl + kUserTile);                                // [4] ORD: wave w sees no use in going on
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int split = blockIdx.x % a.n_splits, utile = blockIdx.x / a.n_splits;
     const int K = a.K;
     const int tiles_total = (a.n_items_local + 31) >> 5;
-    const int tiles_per = (tiles_total + a.n_splits - 1) / a.n_splits;
-    const int t0 = split * tiles_per;
-    const int t1 = min(t0 + tiles_per, tiles_total);
+    // this workgroup's tiles: t0, t0 + stride, ... (nt of them)
+    int t0, stride, nt;
+    if constexpr (ORD) {
+        t0 = split;
+        stride = a.n_splits;
+        nt = t0 < tiles_total ? (tiles_total - t0 + stride - 1) / stride : 0;
+    } else {
+        const int tiles_per = (tiles_total + a.n_splits - 1) / a.n_splits;
+        t0 = split * tiles_per;
+        stride = 1;
+        nt = max(0, min(t0 + tiles_per, tiles_total) - t0);
+    }
+    auto tile_of = [&](int k) { return t0 + k * stride; };
 
     const int row_blk = utile * kUserTile + wave * 32 + j;
     const bool row_ok = row_blk < a.n_users_blk;
@@ -258,7 +372,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
         nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
         const bool adv = nxt < jg1;
-        uint32_t hb = adv ? (1u << ((nxt - jg0) & 31)) : 0u;
+        uint32_t hb = (adv && (!ORD || nxt >= jg0)) ? (1u << ((nxt - jg0) & 31)) : 0u;
         hp += adv ? 1 : 0;
         nxt = adv ? nxt2 : nxt;
         const int64_t idx = hp + 1;
@@ -272,7 +386,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             do {
                 if (nxt < jg1) {
                     const int nn2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
-                    hb |= 1u << ((nxt - jg0) & 31);
+                    if (!ORD || nxt >= jg0) hb |= 1u << ((nxt - jg0) & 31);
                     ++hp;
                     nxt = nn2;
                     nxt2 = (hp + 1 < he) ? a.hist_indices[hp + 1] : 0x7fffffff;
@@ -338,18 +452,20 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             *reinterpret_cast<u32x4*>(Bl + off) = pl[q];
         }
     };
-    auto lane_consts = [&](int t, float& popv, float& niv) {
+    auto lane_consts = [&](int t, float& popv, float& niv, int& idv) {
         const int it = min(t * 32 + j, a.n_items_local - 1);
         niv = aa.I_norm[it];
         popv = 1.0f;
-        if constexpr (HEAD == PDA_HEAD_POP) popv = a.pop[it];
+        if constexpr (HEAD == PDA_HEAD_POP) popv = ORD ? aa.pop_p[it] : a.pop[it];
+        if constexpr (ORD) idv = a.item_offset + aa.order[it];      // the list keeps the item's real id
+        else idv = a.item_offset + t * 32 + j;
     };
 
     // ---- slow path: flagged lanes append (h~, item) to their row's list, lane-parallel --------------------------------
     // `m`: bit 15-r <-> accumulator register r of the previous tile.  Every flagged lane handles its own top flagged
     // register per round (usually one round); row, history bits and s~ are per-lane values, so there is no
     // wave-uniform loop over registers.
-    auto push_flagged = [&](uint32_t m, uint32_t hb, int jg0, float popv, const f32x16& accv) {
+    auto push_flagged = [&](uint32_t m, uint32_t hb, int item_id, float popv, const f32x16& accv) {
         PDA_T0(tq);
         const bool any_hb = __any(hb != 0);
         bool compacted = false;
@@ -377,7 +493,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             float hv = sv;
             if constexpr (HEAD == PDA_HEAD_POP) hv = (sv > 0.0f ? sv + 1.0f : __expf(sv)) * popv;
             const int lrow = wave * 32 + row;
-            const uint64_t key = pda_pack_key(hv, (uint32_t)(jg0 + j));
+            const uint64_t key = pda_pack_key(hv, (uint32_t)item_id);
             for (;;) {
                 bool ov = false;
                 if (p) {
@@ -409,15 +525,17 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t hb_prev = 0, hb_cur = 0;
     float pop_prev = 0.f, pop_cur = 0.f, ni_prev = 0.f, ni_cur = 0.f;
+    int id_prev = 0, id_cur = 0;
     bool ok_prev = false, ok_cur = false;   // lane's item exists
 
-    if (t0 < t1) {
+    if (nt > 0) {
         tile_load(t0, pA_h, pA_l);
-        lane_consts(t0, pop_cur, ni_cur);
+        lane_consts(t0, pop_cur, ni_cur, id_cur);
         tile_store(pA_h, pA_l);
         hb_cur = hist_bits(t0);
         ok_cur = (t0 * 32 + j) < a.n_items_local;
     }
+    if (tid < 4) votes[tid] = 0;
     __syncthreads();
 
     const uint16_t* bhrow = Bh + j * D;
@@ -426,11 +544,13 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 
     // One iteration.  `cur` holds tile t+1 (loaded one iteration ago, stored at the end of this one);
     // `nxt` receives tile t+2.
-    auto iteration = [&](int t, u32x4 (&cur_h)[NLD], u32x4 (&cur_l)[NLD]) {
-        const bool has_next = (t + 1) < t1;
+    auto iteration = [&](int k, u32x4 (&cur_h)[NLD], u32x4 (&cur_l)[NLD]) -> bool {
+        const bool has_next = (k + 1) < nt;
+        const int tn = tile_of(min(k + 1, nt - 1));
         float pop_next, ni_next;
-        tile_load(min(t + 1, t1 - 1), cur_h, cur_l);
-        lane_consts(min(t + 1, t1 - 1), pop_next, ni_next);
+        int id_next;
+        tile_load(tn, cur_h, cur_l);
+        lane_consts(tn, pop_next, ni_next, id_next);
         __builtin_amdgcn_sched_barrier(0);
 
         f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -470,10 +590,28 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         uint32_t hb_next = 0;
         if (has_next) {
             tile_store(cur_h, cur_l);
-            hb_next = hist_bits(t + 1);
+            hb_next = hist_bits(tn);
         }
-        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t - 1) * 32, pop_prev, acc_prev);
+        if (__any(m != 0)) push_flagged(m, hb_prev, id_prev, pop_prev, acc_prev);
+        bool stop = false;
+        if constexpr (ORD) {
+            // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (see the kernel comment)
+            if ((k & 3) == 3 && has_next) {
+                const float sa = aa.sufA[tn], sb = aa.sufB[tn];
+                bool dead = true;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ub = __builtin_fmaf(nu[r] * (1.0f / kEpsScale), sb, sa) * 1.000002f;
+                    dead = dead && (ub < thr[r]);
+                }
+                const bool alldead = __all(dead);
+                if (lane == 0) votes[wave] = alldead ? 1 : 0;
+            }
+        }
         __syncthreads();  // next tile visible
+        if constexpr (ORD) {
+            if ((k & 3) == 3 && has_next) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
+        }
 
         acc_prev = acc_new;
         hb_prev = hb_cur;
@@ -483,10 +621,18 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         hb_cur = hb_next;
         pop_cur = pop_next;
         ni_cur = ni_next;
-        ok_cur = has_next && ((t + 1) * 32 + j) < a.n_items_local;
+        id_prev = id_cur;
+        id_cur = id_next;
+        ok_cur = has_next && (tn * 32 + j) < a.n_items_local;
+        return stop;
     };
-    for (int t = t0; t < t1; ++t) iteration(t, pA_h, pA_l);
-    if (t0 < t1) {   // drain the last tile
+    int n_done = 0;
+    for (int k = 0; k < nt; ++k) {
+        ++n_done;
+        if (iteration(k, pA_h, pA_l)) break;
+    }
+    if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n_done);
+    if (nt > 0) {   // drain the last tile
         uint32_t m = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -495,7 +641,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             m = (m << 1) | ((x > thr[r]) ? 1u : 0u);
         }
         m = ok_prev ? m : 0u;
-        if (__any(m != 0)) push_flagged(m, hb_prev, a.item_offset + (t1 - 1) * 32, pop_prev, acc_prev);
+        if (__any(m != 0)) push_flagged(m, hb_prev, id_prev, pop_prev, acc_prev);
     }
 
     // ---- finalise: exact rescoring of each row's survivors (one lane per candidate, the fmaf chains of v1), exact
@@ -562,18 +708,18 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 #endif
 }
 
-template <int D, int HEAD, int ABL = 0>
+template <int D, int HEAD, bool ORD = false, int ABL = 0>
 int launch_v2(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 16);
+    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 16) + 16;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD, ABL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD, ORD, ABL>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (aa.a.n_users_blk + kUserTile - 1) / kUserTile;
-    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD, ABL>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
+    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD, ORD, ABL>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -591,31 +737,50 @@ extern "C" int pda_debug_counters(unsigned long long* out8, int reset) {
 static inline size_t prep_plane_bytes(int n, int d) { return (((size_t)n * d * 2) + 255) & ~(size_t)255; }
 static inline size_t prep_norm_bytes(int n) { return (((size_t)n * 4) + 255) & ~(size_t)255; }
 
-extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) {
-    // [hi bf16 n*d][lo bf16 n*d][norm f32 n][max norm f32], each section 256-byte aligned
-    return 2 * prep_plane_bytes(n_items_local, d) + prep_norm_bytes(n_items_local) + 256;
+namespace {
+struct PrepLayout {
+    size_t plane, hi, lo, norm, nmax, pop_p, order, pos_of, sufA, sufB, total;
+};
+PrepLayout prep_layout(int n, int d, bool ordered) {
+    PrepLayout L{};
+    L.plane = prep_plane_bytes(n, d);
+    L.hi = 0;
+    L.lo = L.plane;
+    L.norm = 2 * L.plane;
+    L.nmax = L.norm + prep_norm_bytes(n);      // int bits of the max norm at +0, "order is not a permutation" flag at +4
+    L.total = L.nmax + 256;
+    if (ordered) {
+        const size_t tiles = (((size_t)(n + 31) / 32) * 4 + 255) & ~(size_t)255;
+        L.pop_p = L.total;
+        L.order = L.pop_p + prep_norm_bytes(n);
+        L.pos_of = L.order + prep_norm_bytes(n);
+        L.sufA = L.pos_of + prep_norm_bytes(n);
+        L.sufB = L.sufA + tiles;
+        L.total = L.sufB + tiles;
+    }
+    return L;
 }
 
-extern "C" size_t pda_score_topk_workspace_bytes(int n_users_blk) {
-    // [max |pop| f32 (16 B slot)][tile_flags i32 per 128-user tile]
-    const size_t tiles = (size_t)(n_users_blk + kUserTile - 1) / kUserTile;
-    return (16 + tiles * 4 + 255) & ~(size_t)255;
-}
-
-extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream) {
-    if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
-    const size_t plane = prep_plane_bytes(n_items_local, d);
-    uint16_t* hi = reinterpret_cast<uint16_t*>(prep);
-    uint16_t* lo = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(prep) + plane);
-    float* nrm = reinterpret_cast<float*>(reinterpret_cast<char*>(prep) + 2 * plane);
-    int* nmax = reinterpret_cast<int*>(reinterpret_cast<char*>(prep) + 2 * plane + prep_norm_bytes(n_items_local));
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+int run_item_prep(const float* I_shard, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
+    const bool ordered = order != nullptr;
+    const PrepLayout L = prep_layout(n, d, ordered);
+    char* pb = reinterpret_cast<char*>(prep);
+    uint16_t* hi = reinterpret_cast<uint16_t*>(pb + L.hi);
+    uint16_t* lo = reinterpret_cast<uint16_t*>(pb + L.lo);
+    float* nrm = reinterpret_cast<float*>(pb + L.norm);
+    int* nmax = reinterpret_cast<int*>(pb + L.nmax);
+    float* pop_p = ordered && pop ? reinterpret_cast<float*>(pb + L.pop_p) : nullptr;
+    int* pos_of = ordered ? reinterpret_cast<int*>(pb + L.pos_of) : nullptr;
     if (hipMemsetAsync(nmax, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (ordered) {
+        if (hipMemsetAsync(pos_of, 0xFF, (size_t)n * 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
+        if (hipMemcpyAsync(pb + L.order, order, (size_t)n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    }
 #define PDA_PREP(DD)                                                                                         \
     case DD: {                                                                                               \
         constexpr int RPB = 256 / (DD / 8);                                                                  \
-        hipLaunchKernelGGL(item_prep_kernel<DD>, dim3((unsigned)((n_items_local + RPB - 1) / RPB)), dim3(256), 0, s, \
-                           I_shard, n_items_local, hi, lo, nrm, nmax);                                       \
+        hipLaunchKernelGGL(item_prep_kernel<DD>, dim3((unsigned)((n + RPB - 1) / RPB)), dim3(256), 0, s,     \
+                           I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1);              \
         break;                                                                                               \
     }
     switch (d) {
@@ -624,22 +789,30 @@ extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d,
     }
 #undef PDA_PREP
     PDA_CHECK_LAUNCH();
+    if (ordered) {
+        const int n_tiles = (n + 31) / 32;
+        float* tA = reinterpret_cast<float*>(pb + L.sufA);
+        float* tB = reinterpret_cast<float*>(pb + L.sufB);
+        hipLaunchKernelGGL(tile_bound_kernel, dim3((unsigned)((n_tiles + 255) / 256)), dim3(256), 0, s, pop_p, nrm, n, n_tiles, tA, tB);
+        PDA_CHECK_LAUNCH();
+        hipLaunchKernelGGL(suffix_max_kernel, dim3(1), dim3(1024), 0, s, tA, tB, n_tiles);
+        PDA_CHECK_LAUNCH();
+    }
     return PDA_OK;
 }
 
-extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
-                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
-                                          const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
-                                          int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream) {
+int run_score_prepped(const float* U, const float* I_shard, const void* prep, bool ordered, const float* pop_shard,
+                      const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                      const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
+                      int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s) {
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_TOPK_CAP - 4) return PDA_ERR_ARG;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
     if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
-    if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
+    if (hist_indptr && (!hist_indices || (ordered && !hist_indices_ord))) return PDA_ERR_ARG;
     if (n_splits <= 0) n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const size_t plane = prep_plane_bytes(n_items_local, d);
+    const PrepLayout L = prep_layout(n_items_local, d, ordered);
     const char* pb = reinterpret_cast<const char*>(prep);
     int* ws = reinterpret_cast<int*>(workspace);
     if (hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
@@ -647,34 +820,112 @@ extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, 
         hipLaunchKernelGGL(pop_max_kernel, dim3(64), dim3(256), 0, s, pop_shard, n_items_local, ws);
         PDA_CHECK_LAUNCH();
     }
-    ScoreArgs2 aa{{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, n_users_blk, item_offset, n_items_local,
-                   hist_row_mode, K, n_splits, nullptr},
-                  reinterpret_cast<const uint16_t*>(pb), reinterpret_cast<const uint16_t*>(pb + plane),
-                  reinterpret_cast<const float*>(pb + 2 * plane),
-                  reinterpret_cast<const float*>(pb + 2 * plane + prep_norm_bytes(n_items_local)),
-                  reinterpret_cast<const float*>(ws), ws + 4};
+    ScoreArgs2 aa{{U, I_shard, pop_shard, users, hist_indptr, ordered ? hist_indices_ord : hist_indices, out_keys, n_users_blk,
+                   item_offset, n_items_local, hist_row_mode, K, n_splits, nullptr},
+                  reinterpret_cast<const uint16_t*>(pb + L.hi), reinterpret_cast<const uint16_t*>(pb + L.lo),
+                  reinterpret_cast<const float*>(pb + L.norm), reinterpret_cast<const float*>(pb + L.nmax),
+                  reinterpret_cast<const float*>(ws), ws + 4,
+                  ordered ? reinterpret_cast<const int*>(pb + L.order) : nullptr,
+                  ordered ? reinterpret_cast<const float*>(pb + L.pop_p) : nullptr,
+                  ordered ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr,
+                  ordered ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
+                  reinterpret_cast<unsigned long long*>(ws + 2)};
     int rc = PDA_ERR_UNSUPPORTED;
 #ifdef PDA_ABLATION
     if (const char* e = getenv("PDA_ABLATE")) {
-        if (d == 128 && head == PDA_HEAD_POP) switch (atoi(e)) {
-            case 1: return launch_v2<128, PDA_HEAD_POP, 1>(aa, s);
-            case 3: return launch_v2<128, PDA_HEAD_POP, 3>(aa, s);
-            case 7: return launch_v2<128, PDA_HEAD_POP, 7>(aa, s);
-            case 4: return launch_v2<128, PDA_HEAD_POP, 4>(aa, s);
+        if (d == 128 && head == PDA_HEAD_POP && !ordered) switch (atoi(e)) {
+            case 1: return launch_v2<128, PDA_HEAD_POP, false, 1>(aa, s);
+            case 3: return launch_v2<128, PDA_HEAD_POP, false, 3>(aa, s);
+            case 7: return launch_v2<128, PDA_HEAD_POP, false, 7>(aa, s);
+            case 4: return launch_v2<128, PDA_HEAD_POP, false, 4>(aa, s);
             default: break;
         }
     }
 #endif
-#define PDA_V2(DD) \
-    case DD: rc = head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s); break;
+#define PDA_V2(DD)                                                                                                           \
+    case DD:                                                                                                                 \
+        if (ordered) rc = head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP, true>(aa, s) : launch_v2<DD, PDA_HEAD_RAW, true>(aa, s); \
+        else rc = head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s);            \
+        break;
     switch (d) {
         PDA_V2(64) PDA_V2(128) PDA_V2(256)
         default: return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_V2
     if (rc != PDA_OK) return rc;
-    // exact recomputation of the (normally zero) user tiles whose near-tie band overflowed
+    // exact recomputation of the (normally zero) user tiles whose near-tie band overflowed: natural item order, the
+    // caller's original history
     ScoreArgs v1 = aa.a;
+    v1.hist_indices = hist_indices;
     v1.tile_flags = ws + 4;
     return pda_topk::launch_score_v1(v1, d, head, s);
+}
+}  // namespace
+
+extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) {
+    // [hi bf16 n*d][lo bf16 n*d][norm f32 n][max norm f32], each section 256-byte aligned
+    return prep_layout(n_items_local, d, false).total;
+}
+
+extern "C" size_t pda_item_prep_ordered_bytes(int n_items_local, int d) {
+    // ... + [pop in visiting order f32 n][order i32 n][position of item i32 n][suffix bounds 2 x f32 n_tiles]
+    return prep_layout(n_items_local, d, true).total;
+}
+
+extern "C" size_t pda_score_topk_workspace_bytes(int n_users_blk) {
+    // [max |pop| f32][pad][u64 item tiles scored, summed over workgroups][tile_flags i32 per 128-user tile]
+    const size_t tiles = (size_t)(n_users_blk + kUserTile - 1) / kUserTile;
+    return (16 + tiles * 4 + 255) & ~(size_t)255;
+}
+
+extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream) {
+    if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_item_prep(I_shard, nullptr, nullptr, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pda_item_prep_ordered_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local,
+                                         int d, void* prep, void* stream) {
+    if (!I_shard || !order || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_item_prep(I_shard, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pda_item_prep_ordered_check(const void* prep, int n_items_local, int d, void* stream) {
+    if (!prep || n_items_local <= 0) return PDA_ERR_ARG;
+    const PrepLayout L = prep_layout(n_items_local, d, true);
+    int bad = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&bad, reinterpret_cast<const char*>(prep) + L.nmax + 4, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return PDA_ERR_LAUNCH;
+    return bad ? PDA_ERR_ARG : PDA_OK;
+}
+
+extern "C" int pda_hist_reorder(const void* prep, int n_items_local, int d, int item_offset, const int64_t* hist_indptr,
+                                const int32_t* hist_indices, int n_rows, int32_t* out_indices, void* stream) {
+    if (!prep || !hist_indptr || !hist_indices || !out_indices || n_items_local <= 0 || n_rows < 0 || item_offset < 0) return PDA_ERR_ARG;
+    if (n_rows == 0) return PDA_OK;
+    const PrepLayout L = prep_layout(n_items_local, d, true);
+    hipLaunchKernelGGL(hist_reorder_kernel, dim3((unsigned)n_rows), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), hist_indptr,
+                       hist_indices, reinterpret_cast<const int*>(reinterpret_cast<const char*>(prep) + L.pos_of), item_offset,
+                       n_items_local, out_indices);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
+                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                                          const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
+                                          int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream) {
+    return run_score_prepped(U, I_shard, prep, false, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
+                             hist_indices, nullptr, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
+                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                                          const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
+                                          int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
+                                          void* stream) {
+    return run_score_prepped(U, I_shard, prep, true, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
+                             hist_indices, hist_indices_ord, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             reinterpret_cast<hipStream_t>(stream));
 }

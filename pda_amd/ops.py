@@ -94,6 +94,73 @@ def item_prep(I_shard: torch.Tensor) -> torch.Tensor:
     return buf
 
 
+_ORDER_CACHE = {}      # id(pop or table) -> (weakref, _version, order i32[n])
+_PREP_ORD_CACHE = {}   # id(I_shard) -> (weakref(I), I._version, order, pop weakref|None, pop _version, prep buffer)
+
+
+def visiting_order(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor]) -> torch.Tensor:
+    """The order in which the ordered sweep (pda_score_topk_ordered_f32) visits the shard: most popular first
+    (PDA head; does not depend on the weights, so the reordered history survives training), largest norm first (raw
+    head).  Only a heuristic -- any permutation gives the same result -- hence computed here, with torch."""
+    src = pop_shard if pop_shard is not None else I_shard
+    hit = _ORDER_CACHE.get(id(src))
+    if hit is not None and hit[0]() is src and hit[1] == src._version:
+        return hit[2]
+    key = pop_shard.abs() if pop_shard is not None else torch.linalg.vector_norm(I_shard, dim=1)
+    order = torch.argsort(key, descending=True, stable=True).to(torch.int32)
+    for k in [k for k, v in _ORDER_CACHE.items() if v[0]() is None]:
+        del _ORDER_CACHE[k]
+    _ORDER_CACHE[id(src)] = (weakref.ref(src), src._version, order)
+    return order
+
+
+def item_prep_ordered(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], order: Optional[torch.Tensor] = None):
+    """pda_item_prep_ordered_f32, cached per (weight version, pop version, order).  Returns (prep buffer, order)."""
+    lib = _lib.load()
+    if order is None:
+        order = visiting_order(I_shard, pop_shard)
+    n, d = I_shard.shape
+    hit = _PREP_ORD_CACHE.get(id(I_shard))
+    buf = None
+    if hit is not None and hit[0]() is I_shard:
+        buf = hit[5]
+        same_pop = (hit[3] is None and pop_shard is None) or (hit[3] is not None and hit[3]() is pop_shard and hit[4] == pop_shard._version)
+        if hit[1] == I_shard._version and hit[2] is order and same_pop:
+            return buf, order
+    if buf is None:
+        buf = torch.empty(lib.pda_item_prep_ordered_bytes(n, d), dtype=torch.uint8, device=I_shard.device)
+    order = _need(order, torch.int32, "order")
+    if order.numel() != n:
+        raise ValueError("order must have one entry per local item row")
+    check(lib.pda_item_prep_ordered_f32(ptr(I_shard), ptr(pop_shard), ptr(order), n, d, ptr(buf), stream_ptr()),
+          "pda_item_prep_ordered_f32")
+    for k in [k for k, v in _PREP_ORD_CACHE.items() if v[0]() is None]:
+        del _PREP_ORD_CACHE[k]
+    _PREP_ORD_CACHE[id(I_shard)] = (weakref.ref(I_shard), I_shard._version, order,
+                                    weakref.ref(pop_shard) if pop_shard is not None else None,
+                                    pop_shard._version if pop_shard is not None else 0, buf)
+    return buf, order
+
+
+def check_order(prep_ord: torch.Tensor, n: int, d: int):
+    """Synchronising: raises if the order given to item_prep_ordered was not a permutation of 0..n-1."""
+    check(_lib.load().pda_item_prep_ordered_check(ptr(prep_ord), n, d, stream_ptr()), "pda_item_prep_ordered_check")
+
+
+def hist_reordered(hist: "HistoryCSR", prep_ord: torch.Tensor, order: torch.Tensor, item_offset: int, n: int, d: int) -> torch.Tensor:
+    """pda_hist_reorder, cached on the HistoryCSR per visiting order (the order object, not its contents)."""
+    cache = hist.__dict__.setdefault("_ord_cache", [])
+    for o, off, ind in cache:
+        if o is order and off == item_offset:
+            return ind
+    out = torch.empty_like(hist.indices)
+    check(_lib.load().pda_hist_reorder(ptr(prep_ord), n, d, item_offset, ptr(hist.indptr), ptr(hist.indices),
+                                       hist.indptr.numel() - 1, ptr(out), stream_ptr()), "pda_hist_reorder")
+    del cache[:-3]
+    cache.append((order, item_offset, out))
+    return out
+
+
 def mark_modified(*tensors):
     """Tell torch that a kernel wrote these tensors through raw pointers: bumps tensor._version, which is what keys
     the item_prep cache (and autograd's in-place checks)."""
@@ -116,9 +183,21 @@ def score_impl(d: int, K: int, item_hi: int) -> str:
 TOPK_CAP_V2 = _lib.TOPK_CAP - 4
 
 
+def prune_default(head: int) -> bool:
+    """Ordered sweep with early termination: on for the popularity-weighted head (where the bound bites), off for the
+    raw head.  PDA_SCORE_PRUNE=0|1 forces it.  Results are identical either way."""
+    import os
+    forced = os.environ.get("PDA_SCORE_PRUNE", "")
+    if forced in ("0", "1"):
+        return forced == "1"
+    return head == HEAD_POP
+
+
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
-                    item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None) -> torch.Tensor:
-    """pda_score_topk_f32 / pda_score_topk_prepped_f32 -> packed keys int64[n_splits, Bu, K] (uint64 bit patterns), best first."""
+                    item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None,
+                    prune: Optional[bool] = None, stats: Optional[dict] = None) -> torch.Tensor:
+    """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 -> packed keys
+    int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All three return the same keys."""
     lib = _lib.load()
     U = _need(U, torch.float32, "U")
     I_shard = _need(I_shard, torch.float32, "I_shard")
@@ -138,6 +217,20 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     elif out.shape != (n_splits, nu, K) or out.dtype != torch.int64:
         raise ValueError("out must be int64 [n_splits, Bu, K]")
     impl = impl or score_impl(d, K, item_offset + nloc)
+    if prune is None:
+        prune = prune_default(head)
+    if impl == "v2" and prune:
+        prep, order = item_prep_ordered(I_shard, pop_shard if head == HEAD_POP else None)
+        hist_ord = hist_reordered(hist, prep, order, item_offset, nloc, d) if hist else None
+        ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)
+        check(lib.pda_score_topk_ordered_f32(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
+                                             nloc, d, ptr(hist.indptr) if hist else None,
+                                             ptr(hist.indices) if hist else None, ptr(hist_ord), hist.mode if hist else 0,
+                                             K, head, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk_ordered_f32")
+        if stats is not None:            # device scalar (no sync here): item tiles scored, summed over workgroups
+            stats["tiles_scored"] = ws[8:16].view(torch.int64)
+            stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)
+        return out
     if impl == "v2":
         prep = item_prep(I_shard)
         ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)   # per call: re-entrant

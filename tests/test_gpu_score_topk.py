@@ -16,11 +16,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord"])
 def impl(request, monkeypatch):
-    """Every test runs against both kernel generations: v1 = exact fp32 MFMA, v2 = bf16x3 pre-filter + exact
-    rescoring (pda_score_topk_v2.hip).  They must be indistinguishable."""
-    monkeypatch.setenv("PDA_SCORE_IMPL", request.param)
+    """Every test runs against all scoring paths: v1 = exact fp32 MFMA, v2 = bf16x3 pre-filter + exact rescoring
+    (pda_score_topk_v2.hip), v2ord = v2 visiting the catalogue strongest-bound-first with early termination
+    (pda_score_topk_ordered_f32, forced on for BOTH heads here).  They must be indistinguishable."""
+    monkeypatch.setenv("PDA_SCORE_IMPL", "v1" if request.param == "v1" else "v2")
+    monkeypatch.setenv("PDA_SCORE_PRUNE", "1" if request.param == "v2ord" else "0")
     return request.param
 
 
@@ -283,7 +285,7 @@ def test_argument_errors(dev):
 
 @pytest.mark.parametrize("d", [64, 128, 256])
 @pytest.mark.parametrize("head", [0, 1])
-def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head):
+def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head, impl):
     """The bf16x3 pre-filter may only ever over-approximate: packed keys (scores AND order) identical to the exact
     fp32-MFMA kernel, including adversarial magnitudes (large norms => large absolute error bound)."""
     from pda_amd import ops
@@ -300,7 +302,68 @@ def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head):
                 torch.from_numpy(pop).to(dev) if head else None, h, 0)
         k1 = ops.score_topk_keys(*args, n_splits=2, impl="v1")
         k2 = ops.score_topk_keys(*args, n_splits=2, impl="v2")
+        if impl == "v2ord":              # the ordered sweep gives its splits interleaved tiles: compare after the merge
+            k1, k2 = ops.topk_merge(k1, want="keys"), ops.topk_merge(k2, want="keys")
         assert torch.equal(k1, k2), (d, head, scale, int((k1 != k2).sum()))
+
+
+@pytest.mark.parametrize("head", [0, 1])
+@pytest.mark.parametrize("order_kind", ["default", "random", "reverse", "identity"])
+def test_ordered_sweep_is_exact_for_any_order_and_really_stops(dev, head, order_kind):
+    """pda_score_topk_ordered_f32: any visiting order returns the keys of the exact kernel; with a popularity-skewed
+    catalogue and the popular-first order most tiles are never scored (the workspace counter says so)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(4242 + head)
+    nU, nI, d, K = 300, 20000, 64, 50
+    U = (rng.standard_normal((nU, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.1).astype(np.float32)
+    cnt = 1.0 / (1.0 + rng.permutation(nI))                       # Zipf(1) interaction counts
+    pop = ((cnt - cnt.min()) / (cnt.max() - cnt.min())) ** 0.22
+    pop = pop.astype(np.float32)
+    if head == 0:
+        I *= (0.2 + pop[:, None] * 3.0)                           # raw head: popular items carry larger norms
+    hist = [rng.choice(nI, 20, replace=False, p=cnt / cnt.sum()).astype(np.int32) for _ in range(nU)]
+    ip, ix = csr(hist)
+    h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    Ut, It, pt = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.from_numpy(pop).to(dev)
+    users = torch.arange(nU, dtype=torch.int32, device=dev)
+    ref = ops.topk_merge(ops.score_topk_keys(Ut, It, users, K, head, pt if head else None, h, impl="v1"), want="keys")
+    lib = ops._lib.load()
+    if order_kind == "default":
+        order = None
+    elif order_kind == "random":
+        order = torch.from_numpy(rng.permutation(nI).astype(np.int32)).to(dev)
+    elif order_kind == "reverse":
+        order = torch.argsort(pt if head else It.norm(dim=1)).to(torch.int32)   # weakest first: never stops early
+    else:
+        order = torch.arange(nI, dtype=torch.int32, device=dev)
+    prep, order = ops.item_prep_ordered(It, pt if head else None, order)
+    ops.check_order(prep, nI, d)
+    hord = ops.hist_reordered(h, prep, order, 0, nI, d)
+    for splits in (1, 3):
+        keys = torch.empty((splits, nU, K), dtype=torch.int64, device=dev)
+        ws = torch.empty(lib.pda_score_topk_workspace_bytes(nU), dtype=torch.uint8, device=dev)
+        ops.check(lib.pda_score_topk_ordered_f32(ops.ptr(Ut), ops.ptr(It), ops.ptr(prep), ops.ptr(pt) if head else None,
+                                                 ops.ptr(users), nU, 0, nI, d, ops.ptr(h.indptr), ops.ptr(h.indices),
+                                                 ops.ptr(hord), h.mode, K, head, splits, ops.ptr(keys), ops.ptr(ws),
+                                                 ops.stream_ptr()), "ordered")
+        got = ops.topk_merge(keys, want="keys")
+        assert torch.equal(got, ref), (order_kind, splits, int((got != ref).sum()))
+        scored = int(ws[8:16].view(torch.int64)[0])
+        dense = ((nI + 31) // 32) * ((nU + 127) // 128)
+        if order_kind == "default" and head == 1:                  # (Cauchy-Schwarz alone rarely bites on the raw head)
+            assert scored < 0.25 * dense, (scored, dense)          # the stop really happens
+        if order_kind == "reverse":
+            assert scored >= dense - 4 * splits * ((nU + 127) // 128), (scored, dense)
+
+
+def test_ordered_prep_rejects_a_non_permutation(dev):
+    from pda_amd import ops
+    It = torch.randn(640, 64, device=dev)
+    bad = torch.zeros(640, dtype=torch.int32, device=dev)
+    prep, _ = ops.item_prep_ordered(It, None, bad)
+    with pytest.raises(ops._lib.PdaHipError):
+        ops.check_order(prep, 640, 64)
 
 
 def test_item_prep_cache_follows_weight_updates(dev):
