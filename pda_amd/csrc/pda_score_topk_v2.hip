@@ -590,7 +590,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         uint32_t hb_next = 0;
         if (has_next) {
             tile_store(cur_h, cur_l);
+            PDA_T0(th);
             hb_next = hist_bits(tn);
+            PDA_T1(th, dbg_entries);
         }
         if (__any(m != 0)) push_flagged(m, hb_prev, id_prev, pop_prev, acc_prev);
         bool stop = false;
@@ -656,31 +658,45 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         const bool valid = lane < c;
         const int item = valid ? pda_key_item(buf[lane]) : a.item_offset;
         const int urow = __builtin_amdgcn_readlane(uid, rr);
-        const float* up = a.U + (size_t)urow * D;
+        // user row: wave-uniform address -> scalar loads (constant address space; U is read-only for the kernel).
+        // candidate row: the whole row (or 128 floats of it) in flight at once -- the gather latency is what this loop pays.
+        typedef const __attribute__((address_space(4))) float* cfp;
+        cfp up = (cfp)(a.U + (size_t)urow * D);
         const float* ip = a.I + (size_t)(item - a.item_offset) * D;
         float c0 = 0.f, c1 = 0.f;
-#pragma unroll 2
-        for (int c8 = 0; c8 < D / 8; c8 += 2) {
-            const f32x4 u0 = *reinterpret_cast<const f32x4*>(up + 8 * c8), u1 = *reinterpret_cast<const f32x4*>(up + 8 * c8 + 4);
-            const f32x4 i0 = *reinterpret_cast<const f32x4*>(ip + 8 * c8), i1 = *reinterpret_cast<const f32x4*>(ip + 8 * c8 + 4);
-            const f32x4 u2 = *reinterpret_cast<const f32x4*>(up + 8 * c8 + 8), u3 = *reinterpret_cast<const f32x4*>(up + 8 * c8 + 12);
-            const f32x4 i2 = *reinterpret_cast<const f32x4*>(ip + 8 * c8 + 8), i3 = *reinterpret_cast<const f32x4*>(ip + 8 * c8 + 12);
+        float popc = 1.0f;
+        if constexpr (HEAD == PDA_HEAD_POP) popc = a.pop[item - a.item_offset];   // issued with the row gather, not after the chain
+        constexpr int CH = D > 128 ? 128 : D;          // floats per gather step
+#pragma unroll 1
+        for (int base = 0; base < D; base += CH) {
+            f32x4 iv[CH / 4];
 #pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                c0 = __builtin_fmaf(u0[sidx], i0[sidx], c0);
-                c0 = __builtin_fmaf(u1[sidx], i1[sidx], c0);
-            }
+            for (int q = 0; q < CH / 4; ++q) iv[q] = *reinterpret_cast<const f32x4*>(ip + base + 4 * q);
 #pragma unroll
-            for (int sidx = 0; sidx < 4; ++sidx) {
-                c1 = __builtin_fmaf(u2[sidx], i2[sidx], c1);
-                c1 = __builtin_fmaf(u3[sidx], i3[sidx], c1);
+            for (int c8 = 0; c8 < CH / 8; c8 += 2) {
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    c0 = __builtin_fmaf(up[base + 8 * c8 + sidx], iv[2 * c8][sidx], c0);
+                    c0 = __builtin_fmaf(up[base + 8 * c8 + 4 + sidx], iv[2 * c8 + 1][sidx], c0);
+                }
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    c1 = __builtin_fmaf(up[base + 8 * c8 + 8 + sidx], iv[2 * c8 + 2][sidx], c1);
+                    c1 = __builtin_fmaf(up[base + 8 * c8 + 12 + sidx], iv[2 * c8 + 3][sidx], c1);
+                }
             }
         }
         float sc = c0 + c1;
-        if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * a.pop[item - a.item_offset];
+        if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * popc;
         const uint64_t key = valid ? pda_pack_key(sc, (uint32_t)item) : (uint64_t)(63 - lane);
+        // rank = number of better keys.  The exact keys go back into the row's LDS slots and every lane reads all of them
+        // with broadcast (uniform-address) LDS reads: independent loads, no v_readlane -> SGPR -> VALU chain per entry.
+        uint64_t* xbuf = my_lists + rr * kCap2;
+        if (lane < kCap2) xbuf[lane] = key;                 // lanes >= c hold distinct tiny pad keys: never above a real one
+        pda_wave_sync();
         int rank = 0;
-        for (int jj = 0; jj < c; ++jj) rank += (pda_readlane_u64(key, jj) > key) ? 1 : 0;
+#pragma unroll
+        for (int jj = 0; jj < kCap2; ++jj) rank += (xbuf[jj] > key) ? 1 : 0;
         uint64_t* out = a.out_keys + ((size_t)split * a.n_users_blk + rb) * K;
         if (valid && rank < K) out[rank] = key;
         if (lane >= c && lane < K) out[lane] = 0ull;

@@ -4,6 +4,7 @@ sys.path.insert(0, '.')
 from pda_amd import ops, synthetic
 wl = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 Bu = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
+NS = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 dev = torch.device('cuda')
 W = synthetic.make_workload(wl, dev)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
@@ -13,14 +14,14 @@ def run(prune, head, n=3):
     pop = W.pop_last if head else None
     st = {}
     t0 = time.perf_counter()
-    k = ops.score_topk_keys(W.U, W.I, blocks[0], 50, head, pop, hist, prune=prune, stats=st)   # warm-up incl. prep / hist reorder
+    k = ops.score_topk_keys(W.U, W.I, blocks[0], 50, head, pop, hist, prune=prune, stats=st, n_splits=NS if prune else 0)   # warm-up incl. prep / hist reorder
     torch.cuda.synchronize()
     first = time.perf_counter() - t0
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(n):
         for b in blocks:
-            k = ops.score_topk_keys(W.U, W.I, b, 50, head, pop, hist, prune=prune, stats=st)
+            k = ops.score_topk_keys(W.U, W.I, b, 50, head, pop, hist, prune=prune, stats=st, n_splits=NS if prune else 0)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / (n * len(blocks))
     frac = float(st["tiles_scored"][0]) / st["tiles_dense"] if "tiles_scored" in st else 1.0
