@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--train-steps", type=int, default=2048)
     p.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
+    p.add_argument("--train-sharded", action="store_true",
+                   help="N>1 only: also time the item-parallel SGD step (pda_amd.dist.ItemShardedBPR); off by default -- "
+                        "it is latency-bound by its per-step all-gather and buys capacity, not speed")
     return p.parse_args()
 
 
@@ -251,6 +254,38 @@ def bench_train(args, dev):
     return out, W, batches
 
 
+def bench_train_sharded(args, rank, world, dev):
+    """Item-parallel SGD on BASELINE config 2 across `world` ranks: global batch 2048, B_local = 2048 / world, positives
+    and negatives inside the rank's item slice, ONE all-gather of (user grads, ids, loss shares) per step."""
+    import torch.distributed as dist
+    from pda_amd import synthetic
+    from pda_amd.dist import ItemShardedBPR, ShardSampler, shard_range
+    W = synthetic.make_workload("c2" if args.workload != "tiny" else "tiny", dev)
+    Bg = 2048 if args.workload != "tiny" else 512
+    Bl, NB, steps = Bg // world, 32, 256
+    lo, hi = shard_range(W.n_items, rank, world)
+    tr = ItemShardedBPR(W.U, W.I[lo:hi].clone(), lo, regs=1e-2, lr=1e-2, global_batch=Bg, rank=rank, world=world)
+    smp = ShardSampler(W.hist_indptr, W.hist_indices, lo, hi, Bl, seed=2020, rank=rank, train_slots=W.hist_slots,
+                       pop_matrix=W.pop_train)
+    batches = [smp(s) for s in range(NB)]
+    for b in batches[:4]:
+        tr.step(*b)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for s_ in range(steps):
+        loss = tr.step(*batches[s_ % NB])
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    return {"triplets_per_s": Bg * steps / dt, "us_per_step": dt / steps * 1e6, "global_batch": Bg, "steps": steps,
+            "exchange_bytes_per_rank_per_step": Bl * (W.d + 4) * 4, "last_loss": float(loss[0]),
+            "note": "eager; one all_gather_into_tensor per step; strong scaling of one 2048-triplet step"}
+
+
 def cpu_baseline(args, ev_res, train_pack):
     """Reference op sequence on the host cores (torch CPU fp32), bounded sample.  kind = "port"."""
     from oracle import cpu_baseline as cb
@@ -303,6 +338,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
     ev = bench_eval(args, rank, world, dev)
+    sharded_train = bench_train_sharded(args, rank, world, dev) if (world > 1 and args.train_sharded) else None
     train_pack = None
     if world == 1 and not args.no_train:
         train_pack = bench_train(args, dev)
@@ -324,7 +360,7 @@ def main():
                        "users_per_step": ev["Bu"], "sharding": "item-parallel x%d, RCCL all-gather of partial top-K" % world,
                        "train_nnz": W.n_train},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "ordered_sweep": ev["ordered"],
-            "train": train_pack[0] if train_pack else None,
+            "train": train_pack[0] if train_pack else ({"item_parallel_sgd": sharded_train} if sharded_train else None),
         }
         print(json.dumps(line))
     if world > 1:

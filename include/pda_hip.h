@@ -46,6 +46,7 @@ extern "C" {
 #define PDA_UPD_NONE 0       /* loss + per-occurrence gradients only (parity harness)                        */
 #define PDA_UPD_SGD_FUSED 1  /* north_star: in-kernel row update, atomics on item rows                       */
 #define PDA_UPD_DENSE_GRAD 2 /* atomically sum gradients into dense gU/gI (feeds pda_adam_dense_sweep_f32)  */
+#define PDA_UPD_SGD_ITEMS 3  /* internal: what pda_bpr_step_shard_f32 runs (item rows updated, user grads out)   */
 
 #define PDA_MAX_K 64
 #define PDA_TOPK_CAP 60 /* per-user on-chip candidate slots (>= K) */
@@ -155,6 +156,24 @@ int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* po
                      const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
                      int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU, float* gI,
                      float* loss_acc, void* stream);
+
+/* Item-parallel training (north_star "each rank owns an item-embedding slice, BPR negatives sampled
+ * locally"): rank r holds the item rows [item_offset, item_offset + n_local) and a replica of U.  Its sub-batch has
+ * positives AND negatives inside that slice (global ids).  pda_bpr_step_shard_f32 applies the SGD update to the local
+ * item rows (like PDA_UPD_SGD_FUSED), leaves U untouched and writes the per-triplet user gradient to g_user [B_local, d]
+ * (row stride g_stride floats, >= d, multiple of 4);
+ * after ONE all-gather of (users, g_user) every rank calls pda_apply_user_grads_f32 on all R*B_local rows, which keeps
+ * the replicas of U identical.  mean_div = the GLOBAL batch size (the 1/B of the BPR mean, MF/model_api.py:114),
+ * reg_div as in pda_bpr_step_f32; loss_acc receives this rank's share of (loss, mf, reg): their sum over ranks is the
+ * loss of the global batch.  R shard steps + the apply equal one pda_bpr_step_f32(PDA_UPD_SGD_FUSED) on the concatenated
+ * batch (tests/test_gpu_bpr_step.py).  g rows may be strided (g_stride floats, >= d) so that the packed exchange buffer
+ * can be applied in place.  No reference counterpart (single device there). */
+int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_offset, const int32_t* users, const int32_t* pos,
+                           const int32_t* neg, const float* pos_pop, const float* neg_pop, int B_local, int d, float regs,
+                           float reg_div, float mean_div, float lr, float* g_user, int g_stride, float* loss_acc,
+                           void* stream);
+int pda_apply_user_grads_f32(float* U, const int32_t* users, const float* g, int n, int d, int g_stride, float lr,
+                             void* stream);
 
 /* Reorder one batch (all five arrays, in place) so that equal positives are adjacent: pda_bpr_step_f32 then sums each
  * run on chip before touching HBM.  Purely a performance aid (order inside a batch has no meaning); B <= 4096. */

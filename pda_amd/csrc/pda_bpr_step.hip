@@ -32,6 +32,8 @@ struct StepArgs {
     float reg_c;  // regs / reg_div
     float lr;
     int mode;
+    int item_offset;   // pos / neg are global item ids; row = id - item_offset in `I` (an item shard)
+    int g_stride;      // floats between consecutive g_user rows (>= D)
 };
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -59,14 +61,14 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
     const int t = blockIdx.x * TPB + g;
     const bool active = t < a.B;
     const bool with_pop = a.pos_pop != nullptr;
-    const bool scatter = a.mode == PDA_UPD_SGD_FUSED || a.mode == PDA_UPD_DENSE_GRAD;
+    const bool scatter = a.mode == PDA_UPD_SGD_FUSED || a.mode == PDA_UPD_DENSE_GRAD || a.mode == PDA_UPD_SGD_ITEMS;
 
     float maxi = 0.f, sq = 0.f;
     int p = -1;
     float* ptarget = nullptr;
     if (active) {
-        const int u = a.users[t], n = a.neg[t];
-        p = a.pos[t];
+        const int u = a.users[t], n = a.neg[t] - a.item_offset;
+        p = a.pos[t] - a.item_offset;
         float* up = a.U + (size_t)u * D + 4 * e;
         float* pp = a.I + (size_t)p * D + 4 * e;
         float* np_ = a.I + (size_t)n * D + 4 * e;
@@ -109,14 +111,21 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
             atomic_add4(np_, dne * nlr);  // negatives are uniform over the catalogue: duplicates are rare
             dpe = dpe * nlr;
             ptarget = pp;
+        } else if (a.mode == PDA_UPD_SGD_ITEMS) {
+            // item-parallel training: this rank's item rows take their update here; the user gradient leaves through
+            // g_user for the exchange (every rank then applies all of them: pda_apply_user_grads_f32)
+            const float nlr = -a.lr;
+            atomic_add4(np_, dne * nlr);
+            dpe = dpe * nlr;
+            ptarget = pp;
         } else if (a.mode == PDA_UPD_DENSE_GRAD) {
             atomic_add4(a.gU + (size_t)u * D + 4 * e, due);
             atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
             ptarget = a.gI + (size_t)p * D + 4 * e;
         }
         if (scatter) *reinterpret_cast<f32x4*>(s_dpe + g * D + 4 * e) = dpe;
-        if (a.g_user) {
-            *reinterpret_cast<f32x4*>(a.g_user + (size_t)t * D + 4 * e) = due;
+        if (a.g_user) *reinterpret_cast<f32x4*>(a.g_user + (size_t)t * a.g_stride + 4 * e) = due;
+        if (a.g_pos) {
             *reinterpret_cast<f32x4*>(a.g_pos + (size_t)t * D + 4 * e) = dpe_raw;
             *reinterpret_cast<f32x4*>(a.g_neg + (size_t)t * D + 4 * e) = dne;
         }
@@ -257,7 +266,7 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
     if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
     if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
     StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
-               B, 1.0f / (float)B, regs / reg_div, lr, update_mode};
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);
@@ -266,6 +275,49 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
         case 256: return launch_step<256>(a, s);
         default: return PDA_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_offset, const int32_t* users, const int32_t* pos,
+                                      const int32_t* neg, const float* pos_pop, const float* neg_pop, int B_local, int d,
+                                      float regs, float reg_div, float mean_div, float lr, float* g_user, int g_stride,
+                                      float* loss_acc, void* stream) {
+    if (!U || !I_shard || !users || !pos || !neg || !g_user || B_local <= 0 || reg_div <= 0.f || mean_div <= 0.f || item_offset < 0)
+        return PDA_ERR_ARG;
+    if (g_stride < d || (g_stride & 3)) return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    StepArgs a{const_cast<float*>(U), I_shard, users, pos, neg, pos_pop, neg_pop, g_user, nullptr, nullptr, nullptr, nullptr,
+               loss_acc, B_local, 1.0f / mean_div, regs / reg_div, lr, PDA_UPD_SGD_ITEMS, item_offset, g_stride};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (d) {
+        case 32: return launch_step<32>(a, s);
+        case 64: return launch_step<64>(a, s);
+        case 128: return launch_step<128>(a, s);
+        case 256: return launch_step<256>(a, s);
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+}
+
+namespace {
+// U[users[i]] -= lr * g[i]   (one float4 per thread; atomics: the same user may arrive from several ranks)
+__global__ void __launch_bounds__(256) apply_user_grads_kernel(float* __restrict__ U, const int32_t* __restrict__ users,
+                                                              const float* __restrict__ g, size_t n4, int d4, int g_stride, float nlr) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const size_t r = i / d4;
+    const int e = (int)(i % d4);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + r * g_stride + 4 * e);
+    atomic_add4(U + (size_t)users[r] * (4 * d4) + 4 * e, v * nlr);
+}
+}  // namespace
+
+extern "C" int pda_apply_user_grads_f32(float* U, const int32_t* users, const float* g, int n, int d, int g_stride, float lr,
+                                        void* stream) {
+    if (!U || !users || !g || n <= 0 || d <= 0 || (d & 3) || g_stride < d || (g_stride & 3)) return PDA_ERR_ARG;
+    const size_t n4 = (size_t)n * (d / 4);
+    hipLaunchKernelGGL(apply_user_grads_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       U, users, g, n4, d / 4, g_stride, -lr);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
 }
 
 extern "C" int pda_sort_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,

@@ -1,4 +1,4 @@
-"""Item-parallel evaluation across the GPUs of one node (the reference is single-device).
+"""Item-parallel evaluation (and SGD training) across the GPUs of one node (the reference is single-device).
 
 One process per GPU.  Rank r owns the item rows [lo_r, hi_r) (+ their popularity); the user table and the
 history CSR are replicated.  Per user block every rank produces its partial top-K (packed keys), then ONE
@@ -104,3 +104,97 @@ class ItemShardedTopK:
                 pending = (res, done)
         if pending is not None:
             yield hand_over(pending)
+
+
+class ItemShardedBPR:
+    """Item-parallel SGD training step (north_star: "each rank owns an item-embedding slice, BPR negatives sampled
+    locally"; SURVEY 8(e) train row).  Rank r holds the item rows [item_offset, item_offset + n_local) and a replica
+    of U.  Its sub-batch (B_local triplets, the same on every rank) has positives and negatives inside the slice, so
+    both dots are local.  Per step:
+
+        pda_bpr_step_shard_f32   item rows updated in place; user gradients + user ids + this rank's loss share are
+                                 written straight into ONE packed exchange buffer [B_local, d + 4]
+        all_gather_into_tensor   the only collective: B_local * (d + 4) * 4 bytes per rank (RCCL over xGMI)
+        pda_apply_user_grads_f32 every rank applies all R * B_local user gradients -> the replicas of U stay identical
+
+    which equals one fused SGD step of the single-GPU kernel on the concatenated batch (tests/test_gpu_bpr_step.py).
+    The exchange is latency-bound (tens of microseconds against a ~9 us step at B=2048): item-parallel training buys
+    capacity, not speed -- every BASELINE config fits one MI355X (288 GB), hence bench.py trains on one GPU.
+
+    `step_fn` / `apply_fn` default to the HIP entry points; tests inject doubles under gloo on CPU."""
+
+    def __init__(self, U: torch.Tensor, I_shard: torch.Tensor, item_offset: int, *, regs: float, lr: float, global_batch: int,
+                 rank: int = 0, world: int = 1, group=None, step_fn: Optional[Callable] = None, apply_fn: Optional[Callable] = None):
+        if step_fn is None or apply_fn is None:
+            from . import ops
+            step_fn = step_fn or ops.bpr_step_shard
+            apply_fn = apply_fn or ops.apply_user_grads
+        self.U, self.I_shard, self.item_offset = U, I_shard, item_offset
+        self.regs, self.lr, self.global_batch = regs, lr, global_batch
+        self.rank, self.world, self.group = rank, world, group
+        self.step_fn, self.apply_fn = step_fn, apply_fn
+
+    def local_step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
+        """This rank's kernel: updates the local item rows, returns the packed exchange buffer [B_local, d + 4] =
+        [g_user (d) | user id bits | loss, mf, reg shares (row 0 only)]; rows are 16-byte aligned."""
+        Bl, d = users.numel(), self.U.shape[1]
+        if Bl * self.world != self.global_batch:
+            raise ValueError("every rank must bring global_batch / world triplets")
+        buf = torch.zeros((Bl, d + 4), dtype=torch.float32, device=users.device)
+        self.step_fn(self.U, self.I_shard, self.item_offset, users, pos, neg, pos_pop, neg_pop, regs=self.regs,
+                     reg_div=float(self.global_batch), mean_div=float(self.global_batch), lr=self.lr,
+                     g_user=buf[:, :d], loss_acc=buf[0, d + 1:d + 4])
+        buf[:, d].view(torch.int32).copy_(users)
+        return buf
+
+    def exchange(self, buf: torch.Tensor) -> torch.Tensor:
+        """The one collective of a training step: [B_local, d+4] per rank -> [R * B_local, d+4] everywhere."""
+        if self.world == 1:
+            return buf
+        return _all_gather_keys(buf, self.world, self.group).reshape(self.world * buf.shape[0], buf.shape[1])
+
+    def apply(self, allb: torch.Tensor) -> torch.Tensor:
+        """Applies every rank's user gradients to the local replica of U; returns the global (loss, mf, reg)."""
+        d = self.U.shape[1]
+        users_all = allb[:, d].view(torch.int32).contiguous()
+        self.apply_fn(self.U, users_all, allb[:, :d], self.lr)
+        Bl = allb.shape[0] // self.world
+        return allb.view(self.world, Bl, d + 4)[:, 0, d + 1:d + 4].sum(dim=0)
+
+    def step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
+        """One global step; returns the (loss, mf_loss, reg_loss) of the GLOBAL batch as a device tensor (no sync)."""
+        return self.apply(self.exchange(self.local_step(users, pos, neg, pos_pop, neg_pop)))
+
+
+def local_train_csr(train_indptr: torch.Tensor, train_indices: torch.Tensor, lo: int, hi: int, train_slots: Optional[torch.Tensor] = None):
+    """The part of the (replicated) train CSR that falls into the item slice [lo, hi): what a rank samples its
+    positives from and rejects its negatives against.  Returns (indptr int64 [n_users+1], indices int32 (global ids),
+    slots | None, user_pool int32 = users with at least one positive in the slice).  torch plumbing, done once."""
+    keep = (train_indices >= lo) & (train_indices < hi)
+    csum = torch.zeros(train_indices.numel() + 1, dtype=torch.int64, device=train_indices.device)
+    torch.cumsum(keep.to(torch.int64), 0, out=csum[1:])
+    indptr = csum[train_indptr]
+    indices = train_indices[keep].contiguous()
+    slots = None if train_slots is None else train_slots[keep].contiguous()
+    pool = torch.nonzero(indptr[1:] > indptr[:-1]).flatten().to(torch.int32)
+    return indptr.contiguous(), indices, slots, pool
+
+
+class ShardSampler:
+    """Device sampler of one rank of ItemShardedBPR: users from the rank's pool (distinct inside the sub-batch), positive
+    uniform over the user's history INSIDE the slice, negative uniform over the slice minus that history, popularity
+    of the positive's time slot (pda_sample_triplets, the semantics of MF/train_new_api.py:366-412 restricted to a
+    slice -- the deviation SURVEY 8(e) declares: negatives are uniform over 1/R of the catalogue)."""
+
+    def __init__(self, train_indptr, train_indices, lo: int, hi: int, B_local: int, *, seed: int, rank: int = 0,
+                 train_slots=None, pop_matrix=None):
+        self.indptr, self.indices, self.slots, self.pool = local_train_csr(train_indptr, train_indices, lo, hi, train_slots)
+        if self.pool.numel() < B_local:
+            raise ValueError("fewer users with a positive in this item slice than the sub-batch asks for")
+        self.lo, self.hi, self.B, self.seed, self.pop_matrix = lo, hi, B_local, seed + 7919 * rank, pop_matrix
+
+    def __call__(self, step: int):
+        from . import ops
+        return ops.sample_triplets(self.indptr, self.indices, self.B, seed=self.seed, step=step, user_pool=self.pool,
+                                   n_pool=self.pool.numel(), train_slots=self.slots, neg_range=(self.lo, self.hi),
+                                   pop_matrix=self.pop_matrix)

@@ -300,6 +300,43 @@ def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, 
         mark_modified(U, I)
 
 
+def bpr_step_shard(U, I_shard, item_offset: int, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float,
+                   mean_div: float, lr: float, g_user: torch.Tensor, loss_acc: Optional[torch.Tensor] = None):
+    """pda_bpr_step_shard_f32: one rank's part of an item-parallel SGD step.  pos/neg are GLOBAL ids inside
+    [item_offset, item_offset + I_shard.shape[0]); g_user float32 [B_local, >=d] (row stride = g_user.stride(0))."""
+    lib = _lib.load()
+    U = _need(U, torch.float32, "U")
+    I_shard = _need(I_shard, torch.float32, "I_shard")
+    users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
+    pos_pop = _need(pos_pop, torch.float32, "pos_pop", optional=True)
+    neg_pop = _need(neg_pop, torch.float32, "neg_pop", optional=True)
+    if g_user.dtype != torch.float32 or not g_user.is_cuda:
+        raise ValueError("g_user must be a float32 cuda tensor")
+    if loss_acc is not None and (loss_acc.dtype != torch.float32 or not loss_acc.is_cuda or loss_acc.numel() != 3 or loss_acc.stride(0) != 1):
+        raise ValueError("loss_acc must be 3 consecutive float32 on the device")
+    B, d = users.numel(), U.shape[1]
+    if g_user.shape != (B, d) or g_user.stride(1) != 1:
+        raise ValueError("g_user must be float32 [B_local, d] with unit inner stride")
+    check(lib.pda_bpr_step_shard_f32(ptr(U), ptr(I_shard), int(item_offset), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop),
+                                     ptr(neg_pop), B, d, float(regs), float(reg_div), float(mean_div), float(lr),
+                                     ptr(g_user), g_user.stride(0), ptr(loss_acc), stream_ptr()), "pda_bpr_step_shard_f32")
+    mark_modified(I_shard)
+
+
+def apply_user_grads(U, users, g, lr: float):
+    """pda_apply_user_grads_f32: U[users[i]] -= lr * g[i].  g float32 [n, d] whose rows may be strided (a column slice
+    of the packed exchange buffer); its storage must start 16-byte aligned."""
+    lib = _lib.load()
+    U = _need(U, torch.float32, "U")
+    users = _need(users, torch.int32, "users")
+    if g.dtype != torch.float32 or not g.is_cuda or g.stride(1) != 1:
+        raise ValueError("g must be a float32 cuda tensor with unit inner stride")
+    n, d = g.shape
+    check(lib.pda_apply_user_grads_f32(ptr(U), ptr(users), ptr(g), n, d, g.stride(0), float(lr), stream_ptr()),
+          "pda_apply_user_grads_f32")
+    mark_modified(U)
+
+
 def adam_lr_t(lr: float, t: int, beta1=ADAM_BETA1, beta2=ADAM_BETA2) -> float:
     """lr * sqrt(1-beta2^t) / (1-beta1^t)  [TF-ext AdamOptimizer._apply_sparse_shared]."""
     return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)

@@ -113,3 +113,82 @@ def test_item_sharded_eval_two_ranks_gloo():
     assert all(all(r[1]) for r in res), res
     (o0, n0), (o1, n1) = (res[0][2], res[0][3]), (res[1][2], res[1][3])
     assert o0 == 0 and o1 == n0 and n0 + n1 == 777 and n0 % 32 == 0
+
+
+# ---- item-parallel training step (ItemShardedBPR) -----------------------------------------------------------------
+
+def _global_batch(rng, R, nU, nI, Bl):
+    per = nI // R
+    users = rng.permutation(nU)[:R * Bl].astype(np.int32)
+    pos = np.concatenate([rng.integers(r * per, (r + 1) * per, Bl) for r in range(R)]).astype(np.int32)
+    neg = np.concatenate([rng.integers(r * per, (r + 1) * per, Bl) for r in range(R)]).astype(np.int32)
+    pp = (rng.uniform(0, 1, R * Bl) ** 0.22).astype(np.float32)
+    pn = (rng.uniform(0, 1, R * Bl) ** 0.22).astype(np.float32)
+    return users, pos, neg, pp, pn
+
+
+def step_double(U, I_shard, item_offset, users, pos, neg, pos_pop, neg_pop, *, regs, reg_div, mean_div, lr, g_user, loss_acc):
+    """Stand-in for ops.bpr_step_shard (same contract), answered by the float64 oracle: the per-triplet gradients of a
+    sub-batch inside a global batch of `mean_div` triplets are those of a batch padded to that length."""
+    Bl, Bg = users.numel(), int(mean_div)
+    I_full = np.zeros((item_offset + I_shard.shape[0], I_shard.shape[1]), np.float32)
+    I_full[item_offset:] = I_shard.numpy()
+    fw = po.bpr_forward(U.numpy(), I_full, users.numpy(), pos.numpy(), neg.numpy(), pos_pop.numpy(), neg_pop.numpy())
+    scale = Bl / Bg                                        # oracle means over len(batch) = Bl; the global step over Bg
+    due, dpe, dne = po.bpr_grads(fw, 0.0, reg_div, pos_pop.numpy(), neg_pop.numpy())
+    c = regs / reg_div
+    due, dpe, dne = due * scale + c * fw["ue"], dpe * scale + c * fw["pe"], dne * scale + c * fw["ne"]
+    g_user.copy_(torch.from_numpy(due.astype(np.float32)))
+    upd = I_full.astype(np.float64)
+    np.subtract.at(upd, pos.numpy(), lr * dpe)
+    np.subtract.at(upd, neg.numpy(), lr * dne)
+    I_shard.copy_(torch.from_numpy(upd[item_offset:].astype(np.float32)))
+    loss, mf, reg = po.bpr_loss(fw, regs, reg_div)
+    loss_acc += torch.tensor([mf * scale + reg, mf * scale, reg], dtype=torch.float32)
+
+
+def apply_double(U, users_all, g, lr):
+    U.index_add_(0, users_all.long(), g.contiguous(), alpha=-lr)
+
+
+def _train_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pda_amd.dist import ItemShardedBPR
+    rng = np.random.default_rng(11)                                 # same data on every rank
+    nU, nI, d, Bl, regs, lr = 300, 128, 32, 64, 1e-2, 0.5
+    U = (rng.standard_normal((nU, d)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.2).astype(np.float32)
+    per, Bg = nI // world, world * Bl
+    Ut = torch.from_numpy(U.copy())
+    shard = torch.from_numpy(I[rank * per:(rank + 1) * per].copy())
+    tr = ItemShardedBPR(Ut, shard, rank * per, regs=regs, lr=lr, global_batch=Bg, rank=rank, world=world,
+                        step_fn=step_double, apply_fn=apply_double)
+    Uref, Iref, ok = U, I, []
+    for step in range(2):
+        users, pos, neg, pp, pn = _global_batch(rng, world, nU, nI, Bl)
+        sl = slice(rank * Bl, (rank + 1) * Bl)
+        loss = tr.step(*(torch.from_numpy(x[sl].copy()) for x in (users, pos, neg, pp, pn)))
+        Uref, Iref, _, ref_loss = po.train_step(Uref, Iref, users, pos, neg, pp, pn, regs, Bg, lr, optimizer="sgd")
+        ok.append(bool(np.allclose(loss.numpy(), ref_loss, atol=1e-5)))
+        ok.append(bool(np.allclose(Ut.numpy(), Uref, atol=1e-5)))                     # replicas of U agree with the oracle
+        ok.append(bool(np.allclose(shard.numpy(), Iref[rank * per:(rank + 1) * per], atol=1e-5)))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_item_parallel_training_two_ranks_gloo():
+    """ItemShardedBPR orchestration (packed exchange buffer, the ONE all-gather, apply, loss shares) under gloo with
+    oracle-backed doubles: two global steps must reproduce the oracle's SGD steps on the concatenated batches."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(all(r[1]) for r in res), res
