@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         const int tn = tile_of(min(k + 1, nt - 1));
         float pop_next, ni_next;
         int id_next;
-        tile_load(tn, cur_h, cur_l);
+        if constexpr (!(ABL & 8)) tile_load(tn, cur_h, cur_l);
         lane_consts(tn, pop_next, ni_next, id_next);
         __builtin_amdgcn_sched_barrier(0);
 
@@ -559,8 +559,14 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 #pragma unroll
         for (int mm = 0; mm < NM; ++mm) {
             const int off = 8 * ((2 * mm + h) ^ bsw);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + off));
-            const bf16x8 bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(blrow + off));
+            bf16x8 bh, bl;
+            if constexpr (ABL & 16) {
+                bh = __builtin_bit_cast(bf16x8, ah[(mm + 1) % NM]);
+                bl = __builtin_bit_cast(bf16x8, al[(mm + 1) % NM]);
+            } else {
+                bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + off));
+                bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(blrow + off));
+            }
             const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mm]);
             const bf16x8 xl = __builtin_bit_cast(bf16x8, al[mm]);
             if (mm & 1) {
@@ -586,10 +592,10 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         if constexpr (ABL & 2) asm volatile("" ::"v"(acc_prev[0]), "v"(acc_prev[5]), "v"(acc_prev[15]));
         if constexpr (ABL & 1) { asm volatile("" ::"v"(m)); m = 0; }
 
-        __syncthreads();  // every wave is done reading the tile
+        if constexpr (!(ABL & 32)) __syncthreads();  // every wave is done reading the tile
         uint32_t hb_next = 0;
         if (has_next) {
-            tile_store(cur_h, cur_l);
+            if constexpr (!(ABL & 8)) tile_store(cur_h, cur_l);
             PDA_T0(th);
             hb_next = hist_bits(tn);
             PDA_T1(th, dbg_entries);
@@ -610,7 +616,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 if (lane == 0) votes[wave] = alldead ? 1 : 0;
             }
         }
-        __syncthreads();  // next tile visible
+        if constexpr (!(ABL & 32)) __syncthreads();  // next tile visible
         if constexpr (ORD) {
             if ((k & 3) == 3 && has_next) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
         }
@@ -854,6 +860,12 @@ int run_score_prepped(const float* U, const float* I_shard, const void* prep, bo
             case 3: return launch_v2<128, PDA_HEAD_POP, false, 3>(aa, s);
             case 7: return launch_v2<128, PDA_HEAD_POP, false, 7>(aa, s);
             case 4: return launch_v2<128, PDA_HEAD_POP, false, 4>(aa, s);
+            case 15: return launch_v2<128, PDA_HEAD_POP, false, 15>(aa, s);
+            case 31: return launch_v2<128, PDA_HEAD_POP, false, 31>(aa, s);
+            case 47: return launch_v2<128, PDA_HEAD_POP, false, 47>(aa, s);
+            case 63: return launch_v2<128, PDA_HEAD_POP, false, 63>(aa, s);
+            case 39: return launch_v2<128, PDA_HEAD_POP, false, 39>(aa, s);
+            case 23: return launch_v2<128, PDA_HEAD_POP, false, 23>(aa, s);
             default: break;
         }
     }
