@@ -421,8 +421,16 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         }
     };
     refresh_thr();
+    if constexpr (ORD) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) nu[r] = __shfl(nu_row, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+        for (int r = 0; r < 16; ++r) nu[r] = __shfl(nu_row, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+    }
+    // the fast test uses ONE eps scale per wave (the largest row norm): eps is ~1e-4 of the score spread, so the few
+    // per cent more candidates are free, and the test needs no per-register eps any more
+    float nu_max = nu_row;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nu_max = fmaxf(nu_max, __shfl_xor(nu_max, o, 64));
+    nu_max *= 1.001f;
 
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap2;
     long long dbg_entries = 0, dbg_proc = 0, dbg_comp = 0, dbg_push = 0;
@@ -521,6 +529,33 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         PDA_T1(tq, dbg_push);
     };
 
+    // The fast test leaves one 64-bit lane mask per accumulator register in SGPRs (v_cmp writing an SGPR pair: 3 VALU per
+    // register instead of 5, the OR over registers is SALU).  The slow path rebuilds the per-lane bit mask from them.
+    auto push_masks = [&](const uint64_t (&M)[16], uint64_t okm, uint32_t hb, int item_id, float popv, const f32x16& accv) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= ((M[r] >> lane) & 1ull) ? (1u << (15 - r)) : 0u;
+        m = ((okm >> lane) & 1ull) ? m : 0u;
+        push_flagged(m, hb, item_id, popv, accv);
+    };
+    // the fast test of one accumulator register: lanes whose head upper bound can beat the row's threshold.
+    //   PDA head:  (max(s~ + eps, 0) + 1) pop > T   <=>   max(s~, -eps) > T / pop - 1 - eps        (pop > 0; pop = 0 never passes)
+    //   raw head:  s~ + eps > T
+    // per tile and lane: neg_eps = -eps, ipop <= 1/pop, cc = -1 - eps;  per register: v_max, v_fma, v_cmp (to SGPRs)
+    auto test_reg = [&](float sacc, float t, float neg_eps, float ipop, float cc) -> uint64_t {
+        if constexpr (HEAD == PDA_HEAD_POP) return __ballot(fmaxf(sacc, neg_eps) > __builtin_fmaf(t, ipop, cc));
+        else return __ballot(sacc > t + neg_eps);
+    };
+    auto test_consts = [&](float popv, float niv, float& neg_eps, float& ipop, float& cc) {
+        neg_eps = -(nu_max * niv * 1.001f + 3e-6f);        // 3e-6: the roundings of v_fma / v_rcp on values of order <= 10
+        ipop = 0.f;
+        cc = 0.f;
+        if constexpr (HEAD == PDA_HEAD_POP) {
+            ipop = __builtin_amdgcn_rcpf(popv) * 0.9999995f;   // <= 1/pop: a smaller right-hand side only lets more through
+            cc = -1.0f + neg_eps;
+        }
+    };
+
     // ---- main loop (software pipeline as v1: test of tile t-1 in the shadow of the MFMAs of tile t) ----------------
     f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint32_t hb_prev = 0, hb_cur = 0;
@@ -555,7 +590,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 
         f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 acc1 = acc0;
-        uint32_t m = 0;
+        uint64_t M[16];
+        float neg_eps, ipop, cc;
+        test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
 #pragma unroll
         for (int mm = 0; mm < NM; ++mm) {
             const int off = 8 * ((2 * mm + h) ^ bsw);
@@ -579,18 +616,20 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc0, 0, 0, 0);
             }
             // upper-bound test of 16/NM registers of the previous tile
-            if constexpr (!(ABL & 2))
 #pragma unroll
             for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) {
-                float x = __builtin_fmaf(nu[r], ni_prev, acc_prev[r]);                 // s~ + eps >= exact chain score
-                if constexpr (HEAD == PDA_HEAD_POP) x = __builtin_fmaf(fmaxf(x, 0.0f), pop_prev, pop_prev);
-                asm("v_cmp_gt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(m) : "v"(x), "v"(thr[r]) : "vcc");
+                if constexpr (ABL & 2) M[r] = 0;
+                else M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
             }
         }
         const f32x16 acc_new = acc0 + acc1;   // summed here so that only 16 accumulator registers stay live across the slow path
-        m = ok_prev ? m : 0u;
+        uint64_t many = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) many |= M[r];
+        const uint64_t okm = __ballot(ok_prev);
+        many &= okm;
         if constexpr (ABL & 2) asm volatile("" ::"v"(acc_prev[0]), "v"(acc_prev[5]), "v"(acc_prev[15]));
-        if constexpr (ABL & 1) { asm volatile("" ::"v"(m)); m = 0; }
+        if constexpr (ABL & 1) { asm volatile("" ::"s"(many)); many = 0; }
 
         if constexpr (!(ABL & 32)) __syncthreads();  // every wave is done reading the tile
         uint32_t hb_next = 0;
@@ -600,7 +639,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             hb_next = hist_bits(tn);
             PDA_T1(th, dbg_entries);
         }
-        if (__any(m != 0)) push_flagged(m, hb_prev, id_prev, pop_prev, acc_prev);
+        if (many) push_masks(M, okm, hb_prev, id_prev, pop_prev, acc_prev);
         bool stop = false;
         if constexpr (ORD) {
             // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (see the kernel comment)
@@ -641,15 +680,12 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     }
     if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n_done);
     if (nt > 0) {   // drain the last tile
-        uint32_t m = 0;
+        uint64_t M[16];
+        float neg_eps, ipop, cc;
+        test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float x = __builtin_fmaf(nu[r], ni_prev, acc_prev[r]);
-            if constexpr (HEAD == PDA_HEAD_POP) x = __builtin_fmaf(fmaxf(x, 0.0f), pop_prev, pop_prev);
-            m = (m << 1) | ((x > thr[r]) ? 1u : 0u);
-        }
-        m = ok_prev ? m : 0u;
-        if (__any(m != 0)) push_flagged(m, hb_prev, id_prev, pop_prev, acc_prev);
+        for (int r = 0; r < 16; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+        push_masks(M, __ballot(ok_prev), hb_prev, id_prev, pop_prev, acc_prev);
     }
 
     // ---- finalise: exact rescoring of each row's survivors (one lane per candidate, the fmaf chains of v1), exact
