@@ -129,6 +129,27 @@ int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void*
                                int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
                                void* stream);
 
+/* bf16 tables (BASELINE config 5: 10M x 2M, d=256 bf16).  U and I_shard hold bf16 bit patterns (uint16, row-major).
+ * The score of a pair is DEFINED as the same fp32 fmaf chain applied to the widened values -- i.e. these entry points
+ * return exactly the keys pda_score_topk_f32 returns on the tables converted to fp32 (tests/test_gpu_score_topk.py).
+ * Products of two bf16 are exact in fp32, so the pre-filter needs ONE bf16 MFMA per k-step (fp32 tables: three) and no
+ * hi/lo planes: the prep buffer holds the row norms only (plus, ordered, the rows gathered into visiting order).
+ * d in {64,128,256}.  pda_item_prep_ordered_check / pda_hist_reorder serve both table types. */
+size_t pda_item_prep_bf16_bytes(int n_items_local, int d);
+int pda_item_prep_bf16(const uint16_t* I_shard, int n_items_local, int d, void* prep, void* stream);
+int pda_score_topk_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard,
+                        const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                        const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
+                        int n_splits, uint64_t* out_keys, void* workspace, void* stream);
+size_t pda_item_prep_ordered_bf16_bytes(int n_items_local, int d);
+int pda_item_prep_ordered_bf16(const uint16_t* I_shard, const float* pop_shard, const int32_t* order, int n_items_local,
+                               int d, void* prep, void* stream);
+int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard,
+                                const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                                const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
+                                int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
+                                void* stream);
+
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0
  *   out_keys u64 [n_users_blk, K] or NULL;  out_idx i32 / out_val f32 [n_users_blk, K] or NULL.

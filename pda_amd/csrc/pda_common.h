@@ -35,6 +35,20 @@ __device__ __forceinline__ uint64_t pda_readlane_u64(uint64_t v, int src) {
 __device__ __forceinline__ float pda_readlane_f32(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
+// Four consecutive table elements starting at element index `idx` (a multiple of 4) as fp32: f32 tables -> one 16-byte
+// load; bf16 tables (BF) -> one 8-byte load, widened exactly (bf16 is the top half of an fp32).
+template <bool BF>
+__device__ __forceinline__ f32x4 pda_load4(const void* base, size_t idx) {
+    if constexpr (BF) {
+        const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + idx);
+        f32x4 v = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xFFFF0000u), __uint_as_float(w.y << 16),
+                   __uint_as_float(w.y & 0xFFFF0000u)};
+        return v;
+    } else {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + idx);
+    }
+}
+
 // Orders LDS traffic between lanes of ONE wave (no instruction: compiler-level only; the LDS
 // pipeline already executes a wave's DS ops in order).
 __device__ __forceinline__ void pda_wave_sync() {

@@ -35,7 +35,8 @@ using namespace pda_topk;
 
 // ABL: profiling-only ablation bits (0 in the shipped instantiations): 1 skip slow path, 2 skip threshold test,
 // 4 skip history cursor, 8 skip item-tile global loads.  Enabled by building with -DPDA_ABLATION.
-template <int D, int HEAD, int ABL = 0>
+// BF: the tables are bf16 (pda_score_topk_bf16's exact fallback); rows are widened to fp32 on load -- same arithmetic.
+template <int D, int HEAD, int ABL = 0, bool BF = false>
 __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* Bt = reinterpret_cast<float*>(smem);                                   // [32][D] swizzled
@@ -65,11 +66,10 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
 
     f32x4 areg[NC];
     {
-        const float* up = a.U + (size_t)uid * D + 4 * h;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row_ok) v = *reinterpret_cast<const f32x4*>(up + 8 * c);
+            if (row_ok) v = pda_load4<BF>(a.U, (size_t)uid * D + 4 * h + 8 * c);
             areg[c] = v;
         }
     }
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
             const int it = min(t * 32 + jj, a.n_items_local - 1);
-            pre[q] = *reinterpret_cast<const f32x4*>(a.I + (size_t)it * D + 4 * ch);
+            pre[q] = pda_load4<BF>(a.I, (size_t)it * D + 4 * ch);
         }
     };
     auto tile_store = [&]() {
@@ -345,19 +345,19 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) score_topk_kerne
     }
 }
 
-template <int D, int HEAD, int ABL = 0>
+template <int D, int HEAD, int ABL = 0, bool BF = false>
 int launch_score(const ScoreArgs& a, hipStream_t stream) {
     const size_t smem = 32 * D * sizeof(float) + (size_t)kUserTile * (kCap * sizeof(uint64_t) + 8);
     static int attr_set = 0;  // idempotent attribute; benign if raced
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_kernel<D, HEAD, ABL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_kernel<D, HEAD, ABL, BF>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (a.n_users_blk + kUserTile - 1) / kUserTile;
     dim3 grid((unsigned)(utiles * a.n_splits));
-    hipLaunchKernelGGL((score_topk_kernel<D, HEAD, ABL>), grid, dim3(kThreads), smem, stream, a);
+    hipLaunchKernelGGL((score_topk_kernel<D, HEAD, ABL, BF>), grid, dim3(kThreads), smem, stream, a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -435,7 +435,21 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(MergeArgs a) {
 
 }  // namespace
 
-int pda_topk::launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t s) {
+int pda_topk::launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t s, bool bf16) {
+    if (bf16) {
+#define PDA_DISPATCH_BF(DD)                                                             \
+    case DD:                                                                            \
+        return head == PDA_HEAD_POP ? launch_score<DD, PDA_HEAD_POP, 0, true>(a, s)    \
+                                    : launch_score<DD, PDA_HEAD_RAW, 0, true>(a, s);
+        switch (d) {
+            PDA_DISPATCH_BF(64)
+            PDA_DISPATCH_BF(128)
+            PDA_DISPATCH_BF(256)
+            default:
+                return PDA_ERR_UNSUPPORTED;
+        }
+#undef PDA_DISPATCH_BF
+    }
 #ifdef PDA_ABLATION
     if (const char* e = getenv("PDA_ABLATE")) {
         if (d == 128 && head == PDA_HEAD_POP && a.tile_flags == nullptr) switch (atoi(e)) {

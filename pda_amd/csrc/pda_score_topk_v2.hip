@@ -99,8 +99,10 @@ __device__ __forceinline__ int swzb(int row) {   // bf16 tile: D/8 16-byte chunk
 }
 
 // one row per D/8 threads: fp32 -> bf16 hi, bf16 lo, padded norm
-template <int D>
-__global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict__ I, int n, uint16_t* __restrict__ hi,
+// BF: the table is bf16 already -- there is nothing to split; `hi` (may be NULL) receives the row when it has to be
+// gathered into visiting order, `lo` is unused.
+template <int D, bool BF>
+__global__ void __launch_bounds__(256) item_prep_kernel(const void* __restrict__ I, int n, uint16_t* __restrict__ hi,
                                                         uint16_t* __restrict__ lo, float* __restrict__ nrm, int* __restrict__ nrm_max_bits,
                                                         const int* __restrict__ order, const float* __restrict__ pop,
                                                         float* __restrict__ pop_p, int* __restrict__ pos_of, int* __restrict__ bad) {
@@ -117,12 +119,17 @@ __global__ void __launch_bounds__(256) item_prep_kernel(const float* __restrict_
                 if (pop) pop_p[row] = pop[src];
             }
         }
-        const f32x4 a = *reinterpret_cast<const f32x4*>(I + (size_t)src * D + 8 * e);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(I + (size_t)src * D + 8 * e + 4);
-        u32x4 h, l;
-        split8(a, b, h, l);
-        *reinterpret_cast<u32x4*>(hi + (size_t)row * D + 8 * e) = h;
-        *reinterpret_cast<u32x4*>(lo + (size_t)row * D + 8 * e) = l;
+        const f32x4 a = pda_load4<BF>(I, (size_t)src * D + 8 * e);
+        const f32x4 b = pda_load4<BF>(I, (size_t)src * D + 8 * e + 4);
+        if constexpr (BF) {
+            if (hi) *reinterpret_cast<u32x4*>(hi + (size_t)row * D + 8 * e) =
+                        *reinterpret_cast<const u32x4*>(reinterpret_cast<const uint16_t*>(I) + (size_t)src * D + 8 * e);
+        } else {
+            u32x4 h, l;
+            split8(a, b, h, l);
+            *reinterpret_cast<u32x4*>(hi + (size_t)row * D + 8 * e) = h;
+            *reinterpret_cast<u32x4*>(lo + (size_t)row * D + 8 * e) = l;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) ss += a[k] * a[k] + b[k] * b[k];
     }
@@ -287,8 +294,13 @@ __device__ __forceinline__ void compact_band(uint64_t* buf, int* cnt_slot, float
 // the workgroup, nothing behind t can enter any list and the sweep stops.  Any `order` is correct; popular-first makes
 // the suffix bounds fall quickly, which is how PDA's popularity-weighted head lets most of the catalogue go unscored.
 // Item splits take interleaved tiles (t = split, split + n_splits, ...) so that every split sees the strong items early.
-template <int D, int HEAD, bool ORD, int ABL = 0>   // ABL: profiling-only (-DPDA_ABLATION): 1 drop candidates, 2 skip the test, 4 no history
+// NP = MFMAs per k-step: 3 for fp32 tables (bf16 hi/lo split, above), 1 for bf16 tables (pda_score_topk_bf16): the products
+// of two bf16 are exact in fp32, so one v_mfma_f32_32x32x16_bf16 differs from the exact fmaf chain only by the order of the
+// fp32 additions: |s~ - s_chain| <= 2 d 2^-24 sum|u_k i_k| <= 2^-15 ||u|| ||i|| for d <= 256; 2^-14 is used.
+template <int D, int HEAD, bool ORD, int ABL = 0, int NP = 3>   // ABL: profiling-only (-DPDA_ABLATION): 1 drop candidates, 2 skip the test, 4 no history
 __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 aa) {
+    constexpr bool BF = NP == 1;
+    constexpr float kEps = BF ? 6.103515625e-5f : kEpsScale;
     const ScoreArgs& a = aa.a;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int CPR = D / 8;                 // 16-byte chunks per bf16 row
@@ -296,8 +308,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     constexpr int NLD = (32 * CPR) / kThreads; // 16-byte loads per thread per tile, per plane (hi / lo)
     static_assert(NLD >= 1, "v2 needs embed dim >= 64");
     uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);              // [32][D] bf16 hi, swizzled
-    uint16_t* Bl = Bh + 32 * D;                                    // [32][D] bf16 lo
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 2 * 32 * D * sizeof(uint16_t));   // [128][kCap2]
+    uint16_t* Bl = Bh + 32 * D;                                    // [32][D] bf16 lo (NP == 3 only)
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + (BF ? 1 : 2) * 32 * D * sizeof(uint16_t));   // [128][kCap2]
     int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap2);                 // [128]
     float* taul = reinterpret_cast<float*>(cntl + kUserTile);                              // [128]
     int* sortl = reinterpret_cast<int*>(taul + kUserTile);                                 // [128] length of the sorted prefix
@@ -331,21 +343,29 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     u32x4 ah[NM], al[NM];
     float nu_row;
     {
-        const float* up = a.U + (size_t)uid * D + 8 * h;
         float ss = 0.f;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
             if (row_ok) {
-                x = *reinterpret_cast<const f32x4*>(up + 16 * m);
-                y = *reinterpret_cast<const f32x4*>(up + 16 * m + 4);
+                x = pda_load4<BF>(a.U, (size_t)uid * D + 8 * h + 16 * m);
+                y = pda_load4<BF>(a.U, (size_t)uid * D + 8 * h + 16 * m + 4);
             }
-            split8(x, y, ah[m], al[m]);
+            if constexpr (BF) {          // the row IS bf16: keep its bits (the truncating repack is exact)
+                const u32x4 raw = {(__float_as_uint(x[0]) >> 16) | (__float_as_uint(x[1]) & 0xFFFF0000u),
+                                   (__float_as_uint(x[2]) >> 16) | (__float_as_uint(x[3]) & 0xFFFF0000u),
+                                   (__float_as_uint(y[0]) >> 16) | (__float_as_uint(y[1]) & 0xFFFF0000u),
+                                   (__float_as_uint(y[2]) >> 16) | (__float_as_uint(y[3]) & 0xFFFF0000u)};
+                ah[m] = raw;
+                al[m] = raw;             // unused
+            } else {
+                split8(x, y, ah[m], al[m]);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
         }
         ss += __shfl_xor(ss, 32, 64);
-        nu_row = sqrtf(ss) * 1.0009765625f * 1.0001f * kEpsScale;   // eps(u,i) = nu_row * I_norm[i]
+        nu_row = sqrtf(ss) * 1.0009765625f * 1.0001f * kEps;   // eps(u,i) = nu_row * I_norm[i]
     }
 
     // ---- history cursor (as v1) ------------------------------------------------------------------------------
@@ -447,7 +467,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             const int jj = id / CPR, ch = id % CPR;
             const int it = min(t * 32 + jj, a.n_items_local - 1);
             ph[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (size_t)it * D + 8 * ch);
-            pl[q] = *reinterpret_cast<const u32x4*>(aa.I_lo + (size_t)it * D + 8 * ch);
+            if constexpr (!BF) pl[q] = *reinterpret_cast<const u32x4*>(aa.I_lo + (size_t)it * D + 8 * ch);
         }
     };
     auto tile_store = [&](const u32x4 (&ph)[NLD], const u32x4 (&pl)[NLD]) {
@@ -457,7 +477,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             const int jj = id / CPR, ch = id % CPR;
             const int off = jj * D + 8 * (ch ^ swzb<D>(jj));
             *reinterpret_cast<u32x4*>(Bh + off) = ph[q];
-            *reinterpret_cast<u32x4*>(Bl + off) = pl[q];
+            if constexpr (!BF) *reinterpret_cast<u32x4*>(Bl + off) = pl[q];
         }
     };
     auto lane_consts = [&](int t, float& popv, float& niv, int& idv) {
@@ -602,11 +622,15 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 bl = __builtin_bit_cast(bf16x8, al[(mm + 1) % NM]);
             } else {
                 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + off));
-                bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(blrow + off));
+                if constexpr (!BF) bl = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(blrow + off));
+                else bl = bh;
             }
             const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mm]);
             const bf16x8 xl = __builtin_bit_cast(bf16x8, al[mm]);
-            if (mm & 1) {
+            if constexpr (BF) {
+                if (mm & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc0, 0, 0, 0);
+            } else if (mm & 1) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bl, acc1, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xl, bh, acc1, 0, 0, 0);
@@ -648,7 +672,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
                 bool dead = true;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float ub = __builtin_fmaf(nu[r] * (1.0f / kEpsScale), sb, sa) * 1.000002f;
+                    const float ub = __builtin_fmaf(nu[r] * (1.0f / kEps), sb, sa) * 1.000002f;
                     dead = dead && (ub < thr[r]);
                 }
                 const bool alldead = __all(dead);
@@ -703,8 +727,15 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         // user row: wave-uniform address -> scalar loads (constant address space; U is read-only for the kernel).
         // candidate row: the whole row (or 128 floats of it) in flight at once -- the gather latency is what this loop pays.
         typedef const __attribute__((address_space(4))) float* cfp;
+        typedef const __attribute__((address_space(4))) uint16_t* chp;
         cfp up = (cfp)(a.U + (size_t)urow * D);
-        const float* ip = a.I + (size_t)(item - a.item_offset) * D;
+        chp up16 = (chp)(reinterpret_cast<const uint16_t*>(a.U) + (size_t)urow * D);
+        auto uval = [&](int k) -> float {
+            if constexpr (BF) return __uint_as_float((uint32_t)up16[k] << 16);
+            else return up[k];
+        };
+        (void)up; (void)up16;
+        const size_t ibase = (size_t)(item - a.item_offset) * D;
         float c0 = 0.f, c1 = 0.f;
         float popc = 1.0f;
         if constexpr (HEAD == PDA_HEAD_POP) popc = a.pop[item - a.item_offset];   // issued with the row gather, not after the chain
@@ -713,18 +744,18 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         for (int base = 0; base < D; base += CH) {
             f32x4 iv[CH / 4];
 #pragma unroll
-            for (int q = 0; q < CH / 4; ++q) iv[q] = *reinterpret_cast<const f32x4*>(ip + base + 4 * q);
+            for (int q = 0; q < CH / 4; ++q) iv[q] = pda_load4<BF>(a.I, ibase + base + 4 * q);
 #pragma unroll
             for (int c8 = 0; c8 < CH / 8; c8 += 2) {
 #pragma unroll
                 for (int sidx = 0; sidx < 4; ++sidx) {
-                    c0 = __builtin_fmaf(up[base + 8 * c8 + sidx], iv[2 * c8][sidx], c0);
-                    c0 = __builtin_fmaf(up[base + 8 * c8 + 4 + sidx], iv[2 * c8 + 1][sidx], c0);
+                    c0 = __builtin_fmaf(uval(base + 8 * c8 + sidx), iv[2 * c8][sidx], c0);
+                    c0 = __builtin_fmaf(uval(base + 8 * c8 + 4 + sidx), iv[2 * c8 + 1][sidx], c0);
                 }
 #pragma unroll
                 for (int sidx = 0; sidx < 4; ++sidx) {
-                    c1 = __builtin_fmaf(up[base + 8 * c8 + 8 + sidx], iv[2 * c8 + 2][sidx], c1);
-                    c1 = __builtin_fmaf(up[base + 8 * c8 + 12 + sidx], iv[2 * c8 + 3][sidx], c1);
+                    c1 = __builtin_fmaf(uval(base + 8 * c8 + 8 + sidx), iv[2 * c8 + 2][sidx], c1);
+                    c1 = __builtin_fmaf(uval(base + 8 * c8 + 12 + sidx), iv[2 * c8 + 3][sidx], c1);
                 }
             }
         }
@@ -766,18 +797,18 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 #endif
 }
 
-template <int D, int HEAD, bool ORD = false, int ABL = 0>
+template <int D, int HEAD, bool ORD = false, int ABL = 0, int NP = 3>
 int launch_v2(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = 2 * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 16) + 16;
+    const size_t smem = (NP == 1 ? 1 : 2) * 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap2 * sizeof(uint64_t) + 16) + 16;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD, ORD, ABL>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v2_kernel<D, HEAD, ORD, ABL, NP>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (aa.a.n_users_blk + kUserTile - 1) / kUserTile;
-    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD, ORD, ABL>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
+    hipLaunchKernelGGL((score_topk_v2_kernel<D, HEAD, ORD, ABL, NP>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -796,35 +827,40 @@ static inline size_t prep_plane_bytes(int n, int d) { return (((size_t)n * d * 2
 static inline size_t prep_norm_bytes(int n) { return (((size_t)n * 4) + 255) & ~(size_t)255; }
 
 namespace {
+// prep blob: [norm f32 n][max-norm bits, bad-order flag (256 B)] then, ordered only, [pop_p f32 n][order i32 n]
+// [pos_of i32 n][sufA f32 n_tiles][sufB f32 n_tiles]; the bf16 planes come LAST (2 for fp32 tables, 0 / 1 for bf16
+// tables unordered / ordered) so that the offsets of the small arrays do not depend on the table type.
 struct PrepLayout {
     size_t plane, hi, lo, norm, nmax, pop_p, order, pos_of, sufA, sufB, total;
 };
-PrepLayout prep_layout(int n, int d, bool ordered) {
+PrepLayout prep_layout(int n, int d, bool ordered, int n_planes) {
     PrepLayout L{};
     L.plane = prep_plane_bytes(n, d);
-    L.hi = 0;
-    L.lo = L.plane;
-    L.norm = 2 * L.plane;
+    L.norm = 0;
     L.nmax = L.norm + prep_norm_bytes(n);      // int bits of the max norm at +0, "order is not a permutation" flag at +4
-    L.total = L.nmax + 256;
+    size_t off = L.nmax + 256;
     if (ordered) {
         const size_t tiles = (((size_t)(n + 31) / 32) * 4 + 255) & ~(size_t)255;
-        L.pop_p = L.total;
+        L.pop_p = off;
         L.order = L.pop_p + prep_norm_bytes(n);
         L.pos_of = L.order + prep_norm_bytes(n);
         L.sufA = L.pos_of + prep_norm_bytes(n);
         L.sufB = L.sufA + tiles;
-        L.total = L.sufB + tiles;
+        off = L.sufB + tiles;
     }
+    L.hi = off;
+    L.lo = off + L.plane;
+    L.total = off + (size_t)n_planes * L.plane;
     return L;
 }
+inline int planes_of(bool bf16, bool ordered) { return bf16 ? (ordered ? 1 : 0) : 2; }
 
-int run_item_prep(const float* I_shard, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
+int run_item_prep(const void* I_shard, bool bf16, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
     const bool ordered = order != nullptr;
-    const PrepLayout L = prep_layout(n, d, ordered);
+    const PrepLayout L = prep_layout(n, d, ordered, planes_of(bf16, ordered));
     char* pb = reinterpret_cast<char*>(prep);
-    uint16_t* hi = reinterpret_cast<uint16_t*>(pb + L.hi);
-    uint16_t* lo = reinterpret_cast<uint16_t*>(pb + L.lo);
+    uint16_t* hi = planes_of(bf16, ordered) > 0 ? reinterpret_cast<uint16_t*>(pb + L.hi) : nullptr;
+    uint16_t* lo = planes_of(bf16, ordered) > 1 ? reinterpret_cast<uint16_t*>(pb + L.lo) : nullptr;
     float* nrm = reinterpret_cast<float*>(pb + L.norm);
     int* nmax = reinterpret_cast<int*>(pb + L.nmax);
     float* pop_p = ordered && pop ? reinterpret_cast<float*>(pb + L.pop_p) : nullptr;
@@ -837,8 +873,9 @@ int run_item_prep(const float* I_shard, const float* pop, const int* order, int 
 #define PDA_PREP(DD)                                                                                         \
     case DD: {                                                                                               \
         constexpr int RPB = 256 / (DD / 8);                                                                  \
-        hipLaunchKernelGGL(item_prep_kernel<DD>, dim3((unsigned)((n + RPB - 1) / RPB)), dim3(256), 0, s,     \
-                           I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1);              \
+        const dim3 grid((unsigned)((n + RPB - 1) / RPB));                                                    \
+        if (bf16) hipLaunchKernelGGL((item_prep_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1); \
+        else hipLaunchKernelGGL((item_prep_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1); \
         break;                                                                                               \
     }
     switch (d) {
@@ -859,7 +896,7 @@ int run_item_prep(const float* I_shard, const float* pop, const int* order, int 
     return PDA_OK;
 }
 
-int run_score_prepped(const float* U, const float* I_shard, const void* prep, bool ordered, const float* pop_shard,
+int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void* prep, bool ordered, const float* pop_shard,
                       const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                       const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
                       int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s) {
@@ -870,7 +907,7 @@ int run_score_prepped(const float* U, const float* I_shard, const void* prep, bo
     if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
     if (hist_indptr && (!hist_indices || (ordered && !hist_indices_ord))) return PDA_ERR_ARG;
     if (n_splits <= 0) n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
-    const PrepLayout L = prep_layout(n_items_local, d, ordered);
+    const PrepLayout L = prep_layout(n_items_local, d, ordered, planes_of(bf16, ordered));
     const char* pb = reinterpret_cast<const char*>(prep);
     int* ws = reinterpret_cast<int*>(workspace);
     if (hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
@@ -878,9 +915,12 @@ int run_score_prepped(const float* U, const float* I_shard, const void* prep, bo
         hipLaunchKernelGGL(pop_max_kernel, dim3(64), dim3(256), 0, s, pop_shard, n_items_local, ws);
         PDA_CHECK_LAUNCH();
     }
-    ScoreArgs2 aa{{U, I_shard, pop_shard, users, hist_indptr, ordered ? hist_indices_ord : hist_indices, out_keys, n_users_blk,
-                   item_offset, n_items_local, hist_row_mode, K, n_splits, nullptr},
-                  reinterpret_cast<const uint16_t*>(pb + L.hi), reinterpret_cast<const uint16_t*>(pb + L.lo),
+    // bf16 tables, natural order: the B tiles are read from the table itself
+    const uint16_t* plane_hi = (bf16 && !ordered) ? reinterpret_cast<const uint16_t*>(I_shard) : reinterpret_cast<const uint16_t*>(pb + L.hi);
+    ScoreArgs2 aa{{reinterpret_cast<const float*>(U), reinterpret_cast<const float*>(I_shard), pop_shard, users, hist_indptr,
+                   ordered ? hist_indices_ord : hist_indices, out_keys, n_users_blk, item_offset, n_items_local, hist_row_mode, K,
+                   n_splits, nullptr},
+                  plane_hi, reinterpret_cast<const uint16_t*>(pb + L.lo),
                   reinterpret_cast<const float*>(pb + L.norm), reinterpret_cast<const float*>(pb + L.nmax),
                   reinterpret_cast<const float*>(ws), ws + 4,
                   ordered ? reinterpret_cast<const int*>(pb + L.order) : nullptr,
@@ -891,7 +931,7 @@ int run_score_prepped(const float* U, const float* I_shard, const void* prep, bo
     int rc = PDA_ERR_UNSUPPORTED;
 #ifdef PDA_ABLATION
     if (const char* e = getenv("PDA_ABLATE")) {
-        if (d == 128 && head == PDA_HEAD_POP && !ordered) switch (atoi(e)) {
+        if (d == 128 && head == PDA_HEAD_POP && !ordered && !bf16) switch (atoi(e)) {
             case 1: return launch_v2<128, PDA_HEAD_POP, false, 1>(aa, s);
             case 3: return launch_v2<128, PDA_HEAD_POP, false, 3>(aa, s);
             case 7: return launch_v2<128, PDA_HEAD_POP, false, 7>(aa, s);
@@ -906,35 +946,33 @@ int run_score_prepped(const float* U, const float* I_shard, const void* prep, bo
         }
     }
 #endif
-#define PDA_V2(DD)                                                                                                           \
-    case DD:                                                                                                                 \
-        if (ordered) rc = head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP, true>(aa, s) : launch_v2<DD, PDA_HEAD_RAW, true>(aa, s); \
-        else rc = head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP>(aa, s) : launch_v2<DD, PDA_HEAD_RAW>(aa, s);            \
+#define PDA_V2_(DD, ORDV, NPV) \
+    (head == PDA_HEAD_POP ? launch_v2<DD, PDA_HEAD_POP, ORDV, 0, NPV>(aa, s) : launch_v2<DD, PDA_HEAD_RAW, ORDV, 0, NPV>(aa, s))
+#define PDA_V2(DD)                                                                                   \
+    case DD:                                                                                         \
+        if (bf16) rc = ordered ? PDA_V2_(DD, true, 1) : PDA_V2_(DD, false, 1);                       \
+        else rc = ordered ? PDA_V2_(DD, true, 3) : PDA_V2_(DD, false, 3);                            \
         break;
     switch (d) {
         PDA_V2(64) PDA_V2(128) PDA_V2(256)
         default: return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_V2
+#undef PDA_V2_
     if (rc != PDA_OK) return rc;
     // exact recomputation of the (normally zero) user tiles whose near-tie band overflowed: natural item order, the
     // caller's original history
     ScoreArgs v1 = aa.a;
     v1.hist_indices = hist_indices;
     v1.tile_flags = ws + 4;
-    return pda_topk::launch_score_v1(v1, d, head, s);
+    return pda_topk::launch_score_v1(v1, d, head, s, bf16);
 }
 }  // namespace
 
-extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) {
-    // [hi bf16 n*d][lo bf16 n*d][norm f32 n][max norm f32], each section 256-byte aligned
-    return prep_layout(n_items_local, d, false).total;
-}
-
-extern "C" size_t pda_item_prep_ordered_bytes(int n_items_local, int d) {
-    // ... + [pop in visiting order f32 n][order i32 n][position of item i32 n][suffix bounds 2 x f32 n_tiles]
-    return prep_layout(n_items_local, d, true).total;
-}
+extern "C" size_t pda_item_prep_bytes(int n_items_local, int d) { return prep_layout(n_items_local, d, false, 2).total; }
+extern "C" size_t pda_item_prep_ordered_bytes(int n_items_local, int d) { return prep_layout(n_items_local, d, true, 2).total; }
+extern "C" size_t pda_item_prep_bf16_bytes(int n_items_local, int d) { return prep_layout(n_items_local, d, false, 0).total; }
+extern "C" size_t pda_item_prep_ordered_bf16_bytes(int n_items_local, int d) { return prep_layout(n_items_local, d, true, 1).total; }
 
 extern "C" size_t pda_score_topk_workspace_bytes(int n_users_blk) {
     // [max |pop| f32][pad][u64 item tiles scored, summed over workgroups][tile_flags i32 per 128-user tile]
@@ -944,18 +982,26 @@ extern "C" size_t pda_score_topk_workspace_bytes(int n_users_blk) {
 
 extern "C" int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream) {
     if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
-    return run_item_prep(I_shard, nullptr, nullptr, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+    return run_item_prep(I_shard, false, nullptr, nullptr, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
 }
-
+extern "C" int pda_item_prep_bf16(const uint16_t* I_shard, int n_items_local, int d, void* prep, void* stream) {
+    if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_item_prep(I_shard, true, nullptr, nullptr, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
 extern "C" int pda_item_prep_ordered_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local,
                                          int d, void* prep, void* stream) {
     if (!I_shard || !order || !prep || n_items_local <= 0) return PDA_ERR_ARG;
-    return run_item_prep(I_shard, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+    return run_item_prep(I_shard, false, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_item_prep_ordered_bf16(const uint16_t* I_shard, const float* pop_shard, const int32_t* order, int n_items_local,
+                                          int d, void* prep, void* stream) {
+    if (!I_shard || !order || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_item_prep(I_shard, true, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
 }
 
 extern "C" int pda_item_prep_ordered_check(const void* prep, int n_items_local, int d, void* stream) {
     if (!prep || n_items_local <= 0) return PDA_ERR_ARG;
-    const PrepLayout L = prep_layout(n_items_local, d, true);
+    const PrepLayout L = prep_layout(n_items_local, d, true, 0);
     int bad = 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (hipMemcpyAsync(&bad, reinterpret_cast<const char*>(prep) + L.nmax + 4, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return PDA_ERR_LAUNCH;
@@ -967,7 +1013,7 @@ extern "C" int pda_hist_reorder(const void* prep, int n_items_local, int d, int 
                                 const int32_t* hist_indices, int n_rows, int32_t* out_indices, void* stream) {
     if (!prep || !hist_indptr || !hist_indices || !out_indices || n_items_local <= 0 || n_rows < 0 || item_offset < 0) return PDA_ERR_ARG;
     if (n_rows == 0) return PDA_OK;
-    const PrepLayout L = prep_layout(n_items_local, d, true);
+    const PrepLayout L = prep_layout(n_items_local, d, true, 0);      // the small arrays sit in front of the planes
     hipLaunchKernelGGL(hist_reorder_kernel, dim3((unsigned)n_rows), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), hist_indptr,
                        hist_indices, reinterpret_cast<const int*>(reinterpret_cast<const char*>(prep) + L.pos_of), item_offset,
                        n_items_local, out_indices);
@@ -975,21 +1021,32 @@ extern "C" int pda_hist_reorder(const void* prep, int n_items_local, int d, int 
     return PDA_OK;
 }
 
-extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
-                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
-                                          const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K,
-                                          int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream) {
-    return run_score_prepped(U, I_shard, prep, false, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
+#define PDA_SCORE_ARGS_DECL                                                                                                   \
+    const float* pop_shard, const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,                \
+        const int64_t* hist_indptr, const int32_t* hist_indices
+#define PDA_SCORE_TAIL_DECL int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream
+
+extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
+                                          PDA_SCORE_TAIL_DECL) {
+    return run_score_prepped(U, I_shard, false, prep, false, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
                              hist_indices, nullptr, hist_row_mode, K, head, n_splits, out_keys, workspace,
                              reinterpret_cast<hipStream_t>(stream));
 }
-
-extern "C" int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
-                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
-                                          const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
-                                          int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
-                                          void* stream) {
-    return run_score_prepped(U, I_shard, prep, true, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
+extern "C" int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
+                                          const int32_t* hist_indices_ord, PDA_SCORE_TAIL_DECL) {
+    return run_score_prepped(U, I_shard, false, prep, true, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
+                             hist_indices, hist_indices_ord, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_score_topk_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
+                                   PDA_SCORE_TAIL_DECL) {
+    return run_score_prepped(U, I_shard, true, prep, false, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
+                             hist_indices, nullptr, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
+                                           const int32_t* hist_indices_ord, PDA_SCORE_TAIL_DECL) {
+    return run_score_prepped(U, I_shard, true, prep, true, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
                              hist_indices, hist_indices_ord, hist_row_mode, K, head, n_splits, out_keys, workspace,
                              reinterpret_cast<hipStream_t>(stream));
 }

@@ -10,7 +10,7 @@ constexpr int kUserTile = 128;  // users per workgroup
 constexpr int kCap = PDA_TOPK_CAP;
 
 struct ScoreArgs {
-    const float* U;
+    const float* U;   // f32 tables; bf16 tables (uint16 bits) behind the same pointers in the *_bf16 entry points
     const float* I;
     const float* pop;
     const int32_t* users;
@@ -27,7 +27,7 @@ struct ScoreArgs {
 };
 
 // defined in pda_score_topk.hip
-int launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t stream);
+int launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t stream, bool bf16_tables = false);
 
 template <int D>
 __device__ __forceinline__ int swz(int row) {

@@ -86,8 +86,12 @@ def item_prep(I_shard: torch.Tensor) -> torch.Tensor:
         buf = hit[2]
     else:
         n, d = I_shard.shape
-        buf = torch.empty(lib.pda_item_prep_bytes(n, d), dtype=torch.uint8, device=I_shard.device)
-    check(lib.pda_item_prep_f32(ptr(I_shard), I_shard.shape[0], I_shard.shape[1], ptr(buf), stream_ptr()), "pda_item_prep_f32")
+        nbytes = lib.pda_item_prep_bf16_bytes(n, d) if I_shard.dtype == torch.bfloat16 else lib.pda_item_prep_bytes(n, d)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=I_shard.device)
+    if I_shard.dtype == torch.bfloat16:
+        check(lib.pda_item_prep_bf16(ptr(I_shard), I_shard.shape[0], I_shard.shape[1], ptr(buf), stream_ptr()), "pda_item_prep_bf16")
+    else:
+        check(lib.pda_item_prep_f32(ptr(I_shard), I_shard.shape[0], I_shard.shape[1], ptr(buf), stream_ptr()), "pda_item_prep_f32")
     for k in [k for k, v in _PREP_CACHE.items() if v[0]() is None]:
         del _PREP_CACHE[k]                                   # drop entries whose table died
     _PREP_CACHE[key] = (weakref.ref(I_shard), I_shard._version, buf)
@@ -106,7 +110,7 @@ def visiting_order(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor]) -> 
     hit = _ORDER_CACHE.get(id(src))
     if hit is not None and hit[0]() is src and hit[1] == src._version:
         return hit[2]
-    key = pop_shard.abs() if pop_shard is not None else torch.linalg.vector_norm(I_shard, dim=1)
+    key = pop_shard.abs() if pop_shard is not None else torch.linalg.vector_norm(I_shard.float(), dim=1)
     order = torch.argsort(key, descending=True, stable=True).to(torch.int32)
     for k in [k for k, v in _ORDER_CACHE.items() if v[0]() is None]:
         del _ORDER_CACHE[k]
@@ -127,13 +131,15 @@ def item_prep_ordered(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], 
         same_pop = (hit[3] is None and pop_shard is None) or (hit[3] is not None and hit[3]() is pop_shard and hit[4] == pop_shard._version)
         if hit[1] == I_shard._version and hit[2] is order and same_pop:
             return buf, order
+    bf = I_shard.dtype == torch.bfloat16
     if buf is None:
-        buf = torch.empty(lib.pda_item_prep_ordered_bytes(n, d), dtype=torch.uint8, device=I_shard.device)
+        nbytes = lib.pda_item_prep_ordered_bf16_bytes(n, d) if bf else lib.pda_item_prep_ordered_bytes(n, d)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=I_shard.device)
     order = _need(order, torch.int32, "order")
     if order.numel() != n:
         raise ValueError("order must have one entry per local item row")
-    check(lib.pda_item_prep_ordered_f32(ptr(I_shard), ptr(pop_shard), ptr(order), n, d, ptr(buf), stream_ptr()),
-          "pda_item_prep_ordered_f32")
+    fn = lib.pda_item_prep_ordered_bf16 if bf else lib.pda_item_prep_ordered_f32
+    check(fn(ptr(I_shard), ptr(pop_shard), ptr(order), n, d, ptr(buf), stream_ptr()), "pda_item_prep_ordered")
     for k in [k for k, v in _PREP_ORD_CACHE.items() if v[0]() is None]:
         del _PREP_ORD_CACHE[k]
     _PREP_ORD_CACHE[id(I_shard)] = (weakref.ref(I_shard), I_shard._version, order,
@@ -199,11 +205,16 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 -> packed keys
     int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All three return the same keys."""
     lib = _lib.load()
-    U = _need(U, torch.float32, "U")
-    I_shard = _need(I_shard, torch.float32, "I_shard")
+    bf = I_shard is not None and I_shard.dtype == torch.bfloat16       # bf16 tables: pda_score_topk_bf16 (both tables bf16)
+    U = _need(U, torch.bfloat16 if bf else torch.float32, "U")
+    I_shard = _need(I_shard, torch.bfloat16 if bf else torch.float32, "I_shard")
     users = _need(users, torch.int32, "users")
     pop_shard = _need(pop_shard, torch.float32, "pop_shard", optional=True)
     nu, nloc, d = users.numel(), I_shard.shape[0], I_shard.shape[1]
+    if bf:
+        if d not in (64, 128, 256) or K > TOPK_CAP_V2 or impl == "v1":
+            raise ValueError("bf16 tables: embed dim 64/128/256, K <= %d, no v1 entry point" % TOPK_CAP_V2)
+        impl = "v2"
     if U.shape[1] != d:
         raise ValueError("U and I_shard disagree on embed dim")
     if pop_shard is not None and pop_shard.numel() != nloc:
@@ -223,7 +234,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         prep, order = item_prep_ordered(I_shard, pop_shard if head == HEAD_POP else None)
         hist_ord = hist_reordered(hist, prep, order, item_offset, nloc, d) if hist else None
         ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)
-        check(lib.pda_score_topk_ordered_f32(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
+        fn = lib.pda_score_topk_ordered_bf16 if bf else lib.pda_score_topk_ordered_f32
+        check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
                                              nloc, d, ptr(hist.indptr) if hist else None,
                                              ptr(hist.indices) if hist else None, ptr(hist_ord), hist.mode if hist else 0,
                                              K, head, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk_ordered_f32")
@@ -234,7 +246,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     if impl == "v2":
         prep = item_prep(I_shard)
         ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)   # per call: re-entrant
-        check(lib.pda_score_topk_prepped_f32(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
+        fn = lib.pda_score_topk_bf16 if bf else lib.pda_score_topk_prepped_f32
+        check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
                                              nloc, d, ptr(hist.indptr) if hist else None,
                                              ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head,
                                              n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk_prepped_f32")

@@ -384,3 +384,61 @@ def test_item_prep_cache_follows_weight_updates(dev):
     d2 = ops.score_topk_keys(Ut, It, ut, 50, impl="v2")
     d1 = ops.score_topk_keys(Ut, It, ut, 50, impl="v1")
     assert torch.equal(d1, d2) and not torch.equal(d2, b)
+
+
+def _bf16_round(x):
+    """numpy fp32 -> the fp32 value of its bf16 rounding (RNE), via torch (bit-exact with a device .bfloat16())."""
+    return torch.from_numpy(x).bfloat16().float().numpy()
+
+
+@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("head", [0, 1])
+def test_bf16_tables_return_the_keys_of_the_widened_fp32_tables(dev, d, head, impl):
+    """pda_score_topk_bf16 / pda_score_topk_ordered_bf16 (BASELINE config 5's table type): bit-identical to the fp32 path
+    run on the widened tables -- checked against the exact fp32-MFMA kernel AND the C oracle, with history and item
+    splits, natural order (impl v1/v2) and ordered sweep (impl v2ord)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(1300 + d + head)
+    nU, nI, K = 200, 4000, 50
+    for scale in (0.1, 2.0):
+        U, I, pop, hist = make_case(rng, nU, nI, d, scale=scale)
+        I[::9] *= 6.0
+        Uw, Iw = _bf16_round(U), _bf16_round(I)
+        users = np.arange(nU, dtype=np.int32)
+        ip, ix = csr(hist)
+        h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+        ut = torch.from_numpy(users).to(dev)
+        pt = torch.from_numpy(pop).to(dev) if head else None
+        Ub, Ib = torch.from_numpy(Uw).to(dev).bfloat16(), torch.from_numpy(Iw).to(dev).bfloat16()
+        assert torch.equal(Ub.float().cpu(), torch.from_numpy(Uw))
+        ref = ops.topk_merge(ops.score_topk_keys(torch.from_numpy(Uw).to(dev), torch.from_numpy(Iw).to(dev), ut, K, head, pt, h,
+                                                 n_splits=2, impl="v1"), want="keys")
+        got = ops.topk_merge(ops.score_topk_keys(Ub, Ib, ut, K, head, pt, h, n_splits=2), want="keys")
+        assert torch.equal(ref, got), (d, head, scale, int((ref != got).sum()))
+        bip = np.zeros(nU + 1, np.int64)
+        bip[1:] = np.cumsum([len(set(r.tolist())) for r in hist])
+        bix = np.concatenate([np.unique(r) for r in hist]).astype(np.int32)
+        ridx, rval = c_oracle.score_topk(Uw, Iw, users, K, head, pop if head else None, bip, bix, order=1)
+        gidx, gval = ops.unpack_keys(got)
+        np.testing.assert_array_equal(gidx, ridx)
+        np.testing.assert_array_equal(gval, rval)
+
+
+def test_bf16_exact_ties_take_the_exact_fallback(dev):
+    """301 bit-identical items overflow the near-tie band: the user tile is recomputed by the exact kernel reading the
+    bf16 tables (score_topk_kernel<.., BF>)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(31)
+    nU, nI, d, K = 40, 640, 64, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d, max_hist=0)
+    I[100:400] = I[50]
+    Uw, Iw = _bf16_round(U), _bf16_round(I)
+    users = np.arange(nU, dtype=np.int32)
+    ut = torch.from_numpy(users).to(dev)
+    Ub, Ib = torch.from_numpy(Uw).to(dev).bfloat16(), torch.from_numpy(Iw).to(dev).bfloat16()
+    for head, p in ((0, None), (1, pop)):
+        pt = torch.from_numpy(p).to(dev) if head else None
+        got = ops.topk_merge(ops.score_topk_keys(Ub, Ib, ut, K, head, pt, None, n_splits=4), want="keys")
+        ref = ops.topk_merge(ops.score_topk_keys(torch.from_numpy(Uw).to(dev), torch.from_numpy(Iw).to(dev), ut, K, head, pt, None,
+                                                 n_splits=4, impl="v1"), want="keys")
+        assert torch.equal(ref, got)
