@@ -178,6 +178,20 @@ int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* po
                      int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU, float* gI,
                      float* loss_acc, void* stream);
 
+/* bf16 tables (config 5): the forward pass gathers bf16 rows (U_bf16 / I_bf16, uint16 bit patterns) and computes in fp32
+ * exactly as pda_bpr_step_f32 does on the widened rows; gradients are fp32.  bf16 rows cannot take atomic adds, so
+ *   PDA_UPD_NONE        per-occurrence gradients out (masters may be NULL)
+ *   PDA_UPD_SGD_FUSED   the fp32 MASTER tables (U_master / I_master, same shape) take the SGD update; afterwards
+ *                       pda_refresh_rows_bf16 re-rounds (RNE) the touched rows of the bf16 tables from the masters
+ *   PDA_UPD_DENSE_GRAD  gradients summed into gU / gI (fp32) for pda_adam_dense_sweep_f32 on the masters
+ * pda_refresh_rows_bf16(master, shadow, rows, n_rows, d): shadow[rows[i]] = bf16(master[rows[i]]); rows == NULL means
+ * rows 0 .. n_rows-1 (a dense cast of a whole table).  d a multiple of 8. */
+int pda_bpr_step_bf16(const uint16_t* U_bf16, const uint16_t* I_bf16, float* U_master, float* I_master,
+                      const int32_t* users, const int32_t* pos, const int32_t* neg, const float* pos_pop,
+                      const float* neg_pop, int B, int d, float regs, float reg_div, float lr, int update_mode,
+                      float* g_user, float* g_pos, float* g_neg, float* gU, float* gI, float* loss_acc, void* stream);
+int pda_refresh_rows_bf16(const float* master, uint16_t* shadow, const int32_t* rows, int n_rows, int d, void* stream);
+
 /* Item-parallel training (north_star "each rank owns an item-embedding slice, BPR negatives sampled
  * locally"): rank r holds the item rows [item_offset, item_offset + n_local) and a replica of U.  Its sub-batch has
  * positives AND negatives inside that slice (global ids).  pda_bpr_step_shard_f32 applies the SGD update to the local

@@ -34,6 +34,8 @@ struct StepArgs {
     int mode;
     int item_offset;   // pos / neg are global item ids; row = id - item_offset in `I` (an item shard)
     int g_stride;      // floats between consecutive g_user rows (>= D)
+    const void* Ufwd;  // tables the forward pass gathers from: U / I themselves (fp32) or their bf16 shadows
+    const void* Ifwd;  // (pda_bpr_step_bf16: U / I are then the fp32 masters that take the update)
 };
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -50,7 +52,7 @@ __device__ __forceinline__ void atomic_add4(float* p, f32x4 v) {
 // L2 (measured 25 us per 2048-triplet step).  The positives' contributions therefore go through LDS first: runs of
 // equal `pos` inside the block are summed by their first triplet and leave as ONE atomic per element.  Any batch order
 // is correct; a batch sorted by `pos` (pda_sort_triplets_by_pos, done by the device sampler) makes the runs long.
-template <int D>
+template <int D, bool BF>
 __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
     constexpr int L = D / 4;        // lanes per triplet
     constexpr int TPB = 512 / L;    // triplets per block
@@ -72,9 +74,9 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
         float* up = a.U + (size_t)u * D + 4 * e;
         float* pp = a.I + (size_t)p * D + 4 * e;
         float* np_ = a.I + (size_t)n * D + 4 * e;
-        const f32x4 ue = *reinterpret_cast<const f32x4*>(up);
-        const f32x4 pe = *reinterpret_cast<const f32x4*>(pp);
-        const f32x4 ne = *reinterpret_cast<const f32x4*>(np_);
+        const f32x4 ue = pda_load4<BF>(a.Ufwd, (size_t)u * D + 4 * e);
+        const f32x4 pe = pda_load4<BF>(a.Ifwd, (size_t)p * D + 4 * e);
+        const f32x4 ne = pda_load4<BF>(a.Ifwd, (size_t)n * D + 4 * e);
         float ps = dot4(ue, pe), ns = dot4(ue, ne);
         sq = dot4(ue, ue) + dot4(pe, pe) + dot4(ne, ne);
 #pragma unroll
@@ -246,12 +248,32 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, fl
     *reinterpret_cast<f32x4*>(g + off) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-template <int D>
+template <int D, bool BF = false>
 int launch_step(const StepArgs& a, hipStream_t s) {
     constexpr int TPB = 512 / (D / 4);
-    hipLaunchKernelGGL(bpr_step_kernel<D>, dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((bpr_step_kernel<D, BF>), dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
+}
+
+// shadow[row] = RNE_bf16(master[row]) for a list of rows (duplicates harmless); one 16-byte store per thread
+__global__ void __launch_bounds__(256) refresh_rows_kernel(const float* __restrict__ master, uint16_t* __restrict__ shadow,
+                                                          const int32_t* __restrict__ rows, int row_offset, size_t n8, int d8) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const size_t r = rows ? (size_t)(rows[i / d8] - row_offset) : i / d8;
+    const size_t off = r * (8 * (size_t)d8) + 8 * (i % d8);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(master + off), b = *reinterpret_cast<const f32x4*>(master + off + 4);
+    auto rne = [](float x) -> uint32_t {
+        const uint32_t u = __float_as_uint(x);
+        return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+    };
+    uint4 o;
+    o.x = rne(a[0]) | (rne(a[1]) << 16);
+    o.y = rne(a[2]) | (rne(a[3]) << 16);
+    o.z = rne(b[0]) | (rne(b[1]) << 16);
+    o.w = rne(b[2]) | (rne(b[3]) << 16);
+    *reinterpret_cast<uint4*>(shadow + off) = o;
 }
 
 }  // namespace
@@ -266,7 +288,7 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
     if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
     if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
     StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
-               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d};
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);
@@ -286,7 +308,7 @@ extern "C" int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_o
     if (g_stride < d || (g_stride & 3)) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     StepArgs a{const_cast<float*>(U), I_shard, users, pos, neg, pos_pop, neg_pop, g_user, nullptr, nullptr, nullptr, nullptr,
-               loss_acc, B_local, 1.0f / mean_div, regs / reg_div, lr, PDA_UPD_SGD_ITEMS, item_offset, g_stride};
+               loss_acc, B_local, 1.0f / mean_div, regs / reg_div, lr, PDA_UPD_SGD_ITEMS, item_offset, g_stride, U, I_shard};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);
@@ -362,6 +384,37 @@ extern "C" int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const
         default: return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_ROWS
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_bpr_step_bf16(const uint16_t* U_bf16, const uint16_t* I_bf16, float* U_master, float* I_master,
+                                 const int32_t* users, const int32_t* pos, const int32_t* neg, const float* pos_pop,
+                                 const float* neg_pop, int B, int d, float regs, float reg_div, float lr, int update_mode,
+                                 float* g_user, float* g_pos, float* g_neg, float* gU, float* gI, float* loss_acc, void* stream) {
+    if (!U_bf16 || !I_bf16 || !users || !pos || !neg || B <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    if (update_mode < PDA_UPD_NONE || update_mode > PDA_UPD_DENSE_GRAD) return PDA_ERR_ARG;
+    if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
+    if (update_mode == PDA_UPD_SGD_FUSED && (!U_master || !I_master)) return PDA_ERR_ARG;   // bf16 rows take no atomics
+    if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
+    StepArgs a{U_master, I_master, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U_bf16, I_bf16};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (d) {
+        case 32: return launch_step<32, true>(a, s);
+        case 64: return launch_step<64, true>(a, s);
+        case 128: return launch_step<128, true>(a, s);
+        case 256: return launch_step<256, true>(a, s);
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int pda_refresh_rows_bf16(const float* master, uint16_t* shadow, const int32_t* rows, int n_rows, int d, void* stream) {
+    if (!master || !shadow || n_rows <= 0 || d <= 0 || (d & 7)) return PDA_ERR_ARG;
+    const size_t n8 = (size_t)n_rows * (d / 8);
+    hipLaunchKernelGGL(refresh_rows_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       master, shadow, rows, 0, n8, d / 8);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

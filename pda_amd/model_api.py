@@ -13,6 +13,10 @@ Optimisers (`args.optimizer`):
                (= pda_bpr_step_f32(DENSE_GRAD) + pda_adam_dense_sweep_f32 on both tables).  Reference-faithful.
     lazy_adam  the same update restricted to the rows touched by the batch (declared deviation).
     sgd        the north_star's fused in-kernel scatter update (declared deviation from MF/model_api.py:83).
+
+Table type (`args.table_dtype`, extension; BASELINE config 5): with "bf16" the forward pass and the evaluation read bf16
+copies of the tables (`score_tables()`), gradients stay fp32 and `weights[...]` are the fp32 masters that take the
+update; the touched rows (sgd / lazy_adam) or the whole tables (adam) are re-rounded after every step.
 """
 from __future__ import annotations
 
@@ -54,10 +58,16 @@ class _MFBase:
         self.optimizer = getattr(args, "optimizer", "adam")
         if self.optimizer not in ("adam", "lazy_adam", "sgd"):
             raise NotImplementedError("optimizer must be adam | lazy_adam | sgd")
+        self.table_dtype = getattr(args, "table_dtype", "f32")
+        if self.table_dtype not in ("f32", "bf16"):
+            raise NotImplementedError("table_dtype must be f32 | bf16")
         self.device = torch.device(device if device is not None else "cuda")
         gen = torch.Generator(device=self.device)
         gen.manual_seed(seed)                        # tf.set_random_seed(2021), MF/train_new_api.py:936
         self.weights = self.init_weights(gen)
+        self.tables16 = None
+        if self.table_dtype == "bf16":
+            self.tables16 = {k: v.bfloat16() for k, v in self.weights.items()}
         self._t = 0
         self._state = None
         self._loss = torch.zeros(3, dtype=torch.float32, device=self.device)
@@ -82,6 +92,36 @@ class _MFBase:
             self._state = {"mU": z(U), "vU": z(U), "gU": z(U), "mI": z(I), "vI": z(I), "gI": z(I)}
         return self._state
 
+    def score_tables(self):
+        """(U, I) the evaluation kernels read: the weights, or their bf16 copies when table_dtype == 'bf16'."""
+        t = self.tables16 if self.tables16 is not None else self.weights
+        return t["user_embedding"], t["item_embedding"]
+
+    def _train_step_bf16(self, users, pos, neg, pos_pop, neg_pop):
+        U, I = self.weights["user_embedding"], self.weights["item_embedding"]
+        U16, I16 = self.tables16["user_embedding"], self.tables16["item_embedding"]
+        if self.optimizer == "sgd":
+            ops.bpr_step_bf16(U16, I16, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr,
+                              mode=ops.UPD_SGD_FUSED, U_master=U, I_master=I, loss_acc=self._loss)
+            return self._loss
+        st = self._opt_state()
+        self._t += 1
+        lr_t = ops.adam_lr_t(self.lr, self._t)
+        ops.bpr_step_bf16(U16, I16, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
+                          mode=ops.UPD_DENSE_GRAD, gU=st["gU"], gI=st["gI"], loss_acc=self._loss)
+        if self.optimizer == "adam":
+            ops.adam_dense_sweep(U, st["mU"], st["vU"], st["gU"], lr_t)
+            ops.adam_dense_sweep(I, st["mI"], st["vI"], st["gI"], lr_t)
+            ops.refresh_rows_bf16(U, U16)                      # dense decay moves every row
+            ops.refresh_rows_bf16(I, I16)
+        else:
+            ru, ri = torch.unique(users).int(), torch.unique(torch.cat([pos, neg])).int()
+            ops.adam_rows(U, st["mU"], st["vU"], st["gU"], ru, lr_t)
+            ops.adam_rows(I, st["mI"], st["vI"], st["gI"], ri, lr_t)
+            ops.refresh_rows_bf16(U, U16, ru)
+            ops.refresh_rows_bf16(I, I16, ri)
+        return self._loss
+
     # ---- one training step (A1-A5) --------------------------------------------------------------------
     def train_step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
         """Forward + loss + gradient + update on one batch of device tensors (int32 / float32).
@@ -92,6 +132,8 @@ class _MFBase:
         elif pos_pop is None or neg_pop is None:
             raise ValueError("PD/PDA needs pos_pop and neg_pop")
         self._loss.zero_()
+        if self.tables16 is not None:
+            return self._train_step_bf16(users, pos, neg, pos_pop, neg_pop)
         if self.optimizer == "sgd":
             ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr,
                          mode=ops.UPD_SGD_FUSED, loss_acc=self._loss)
@@ -120,6 +162,9 @@ class _MFBase:
     def load_state_dict(self, sd):
         self.weights["user_embedding"].copy_(sd["user_embedding"])
         self.weights["item_embedding"].copy_(sd["item_embedding"])
+        if self.tables16 is not None:
+            for k in self.tables16:
+                ops.refresh_rows_bf16(self.weights[k], self.tables16[k])
         self._t = int(sd.get("adam_t", 0))
         if "mU" in sd:
             st = self._opt_state()

@@ -313,6 +313,47 @@ def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, 
         mark_modified(U, I)
 
 
+def bpr_step_bf16(U16, I16, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float = 0.0,
+                  mode: int = UPD_NONE, U_master=None, I_master=None, grads_out=None, gU=None, gI=None,
+                  loss_acc: Optional[torch.Tensor] = None, refresh: bool = True):
+    """pda_bpr_step_bf16 (+ pda_refresh_rows_bf16 of the touched rows after a fused SGD update)."""
+    lib = _lib.load()
+    U16 = _need(U16, torch.bfloat16, "U16")
+    I16 = _need(I16, torch.bfloat16, "I16")
+    users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
+    pos_pop = _need(pos_pop, torch.float32, "pos_pop", optional=True)
+    neg_pop = _need(neg_pop, torch.float32, "neg_pop", optional=True)
+    U_master = _need(U_master, torch.float32, "U_master", optional=True)
+    I_master = _need(I_master, torch.float32, "I_master", optional=True)
+    B, d = users.numel(), U16.shape[1]
+    gu = gp = gn = None
+    if grads_out is not None:
+        gu, gp, gn = (_need(t, torch.float32, "grads_out") for t in grads_out)
+    gU = _need(gU, torch.float32, "gU", optional=True)
+    gI = _need(gI, torch.float32, "gI", optional=True)
+    loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
+    check(lib.pda_bpr_step_bf16(ptr(U16), ptr(I16), ptr(U_master), ptr(I_master), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop),
+                                ptr(neg_pop), B, d, float(regs), float(reg_div), float(lr), mode, ptr(gu), ptr(gp), ptr(gn),
+                                ptr(gU), ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_bf16")
+    if mode == UPD_SGD_FUSED:
+        mark_modified(U_master, I_master)
+        if refresh:
+            refresh_rows_bf16(U_master, U16, users)
+            refresh_rows_bf16(I_master, I16, pos)
+            refresh_rows_bf16(I_master, I16, neg)
+
+
+def refresh_rows_bf16(master, shadow, rows=None):
+    """pda_refresh_rows_bf16: shadow[rows] = bf16(master[rows]) (RNE); rows None = the whole table."""
+    lib = _lib.load()
+    master = _need(master, torch.float32, "master")
+    shadow = _need(shadow, torch.bfloat16, "shadow")
+    rows = _need(rows, torch.int32, "rows", optional=True)
+    n = rows.numel() if rows is not None else master.shape[0]
+    check(lib.pda_refresh_rows_bf16(ptr(master), ptr(shadow), ptr(rows), n, master.shape[1], stream_ptr()), "pda_refresh_rows_bf16")
+    mark_modified(shadow)
+
+
 def bpr_step_shard(U, I_shard, item_offset: int, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float,
                    mean_div: float, lr: float, g_user: torch.Tensor, loss_acc: Optional[torch.Tensor] = None):
     """pda_bpr_step_shard_f32: one rank's part of an item-parallel SGD step.  pos/neg are GLOBAL ids inside

@@ -116,7 +116,7 @@ class DatasetApi_Model:
 
     # ---- scoring side ---------------------------------------------------------------------------------
     def _tables(self, items):
-        I = self.Recommender.weights["item_embedding"]
+        I = self.Recommender.score_tables()[1]
         if items is None or (len(items) == I.shape[0] and (len(items) == 0 or (items[0] == 0 and items[-1] == I.shape[0] - 1))):
             return I, None
         sel = torch.as_tensor(np.asarray(items, dtype=np.int64), device=self.device)
@@ -151,7 +151,7 @@ class DatasetApi_Model:
         if self._shard is not None and _sel is None:
             self._shard.set_popularity(pop_t)
             return self._shard.topk(users, K, head, hist)
-        return ops.recommend_topk(self.Recommender.weights["user_embedding"], I, users, K, head, pop_t, hist)
+        return ops.recommend_topk(self.Recommender.score_tables()[0], I, users, K, head, pop_t, hist)
 
     def testing(self, sess, batch_users, items, model_type, pos_pop=None):
         """Dense scores f32 [B, len(items)] (:642-669).  Compatibility surface for the NeuRec evaluators (which the
@@ -159,7 +159,7 @@ class DatasetApi_Model:
         U = self.Recommender.weights["user_embedding"]
         users = torch.as_tensor(np.asarray(batch_users, dtype=np.int64), device=self.device)
         I, _ = self._tables(items)
-        R = U.index_select(0, users) @ I.t()
+        R = U.index_select(0, users) @ I.float().t()
         if model_type == "main_branch":
             return R.cpu().numpy()
         if model_type == "condition":

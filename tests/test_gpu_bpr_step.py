@@ -284,3 +284,50 @@ def test_item_parallel_training_with_shard_samplers_learns(dev):
             bufs.append(trainers[r].local_step(users, pos, neg, pp, pn))
         losses.append(float(trainers[0].apply(torch.cat(bufs))[1]))
     assert np.isfinite(losses).all() and np.mean(losses[-4:]) < np.mean(losses[:4]) - 1e-2, (losses[:4], losses[-4:])
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_bf16_tables_step(dev, d):
+    """pda_bpr_step_bf16: forward on the bf16 rows == the fp32 step on the widened rows (loss, per-occurrence gradients);
+    fused SGD moves the fp32 masters by exactly those gradients and pda_refresh_rows_bf16 re-rounds the touched rows."""
+    from pda_amd import ops
+    rng = np.random.default_rng(70 + d)
+    nU, nI, B, regs, lr = 3000, 900, 1024, 1e-2, 0.5
+    Um = (rng.standard_normal((nU, d)) * 0.3).astype(np.float32)          # fp32 masters
+    Im = (rng.standard_normal((nI, d)) * 0.3).astype(np.float32)
+    Ub, Ib = torch.from_numpy(Um).to(dev).bfloat16(), torch.from_numpy(Im).to(dev).bfloat16()
+    Uw, Iw = Ub.float().cpu().numpy(), Ib.float().cpu().numpy()           # what the forward pass sees
+    users, pos, neg = triplets(rng, nU, nI, B)
+    pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    fw = po.bpr_forward(Uw, Iw, users, pos, neg, pp, pn)
+    ref_loss = po.bpr_loss(fw, regs, B)
+    rdu, rdp, rdn = po.bpr_grads(fw, regs, B, pp, pn)
+    ut, pt, nt, ppt, pnt = to(dev, users, pos, neg, pp, pn)
+    gu, gp, gn = (torch.empty(B, d, device=dev) for _ in range(3))
+    loss = torch.zeros(3, device=dev)
+    ops.bpr_step_bf16(Ub, Ib, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, mode=ops.UPD_NONE, grads_out=(gu, gp, gn), loss_acc=loss)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+    for g, r in ((gu, rdu), (gp, rdp), (gn, rdn)):
+        np.testing.assert_allclose(g.cpu().numpy(), r, atol=TOL)
+
+    Umt, Imt = torch.from_numpy(Um).to(dev), torch.from_numpy(Im).to(dev)
+    Ub0, Ib0 = Ub.clone(), Ib.clone()
+    loss.zero_()
+    ops.bpr_step_bf16(Ub, Ib, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, U_master=Umt,
+                      I_master=Imt, loss_acc=loss)
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+    U1, I1 = Um.astype(np.float64), Im.astype(np.float64)
+    np.subtract.at(U1, users, lr * rdu)
+    np.subtract.at(I1, pos, lr * rdp)
+    np.subtract.at(I1, neg, lr * rdn)
+    np.testing.assert_allclose(Umt.cpu().numpy(), U1, atol=TOL)
+    np.testing.assert_allclose(Imt.cpu().numpy(), I1, atol=TOL)
+    # touched rows of the bf16 tables = RNE of the masters, bit for bit; untouched rows untouched
+    tu, ti = np.unique(users), np.unique(np.concatenate([pos, neg]))
+    assert torch.equal(Ub[tu], Umt[tu].bfloat16()) and torch.equal(Ib[ti], Imt[ti].bfloat16())
+    mu, mi = np.ones(nU, bool), np.ones(nI, bool)
+    mu[tu] = False
+    mi[ti] = False
+    assert torch.equal(Ub[mu], Ub0[mu]) and torch.equal(Ib[mi], Ib0[mi])
+    assert not torch.equal(Ib[ti], Ib0[ti])

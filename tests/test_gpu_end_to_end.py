@@ -27,7 +27,9 @@ def _argv(toy, save, train, extra=()):
 
 @pytest.mark.parametrize("train,extra", [("s_condition", ()), ("normal", ("--sampler", "host")),
                                          ("s_condition", ("--optimizer", "sgd", "--lr", "0.05")),
-                                         ("s_condition", ("--optimizer", "lazy_adam"))])
+                                         ("s_condition", ("--optimizer", "lazy_adam")),
+                                         ("s_condition", ("--table_dtype", "bf16")),                     # bf16 tables, faithful Adam on the masters
+                                         ("normal", ("--table_dtype", "bf16", "--optimizer", "sgd", "--lr", "0.05"))])
 def test_main_runs_like_the_reference_script(dev, toy, tmp_path, capsys, train, extra):
     from pda_amd import train_new_api as t
     cfg, cfg_main = t.main(_argv(toy, str(tmp_path) + "/", train, extra))
