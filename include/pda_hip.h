@@ -115,6 +115,9 @@ int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void*
  *        out_indices i32 [nnz]: in-shard ids replaced by item_offset + position, every row sorted again
  *   pda_score_topk_ordered_f32(.. as pda_score_topk_prepped_f32, with hist_indices_ord after hist_indices ..)
  *        hist_indices stays the ORIGINAL (item-id) history: the exact-kernel recomputation of overflowed tiles uses it.
+ *        early_stop = 1: stop as described.  early_stop = 0: every tile is scored (a dense sweep) but still in visiting
+ *        order -- strong items first raise the running thresholds quickly, which alone removes most of the candidate
+ *        handling (C3: 10.4 ms instead of 14.6 ms per 65 536 users).
  * With n_splits > 1 the splits take interleaved tiles of the visiting order.
  * No reference counterpart: the reference scores the full [Bu, I] matrix (MF/train_new_api.py:594-612). */
 size_t pda_item_prep_ordered_bytes(int n_items_local, int d);
@@ -126,8 +129,8 @@ int pda_hist_reorder(const void* prep, int n_items_local, int d, int item_offset
 int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard,
                                const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                                const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
-                               int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
-                               void* stream);
+                               int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys,
+                               void* workspace, void* stream);
 
 /* bf16 tables (BASELINE config 5: 10M x 2M, d=256 bf16).  U and I_shard hold bf16 bit patterns (uint16, row-major).
  * The score of a pair is DEFINED as the same fp32 fmaf chain applied to the widened values -- i.e. these entry points
@@ -147,8 +150,8 @@ int pda_item_prep_ordered_bf16(const uint16_t* I_shard, const float* pop_shard, 
 int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard,
                                 const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                                 const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
-                                int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace,
-                                void* stream);
+                                int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys,
+                                void* workspace, void* stream);
 
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0

@@ -36,13 +36,13 @@ SIGNATURES = {
     "pda_item_prep_ordered_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pda_item_prep_ordered_check": (_i, [_vp, _i, _i, _vp]),
     "pda_hist_reorder": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp]),
-    "pda_score_topk_ordered_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pda_score_topk_ordered_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_item_prep_bf16_bytes": (_sz, [_i, _i]),
     "pda_item_prep_bf16": (_i, [_vp, _i, _i, _vp, _vp]),
     "pda_score_topk_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_item_prep_ordered_bf16_bytes": (_sz, [_i, _i]),
     "pda_item_prep_ordered_bf16": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
-    "pda_score_topk_ordered_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pda_score_topk_ordered_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_bpr_step_shard_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _i, _vp, _vp]),

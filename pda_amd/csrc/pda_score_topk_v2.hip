@@ -667,7 +667,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         bool stop = false;
         if constexpr (ORD) {
             // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (see the kernel comment)
-            if ((k & 3) == 3 && has_next) {
+            if ((k & 3) == 3 && has_next && aa.sufA != nullptr) {
                 const float sa = aa.sufA[tn], sb = aa.sufB[tn];
                 bool dead = true;
 #pragma unroll
@@ -681,7 +681,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         }
         if constexpr (!(ABL & 32)) __syncthreads();  // next tile visible
         if constexpr (ORD) {
-            if ((k & 3) == 3 && has_next) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
+            if ((k & 3) == 3 && has_next && aa.sufA != nullptr) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
         }
 
         acc_prev = acc_new;
@@ -899,7 +899,8 @@ int run_item_prep(const void* I_shard, bool bf16, const float* pop, const int* o
 int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void* prep, bool ordered, const float* pop_shard,
                       const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
                       const int64_t* hist_indptr, const int32_t* hist_indices, const int32_t* hist_indices_ord,
-                      int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s) {
+                      int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace,
+                      hipStream_t s) {
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_TOPK_CAP - 4) return PDA_ERR_ARG;
@@ -925,8 +926,8 @@ int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void*
                   reinterpret_cast<const float*>(ws), ws + 4,
                   ordered ? reinterpret_cast<const int*>(pb + L.order) : nullptr,
                   ordered ? reinterpret_cast<const float*>(pb + L.pop_p) : nullptr,
-                  ordered ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr,
-                  ordered ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
+                  ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr,   // NULL: visit everything
+                  ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
                   reinterpret_cast<unsigned long long*>(ws + 2)};
     int rc = PDA_ERR_UNSUPPORTED;
 #ifdef PDA_ABLATION
@@ -1025,28 +1026,30 @@ extern "C" int pda_hist_reorder(const void* prep, int n_items_local, int d, int 
     const float* pop_shard, const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,                \
         const int64_t* hist_indptr, const int32_t* hist_indices
 #define PDA_SCORE_TAIL_DECL int hist_row_mode, int K, int head, int n_splits, uint64_t* out_keys, void* workspace, void* stream
+#define PDA_SCORE_TAIL_ORD_DECL \
+    int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, void* stream
 
 extern "C" int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
                                           PDA_SCORE_TAIL_DECL) {
     return run_score_prepped(U, I_shard, false, prep, false, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
-                             hist_indices, nullptr, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             hist_indices, nullptr, hist_row_mode, K, head, 0, n_splits, out_keys, workspace,
                              reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
-                                          const int32_t* hist_indices_ord, PDA_SCORE_TAIL_DECL) {
+                                          const int32_t* hist_indices_ord, PDA_SCORE_TAIL_ORD_DECL) {
     return run_score_prepped(U, I_shard, false, prep, true, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
-                             hist_indices, hist_indices_ord, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             hist_indices, hist_indices_ord, hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace,
                              reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int pda_score_topk_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
                                    PDA_SCORE_TAIL_DECL) {
     return run_score_prepped(U, I_shard, true, prep, false, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
-                             hist_indices, nullptr, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             hist_indices, nullptr, hist_row_mode, K, head, 0, n_splits, out_keys, workspace,
                              reinterpret_cast<hipStream_t>(stream));
 }
 extern "C" int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, PDA_SCORE_ARGS_DECL,
-                                           const int32_t* hist_indices_ord, PDA_SCORE_TAIL_DECL) {
+                                           const int32_t* hist_indices_ord, PDA_SCORE_TAIL_ORD_DECL) {
     return run_score_prepped(U, I_shard, true, prep, true, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr,
-                             hist_indices, hist_indices_ord, hist_row_mode, K, head, n_splits, out_keys, workspace,
+                             hist_indices, hist_indices_ord, hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace,
                              reinterpret_cast<hipStream_t>(stream));
 }

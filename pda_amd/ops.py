@@ -189,19 +189,24 @@ def score_impl(d: int, K: int, item_hi: int) -> str:
 TOPK_CAP_V2 = _lib.TOPK_CAP - 4
 
 
-def prune_default(head: int) -> bool:
-    """Ordered sweep with early termination: on for the popularity-weighted head (where the bound bites), off for the
-    raw head.  PDA_SCORE_PRUNE=0|1 forces it.  Results are identical either way."""
+def prune_default(head: int):
+    """How the catalogue is swept (results are identical in all three):
+        True     visiting order (popular first) + exact early termination -- the default for the popularity-weighted head
+        "order"  visiting order, every tile scored (a dense sweep whose thresholds rise early: far fewer candidates)
+        False    natural item order, every tile scored -- the default for the raw head
+    PDA_SCORE_PRUNE=0|1|order forces one."""
     import os
     forced = os.environ.get("PDA_SCORE_PRUNE", "")
     if forced in ("0", "1"):
         return forced == "1"
+    if forced == "order":
+        return "order"
     return head == HEAD_POP
 
 
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
                     item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None,
-                    prune: Optional[bool] = None, stats: Optional[dict] = None) -> torch.Tensor:
+                    prune=None, stats: Optional[dict] = None) -> torch.Tensor:
     """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 -> packed keys
     int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All three return the same keys."""
     lib = _lib.load()
@@ -238,7 +243,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset,
                                              nloc, d, ptr(hist.indptr) if hist else None,
                                              ptr(hist.indices) if hist else None, ptr(hist_ord), hist.mode if hist else 0,
-                                             K, head, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk_ordered_f32")
+                                             K, head, 0 if prune == "order" else 1, n_splits, ptr(out), ptr(ws), stream_ptr()),
+              "pda_score_topk_ordered")
         if stats is not None:            # device scalar (no sync here): item tiles scored, summed over workgroups
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)

@@ -16,13 +16,13 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only"])
 def impl(request, monkeypatch):
     """Every test runs against all scoring paths: v1 = exact fp32 MFMA, v2 = bf16x3 pre-filter + exact rescoring
     (pda_score_topk_v2.hip), v2ord = v2 visiting the catalogue strongest-bound-first with early termination
     (pda_score_topk_ordered_f32, forced on for BOTH heads here).  They must be indistinguishable."""
     monkeypatch.setenv("PDA_SCORE_IMPL", "v1" if request.param == "v1" else "v2")
-    monkeypatch.setenv("PDA_SCORE_PRUNE", "1" if request.param == "v2ord" else "0")
+    monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order"}.get(request.param, "0"))
     return request.param
 
 
@@ -302,7 +302,7 @@ def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head, impl):
                 torch.from_numpy(pop).to(dev) if head else None, h, 0)
         k1 = ops.score_topk_keys(*args, n_splits=2, impl="v1")
         k2 = ops.score_topk_keys(*args, n_splits=2, impl="v2")
-        if impl == "v2ord":              # the ordered sweep gives its splits interleaved tiles: compare after the merge
+        if impl in ("v2ord", "v2order_only"):   # the ordered sweep gives its splits interleaved tiles: compare after the merge
             k1, k2 = ops.topk_merge(k1, want="keys"), ops.topk_merge(k2, want="keys")
         assert torch.equal(k1, k2), (d, head, scale, int((k1 != k2).sum()))
 
@@ -340,18 +340,20 @@ def test_ordered_sweep_is_exact_for_any_order_and_really_stops(dev, head, order_
     prep, order = ops.item_prep_ordered(It, pt if head else None, order)
     ops.check_order(prep, nI, d)
     hord = ops.hist_reordered(h, prep, order, 0, nI, d)
-    for splits in (1, 3):
+    for splits, stop in ((1, 1), (3, 1), (2, 0)):
         keys = torch.empty((splits, nU, K), dtype=torch.int64, device=dev)
         ws = torch.empty(lib.pda_score_topk_workspace_bytes(nU), dtype=torch.uint8, device=dev)
         ops.check(lib.pda_score_topk_ordered_f32(ops.ptr(Ut), ops.ptr(It), ops.ptr(prep), ops.ptr(pt) if head else None,
                                                  ops.ptr(users), nU, 0, nI, d, ops.ptr(h.indptr), ops.ptr(h.indices),
-                                                 ops.ptr(hord), h.mode, K, head, splits, ops.ptr(keys), ops.ptr(ws),
+                                                 ops.ptr(hord), h.mode, K, head, stop, splits, ops.ptr(keys), ops.ptr(ws),
                                                  ops.stream_ptr()), "ordered")
         got = ops.topk_merge(keys, want="keys")
         assert torch.equal(got, ref), (order_kind, splits, int((got != ref).sum()))
         scored = int(ws[8:16].view(torch.int64)[0])
         dense = ((nI + 31) // 32) * ((nU + 127) // 128)
-        if order_kind == "default" and head == 1:                  # (Cauchy-Schwarz alone rarely bites on the raw head)
+        if stop == 0:
+            assert scored == dense                                  # early_stop = 0: every tile scored
+        elif order_kind == "default" and head == 1:                # (Cauchy-Schwarz alone rarely bites on the raw head)
             assert scored < 0.25 * dense, (scored, dense)          # the stop really happens
         if order_kind == "reverse":
             assert scored >= dense - 4 * splits * ((nU + 127) // 128), (scored, dense)
