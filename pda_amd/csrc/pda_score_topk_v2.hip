@@ -39,9 +39,6 @@ using namespace pda_topk;
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 constexpr int kCap2 = PDA_TOPK_CAP - 2;  // 58 slots per user list
 constexpr float kEpsScale = 1.220703125e-4f;  // 2^-13
 
@@ -53,50 +50,6 @@ __device__ unsigned long long pda_dbg[8];   // per-wave sums: 0 ring entries, 1 
 #define PDA_T0(v) do {} while (0)
 #define PDA_T1(v, acc) do {} while (0)
 #endif
-
-struct ScoreArgs2 {
-    ScoreArgs a;
-    const uint16_t* I_hi;   // bf16 [n_items_local, d]
-    const uint16_t* I_lo;   // bf16 [n_items_local, d]
-    const float* I_norm;    // f32  [n_items_local]   ||i||_2 * (1+2^-10), followed (256-B aligned) by the max over the shard
-    const float* I_norm_max;
-    const float* pop_max;   // workspace: max |pop| over the shard (PDA_HEAD_POP)
-    int* tile_flags;        // workspace: [n_user_tiles], set when a row's near-tie band overflowed
-    // ordered sweep (pda_score_topk_ordered_f32): the planes / norms above are stored in VISITING order
-    const int* order;       // [n_items_local] visiting position -> local item id
-    const float* pop_p;     // [n_items_local] pop in visiting order (PDA_HEAD_POP)
-    const float* sufA;      // [n_tiles] max over positions >= 32 t of |pop|            (1 for PDA_HEAD_RAW -> unused, 0)
-    const float* sufB;      // [n_tiles] max over positions >= 32 t of |pop| * ||i||    (||i|| for PDA_HEAD_RAW)
-    unsigned long long* visited;   // workspace: item tiles actually scored, summed over workgroups (statistics)
-};
-
-__device__ __forceinline__ uint32_t bf16_rne(float x) {
-    uint32_t u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-// split 8 floats into packed bf16 hi / lo words
-__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
-    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
-    uint32_t h[8], l[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        h[k] = bf16_rne(v[k]);
-        l[k] = bf16_rne(v[k] - __uint_as_float(h[k] << 16));
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        hi[k] = h[2 * k] | (h[2 * k + 1] << 16);
-        lo[k] = l[2 * k] | (l[2 * k + 1] << 16);
-    }
-}
-
-template <int D>
-__device__ __forceinline__ int swzb(int row) {   // bf16 tile: D/8 16-byte chunks per row
-    constexpr int CPR = D / 8;
-    if constexpr (CPR >= 16) return row & 15;
-    else if constexpr (CPR == 8) return (row >> 1) & 7;
-    else return (row >> 2) & 3;
-}
 
 // one row per D/8 threads: fp32 -> bf16 hi, bf16 lo, padded norm
 // BF: the table is bf16 already -- there is nothing to split; `hi` (may be NULL) receives the row when it has to be
@@ -187,7 +140,7 @@ __global__ void __launch_bounds__(64) hist_reorder_kernel(const int64_t* __restr
     const int64_t b = indptr[blockIdx.x], e = indptr[blockIdx.x + 1];
     const int64_t L = e - b;
     if (L <= 0) return;
-    auto mapped = [&](int64_t i) {
+    auto mapped = [&](int64_t i) __attribute__((always_inline)) {
         const int v = indices[b + i];
         const int loc = v - item_offset;
         return (loc >= 0 && loc < n_items_local) ? item_offset + pos_of[loc] : v;
@@ -333,7 +286,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         stride = 1;
         nt = max(0, min(t0 + tiles_per, tiles_total) - t0);
     }
-    auto tile_of = [&](int k) { return t0 + k * stride; };
+    auto tile_of = [&](int k) __attribute__((always_inline)) { return t0 + k * stride; };
 
     const int row_blk = utile * kUserTile + wave * 32 + j;
     const bool row_ok = row_blk < a.n_users_blk;
@@ -387,7 +340,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         if (hp < he) nxt = a.hist_indices[hp];
         if (hp + 1 < he) nxt2 = a.hist_indices[hp + 1];
     }
-    auto hist_bits = [&](int t) -> uint32_t {
+    auto hist_bits = [&](int t) __attribute__((always_inline)) -> uint32_t {
         if (!hist_on) return 0u;
         const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
         nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
@@ -431,7 +384,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     bool ovf_tile = false;   // wave-uniform: some row's near-tie band overflowed -> tile recomputed by v1
     f32x16 thr;    // lower-bound thresholds T, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
     f32x16 nu;     // eps scale of the row behind each accumulator register
-    auto refresh_thr = [&]() {
+    auto refresh_thr = [&]() __attribute__((always_inline)) {
         int hv = h;
         asm volatile("" : "+v"(hv));
 #pragma unroll
@@ -460,7 +413,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     // ---- item tile staging (register prefetch, unconditional clamped loads) ------------------------------------
     // (a second register set, i.e. prefetching two tiles ahead, was measured: no gain -- the loads are not what waves wait for)
     u32x4 pA_h[NLD], pA_l[NLD];
-    auto tile_load = [&](int t, u32x4 (&ph)[NLD], u32x4 (&pl)[NLD]) {
+    auto tile_load = [&](int t, u32x4 (&ph)[NLD], u32x4 (&pl)[NLD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
@@ -470,7 +423,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             if constexpr (!BF) pl[q] = *reinterpret_cast<const u32x4*>(aa.I_lo + (size_t)it * D + 8 * ch);
         }
     };
-    auto tile_store = [&](const u32x4 (&ph)[NLD], const u32x4 (&pl)[NLD]) {
+    auto tile_store = [&](const u32x4 (&ph)[NLD], const u32x4 (&pl)[NLD]) __attribute__((always_inline)) {
 #pragma unroll
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
@@ -480,7 +433,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
             if constexpr (!BF) *reinterpret_cast<u32x4*>(Bl + off) = pl[q];
         }
     };
-    auto lane_consts = [&](int t, float& popv, float& niv, int& idv) {
+    auto lane_consts = [&](int t, float& popv, float& niv, int& idv) __attribute__((always_inline)) {
         const int it = min(t * 32 + j, a.n_items_local - 1);
         niv = aa.I_norm[it];
         popv = 1.0f;
@@ -493,7 +446,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     // `m`: bit 15-r <-> accumulator register r of the previous tile.  Every flagged lane handles its own top flagged
     // register per round (usually one round); row, history bits and s~ are per-lane values, so there is no
     // wave-uniform loop over registers.
-    auto push_flagged = [&](uint32_t m, uint32_t hb, int item_id, float popv, const f32x16& accv) {
+    auto push_flagged = [&](uint32_t m, uint32_t hb, int item_id, float popv, const f32x16& accv) __attribute__((always_inline)) {
         PDA_T0(tq);
         const bool any_hb = __any(hb != 0);
         bool compacted = false;
@@ -551,7 +504,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 
     // The fast test leaves one 64-bit lane mask per accumulator register in SGPRs (v_cmp writing an SGPR pair: 3 VALU per
     // register instead of 5, the OR over registers is SALU).  The slow path rebuilds the per-lane bit mask from them.
-    auto push_masks = [&](const uint64_t (&M)[16], uint64_t okm, uint32_t hb, int item_id, float popv, const f32x16& accv) {
+    auto push_masks = [&](const uint64_t (&M)[16], uint64_t okm, uint32_t hb, int item_id, float popv, const f32x16& accv) __attribute__((always_inline)) {
         uint32_t m = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) m |= ((M[r] >> lane) & 1ull) ? (1u << (15 - r)) : 0u;
@@ -562,11 +515,11 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     //   PDA head:  (max(s~ + eps, 0) + 1) pop > T   <=>   max(s~, -eps) > T / pop - 1 - eps        (pop > 0; pop = 0 never passes)
     //   raw head:  s~ + eps > T
     // per tile and lane: neg_eps = -eps, ipop <= 1/pop, cc = -1 - eps;  per register: v_max, v_fma, v_cmp (to SGPRs)
-    auto test_reg = [&](float sacc, float t, float neg_eps, float ipop, float cc) -> uint64_t {
+    auto test_reg = [&](float sacc, float t, float neg_eps, float ipop, float cc) __attribute__((always_inline)) -> uint64_t {
         if constexpr (HEAD == PDA_HEAD_POP) return __ballot(fmaxf(sacc, neg_eps) > __builtin_fmaf(t, ipop, cc));
         else return __ballot(sacc > t + neg_eps);
     };
-    auto test_consts = [&](float popv, float niv, float& neg_eps, float& ipop, float& cc) {
+    auto test_consts = [&](float popv, float niv, float& neg_eps, float& ipop, float& cc) __attribute__((always_inline)) {
         neg_eps = -(nu_max * niv * 1.001f + 3e-6f);        // 3e-6: the roundings of v_fma / v_rcp on values of order <= 10
         ipop = 0.f;
         cc = 0.f;
@@ -599,7 +552,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
 
     // One iteration.  `cur` holds tile t+1 (loaded one iteration ago, stored at the end of this one);
     // `nxt` receives tile t+2.
-    auto iteration = [&](int k, u32x4 (&cur_h)[NLD], u32x4 (&cur_l)[NLD]) -> bool {
+    auto iteration = [&](int k, u32x4 (&cur_h)[NLD], u32x4 (&cur_l)[NLD]) __attribute__((always_inline)) -> bool {
         const bool has_next = (k + 1) < nt;
         const int tn = tile_of(min(k + 1, nt - 1));
         float pop_next, ni_next;
@@ -730,7 +683,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
         typedef const __attribute__((address_space(4))) uint16_t* chp;
         cfp up = (cfp)(a.U + (size_t)urow * D);
         chp up16 = (chp)(reinterpret_cast<const uint16_t*>(a.U) + (size_t)urow * D);
-        auto uval = [&](int k) -> float {
+        auto uval = [&](int k) __attribute__((always_inline)) -> float {
             if constexpr (BF) return __uint_as_float((uint32_t)up16[k] << 16);
             else return up[k];
         };
@@ -929,6 +882,16 @@ int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void*
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr,   // NULL: visit everything
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
                   reinterpret_cast<unsigned long long*>(ws + 2)};
+    // Which pre-filtered kernel: v3 (1 MFMA per k-step, candidate ring, exact lists) wins wherever every tile is scored
+    // and at d = 256 (v2's two operand planes do not fit the register file there); v2 (approximate lists) wins for the
+    // early-terminating sweep, whose time is dominated by the first, candidate-rich tiles, and for bf16 tables, where
+    // it needs one MFMA per k-step as well.  PDA_SCORE_KERNEL=v2|v3 forces one (A/B measurements, cross-checks).
+    bool use_v3 = !bf16 && (d == 256 || !(ordered && early_stop));
+    if (const char* kk = getenv("PDA_SCORE_KERNEL")) {
+        if (kk[0] == 'v' && kk[1] == '3') use_v3 = true;
+        if (kk[0] == 'v' && kk[1] == '2') use_v3 = false;
+    }
+    if (use_v3) return pda_topk::launch_score_v3(aa, d, head, ordered, bf16, s);
     int rc = PDA_ERR_UNSUPPORTED;
 #ifdef PDA_ABLATION
     if (const char* e = getenv("PDA_ABLATE")) {

@@ -1,0 +1,486 @@
+// score + mask + top-K, generation 3: ONE bf16 MFMA per k-step as pre-filter + candidate ring + exact fp32 rescoring.
+// Same packed keys as v1 / v2, bit for bit (tests/test_gpu_score_topk.py runs every case through all of them).
+//
+// v2 spends 3 bf16 MFMAs per k-step (hi/lo split of both operands) because its per-user lists are keyed by the
+// APPROXIMATE head and have to stay within a narrow band.  Measured (C3, visiting order): the pure MFMA loop is 6.2 ms
+// of the 10.0 ms, at a power-throttled 1.8 GHz -- the matrix pipe, not the epilogue, is what is left to cut.  v3 uses
+//     s~ = bf16(u) . bf16(i)                    one v_mfma_f32_32x32x16_bf16 per 16 k:  3x less pipe time again
+//     |s~ - s_exact| <= eps(u,i) = 2^-8 (1.01) ||u|| ||i||       (fp32 tables; bf16 tables: 2^-14, only the add order differs)
+// as a FILTER only: pairs whose head upper bound beats the user's exact running threshold go into a per-wave LDS ring
+// (4 bytes each: row, item id) and are rescored with the exact fp32 fmaf chain of v1 when the ring fills -- 16 candidates
+// per pass, four lanes per candidate, all four waves of the workgroup draining in the same iteration.  The per-user
+// lists therefore hold EXACT keys: thresholds are exact, there is no band, no end-of-sweep rescoring and no fallback
+// kernel.  The coarser eps lets ~15 % more candidates through than an exact test would; what makes the design pay is the
+// visiting order (popular first: a few hundred candidates per user instead of K ln(I/K)).
+//
+// Error bound, fp32 tables: u_k = uh_k + du_k, |du_k| <= 2^-9 |u_k| (RNE to 8 significant bits), same for i:
+//   u_k i_k - uh_k ih_k = du_k i_k + uh_k di_k,  |.| <= 2^-9 (2 + 2^-9) |u_k i_k|;  summed, Cauchy-Schwarz: 2^-8 (1 + 2^-10) ||u|| ||i||.
+//   bf16 products are exact in fp32; fp32 accumulation of d terms (any order) and the rounding of the exact chain add
+//   <= 2 d 2^-24 sum|u_k i_k| <= 2^-15 ||u|| ||i|| for d <= 256.  Norms are padded by (1+2^-10)(1+1e-4).  Used: 2^-8 * 1.01.
+#include "pda_topk_common.h"
+#include <cstdlib>
+
+using namespace pda_topk;
+
+namespace {
+
+constexpr int kCap3 = PDA_TOPK_CAP - 1;   // 59 slots per user list
+constexpr int kRing = 192;                // ring entries per wave (u32 each); a push needs kRing - 64 free
+constexpr int kRingTrig = 64;             // a wave above this asks the whole workgroup to drain
+
+template <int D, int HEAD, bool ORD, bool BF>
+__global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 aa) {
+    const ScoreArgs& a = aa.a;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
+    constexpr int CPR = D / 8;                 // 16-byte chunks per bf16 row
+    constexpr int NM = D / 16;                 // MFMA k-steps
+    constexpr int NLD = (32 * CPR) / kThreads; // 16-byte loads per thread per tile
+    static_assert(NLD >= 1, "v3 needs embed dim >= 64");
+    uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);                                       // [32][D] bf16, swizzled
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 32 * D * sizeof(uint16_t));        // [128][kCap3] EXACT keys
+    int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap3);                  // [128]
+    float* taul = reinterpret_cast<float*>(cntl + kUserTile);                               // [128] exact K-th value (-inf until K entries)
+    uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                        // [4][kRing]
+    int* wgflag = reinterpret_cast<int*>(rings + 4 * kRing);                                // [2] "some wave wants to drain its ring"
+    int* votes = wgflag + 2;                                                                // [4] ORD: wave w sees no use in going on
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x % a.n_splits, utile = blockIdx.x / a.n_splits;
+    const int K = a.K;
+    const int tiles_total = (a.n_items_local + 31) >> 5;
+    int t0, stride, nt;                        // this workgroup's tiles: t0, t0 + stride, ... (nt of them)
+    if constexpr (ORD) {
+        t0 = split;
+        stride = a.n_splits;
+        nt = t0 < tiles_total ? (tiles_total - t0 + stride - 1) / stride : 0;
+    } else {
+        const int tiles_per = (tiles_total + a.n_splits - 1) / a.n_splits;
+        t0 = split * tiles_per;
+        stride = 1;
+        nt = max(0, min(t0 + tiles_per, tiles_total) - t0);
+    }
+    auto tile_of = [&](int k) __attribute__((always_inline)) { return t0 + k * stride; };   // (every lambda is force-inlined: a closure
+    // that the inliner leaves out of line lives in scratch together with everything it captures -- measured 3x slower)
+
+    const int row_blk = utile * kUserTile + wave * 32 + j;
+    const bool row_ok = row_blk < a.n_users_blk;
+    const int uid = row_ok ? a.users[row_blk] : 0;
+
+    // ---- A operand: this lane's user row (k = 16m + 8h .. +7) rounded to bf16; padded row norm --------------------
+    u32x4 ah[NM];
+    float nu_row;
+    {
+        float ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+            if (row_ok) {
+                x = pda_load4<BF>(a.U, (size_t)uid * D + 8 * h + 16 * m);
+                y = pda_load4<BF>(a.U, (size_t)uid * D + 8 * h + 16 * m + 4);
+            }
+            u32x4 lo_unused;
+            split8(x, y, ah[m], lo_unused);    // bf16 tables: the RNE of a bf16 value is itself
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        nu_row = sqrtf(ss) * 1.0009765625f * 1.0001f;              // padded ||u||
+    }
+
+    // ---- history cursor (as v1 / v2) --------------------------------------------------------------------------------
+    int64_t hp = 0, he = 0;
+    int nxt = 0x7fffffff, nxt2 = 0x7fffffff, pend_v = 0x7fffffff;
+    bool pend_flag = false, pend_ok = false;
+    const bool hist_on = a.hist_indptr != nullptr;
+    if (hist_on && row_ok) {
+        const int64_t hr = a.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)row_blk;
+        hp = a.hist_indptr[hr];
+        he = a.hist_indptr[hr + 1];
+        const int lo_item = a.item_offset + t0 * 32;
+        int64_t lo = hp, hi = he;
+        while (lo < hi) {
+            int64_t mid = (lo + hi) >> 1;
+            if (a.hist_indices[mid] < lo_item) lo = mid + 1; else hi = mid;
+        }
+        hp = lo;
+        if (hp < he) nxt = a.hist_indices[hp];
+        if (hp + 1 < he) nxt2 = a.hist_indices[hp + 1];
+    }
+    auto hist_bits = [&](int t) __attribute__((always_inline)) -> uint32_t {
+        if (!hist_on) return 0u;
+        const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
+        nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
+        const bool adv = nxt < jg1;
+        uint32_t hb = (adv && (!ORD || nxt >= jg0)) ? (1u << ((nxt - jg0) & 31)) : 0u;
+        hp += adv ? 1 : 0;
+        nxt = adv ? nxt2 : nxt;
+        const int64_t idx = hp + 1;
+        pend_ok = idx < he;
+        pend_flag = adv;
+        // never predicated (exact vmcnt bookkeeping); lanes that did not advance all read element 0: one cache line
+        const int64_t idc = adv ? max((int64_t)0, min(idx, he - 1)) : (int64_t)0;
+        pend_v = a.hist_indices[idc];
+        if (__builtin_expect(__any(nxt < jg1), 0)) {
+            do {
+                if (nxt < jg1) {
+                    const int nn2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
+                    if (!ORD || nxt >= jg0) hb |= 1u << ((nxt - jg0) & 31);
+                    ++hp;
+                    nxt = nn2;
+                    nxt2 = (hp + 1 < he) ? a.hist_indices[hp + 1] : 0x7fffffff;
+                    pend_flag = false;
+                }
+            } while (__any(nxt < jg1));
+        }
+        return hb;
+    };
+
+    // ---- per-row state in LDS -----------------------------------------------------------------------------------------
+    if (lane < 32) {
+        cntl[wave * 32 + lane] = 0;
+        taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
+    }
+    if (tid < 2) wgflag[tid] = 0;
+    if (tid < 4) votes[tid] = 0;
+    pda_wave_sync();
+    f32x16 thr;    // the rows' exact thresholds, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
+    auto refresh_thr = [&]() __attribute__((always_inline)) {
+        int hv = h;
+        asm volatile("" : "+v"(hv));
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float tq = taul[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv];
+            // strictly below tau (also for tau == 0): an item that TIES the K-th value must get through -- in visiting
+            // order it may carry the lower id and win
+            thr[r] = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
+        }
+    };
+    refresh_thr();
+    f32x16 un;     // ORD: padded norm of the row behind each accumulator register (termination bound)
+    if constexpr (ORD) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) un[r] = __shfl(nu_row, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
+    }
+    float nu_max = nu_row;                     // ONE eps scale per wave (largest row norm)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nu_max = fmaxf(nu_max, __shfl_xor(nu_max, o, 64));
+    nu_max *= kEps * 1.001f;
+
+    uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap3;
+    uint32_t* ring = rings + wave * kRing;
+    int ring_cnt = 0;   // wave-uniform
+
+    // ---- item tile staging ---------------------------------------------------------------------------------------------
+    u32x4 pA_h[NLD];
+    auto tile_load = [&](int t, u32x4 (&ph)[NLD]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int id = tid + kThreads * q;
+            const int jj = id / CPR, ch = id % CPR;
+            const int it = min(t * 32 + jj, a.n_items_local - 1);
+            ph[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (size_t)it * D + 8 * ch);
+        }
+    };
+    auto tile_store = [&](const u32x4 (&ph)[NLD]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int id = tid + kThreads * q;
+            const int jj = id / CPR, ch = id % CPR;
+            *reinterpret_cast<u32x4*>(Bh + jj * D + 8 * (ch ^ swzb<D>(jj))) = ph[q];
+        }
+    };
+    auto lane_consts = [&](int t, float& popv, float& niv, int& idv) __attribute__((always_inline)) {
+        const int it = min(t * 32 + j, a.n_items_local - 1);
+        niv = aa.I_norm[it];
+        popv = 1.0f;
+        if constexpr (HEAD == PDA_HEAD_POP) popv = ORD ? aa.pop_p[it] : a.pop[it];
+        if constexpr (ORD) idv = a.item_offset + aa.order[it];      // the ring keeps the item's real id
+        else idv = a.item_offset + t * 32 + j;
+    };
+
+    // ---- exact rescoring of the ring: D/32 lanes per candidate, 64/(D/32) candidates per pass -------------------------
+    // Lane LPC*ci+q loads k = 32q .. 32q+31 of candidate ci's user row and item row (contiguous across the lanes of a
+    // candidate), and the two fmaf chains of v1 (even / odd k-chunks, k ascending) are carried from lane to lane: phase
+    // p completes the 32 k's of lane p and hands the accumulators to lane p+1.  The last lane ends up with the bit-exact
+    // v1 score and appends to the row's list.
+    auto process_ring = [&]() __attribute__((always_inline)) {
+        constexpr int LPC = D / 32;                 // lanes per candidate: each owns 32 consecutive k (4 chunks of 8)
+        constexpr int CPP = 64 / LPC;               // candidates per pass
+        const int q = lane % LPC, ci = lane / LPC;
+        for (int base = 0; base < ring_cnt; base += CPP) {
+            const int e = base + ci;
+            const bool valid = e < ring_cnt;
+            const uint32_t word = valid ? ring[e] : 0u;
+            const int row = (int)(word >> 27);
+            const int item = valid ? (int)(word & 0x7FFFFFFu) : a.item_offset;     // global item id
+            const int urow = __shfl(uid, row, 64);
+            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)(item - a.item_offset) * D + q * 32;
+            f32x4 uu[8], ii[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                uu[c] = pda_load4<BF>(a.U, ub + 4 * c);
+                ii[c] = pda_load4<BF>(a.I, ib + 4 * c);
+            }
+            float pv = 1.0f;
+            if constexpr (HEAD == PDA_HEAD_POP) pv = a.pop[item - a.item_offset];
+            float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < LPC; ++ph) {
+                o0 = c0;
+                o1 = c1;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {      // chunk 4 q + cc of the row: even chunks feed chain 0, odd ones chain 1
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        if (cc & 1) {
+                            o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
+                            o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
+                        } else {
+                            o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
+                            o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
+                        }
+                    }
+                }
+                if (ph < LPC - 1) {
+                    const float r0 = __shfl_up(o0, 1, 64), r1 = __shfl_up(o1, 1, 64);
+                    if (q == ph + 1) {
+                        c0 = r0;
+                        c1 = r1;
+                    }
+                }
+            }
+            float sc = o0 + o1;                               // meaningful on the candidate's last lane
+            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+            const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
+            const int lrow = wave * 32 + row;
+            // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in
+            bool p = valid && q == LPC - 1 && (tt >= taul[lrow]);
+            const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+            for (;;) {
+                bool ov = false;
+                if (p) {
+                    const int slot = atomicAdd(&cntl[lrow], 1);
+                    if (slot < kCap3) lists[(size_t)lrow * kCap3 + slot] = key;
+                    else ov = true;
+                }
+                if (!__any(ov)) break;
+                pda_wave_sync();
+                uint64_t full = __ballot(lane < 32 && cntl[wave * 32 + (lane & 31)] >= kCap3);
+                while (full) {
+                    const int rr = __builtin_ctzll(full);
+                    full &= full - 1ull;
+                    compact_list<kCap3>(my_lists + rr * kCap3, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+                }
+                p = ov && (tt >= taul[lrow]);
+            }
+        }
+        ring_cnt = 0;
+        pda_wave_sync();
+        refresh_thr();
+    };
+
+    // ---- push the flagged lanes of the previous tile into the ring ------------------------------------------------------
+    // The fast test leaves one 64-bit lane mask per accumulator register in SGPRs; the per-lane bit mask is rebuilt here.
+    // Lane-parallel: every flagged lane pushes ITS OWN top flagged register per round (usually one round).
+    auto push_masks = [&](const uint64_t (&M)[16], uint64_t okm, uint32_t hb, int item_id) __attribute__((always_inline)) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= ((M[r] >> lane) & 1ull) ? (1u << (15 - r)) : 0u;
+        m = ((okm >> lane) & 1ull) ? m : 0u;
+        const bool any_hb = __any(hb != 0);
+        while (__any(m != 0)) {
+            const bool act = m != 0;
+            const int bit = 31 - __builtin_clz(m | 1u);
+            const int r = 15 - bit;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            m &= ~(1u << bit);
+            bool p = act;
+            if (any_hb) {
+                const uint32_t hbr = (uint32_t)__shfl((int)hb, row, 64);           // train items never enter
+                if ((hbr >> j) & 1u) p = false;
+            }
+            const uint64_t pm = __ballot(p);
+            if (!pm) continue;
+            if (ring_cnt + 64 > kRing) process_ring();
+            const int slot = ring_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
+            if (p) ring[slot] = ((uint32_t)row << 27) | (uint32_t)item_id;
+            ring_cnt += __popcll(pm);
+        }
+    };
+    // the fast test of one accumulator register (see pda_score_topk_v2.hip):
+    //   PDA head:  (max(s~ + eps, 0) + 1) pop > T   <=>   max(s~, -eps) > T / pop - 1 - eps      raw head:  s~ + eps > T
+    auto test_reg = [&](float sacc, float t, float neg_eps, float ipop, float cc) __attribute__((always_inline)) -> uint64_t {
+        if constexpr (HEAD == PDA_HEAD_POP) return __ballot(fmaxf(sacc, neg_eps) > __builtin_fmaf(t, ipop, cc));
+        else return __ballot(sacc > t + neg_eps);
+    };
+    auto test_consts = [&](float popv, float niv, float& neg_eps, float& ipop, float& cc) __attribute__((always_inline)) {
+        neg_eps = -(nu_max * niv + 3e-6f);
+        ipop = 0.f;
+        cc = 0.f;
+        if constexpr (HEAD == PDA_HEAD_POP) {
+            ipop = __builtin_amdgcn_rcpf(popv) * 0.9999995f;
+            cc = -1.0f + neg_eps;
+        }
+    };
+
+    // ---- main loop (test of tile t-1 in the shadow of the MFMAs of tile t) -------------------------------------------------
+    f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    uint32_t hb_prev = 0, hb_cur = 0;
+    float pop_prev = 0.f, pop_cur = 0.f, ni_prev = 0.f, ni_cur = 0.f;
+    int id_prev = 0, id_cur = 0;
+    bool ok_prev = false, ok_cur = false;   // lane's item exists
+
+    if (nt > 0) {
+        tile_load(t0, pA_h);
+        lane_consts(t0, pop_cur, ni_cur, id_cur);
+        tile_store(pA_h);
+        hb_cur = hist_bits(t0);
+        ok_cur = (t0 * 32 + j) < a.n_items_local;
+    }
+    __syncthreads();
+
+    const uint16_t* bhrow = Bh + j * D;
+    const int bsw = swzb<D>(j);
+
+    auto iteration = [&](int k, u32x4 (&cur_h)[NLD]) __attribute__((always_inline)) -> bool {
+        const bool has_next = (k + 1) < nt;
+        const int tn = tile_of(min(k + 1, nt - 1));
+        float pop_next, ni_next;
+        int id_next;
+        tile_load(tn, cur_h);
+        lane_consts(tn, pop_next, ni_next, id_next);
+        __builtin_amdgcn_sched_barrier(0);
+
+        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f32x16 acc1 = acc0;
+        uint64_t M[16];
+        float neg_eps, ipop, cc;
+        test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
+#pragma unroll
+        for (int mm = 0; mm < NM; ++mm) {
+            const int off = 8 * ((2 * mm + h) ^ bsw);
+            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + off));
+            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mm]);
+            if (mm & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc0, 0, 0, 0);
+#pragma unroll
+            for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+        }
+        const f32x16 acc_new = acc0 + acc1;
+        uint64_t many = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) many |= M[r];
+        const uint64_t okm = __ballot(ok_prev);
+        many &= okm;
+
+        // All four waves drain their rings in the SAME iteration (flag set by whichever wave is filling up): the
+        // latency-bound rescoring of the four waves then overlaps instead of stalling the workgroup four times.
+        if (ring_cnt > kRingTrig && lane == 0) wgflag[k & 1] = 1;
+        __syncthreads();  // every wave is done reading the tile
+        const bool drain = wgflag[k & 1] != 0;
+        if (tid == 0) wgflag[(k + 1) & 1] = 0;   // flag of iteration k-1: everyone has read it, nobody sets it before k+1
+        uint32_t hb_next = 0;
+        if (has_next) {
+            tile_store(cur_h);
+            hb_next = hist_bits(tn);
+        }
+        if (many) push_masks(M, okm, hb_prev, id_prev);
+        bool stop = false;
+        if constexpr (ORD) {
+            // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (bound: pda_score_topk_v2.hip)
+            // Candidates still waiting in the ring can only raise thresholds: with them pending the vote is "go on".
+            if ((k & 3) == 3 && has_next && aa.sufA != nullptr) {
+                const float sa = aa.sufA[tn], sb = aa.sufB[tn];
+                bool dead = true;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float ub = __builtin_fmaf(un[r], sb, sa) * 1.000002f;
+                    dead = dead && (ub < thr[r]);
+                }
+                const bool alldead = __all(dead);
+                if (lane == 0) votes[wave] = alldead ? 1 : 0;
+            }
+        }
+        if (drain && ring_cnt > 0) process_ring();
+        __syncthreads();  // next tile visible
+        if constexpr (ORD) {
+            if ((k & 3) == 3 && has_next && aa.sufA != nullptr) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
+        }
+
+        acc_prev = acc_new;
+        hb_prev = hb_cur;
+        pop_prev = pop_cur;
+        ni_prev = ni_cur;
+        ok_prev = ok_cur;
+        hb_cur = hb_next;
+        pop_cur = pop_next;
+        ni_cur = ni_next;
+        id_prev = id_cur;
+        id_cur = id_next;
+        ok_cur = has_next && (tn * 32 + j) < a.n_items_local;
+        return stop;
+    };
+    int n_done = 0;
+    for (int k = 0; k < nt; ++k) {
+        ++n_done;
+        if (iteration(k, pA_h)) break;
+    }
+    if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n_done);
+    if (nt > 0) {   // drain the last tile
+        uint64_t M[16];
+        float neg_eps, ipop, cc;
+        test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+        push_masks(M, __ballot(ok_prev), hb_prev, id_prev);
+    }
+    if (ring_cnt > 0) process_ring();
+
+    // ---- finalise: the lists are exact; sort and emit ---------------------------------------------------------------------
+    for (int rr = 0; rr < 32; ++rr) {
+        uint64_t* buf = my_lists + rr * kCap3;
+        compact_list<kCap3>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+        const int c = cntl[wave * 32 + rr];
+        const int rb = utile * kUserTile + wave * 32 + rr;
+        if (rb < a.n_users_blk && lane < K) {
+            const uint64_t k = lane < c ? buf[lane] : 0ull;
+            a.out_keys[((size_t)split * a.n_users_blk + rb) * K + lane] = k;
+        }
+    }
+}
+
+template <int D, int HEAD, bool ORD, bool BF>
+int launch_v3(const ScoreArgs2& aa, hipStream_t stream) {
+    const size_t smem = 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 32;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v3_kernel<D, HEAD, ORD, BF>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return PDA_ERR_LAUNCH;
+        attr_set = 1;
+    }
+    const int utiles = (aa.a.n_users_blk + kUserTile - 1) / kUserTile;
+    hipLaunchKernelGGL((score_topk_v3_kernel<D, HEAD, ORD, BF>), dim3((unsigned)(utiles * aa.a.n_splits)), dim3(kThreads), smem, stream, aa);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+}  // namespace
+
+int pda_topk::launch_score_v3(const ScoreArgs2& aa, int d, int head, bool ordered, bool bf16, hipStream_t s) {
+    if ((uint64_t)aa.a.item_offset + (uint64_t)aa.a.n_items_local > (1ull << 27)) return PDA_ERR_UNSUPPORTED;   // ring: 27-bit item ids
+#define PDA_V3_(DD, ORDV, BFV) \
+    (head == PDA_HEAD_POP ? launch_v3<DD, PDA_HEAD_POP, ORDV, BFV>(aa, s) : launch_v3<DD, PDA_HEAD_RAW, ORDV, BFV>(aa, s))
+#define PDA_V3(DD)                                                             \
+    case DD:                                                                   \
+        if (bf16) return ordered ? PDA_V3_(DD, true, true) : PDA_V3_(DD, false, true);   \
+        return ordered ? PDA_V3_(DD, true, false) : PDA_V3_(DD, false, false);
+    switch (d) {
+        PDA_V3(64) PDA_V3(128) PDA_V3(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_V3
+#undef PDA_V3_
+}

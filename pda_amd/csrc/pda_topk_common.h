@@ -26,6 +26,57 @@ struct ScoreArgs {
     const int* tile_flags;   // optional [n_user_tiles]: only flagged tiles are computed (v2's exact fallback)
 };
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// arguments of the pre-filtered kernels (v2: approximate lists; v3: candidate ring + exact lists)
+struct ScoreArgs2 {
+    ScoreArgs a;
+    const uint16_t* I_hi;   // bf16 [n_items_local, d]
+    const uint16_t* I_lo;   // bf16 [n_items_local, d]
+    const float* I_norm;    // f32  [n_items_local]   ||i||_2 * (1+2^-10), followed (256-B aligned) by the max over the shard
+    const float* I_norm_max;
+    const float* pop_max;   // workspace: max |pop| over the shard (PDA_HEAD_POP)
+    int* tile_flags;        // workspace: [n_user_tiles], set when a row's near-tie band overflowed
+    // ordered sweep (pda_score_topk_ordered_f32): the planes / norms above are stored in VISITING order
+    const int* order;       // [n_items_local] visiting position -> local item id
+    const float* pop_p;     // [n_items_local] pop in visiting order (PDA_HEAD_POP)
+    const float* sufA;      // [n_tiles] max over positions >= 32 t of |pop|            (1 for PDA_HEAD_RAW -> unused, 0)
+    const float* sufB;      // [n_tiles] max over positions >= 32 t of |pop| * ||i||    (||i|| for PDA_HEAD_RAW)
+    unsigned long long* visited;   // workspace: item tiles actually scored, summed over workgroups (statistics)
+};
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// split 8 floats into packed bf16 hi / lo words
+__device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
+    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    uint32_t h[8], l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        h[k] = bf16_rne(v[k]);
+        l[k] = bf16_rne(v[k] - __uint_as_float(h[k] << 16));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        hi[k] = h[2 * k] | (h[2 * k + 1] << 16);
+        lo[k] = l[2 * k] | (l[2 * k + 1] << 16);
+    }
+}
+
+template <int D>
+__device__ __forceinline__ int swzb(int row) {   // bf16 tile: D/8 16-byte chunks per row
+    constexpr int CPR = D / 8;
+    if constexpr (CPR >= 16) return row & 15;
+    else if constexpr (CPR == 8) return (row >> 1) & 7;
+    else return (row >> 2) & 3;
+}
+
+// defined in pda_score_topk_v3.hip: 1-MFMA pre-filter + candidate ring + exact rescoring (no fallback needed)
+int launch_score_v3(const ScoreArgs2& aa, int d, int head, bool ordered, bool bf16_tables, hipStream_t stream);
+
 // defined in pda_score_topk.hip
 int launch_score_v1(const ScoreArgs& a, int d, int head, hipStream_t stream, bool bf16_tables = false);
 

@@ -176,11 +176,11 @@ def mark_modified(*tensors):
 
 
 def score_impl(d: int, K: int, item_hi: int) -> str:
-    """'v2' (bf16x3 pre-filter + exact rescoring) where it applies, else 'v1' (exact fp32 MFMA).  Same results.
-    PDA_SCORE_IMPL=v1|v2 forces one (A/B measurements, cross-checks)."""
+    """'v2' = the pre-filtered kernels (bf16 MFMA filter + exact fp32 rescoring: pda_score_topk_v2.hip / _v3.hip) where they
+    apply, else 'v1' (exact fp32 MFMA).  Same results.  PDA_SCORE_IMPL=v1|v2 forces one (A/B measurements, cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_IMPL", "")
-    ok = d in (64, 128) and K <= TOPK_CAP_V2          # d=256 spills in v2 (two A planes of 128 VGPRs): v1 for now
+    ok = d in (64, 128, 256) and K <= TOPK_CAP_V2     # the library picks v2 or v3 inside (pda_score_topk_v2.hip, run_score_prepped)
     if forced == "v1" or not ok:
         return "v1"
     return "v2"

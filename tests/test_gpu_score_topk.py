@@ -16,13 +16,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k2", "k3"])
 def impl(request, monkeypatch):
     """Every test runs against all scoring paths: v1 = exact fp32 MFMA, v2 = bf16x3 pre-filter + exact rescoring
     (pda_score_topk_v2.hip), v2ord = v2 visiting the catalogue strongest-bound-first with early termination
     (pda_score_topk_ordered_f32, forced on for BOTH heads here).  They must be indistinguishable."""
+    # k2 / k3 force ONE of the two pre-filtered kernels (approximate lists / candidate ring) for every sweep mode, so that
+    # each of them is checked in the modes the default policy would not give it
     monkeypatch.setenv("PDA_SCORE_IMPL", "v1" if request.param == "v1" else "v2")
-    monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order"}.get(request.param, "0"))
+    monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order", "k2": "order", "k3": "1"}.get(request.param, "0"))
+    if request.param in ("k2", "k3"):
+        monkeypatch.setenv("PDA_SCORE_KERNEL", "v2" if request.param == "k2" else "v3")
+    else:
+        monkeypatch.delenv("PDA_SCORE_KERNEL", raising=False)
     return request.param
 
 
@@ -302,7 +308,7 @@ def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head, impl):
                 torch.from_numpy(pop).to(dev) if head else None, h, 0)
         k1 = ops.score_topk_keys(*args, n_splits=2, impl="v1")
         k2 = ops.score_topk_keys(*args, n_splits=2, impl="v2")
-        if impl in ("v2ord", "v2order_only"):   # the ordered sweep gives its splits interleaved tiles: compare after the merge
+        if impl in ("v2ord", "v2order_only", "k2", "k3"):   # the ordered sweep gives its splits interleaved tiles: compare after the merge
             k1, k2 = ops.topk_merge(k1, want="keys"), ops.topk_merge(k2, want="keys")
         assert torch.equal(k1, k2), (d, head, scale, int((k1 != k2).sum()))
 
