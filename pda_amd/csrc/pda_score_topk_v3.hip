@@ -171,6 +171,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap3;
     uint32_t* ring = rings + wave * kRing;
     int ring_cnt = 0;   // wave-uniform
+    unsigned n_cand = 0;   // statistics: pairs this wave rescored exactly
 
     // ---- item tile staging ---------------------------------------------------------------------------------------------
     u32x4 pA_h[NLD];
@@ -209,6 +210,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         constexpr int LPC = D / 32;                 // lanes per candidate: each owns 32 consecutive k (4 chunks of 8)
         constexpr int CPP = 64 / LPC;               // candidates per pass
         const int q = lane % LPC, ci = lane / LPC;
+        n_cand += (unsigned)ring_cnt;
         for (int base = 0; base < ring_cnt; base += CPP) {
             const int e = base + ci;
             const bool valid = e < ring_cnt;
@@ -428,6 +430,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         if (iteration(k, pA_h)) break;
     }
     if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n_done);
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(aa.visited) - 1, n_cand);   // workspace + 4: u32 "pairs rescored"
     if (nt > 0) {   // drain the last tile
         uint64_t M[16];
         float neg_eps, ipop, cc;

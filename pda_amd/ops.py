@@ -247,6 +247,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
               "pda_score_topk_ordered")
         if stats is not None:            # device scalar (no sync here): item tiles scored, summed over workgroups
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
+            stats["pairs_rescored"] = ws[4:8].view(torch.int32)        # v3 kernel only (0 otherwise)
             stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)
         return out
     if impl == "v2":

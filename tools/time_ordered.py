@@ -25,9 +25,12 @@ def run(prune, head, n=3):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / (n * len(blocks))
     frac = float(st["tiles_scored"][0]) / st["tiles_dense"] if "tiles_scored" in st else 1.0
+    global CAND
+    CAND = float(st["pairs_rescored"][0]) / Bu if "pairs_rescored" in st else 0.0
     return ms, frac, first, k
 for head in (1, 0):
     a = run(False, head); b = run(True, head)
     same = torch.equal(ops.topk_merge(a[3], want="keys"), ops.topk_merge(b[3], want="keys"))
+    print("cand/user %.0f " % CAND, end="")
     print("head=%d  dense %.3f ms  ordered %.3f ms (tiles scored %.4f of dense; first call incl. prep+hist reorder %.1f ms)  same=%s  -> %.2fM users/s"
           % (head, a[0], b[0], b[1], b[2] * 1e3, same, Bu / b[0] / 1e3))
