@@ -180,8 +180,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
-            const int it = min(t * 32 + jj, a.n_items_local - 1);
-            ph[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (size_t)it * D + 8 * ch);
+            const uint32_t it = (uint32_t)min(t * 32 + jj, a.n_items_local - 1);
+            ph[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (it * (uint32_t)D + 8u * (uint32_t)ch));   // 32-bit element offset
         }
     };
     auto tile_store = [&](const u32x4 (&ph)[NLD]) __attribute__((always_inline)) {
@@ -314,8 +314,13 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // the fast test of one accumulator register (see pda_score_topk_v2.hip):
     //   PDA head:  (max(s~ + eps, 0) + 1) pop > T   <=>   max(s~, -eps) > T / pop - 1 - eps      raw head:  s~ + eps > T
     auto test_reg = [&](float sacc, float t, float neg_eps, float ipop, float cc) __attribute__((always_inline)) -> uint64_t {
-        if constexpr (HEAD == PDA_HEAD_POP) return __ballot(fmaxf(sacc, neg_eps) > __builtin_fmaf(t, ipop, cc));
-        else return __ballot(sacc > t + neg_eps);
+        if constexpr (HEAD == PDA_HEAD_POP) {
+            float mx;      // plain v_max_f32: fmaxf() would first canonicalise the MFMA result with a second v_max (x, x)
+            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(sacc), "v"(neg_eps));
+            return __ballot(mx > __builtin_fmaf(t, ipop, cc));
+        } else {
+            return __ballot(sacc > t + neg_eps);
+        }
     };
     auto test_consts = [&](float popv, float niv, float& neg_eps, float& ipop, float& cc) __attribute__((always_inline)) {
         neg_eps = -(nu_max * niv + 3e-6f);
@@ -357,7 +362,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 
         f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         f32x16 acc1 = acc0;
-        uint64_t M[16];
+        // Only the OR of the 16 lane masks stays live (16 SGPR pairs would spill into VGPR lanes); the rare slow path
+        // recomputes them from acc_prev, which it needs anyway.
+        uint64_t many = 0;
         float neg_eps, ipop, cc;
         test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
 #pragma unroll
@@ -368,12 +375,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             if (mm & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc0, 0, 0, 0);
 #pragma unroll
-            for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+            for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) many |= test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
         }
         const f32x16 acc_new = acc0 + acc1;
-        uint64_t many = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) many |= M[r];
         const uint64_t okm = __ballot(ok_prev);
         many &= okm;
 
@@ -388,7 +392,12 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             tile_store(cur_h);
             hb_next = hist_bits(tn);
         }
-        if (many) push_masks(M, okm, hb_prev, id_prev);
+        if (many) {
+            uint64_t M[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+            push_masks(M, okm, hb_prev, id_prev);
+        }
         bool stop = false;
         if constexpr (ORD) {
             // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (bound: pda_score_topk_v2.hip)
@@ -474,6 +483,7 @@ int launch_v3(const ScoreArgs2& aa, hipStream_t stream) {
 
 int pda_topk::launch_score_v3(const ScoreArgs2& aa, int d, int head, bool ordered, bool bf16, hipStream_t s) {
     if ((uint64_t)aa.a.item_offset + (uint64_t)aa.a.n_items_local > (1ull << 27)) return PDA_ERR_UNSUPPORTED;   // ring: 27-bit item ids
+    if ((uint64_t)aa.a.n_items_local * (uint64_t)d >= (1ull << 32)) return PDA_ERR_UNSUPPORTED;                  // 32-bit plane offsets
 #define PDA_V3_(DD, ORDV, BFV) \
     (head == PDA_HEAD_POP ? launch_v3<DD, PDA_HEAD_POP, ORDV, BFV>(aa, s) : launch_v3<DD, PDA_HEAD_RAW, ORDV, BFV>(aa, s))
 #define PDA_V3(DD)                                                             \
