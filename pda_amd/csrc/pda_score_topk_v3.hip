@@ -35,10 +35,17 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
     constexpr int CPR = D / 8;                 // 16-byte chunks per bf16 row
     constexpr int NM = D / 16;                 // MFMA k-steps
-    constexpr int NLD = (32 * CPR) / kThreads; // 16-byte loads per thread per tile
+    // Item tile = NB blocks of 32 columns.  The loop is instruction-issue bound (PMC: ~260 instructions per wave and 32
+    // items around 8 MFMAs), and roughly 60 % of them do not depend on the tile width (history cursor, staging addresses,
+    // barriers, drain / stop flags, loop control): two blocks per tile halve that share.  d = 256: one block (LDS).
+    // Natural item order keeps one block: there the candidate-rich slow path dominates and the staler thresholds of a
+    // wider tile cost more than the bookkeeping saves (measured 12.2 vs 11.5 ms at C3).
+    constexpr int NB = (ORD && D <= 128) ? 2 : 1;
+    constexpr int TW = 32 * NB;
+    constexpr int NLD = (TW * CPR) / kThreads; // 16-byte loads per thread per tile
     static_assert(NLD >= 1, "v3 needs embed dim >= 64");
-    uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);                                       // [32][D] bf16, swizzled
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 32 * D * sizeof(uint16_t));        // [128][kCap3] EXACT keys
+    uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);                                       // [TW][D] bf16, swizzled
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + TW * D * sizeof(uint16_t));        // [128][kCap3] EXACT keys
     int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap3);                  // [128]
     float* taul = reinterpret_cast<float*>(cntl + kUserTile);                               // [128] exact K-th value (-inf until K entries)
     uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                        // [4][kRing]
@@ -49,7 +56,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     const int j = lane & 31, h = lane >> 5;
     const int split = blockIdx.x % a.n_splits, utile = blockIdx.x / a.n_splits;
     const int K = a.K;
-    const int tiles_total = (a.n_items_local + 31) >> 5;
+    const int tiles_total = (a.n_items_local + TW - 1) / TW;
     int t0, stride, nt;                        // this workgroup's tiles: t0, t0 + stride, ... (nt of them)
     if constexpr (ORD) {
         t0 = split;
@@ -98,7 +105,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         const int64_t hr = a.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)row_blk;
         hp = a.hist_indptr[hr];
         he = a.hist_indptr[hr + 1];
-        const int lo_item = a.item_offset + t0 * 32;
+        const int lo_item = a.item_offset + t0 * TW;
         int64_t lo = hp, hi = he;
         while (lo < hi) {
             int64_t mid = (lo + hi) >> 1;
@@ -108,12 +115,12 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         if (hp < he) nxt = a.hist_indices[hp];
         if (hp + 1 < he) nxt2 = a.hist_indices[hp + 1];
     }
-    auto hist_bits = [&](int t) __attribute__((always_inline)) -> uint32_t {
-        if (!hist_on) return 0u;
-        const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
+    auto hist_bits = [&](int t) __attribute__((always_inline)) -> uint64_t {
+        if (!hist_on) return 0ull;
+        const int jg0 = a.item_offset + t * TW, jg1 = jg0 + TW;
         nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
         const bool adv = nxt < jg1;
-        uint32_t hb = (adv && (!ORD || nxt >= jg0)) ? (1u << ((nxt - jg0) & 31)) : 0u;
+        uint64_t hb = (adv && (!ORD || nxt >= jg0)) ? (1ull << ((nxt - jg0) & (TW - 1))) : 0ull;
         hp += adv ? 1 : 0;
         nxt = adv ? nxt2 : nxt;
         const int64_t idx = hp + 1;
@@ -126,7 +133,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             do {
                 if (nxt < jg1) {
                     const int nn2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
-                    if (!ORD || nxt >= jg0) hb |= 1u << ((nxt - jg0) & 31);
+                    if (!ORD || nxt >= jg0) hb |= 1ull << ((nxt - jg0) & (TW - 1));
                     ++hp;
                     nxt = nn2;
                     nxt2 = (hp + 1 < he) ? a.hist_indices[hp + 1] : 0x7fffffff;
@@ -158,14 +165,10 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         }
     };
     refresh_thr();
-    f32x16 un;     // ORD: padded norm of the row behind each accumulator register (termination bound)
-    if constexpr (ORD) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) un[r] = __shfl(nu_row, (r & 3) + 8 * (r >> 2) + 4 * h, 64);
-    }
-    float nu_max = nu_row;                     // ONE eps scale per wave (largest row norm)
-#pragma unroll
+    float nu_max = nu_row;                     // ONE norm per wave (the largest): eps scale of the filter, and the
+#pragma unroll                                 // termination bound of the ordered sweep
     for (int o = 32; o > 0; o >>= 1) nu_max = fmaxf(nu_max, __shfl_xor(nu_max, o, 64));
+    const float un_wmax = nu_max;
     nu_max *= kEps * 1.001f;
 
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap3;
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         for (int q = 0; q < NLD; ++q) {
             const int id = tid + kThreads * q;
             const int jj = id / CPR, ch = id % CPR;
-            const uint32_t it = (uint32_t)min(t * 32 + jj, a.n_items_local - 1);
+            const uint32_t it = (uint32_t)min(t * TW + jj, a.n_items_local - 1);
             ph[q] = *reinterpret_cast<const u32x4*>(aa.I_hi + (it * (uint32_t)D + 8u * (uint32_t)ch));   // 32-bit element offset
         }
     };
@@ -192,13 +195,16 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             *reinterpret_cast<u32x4*>(Bh + jj * D + 8 * (ch ^ swzb<D>(jj))) = ph[q];
         }
     };
-    auto lane_consts = [&](int t, float& popv, float& niv, int& idv) __attribute__((always_inline)) {
-        const int it = min(t * 32 + j, a.n_items_local - 1);
-        niv = aa.I_norm[it];
-        popv = 1.0f;
-        if constexpr (HEAD == PDA_HEAD_POP) popv = ORD ? aa.pop_p[it] : a.pop[it];
-        if constexpr (ORD) idv = a.item_offset + aa.order[it];      // the ring keeps the item's real id
-        else idv = a.item_offset + t * 32 + j;
+    auto lane_consts = [&](int t, float (&popv)[NB], float (&niv)[NB], int (&idv)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const int it = min(t * TW + 32 * cb + j, a.n_items_local - 1);
+            niv[cb] = aa.I_norm[it];
+            popv[cb] = 1.0f;
+            if constexpr (HEAD == PDA_HEAD_POP) popv[cb] = ORD ? aa.pop_p[it] : a.pop[it];
+            if constexpr (ORD) idv[cb] = a.item_offset + aa.order[it];      // the ring keeps the item's real id
+            else idv[cb] = a.item_offset + t * TW + 32 * cb + j;
+        }
     };
 
     // ---- exact rescoring of the ring: D/32 lanes per candidate, 64/(D/32) candidates per pass -------------------------
@@ -286,28 +292,31 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // ---- push the flagged lanes of the previous tile into the ring ------------------------------------------------------
     // The fast test leaves one 64-bit lane mask per accumulator register in SGPRs; the per-lane bit mask is rebuilt here.
     // Lane-parallel: every flagged lane pushes ITS OWN top flagged register per round (usually one round).
-    auto push_masks = [&](const uint64_t (&M)[16], uint64_t okm, uint32_t hb, int item_id) __attribute__((always_inline)) {
-        uint32_t m = 0;
+    auto push_masks = [&](const uint64_t (&M)[NB][16], const uint64_t (&okm)[NB], uint64_t hb, const int (&item_id)[NB]) __attribute__((always_inline)) {
+        uint32_t m = 0;        // bit 16 cb + 15 - r  <->  accumulator register r of column block cb
 #pragma unroll
-        for (int r = 0; r < 16; ++r) m |= ((M[r] >> lane) & 1ull) ? (1u << (15 - r)) : 0u;
-        m = ((okm >> lane) & 1ull) ? m : 0u;
-        const bool any_hb = __any(hb != 0);
+        for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m |= (((M[cb][r] & okm[cb]) >> lane) & 1ull) ? (1u << (16 * cb + 15 - r)) : 0u;
+        const bool any_hb = __any(hb != 0ull);
         while (__any(m != 0)) {
             const bool act = m != 0;
             const int bit = 31 - __builtin_clz(m | 1u);
-            const int r = 15 - bit;
+            const int cb = bit >> 4, r = 15 - (bit & 15);
             const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             m &= ~(1u << bit);
             bool p = act;
-            if (any_hb) {
-                const uint32_t hbr = (uint32_t)__shfl((int)hb, row, 64);           // train items never enter
-                if ((hbr >> j) & 1u) p = false;
+            if (any_hb) {                                                           // train items never enter
+                const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)hb, row, 64), hi = (uint32_t)__shfl((int)(uint32_t)(hb >> 32), row, 64);
+                if (((cb ? hi : lo) >> j) & 1u) p = false;
             }
             const uint64_t pm = __ballot(p);
             if (!pm) continue;
             if (ring_cnt + 64 > kRing) process_ring();
             const int slot = ring_cnt + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
-            if (p) ring[slot] = ((uint32_t)row << 27) | (uint32_t)item_id;
+            int idsel = item_id[0];
+            if constexpr (NB == 2) idsel = cb ? item_id[1] : item_id[0];
+            if (p) ring[slot] = ((uint32_t)row << 27) | (uint32_t)idsel;
             ring_cnt += __popcll(pm);
         }
     };
@@ -333,18 +342,27 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     };
 
     // ---- main loop (test of tile t-1 in the shadow of the MFMAs of tile t) -------------------------------------------------
-    f32x16 acc_prev = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint32_t hb_prev = 0, hb_cur = 0;
-    float pop_prev = 0.f, pop_cur = 0.f, ni_prev = 0.f, ni_cur = 0.f;
-    int id_prev = 0, id_cur = 0;
-    bool ok_prev = false, ok_cur = false;   // lane's item exists
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 acc_prev[NB];
+    uint64_t hb_prev = 0, hb_cur = 0;
+    float pop_prev[NB], pop_cur[NB], ni_prev[NB], ni_cur[NB];
+    int id_prev[NB], id_cur[NB];
+    bool ok_prev[NB], ok_cur[NB];   // lane's item exists
+#pragma unroll
+    for (int cb = 0; cb < NB; ++cb) {
+        acc_prev[cb] = zero16;
+        pop_prev[cb] = pop_cur[cb] = ni_prev[cb] = ni_cur[cb] = 0.f;
+        id_prev[cb] = id_cur[cb] = 0;
+        ok_prev[cb] = ok_cur[cb] = false;
+    }
 
     if (nt > 0) {
         tile_load(t0, pA_h);
         lane_consts(t0, pop_cur, ni_cur, id_cur);
         tile_store(pA_h);
         hb_cur = hist_bits(t0);
-        ok_cur = (t0 * 32 + j) < a.n_items_local;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) ok_cur[cb] = (t0 * TW + 32 * cb + j) < a.n_items_local;
     }
     __syncthreads();
 
@@ -354,32 +372,50 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     auto iteration = [&](int k, u32x4 (&cur_h)[NLD]) __attribute__((always_inline)) -> bool {
         const bool has_next = (k + 1) < nt;
         const int tn = tile_of(min(k + 1, nt - 1));
-        float pop_next, ni_next;
-        int id_next;
+        float pop_next[NB], ni_next[NB];
+        int id_next[NB];
         tile_load(tn, cur_h);
         lane_consts(tn, pop_next, ni_next, id_next);
         __builtin_amdgcn_sched_barrier(0);
 
-        f32x16 acc0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        f32x16 acc1 = acc0;
-        // Only the OR of the 16 lane masks stays live (16 SGPR pairs would spill into VGPR lanes); the rare slow path
+        // two independent accumulator chains: the two column blocks (NB = 2), or even / odd k-steps of the one block
+        f32x16 acc[2] = {zero16, zero16};
+        // Only the OR of the lane masks stays live (16 NB SGPR pairs would spill into VGPR lanes); the rare slow path
         // recomputes them from acc_prev, which it needs anyway.
-        uint64_t many = 0;
-        float neg_eps, ipop, cc;
-        test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
+        uint64_t many_c[NB];
+        float neg_eps[NB], ipop[NB], cc[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            many_c[cb] = 0;
+            test_consts(pop_prev[cb], ni_prev[cb], neg_eps[cb], ipop[cb], cc[cb]);
+        }
 #pragma unroll
         for (int mm = 0; mm < NM; ++mm) {
             const int off = 8 * ((2 * mm + h) ^ bsw);
-            const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + off));
             const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mm]);
-            if (mm & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc1, 0, 0, 0);
-            else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc0, 0, 0, 0);
 #pragma unroll
-            for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r) many |= test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+            for (int cb = 0; cb < NB; ++cb) {
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + cb * (32 * D) + off));
+                const int ai = NB == 2 ? cb : (mm & 1);
+                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[ai], 0, 0, 0);
+#pragma unroll
+                for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r)
+                    many_c[cb] |= test_reg(acc_prev[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+            }
         }
-        const f32x16 acc_new = acc0 + acc1;
-        const uint64_t okm = __ballot(ok_prev);
-        many &= okm;
+        f32x16 acc_new[NB];
+        if constexpr (NB == 2) {
+            acc_new[0] = acc[0];
+            acc_new[NB - 1] = acc[1];
+        } else {
+            acc_new[0] = acc[0] + acc[1];
+        }
+        uint64_t okm[NB], many = 0;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            okm[cb] = __ballot(ok_prev[cb]);
+            many |= many_c[cb] & okm[cb];
+        }
 
         // All four waves drain their rings in the SAME iteration (flag set by whichever wave is filling up): the
         // latency-bound rescoring of the four waves then overlaps instead of stalling the workgroup four times.
@@ -387,29 +423,29 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         __syncthreads();  // every wave is done reading the tile
         const bool drain = wgflag[k & 1] != 0;
         if (tid == 0) wgflag[(k + 1) & 1] = 0;   // flag of iteration k-1: everyone has read it, nobody sets it before k+1
-        uint32_t hb_next = 0;
+        uint64_t hb_next = 0;
         if (has_next) {
             tile_store(cur_h);
             hb_next = hist_bits(tn);
         }
         if (many) {
-            uint64_t M[16];
+            uint64_t M[NB][16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
+            for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(acc_prev[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
             push_masks(M, okm, hb_prev, id_prev);
         }
         bool stop = false;
         if constexpr (ORD) {
-            // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (bound: pda_score_topk_v2.hip)
-            // Candidates still waiting in the ring can only raise thresholds: with them pending the vote is "go on".
+            // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (bound: pda_score_topk_v2.hip,
+            // with the wave's largest row norm.)  Candidates still waiting in the ring can only raise thresholds.
             if ((k & 3) == 3 && has_next && aa.sufA != nullptr) {
-                const float sa = aa.sufA[tn], sb = aa.sufB[tn];
+                const float sa = aa.sufA[tn * NB], sb = aa.sufB[tn * NB];
+                const float ub = __builtin_fmaf(un_wmax, sb, sa) * 1.000002f;
                 bool dead = true;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ub = __builtin_fmaf(un[r], sb, sa) * 1.000002f;
-                    dead = dead && (ub < thr[r]);
-                }
+                for (int r = 0; r < 16; ++r) dead = dead && (ub < thr[r]);
                 const bool alldead = __all(dead);
                 if (lane == 0) votes[wave] = alldead ? 1 : 0;
             }
@@ -420,35 +456,42 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             if ((k & 3) == 3 && has_next && aa.sufA != nullptr) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
         }
 
-        acc_prev = acc_new;
         hb_prev = hb_cur;
-        pop_prev = pop_cur;
-        ni_prev = ni_cur;
-        ok_prev = ok_cur;
         hb_cur = hb_next;
-        pop_cur = pop_next;
-        ni_cur = ni_next;
-        id_prev = id_cur;
-        id_cur = id_next;
-        ok_cur = has_next && (tn * 32 + j) < a.n_items_local;
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            acc_prev[cb] = acc_new[cb];
+            pop_prev[cb] = pop_cur[cb];
+            ni_prev[cb] = ni_cur[cb];
+            ok_prev[cb] = ok_cur[cb];
+            id_prev[cb] = id_cur[cb];
+            pop_cur[cb] = pop_next[cb];
+            ni_cur[cb] = ni_next[cb];
+            id_cur[cb] = id_next[cb];
+            ok_cur[cb] = has_next && (tn * TW + 32 * cb + j) < a.n_items_local;
+        }
         return stop;
     };
-    int n_done = 0;
+    int n32 = 0;       // statistics: 32-item tiles scored
     for (int k = 0; k < nt; ++k) {
-        ++n_done;
+        n32 += min(NB, (a.n_items_local - tile_of(k) * TW + 31) >> 5);
         if (iteration(k, pA_h)) break;
     }
-    if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n_done);
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(aa.visited) - 1, n_cand);   // workspace + 4: u32 "pairs rescored"
+    if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n32);
     if (nt > 0) {   // drain the last tile
-        uint64_t M[16];
-        float neg_eps, ipop, cc;
-        test_consts(pop_prev, ni_prev, neg_eps, ipop, cc);
+        uint64_t M[NB][16], okm[NB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) M[r] = test_reg(acc_prev[r], thr[r], neg_eps, ipop, cc);
-        push_masks(M, __ballot(ok_prev), hb_prev, id_prev);
+        for (int cb = 0; cb < NB; ++cb) {
+            float neg_eps, ipop, cc;
+            test_consts(pop_prev[cb], ni_prev[cb], neg_eps, ipop, cc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(acc_prev[cb][r], thr[r], neg_eps, ipop, cc);
+            okm[cb] = __ballot(ok_prev[cb]);
+        }
+        push_masks(M, okm, hb_prev, id_prev);
     }
     if (ring_cnt > 0) process_ring();
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(aa.visited) - 1, n_cand);   // workspace + 4: u32 "pairs rescored"
 
     // ---- finalise: the lists are exact; sort and emit ---------------------------------------------------------------------
     for (int rr = 0; rr < 32; ++rr) {
@@ -465,7 +508,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 
 template <int D, int HEAD, bool ORD, bool BF>
 int launch_v3(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = 32 * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 32;
+    const size_t smem = ((ORD && D <= 128) ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 32;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v3_kernel<D, HEAD, ORD, BF>),

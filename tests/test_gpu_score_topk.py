@@ -308,8 +308,8 @@ def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head, impl):
                 torch.from_numpy(pop).to(dev) if head else None, h, 0)
         k1 = ops.score_topk_keys(*args, n_splits=2, impl="v1")
         k2 = ops.score_topk_keys(*args, n_splits=2, impl="v2")
-        if impl in ("v2ord", "v2order_only", "k2", "k3"):   # the ordered sweep gives its splits interleaved tiles: compare after the merge
-            k1, k2 = ops.topk_merge(k1, want="keys"), ops.topk_merge(k2, want="keys")
+        # item splits differ between kernels (32- vs 64-item tiles, interleaved tiles in visiting order): compare after the merge
+        k1, k2 = ops.topk_merge(k1, want="keys"), ops.topk_merge(k2, want="keys")
         assert torch.equal(k1, k2), (d, head, scale, int((k1 != k2).sum()))
 
 
