@@ -264,6 +264,21 @@ def bench_train(args, dev):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out["sgd_fused_with_device_sampler_eager"] = {"triplets_per_s": n * B / dt, "us_per_step": dt / n * 1e6, "steps": n}
+
+    # the same pipeline (sample -> sort by positive -> fused step) captured in HIP graphs: the batch counter lives in
+    # device memory (pda_sample_triplets_dev + pda_counter_add), so every replayed step draws a NEW batch
+    U, I = W.U.clone(), W.I.clone()
+    step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    bufs = (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+            torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+            torch.empty(B, dtype=torch.float32, device=dev))
+
+    def graph_sampled_body(i):
+        ops.sample_triplets_into(bufs, W.hist_indptr, W.hist_indices, seed=7, step_dev=step_dev, n_pool=W.n_users,
+                                 train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+        ops.bpr_step(U, I, *bufs, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
+    out["sgd_fused_with_device_sampler_graph"] = timed_graph(graph_sampled_body, max(256, args.train_steps // 2))
+    out["sgd_fused_with_device_sampler_graph"]["batches_drawn"] = int(step_dev.item())
     return out, W, batches
 
 
@@ -318,7 +333,21 @@ def cpu_baseline(args, ev_res, train_pack):
         coos.append((rows, indices[lo:hi].long()))
     rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, "condition" if args.head == "condition" else "main_branch",
                            budget_s=args.cpu_budget)
-    out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    # also a single-thread figure (a short sample: one or two reference blocks)
+    torch.set_num_threads(1)
+    rate1, n1 = cb.time_eval(U, I, pop, blocks, coos, args.K, "condition" if args.head == "condition" else "main_branch",
+                             budget_s=min(4.0, args.cpu_budget / 4))
+    torch.set_num_threads(cores)
+    out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+           "single_thread": {"value": rate1, "unit": "users/s", "users": n1},
            "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d (torch-CPU restatement of "
                      "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk)" % (n, W.n_items, W.d)}
     if train_pack is not None:

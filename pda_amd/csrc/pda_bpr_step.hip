@@ -176,29 +176,53 @@ __global__ void __launch_bounds__(1024) sort_by_pos_kernel(int32_t* users, int32
     const int tid = threadIdx.x;
     for (int i = tid; i < n_pow2; i += 1024) keys[i] = i < B ? (((uint64_t)(uint32_t)pos[i] << 32) | (uint32_t)i) : ~0ull;
     __syncthreads();
+    // Bitonic network over compare-exchange PAIRS: pair q of a step with distance jj touches i = ((q & ~(jj-1)) << 1) | (q & (jj-1))
+    // and i + jj.  A wave's 64 consecutive pairs stay inside one aligned 128-element chunk as long as jj <= 64, so those
+    // steps (51 of the 66 at n = 2048) need no workgroup barrier -- the wave owns its chunk and LDS executes its accesses in
+    // order; only the steps with jj >= 128 are fenced by __syncthreads().  (Keys in registers with ds_bpermute exchanges
+    // for jj <= 64 were measured slower: four 32-bit permutes per step.)
+    const int half = n_pow2 >> 1;
+    bool fenced = true;                      // the last thing that happened was a workgroup barrier
     for (int k = 2; k <= n_pow2; k <<= 1)
         for (int jj = k >> 1; jj > 0; jj >>= 1) {
-            for (int i = tid; i < n_pow2; i += 1024) {
-                const int ixj = i ^ jj;
-                if (ixj > i) {
-                    const uint64_t x = keys[i], y = keys[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) {
-                        keys[i] = y;
-                        keys[ixj] = x;
-                    }
+            const bool cross = jj >= 128;
+            if (cross && !fenced) __syncthreads();
+            for (int q = tid; q < half; q += 1024) {
+                const int i = ((q & ~(jj - 1)) << 1) | (q & (jj - 1)), p2 = i + jj;
+                const uint64_t x = keys[i], y = keys[p2];
+                const bool up = (i & k) == 0;
+                if ((x > y) == up) {
+                    keys[i] = y;
+                    keys[p2] = x;
                 }
             }
-            __syncthreads();
+            if (cross) { __syncthreads(); fenced = true; }
+            else { pda_wave_sync(); fenced = false; }
         }
+    __syncthreads();
+    // permutation of the five arrays, in place: every thread first GATHERS all its values (all loads in flight at once),
+    // the workgroup barrier separates the reads from the writes
     int32_t* arrs[5] = {users, pos, neg, reinterpret_cast<int32_t*>(pos_pop), reinterpret_cast<int32_t*>(neg_pop)};
-    for (int q = 0; q < 5; ++q) {
-        int32_t* arr = arrs[q];
-        if (!arr) continue;
-        for (int i = tid; i < B; i += 1024) buf[i] = arr[i];
-        __syncthreads();
-        for (int i = tid; i < B; i += 1024) arr[i] = buf[(uint32_t)keys[i]];
-        __syncthreads();
+    (void)buf;
+    int32_t vals[4][5];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < B) {
+            const uint32_t src = (uint32_t)keys[i];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) vals[e][q] = arrs[q] ? arrs[q][src] : 0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = tid + 1024 * e;
+        if (i < B) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q)
+                if (arrs[q]) arrs[q][i] = vals[e][q];
+        }
     }
 }
 

@@ -460,6 +460,24 @@ def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int
     return users, pos, neg, pp, pn
 
 
+def sample_triplets_into(out, train_indptr, train_indices, *, seed: int, step_dev: torch.Tensor, user_pool=None, n_pool: int = 0,
+                          train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = True, advance: bool = True):
+    """Graph-capturable sampler: writes one batch into the preallocated `out` = (users, pos, neg, pos_pop|None, neg_pop|None),
+    taking the step from the device counter `step_dev` (int64[1]) and, with `advance`, incrementing it afterwards."""
+    lib = _lib.load()
+    users, pos, neg, pp, pn = out
+    n_slots = pop_matrix.shape[1] if pop_matrix is not None else 0
+    check(lib.pda_sample_triplets_dev(ptr(users), 1, ptr(user_pool), int(n_pool), users.numel(), ptr(train_indptr),
+                                      ptr(train_indices), ptr(train_slots), int(neg_range[0]), int(neg_range[1]),
+                                      ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), ptr(step_dev), ptr(pos), ptr(neg), ptr(pp),
+                                      ptr(pn), stream_ptr()), "pda_sample_triplets_dev")
+    if sort_by_pos:
+        sort_triplets_by_pos(users, pos, neg, pp, pn)
+    if advance:
+        check(lib.pda_counter_add(ptr(step_dev), 1, stream_ptr()), "pda_counter_add")
+    return out
+
+
 def sort_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):
     """pda_sort_triplets_by_pos (in place).  Batches above 4096 triplets are left as they are."""
     lib = _lib.load()

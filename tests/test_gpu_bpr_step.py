@@ -331,3 +331,21 @@ def test_bf16_tables_step(dev, d):
     mi[ti] = False
     assert torch.equal(Ub[mu], Ub0[mu]) and torch.equal(Ib[mi], Ib0[mi])
     assert not torch.equal(Ib[ti], Ib0[ti])
+
+
+def test_device_counter_sampler_draws_the_same_batches(dev):
+    """pda_sample_triplets_dev(seed, *step_dev) == pda_sample_triplets(seed, step); pda_counter_add advances the stream."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("tiny", dev)
+    B = 256
+    step_dev = torch.full((1,), 5, dtype=torch.int64, device=dev)
+    bufs = (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+            torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
+    for want_step in (5, 6):
+        ops.sample_triplets_into(bufs, W.hist_indptr, W.hist_indices, seed=11, step_dev=step_dev, n_pool=W.n_users,
+                                 train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+        ref = ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=11, step=want_step, n_pool=W.n_users,
+                                  train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+        for a, b in zip(bufs, ref):
+            assert torch.equal(a, b)
+    assert int(step_dev.item()) == 7
