@@ -81,18 +81,22 @@ int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_sh
                        const int32_t* hist_indices, int hist_row_mode, int K, int head, int n_splits,
                        uint64_t* out_keys, void* stream);
 
-/* Generation-2 path: bf16x3 MFMA pre-filter + exact fp32 rescoring; returns exactly the keys of pda_score_topk_f32
- * (see pda_amd/csrc/pda_score_topk_v2.hip for the error bound).  The item shard is pre-split once per weight
- * version into bf16 hi / lo planes + padded row norms:
+/* Pre-filtered path: a bf16 MFMA pass scores every pair approximately with a rigorous error bound, only the pairs that
+ * can still beat a user's running threshold are rescored with the exact fp32 chain; returns exactly the keys of
+ * pda_score_topk_f32.  Two kernels sit behind these entry points and the library picks per call (PDA_SCORE_KERNEL=v2|v3
+ * forces one): v3 (pda_score_topk_v3.hip: ONE bf16 MFMA per k-step, candidate ring, exact lists) for every sweep that
+ * scores all tiles and for d = 256; v2 (pda_score_topk_v2.hip: hi/lo split = three MFMAs per k-step, approximate lists,
+ * exact finish, exact-kernel recomputation of user tiles whose near-tie band overflows) for the early-terminating sweep.
+ * The item shard is pre-split once per weight version into bf16 planes + padded row norms:
  *   pda_item_prep_bytes(n, d)  -> size of the caller-owned `prep` buffer (device)
  *   pda_item_prep_f32(I_shard, n, d, prep, stream)
  *   pda_score_topk_workspace_bytes(n_users_blk) -> size of the per-call scratch `workspace` (device; the call
  *                                 clears it itself, stream-ordered; one workspace per concurrent call).  After the
  *                                 call, the u64 at byte offset 8 holds the number of 32-item tiles scored, summed
- *                                 over workgroups (statistics: (n_items/32) * ceil(n_users/128) when nothing was skipped)
+ *                                 over workgroups (statistics: (n_items/32) * ceil(n_users/128) when nothing was skipped),
+ *                                 and the u32 at byte offset 4 the number of pairs rescored exactly (v3 only)
  *   pda_score_topk_prepped_f32(..arguments of pda_score_topk_f32 plus `prep` after I_shard and `workspace` before stream..)
- * d in {64,128,256}; K <= PDA_TOPK_CAP-4.  User tiles whose near-tie band overflows the on-chip list are
- * recomputed by the exact fp32 kernel inside the same call. */
+ * d in {64,128,256}; K <= PDA_TOPK_CAP-4; item_offset + n_items_local <= 2^27. */
 size_t pda_item_prep_bytes(int n_items_local, int d);
 int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream);
 size_t pda_score_topk_workspace_bytes(int n_users_blk);
