@@ -5,14 +5,19 @@ and BPR triplets/s (reported beside it), on synthetic Douban-shaped data (pda_am
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
 
 A "step" is one pass of the evaluation hot path over one block of `--eval-block` users against the WHOLE item
-catalogue: score (fp32 MFMA) + history mask + top-K on every rank's item shard, one RCCL all-gather of the
-packed partial lists, merge.  Inputs are resident in HBM before the timed region.  Scaling is STRONG: the
-catalogue and the users per step are fixed while N grows (item-parallel sharding of BASELINE config 3 -> 4).
+catalogue: score + history mask + top-K on every rank's item shard (bf16 MFMA pre-filter, exact fp32 rescoring of the
+survivors: bit-identical to the exact fp32 kernel), for N > 1 one RCCL all-to-all of the packed partial lists (rank r
+receives every shard's list for ITS slice of the users) and the merge.  Inputs are resident in HBM before the timed
+region.  Scaling is STRONG: the catalogue and the users per step are fixed while N grows (item-parallel sharding of
+BASELINE config 3 -> 4).
 
-The JSON line also carries: `roofline` (dominant kernel = score_topk_kernel, bound = fp32 MFMA; achieved from the
-algorithmic flops 2*Bu*I_local*d per launch and the kernel's HIP-event duration), `cpu_baseline` (torch-CPU
-restatement of the reference op sequence, oracle/cpu_baseline.py, bounded sample, rank 0, N=1 only) and `train`
-(fused BPR step throughput on BASELINE config 2, N=1 only).
+The headline is a DENSE sweep: every user x item pair is scored, the catalogue being visited most popular first.  Beside
+it: `dense_natural_order` (the same in item-id order), `ordered_sweep` (the product default for the PDA head: the same
+visiting order with exact early termination on a popularity bound -- same results, most of the catalogue never scored),
+`roofline` (dominant kernel = the score kernel, bound = bf16 MFMA; achieved from the algorithmic flops 2*Bu*I_local*d per
+launch and the kernel's HIP-event duration), `cpu_baseline` (torch-CPU restatement of the reference op sequence,
+oracle/cpu_baseline.py, bounded sample, rank 0, N=1 only) and `train` (fused BPR step throughput on BASELINE config 2,
+N=1 only).
 """
 import argparse
 import json
@@ -112,7 +117,8 @@ def bench_eval(args, rank, world, dev):
     sink = []
 
     def run(bl):
-        for idx, val in ev.topk_blocks(bl, args.K, head, hist):
+        # N > 1: the all-to-all exchange -- every rank merges and keeps the lists of its slice of the users
+        for idx, val in ev.topk_blocks(bl, args.K, head, hist, sharded=world > 1):
             sink.append(idx[0, 0])                        # keep the result alive without a sync
 
     def timed_pass(prune):
@@ -399,7 +405,8 @@ def main():
                                    % (args.workload.upper(), W.n_users, W.n_items, W.d,
                                       "PDA condition ((elu+1)*pop^%.2f)" % W.gamma if args.head == "condition" else "raw",
                                       args.K),
-                       "users_per_step": ev["Bu"], "sharding": "item-parallel x%d, RCCL all-gather of partial top-K" % world,
+                       "users_per_step": ev["Bu"], "sharding": ("item-parallel x%d, one RCCL all-to-all of the partial top-K lists per step, result sharded by user slice" % world)
+                                   if world > 1 else "single GPU",
                        "train_nnz": W.n_train},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "dense_natural_order": ev["natural"],
             "ordered_sweep": ev["ordered"],

@@ -1,9 +1,13 @@
 """Item-parallel evaluation (and SGD training) across the GPUs of one node (the reference is single-device).
 
 One process per GPU.  Rank r owns the item rows [lo_r, hi_r) (+ their popularity); the user table and the
-history CSR are replicated.  Per user block every rank produces its partial top-K (packed keys), then ONE
-RCCL all-gather over xGMI moves Bu*K*8 bytes per rank and every rank merges the R lists with
-pda_topk_merge.  The all-gather + merge of block b runs on a side stream while block b+1 is being scored.
+history CSR are replicated.  Per user block every rank produces its partial top-K (packed keys), then ONE RCCL
+collective over xGMI and a merge with pda_topk_merge:
+    topk           all-gather (Bu*K*8 bytes per rank out, R times that in): every rank ends up with the full [Bu, K]
+    topk_sharded   all-to-all (R times less traffic, R-1 links in parallel on the full mesh): rank r merges and keeps the
+                   lists of ITS slice of the users -- what bench.py times for N > 1 (at R = 8 the all-gather would move
+                   183 MB per rank and 65 536-user block, more time than the scoring)
+The collective + merge of block b run on a side stream while block b+1 is being scored.
 
 `score_fn` / `merge_fn` default to the HIP entry points; tests inject doubles to exercise the
 orchestration under gloo on CPU (there is no CPU product path).
@@ -31,6 +35,22 @@ def _all_gather_keys(keys: torch.Tensor, world: int, group=None) -> torch.Tensor
         dist.all_gather(parts, keys.contiguous(), group=group)
         return torch.stack(parts)
     dist.all_gather_into_tensor(out, keys.contiguous(), group=group)
+    return out
+
+
+def _exchange_user_slices(keys: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """All-to-all of the packed partial lists: keys [Bu, K] (this rank's item shard, all users) -> [R, Bu/R, K], where
+    entry r holds rank r's list for MY slice of the users.  Each rank ships (R-1)/R of its keys once and receives as much
+    -- R times less than the all-gather -- and on the xGMI full mesh the R-1 transfers run on R-1 separate links."""
+    Bu, K = keys.shape
+    out = torch.empty((world, Bu // world, K), dtype=keys.dtype, device=keys.device)
+    if dist.get_backend(group) == "gloo" and keys.is_cuda:       # plumbing check on one GPU (tools/two_rank_smoke.sh)
+        parts = list(torch.empty((world, Bu, K), dtype=keys.dtype, device=keys.device).unbind(0))
+        dist.all_gather(parts, keys.contiguous(), group=group)
+        r = dist.get_rank(group)
+        per = Bu // world
+        return torch.stack([p[r * per:(r + 1) * per] for p in parts])
+    dist.all_to_all_single(out.view(-1), keys.contiguous().view(-1), group=group)
     return out
 
 
@@ -72,11 +92,39 @@ class ItemShardedTopK:
             keys = _all_gather_keys(keys, self.world, self.group)     # [R, Bu, K] -- the one collective
         return self.merge_fn(keys, users, hist, want="idx_val")
 
+    def user_slice(self, n_users: int) -> Tuple[int, int]:
+        """Rows of a user block whose final lists THIS rank produces in sharded mode."""
+        per = n_users // self.world
+        return self.rank * per, (self.rank + 1) * per
+
+    def _finish(self, keys, users, hist, sharded: bool):
+        """The exchange + final merge of one block.  sharded: all-to-all, this rank merges its slice of the users and
+        returns (idx, val) for those rows only; else all-gather and every rank merges everything."""
+        if sharded and users.numel() % self.world == 0 and (hist is None or getattr(hist, "mode", 1) == 1):
+            lo, hi = self.user_slice(users.numel())
+            allk = _exchange_user_slices(keys, self.world, self.group)
+            return self.merge_fn(allk, users[lo:hi].contiguous(), hist, want="idx_val")
+        allk = _all_gather_keys(keys, self.world, self.group)
+        res = self.merge_fn(allk, users, hist, want="idx_val")
+        if sharded:                                   # block not divisible by the world size: slice the full result
+            per = -(-users.numel() // self.world)
+            lo = min(self.rank * per, users.numel())
+            return tuple(t[lo:lo + per] for t in res)
+        return res
+
+    def topk_sharded(self, users, K=50, head=0, hist=None):
+        """(idx, val) of this rank's user slice (`user_slice`): the multi-GPU path with R times less traffic; the union
+        over ranks is what `topk` returns on every rank."""
+        keys = self.local_keys(users, K, head, hist)
+        if self.world == 1:
+            return self.merge_fn(keys, users, hist, want="idx_val")
+        return self._finish(keys, users, hist, True)
+
     # -- many blocks, collective + merge of block b overlapped with scoring of block b+1 ----------
-    def topk_blocks(self, blocks: Iterable[torch.Tensor], K=50, head=0, hist=None) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
+    def topk_blocks(self, blocks: Iterable[torch.Tensor], K=50, head=0, hist=None, sharded: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         if self.world == 1 or self._side is None:
             for users in blocks:
-                yield self.topk(users, K, head, hist)
+                yield self.topk_sharded(users, K, head, hist) if sharded else self.topk(users, K, head, hist)
             return
         main = torch.cuda.current_stream()
         pending = None                       # (result, done-event) of the previous block, produced on the side stream
@@ -97,8 +145,7 @@ class ItemShardedTopK:
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
                 keys.record_stream(self._side)
-                allk = _all_gather_keys(keys, self.world, self.group)
-                res = self.merge_fn(allk, users, hist, want="idx_val")
+                res = self._finish(keys, users, hist, sharded)
                 done = torch.cuda.Event()
                 done.record(self._side)
                 pending = (res, done)

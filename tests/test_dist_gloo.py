@@ -87,6 +87,15 @@ def _worker(rank, world, port, q):
         bix = np.concatenate([rows[x] for x in u])
         ridx, rval = c_oracle.score_topk(U, I, u, K, 1, pop, bip, bix, order=1)
         out.append(bool(np.array_equal(idx.numpy(), ridx) and np.array_equal(val.numpy(), rval)))
+    # sharded mode: all-to-all, this rank merges only its slice of the users
+    u = blocks[0].numpy()
+    bip = np.zeros(len(u) + 1, np.int64)
+    bip[1:] = np.cumsum([len(rows[x]) for x in u])
+    bix = np.concatenate([rows[x] for x in u])
+    ridx, rval = c_oracle.score_topk(U, I, u, K, 1, pop, bip, bix, order=1)
+    lo, hi = ev.user_slice(len(u))
+    sidx, sval = ev.topk_sharded(blocks[0], K, 1, (ip, ix))
+    out.append(bool(sidx.shape[0] == hi - lo and np.array_equal(sidx.numpy(), ridx[lo:hi]) and np.array_equal(sval.numpy(), rval[lo:hi])))
     # a new popularity vector is re-sliced per shard (evaluation.set_testing_popularity)
     pop2 = (pop * 0.5).astype(np.float32)
     ev.set_popularity(torch.from_numpy(pop2))
