@@ -887,8 +887,11 @@ int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void*
     // early-terminating sweep, whose time is dominated by the first, candidate-rich tiles, and for bf16 tables, where
     // it needs one MFMA per k-step as well.  PDA_SCORE_KERNEL=v2|v3 forces one (A/B measurements, cross-checks).
     bool use_v3 = !bf16 && (d == 256 || !(ordered && early_stop));
+    // v3 packs (row, item id) into 32-bit ring words and uses 32-bit plane offsets
+    const bool v3_fits = (uint64_t)item_offset + (uint64_t)n_items_local <= (1ull << 27) && (uint64_t)n_items_local * (uint64_t)d < (1ull << 32);
+    use_v3 = use_v3 && v3_fits;
     if (const char* kk = getenv("PDA_SCORE_KERNEL")) {
-        if (kk[0] == 'v' && kk[1] == '3') use_v3 = true;
+        if (kk[0] == 'v' && kk[1] == '3') use_v3 = v3_fits;
         if (kk[0] == 'v' && kk[1] == '2') use_v3 = false;
     }
     if (use_v3) return pda_topk::launch_score_v3(aa, d, head, ordered, bf16, s);

@@ -450,3 +450,22 @@ def test_bf16_exact_ties_take_the_exact_fallback(dev):
         ref = ops.topk_merge(ops.score_topk_keys(torch.from_numpy(Uw).to(dev), torch.from_numpy(Iw).to(dev), ut, K, head, pt, None,
                                                  n_splits=4, impl="v1"), want="keys")
         assert torch.equal(ref, got)
+
+
+@pytest.mark.parametrize("K", [1, 7, 33, 56])
+@pytest.mark.parametrize("nI", [40, 63, 65, 200])
+def test_small_catalogues_and_other_k(dev, K, nI, impl):
+    """Catalogues around the 32- / 64-item tile sizes and K from 1 to the largest the pre-filtered kernels take (56),
+    every sweep mode and kernel, both heads, history, three item splits: merged keys equal the exact kernel's."""
+    from pda_amd import ops
+    rng = np.random.default_rng(1000 * K + nI)
+    nU, d = 130, 64
+    U, I, pop, hist = make_case(rng, nU, nI, d, max_hist=min(20, nI // 2))
+    ip, ix = csr(hist)
+    h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    Ut, It, ut = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.arange(nU, dtype=torch.int32, device=dev)
+    for head in (0, 1):
+        pt = torch.from_numpy(pop).to(dev) if head else None
+        ref = ops.topk_merge(ops.score_topk_keys(Ut, It, ut, K, head, pt, h, n_splits=1, impl="v1"), want="keys")
+        got = ops.topk_merge(ops.score_topk_keys(Ut, It, ut, K, head, pt, h, n_splits=3), want="keys")
+        assert torch.equal(ref, got), (K, nI, head, int((ref != got).sum()))
