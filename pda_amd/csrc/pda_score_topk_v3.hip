@@ -19,6 +19,12 @@
 //   <= 2 d 2^-24 sum|u_k i_k| <= 2^-15 ||u|| ||i|| for d <= 256.  Norms are padded by (1+2^-10)(1+1e-4).  Used: 2^-8 * 1.01.
 #include "pda_topk_common.h"
 #include <cstdlib>
+#ifndef PDA_KWARM
+#define PDA_KWARM 4
+#endif
+#ifndef PDA_VOTE
+#define PDA_VOTE 3
+#endif
 
 using namespace pda_topk;
 
@@ -27,6 +33,11 @@ namespace {
 constexpr int kCap3 = PDA_TOPK_CAP - 1;   // 59 slots per user list
 constexpr int kRing = 192;                // ring entries per wave (u32 each); a push needs kRing - 64 free
 constexpr int kRingTrig = 64;             // a wave above this asks the whole workgroup to drain
+
+__device__ __forceinline__ f32x16 zero16w() {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return z;
+}
 
 template <int D, int HEAD, bool ORD, bool BF>
 __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 aa) {
@@ -51,6 +62,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                        // [4][kRing]
     int* wgflag = reinterpret_cast<int*>(rings + 4 * kRing);                                // [2] "some wave wants to drain its ring"
     int* votes = wgflag + 2;                                                                // [4] ORD: wave w sees no use in going on
+    float* unl = reinterpret_cast<float*>(votes + 4) + 2;                                   // [128] ORD: padded row norms (termination bound)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -151,6 +163,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     }
     if (tid < 2) wgflag[tid] = 0;
     if (tid < 4) votes[tid] = 0;
+    if (lane < 32) unl[wave * 32 + lane] = nu_row;
     pda_wave_sync();
     f32x16 thr;    // the rows' exact thresholds, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
     auto refresh_thr = [&]() __attribute__((always_inline)) {
@@ -168,7 +181,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     float nu_max = nu_row;                     // ONE norm per wave (the largest): eps scale of the filter, and the
 #pragma unroll                                 // termination bound of the ordered sweep
     for (int o = 32; o > 0; o >>= 1) nu_max = fmaxf(nu_max, __shfl_xor(nu_max, o, 64));
-    const float un_wmax = nu_max;
     nu_max *= kEps * 1.001f;
 
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap3;
@@ -356,13 +368,110 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         ok_prev[cb] = ok_cur[cb] = false;
     }
 
-    if (nt > 0) {
-        tile_load(t0, pA_h);
-        lane_consts(t0, pop_cur, ni_cur, id_cur);
-        tile_store(pA_h);
-        hb_cur = hist_bits(t0);
+    // ---- exact warm-up (ordered sweeps): the first kWarm tiles go through the fp32 matrix cores ---------------------------
+    // In visiting order most of a user's final top K sits in the first few tiles, and until a list holds K entries EVERY
+    // pair is a candidate: through the ring that is ~1000 exact rescorings per wave and tile, each pass a gather latency.
+    // v_mfma_f32_32x32x2_f32 in the k order of v1 gives the same bits as the fmaf chain (that is what v1 is), so these
+    // tiles are scored exactly on the matrix cores and their keys go straight into the lists: 64 MFMAs of 64 cycles per
+    // 32 items, paid for 2 tiles only.
+    constexpr int kWarm = (ORD && NB == 2) ? PDA_KWARM : 0;
+    int k0 = 0;          // first tile of the pre-filtered loop
+    int n32 = 0;         // statistics: 32-item tiles scored
+    if constexpr (kWarm > 0) {
+        constexpr int NC = D / 8;                 // k-chunks of 8
+        constexpr int CPR4 = D / 4;               // 16-byte chunks per fp32 row
+        constexpr int NLD4 = (32 * CPR4) / kThreads;
+        float* Bt = reinterpret_cast<float*>(smem);          // [32][D] fp32, swizzled: exactly the bytes of the [64][D] bf16 tile
+        const int nwarm = min(kWarm, nt);
+        f32x4 areg[NC];
 #pragma unroll
-        for (int cb = 0; cb < NB; ++cb) ok_cur[cb] = (t0 * TW + 32 * cb + j) < a.n_items_local;
+        for (int c = 0; c < NC; ++c) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row_ok) v = pda_load4<BF>(a.U, (size_t)uid * D + 4 * h + 8 * c);
+            areg[c] = v;
+        }
+        const float* brow = Bt + j * D;
+        const int bswz = swz<D>(j);
+        for (int w = 0; w < nwarm; ++w) {
+            const int t = tile_of(w);
+            n32 += min(NB, (a.n_items_local - t * TW + 31) >> 5);
+            float popw[NB], niw[NB];
+            int idw[NB];
+            lane_consts(t, popw, niw, idw);
+            const uint64_t hbw = hist_bits(t);
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                __syncthreads();                  // the previous block has been read by everyone
+#pragma unroll
+                for (int q = 0; q < NLD4; ++q) {
+                    const int id = tid + kThreads * q;
+                    const int jj = id / CPR4, ch = id % CPR4;
+                    const int pos = min(t * TW + 32 * cb + jj, a.n_items_local - 1);
+                    const uint32_t item = (uint32_t)aa.order[pos];
+                    *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pda_load4<BF>(a.I, (size_t)item * D + 4 * ch);
+                }
+                __syncthreads();
+                f32x16 acc0 = zero16w(), acc1 = zero16w();
+#pragma unroll
+                for (int c = 0; c < NC; c += 2) {
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + h) ^ bswz));
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + 2 + h) ^ bswz));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][q], b0[q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c + 1][q], b1[q], acc1, 0, 0, 0);
+                    }
+                }
+                const f32x16 accx = acc0 + acc1;
+                const bool okw = (t * TW + 32 * cb + j) < a.n_items_local;
+                const uint32_t hbits = cb ? (uint32_t)(hbw >> 32) : (uint32_t)hbw;
+                const bool any_hb = __any(hbits != 0u);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int lrow = wave * 32 + row;
+                    float sc = accx[r];
+                    if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * popw[cb];
+                    bool p = okw && (sc >= taul[lrow]);
+                    if (any_hb) {
+                        const uint32_t hbr = (uint32_t)__shfl((int)hbits, row, 64);          // train items never enter
+                        if ((hbr >> j) & 1u) p = false;
+                    }
+                    const uint64_t key = pda_pack_key(sc, (uint32_t)idw[cb]);
+                    for (;;) {
+                        bool ov = false;
+                        if (p) {
+                            const int slot = atomicAdd(&cntl[lrow], 1);
+                            if (slot < kCap3) lists[(size_t)lrow * kCap3 + slot] = key;
+                            else ov = true;
+                        }
+                        if (!__any(ov)) break;
+                        pda_wave_sync();
+                        uint64_t full = __ballot(lane < 32 && cntl[wave * 32 + (lane & 31)] >= kCap3);
+                        while (full) {
+                            const int rr = __builtin_ctzll(full);
+                            full &= full - 1ull;
+                            compact_list<kCap3>(my_lists + rr * kCap3, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+                        }
+                        p = ov && (sc >= taul[lrow]);
+                    }
+                }
+            }
+        }
+        __syncthreads();                          // the last fp32 block has been read: the bf16 tiles may overwrite it
+        pda_wave_sync();
+        refresh_thr();
+        k0 = nwarm;
+    }
+
+    if (k0 < nt) {
+        const int tk = tile_of(k0);
+        tile_load(tk, pA_h);
+        lane_consts(tk, pop_cur, ni_cur, id_cur);
+        tile_store(pA_h);
+        hb_cur = hist_bits(tk);
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) ok_cur[cb] = (tk * TW + 32 * cb + j) < a.n_items_local;
     }
     __syncthreads();
 
@@ -439,13 +548,17 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         bool stop = false;
         if constexpr (ORD) {
             // every 4th tile: can anything at or behind the next tile still reach one of my rows?  (bound: pda_score_topk_v2.hip,
-            // with the wave's largest row norm.)  Candidates still waiting in the ring can only raise thresholds.
-            if ((k & 3) == 3 && has_next && aa.sufA != nullptr) {
+            // row norms from LDS.)  Candidates still waiting in the ring can only raise thresholds.
+            if ((k & PDA_VOTE) == PDA_VOTE && has_next && aa.sufA != nullptr) {
                 const float sa = aa.sufA[tn * NB], sb = aa.sufB[tn * NB];
-                const float ub = __builtin_fmaf(un_wmax, sb, sa) * 1.000002f;
                 bool dead = true;
+                int hv = h;
+                asm volatile("" : "+v"(hv));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dead = dead && (ub < thr[r]);
+                for (int r = 0; r < 16; ++r) {
+                    const float ub = __builtin_fmaf(unl[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv], sb, sa) * 1.000002f;
+                    dead = dead && (ub < thr[r]);
+                }
                 const bool alldead = __all(dead);
                 if (lane == 0) votes[wave] = alldead ? 1 : 0;
             }
@@ -453,7 +566,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         if (drain && ring_cnt > 0) process_ring();
         __syncthreads();  // next tile visible
         if constexpr (ORD) {
-            if ((k & 3) == 3 && has_next && aa.sufA != nullptr) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
+            if ((k & PDA_VOTE) == PDA_VOTE && has_next && aa.sufA != nullptr) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
         }
 
         hb_prev = hb_cur;
@@ -472,13 +585,12 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         }
         return stop;
     };
-    int n32 = 0;       // statistics: 32-item tiles scored
-    for (int k = 0; k < nt; ++k) {
+    for (int k = k0; k < nt; ++k) {
         n32 += min(NB, (a.n_items_local - tile_of(k) * TW + 31) >> 5);
         if (iteration(k, pA_h)) break;
     }
     if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n32);
-    if (nt > 0) {   // drain the last tile
+    if (k0 < nt) {   // drain the last tile
         uint64_t M[NB][16], okm[NB];
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
@@ -508,7 +620,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 
 template <int D, int HEAD, bool ORD, bool BF>
 int launch_v3(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = ((ORD && D <= 128) ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 32;
+    const size_t smem = ((ORD && D <= 128) ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8 + 4) + 4 * kRing * sizeof(uint32_t) + 32;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v3_kernel<D, HEAD, ORD, BF>),
