@@ -49,6 +49,8 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--train-steps", type=int, default=2048)
     p.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
+    p.add_argument("--headline-only", action="store_true",
+                   help="time only the headline sweep (PMC passes: the other sweep modes launch the same kernel template)")
     p.add_argument("--train-sharded", action="store_true",
                    help="N>1 only: also time the item-parallel SGD step (pda_amd.dist.ItemShardedBPR); off by default -- "
                         "it is latency-bound by its per-step all-gather and buys capacity, not speed")
@@ -149,7 +151,7 @@ def bench_eval(args, rank, world, dev):
     v2 = ops.score_impl(W.d, args.K, W.n_items) == "v2"
     use_order = head == ops.HEAD_POP and v2
     natural = None
-    if use_order:
+    if use_order and not args.headline_only:
         dt_n, k_ms_n, _ = timed_pass(False)
         natural = {"value": Bu * args.steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / args.steps * 1e3, "kernel_ms": k_ms_n}
     dt, k_ms, st_d = timed_pass("order" if use_order else False)
@@ -157,7 +159,7 @@ def bench_eval(args, rank, world, dev):
         assert int(st_d["tiles_scored"][0]) == st_d["tiles_dense"], "the dense sweep must score every tile"
     # beside it: the product default for the PDA head -- ordered sweep WITH exact early termination (same keys).
     ordered = None
-    if use_order:
+    if use_order and not args.headline_only:
         dt_o, k_ms_o, st = timed_pass(True)
         frac = float(st["tiles_scored"][0]) / st["tiles_dense"] if "tiles_scored" in st else None
         ordered = {"value": Bu * args.steps / dt_o, "unit": "users/s", "ms_per_step": dt_o / args.steps * 1e3,

@@ -11,6 +11,15 @@ with open(os.path.join(dst, name + "_kernel_stats.csv"), "w", newline="") as f:
     for r in rows[1:13]:
         r[0] = r[0][:160]
         w.writerow(r)
+hl = os.path.join(src, "stats_headline", "bench_kernel_stats.csv")
+if os.path.exists(hl):
+    rows = list(csv.reader(open(hl)))
+    with open(os.path.join(dst, name + "_kernel_stats_headline_only.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:7]:
+            r[0] = r[0][:160]
+            w.writerow(r)
 pat = sys.argv[3] if len(sys.argv) > 3 else "score_topk"
 pm = "# kernel pattern: %s\n" % pat + subprocess.check_output([sys.executable, "tools/pmc_summary.py", src, pat]).decode()
 open(os.path.join(dst, name + "_pmc.txt"), "w").write(
