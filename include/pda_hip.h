@@ -222,6 +222,12 @@ int pda_apply_user_grads_f32(float* U, const int32_t* users, const float* g, int
 int pda_sort_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
                              void* stream);
 
+/* The same purpose, without a sorting network: the batch is permuted so that every run of equal positives is contiguous
+ * (order: hash bucket of pos, then pos, then original index -- deterministic).  ~5x faster than the sort; what the device
+ * sampler uses.  B <= 4096. */
+int pda_group_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
+                              void* stream);
+
 /* TF-1.14 AdamOptimizer `_apply_sparse_shared`: decay m,v on EVERY row, add the (pre-summed) sparse
  * gradient, update EVERY row (MF/model_api.py:83,:470-471 [TF-ext]).  `g` is the dense accumulator
  * filled by PDA_UPD_DENSE_GRAD; it is reset to zero by this sweep.  n = rows*d.  lr_t is the

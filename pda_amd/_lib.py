@@ -49,6 +49,7 @@ SIGNATURES = {
     "pda_apply_user_grads_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "pda_bpr_step_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_refresh_rows_bf16": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "pda_group_triplets_by_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_sort_triplets_by_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_adam_dense_sweep_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),

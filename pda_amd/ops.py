@@ -456,7 +456,7 @@ def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int
                                   ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), step, ptr(pos), ptr(neg), ptr(pp),
                                   ptr(pn), stream_ptr()), "pda_sample_triplets")
     if sort_by_pos:
-        sort_triplets_by_pos(users, pos, neg, pp, pn)
+        group_triplets_by_pos(users, pos, neg, pp, pn)
     return users, pos, neg, pp, pn
 
 
@@ -472,10 +472,19 @@ def sample_triplets_into(out, train_indptr, train_indices, *, seed: int, step_de
                                       ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), ptr(step_dev), ptr(pos), ptr(neg), ptr(pp),
                                       ptr(pn), stream_ptr()), "pda_sample_triplets_dev")
     if sort_by_pos:
-        sort_triplets_by_pos(users, pos, neg, pp, pn)
+        group_triplets_by_pos(users, pos, neg, pp, pn)
     if advance:
         check(lib.pda_counter_add(ptr(step_dev), 1, stream_ptr()), "pda_counter_add")
     return out
+
+
+def group_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):
+    """pda_group_triplets_by_pos (in place): equal positives become contiguous.  Batches above 4096 triplets are left alone."""
+    lib = _lib.load()
+    if users.numel() > 4096:
+        return
+    check(lib.pda_group_triplets_by_pos(ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), users.numel(), stream_ptr()),
+          "pda_group_triplets_by_pos")
 
 
 def sort_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):

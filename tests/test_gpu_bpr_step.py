@@ -349,3 +349,30 @@ def test_device_counter_sampler_draws_the_same_batches(dev):
         for a, b in zip(bufs, ref):
             assert torch.equal(a, b)
     assert int(step_dev.item()) == 7
+
+
+@pytest.mark.parametrize("B", [1, 37, 2048, 4096])
+def test_group_triplets_by_pos(dev, B):
+    """pda_group_triplets_by_pos: a permutation of whole triplets (all five arrays together) in which every run of equal
+    positives is contiguous, deterministic from call to call."""
+    from pda_amd import ops
+    rng = np.random.default_rng(B)
+    nI = 300
+    w = 1.0 / np.arange(1, nI + 1)
+    users = rng.integers(0, 10 ** 6, B).astype(np.int32)
+    pos = rng.choice(nI, size=B, p=w / w.sum()).astype(np.int32) * 7919          # spread ids, hot head
+    neg = rng.integers(0, 10 ** 6, B).astype(np.int32)
+    pp, pn = rng.uniform(0, 1, B).astype(np.float32), rng.uniform(0, 1, B).astype(np.float32)
+    outs = []
+    for _ in range(2):
+        ut, pt, nt, ppt, pnt = to(dev, users, pos, neg, pp, pn)
+        ops.group_triplets_by_pos(ut, pt, nt, ppt, pnt)
+        got = [t.cpu().numpy() for t in (ut, pt, nt, ppt, pnt)]
+        rows = sorted(zip(*(g.tolist() for g in got)))
+        assert rows == sorted(zip(users.tolist(), pos.tolist(), neg.tolist(), pp.tolist(), pn.tolist()))
+        p = got[1]
+        starts = np.flatnonzero(np.r_[True, p[1:] != p[:-1]])
+        assert len(starts) == len(np.unique(p))                                   # one run per distinct positive
+        outs.append(got)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
