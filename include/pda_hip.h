@@ -96,7 +96,9 @@ int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_sh
  *                                 over workgroups (statistics: (n_items/32) * ceil(n_users/128) when nothing was skipped),
  *                                 and the u32 at byte offset 4 the number of pairs rescored exactly (v3 only)
  *   pda_score_topk_prepped_f32(..arguments of pda_score_topk_f32 plus `prep` after I_shard and `workspace` before stream..)
- * d in {64,128,256}; K <= PDA_TOPK_CAP-4; item_offset + n_items_local <= 2^27. */
+ * d in {64,128,256}; K <= PDA_TOPK_CAP-4.  PDA_HEAD_POP: pop_shard must be >= 0 (NaN entries never rank; it is pop^gamma of a
+ * normalised count, MF/train_new_api.py:952-959) -- the filter is derived for that; the exact kernel pda_score_topk_f32
+ * has no such requirement. */
 size_t pda_item_prep_bytes(int n_items_local, int d);
 int pda_item_prep_f32(const float* I_shard, int n_items_local, int d, void* prep, void* stream);
 size_t pda_score_topk_workspace_bytes(int n_users_blk);

@@ -189,6 +189,23 @@ def score_impl(d: int, K: int, item_hi: int) -> str:
 TOPK_CAP_V2 = _lib.TOPK_CAP - 4
 
 
+_POP_OK = {}           # id(pop) -> (weakref, _version): popularity vectors already checked
+
+
+def _check_pop(pop_shard: torch.Tensor):
+    """The PDA head's filters and bounds are derived for pop >= 0 (it is pop^gamma of a min-max-normalised count,
+    MF/train_new_api.py:952-959).  Checked once per tensor version (one device sync).  NaN entries are tolerated: their
+    head is NaN, every comparison with it is false, the item is never recommended."""
+    hit = _POP_OK.get(id(pop_shard))
+    if hit is not None and hit[0]() is pop_shard and hit[1] == pop_shard._version:
+        return
+    if bool((pop_shard < 0).any()):        # NaN passes: such items simply never rank (the reference's BPRMF-A search feeds NaNs, SURVEY 9)
+        raise ValueError("pop_shard must be >= 0 (it is pop**gamma of a normalised count)")
+    for k in [k for k, v in _POP_OK.items() if v[0]() is None]:
+        del _POP_OK[k]
+    _POP_OK[id(pop_shard)] = (weakref.ref(pop_shard), pop_shard._version)
+
+
 def prune_default(head: int):
     """How the catalogue is swept (results are identical in all three):
         True     visiting order (popular first) + exact early termination -- the default for the popularity-weighted head
@@ -224,6 +241,10 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         raise ValueError("U and I_shard disagree on embed dim")
     if pop_shard is not None and pop_shard.numel() != nloc:
         raise ValueError("pop_shard must have one entry per local item row")
+    if head == HEAD_POP:
+        if pop_shard is None:
+            raise ValueError("HEAD_POP needs pop_shard")
+        _check_pop(pop_shard)
     if hist is not None and hist.indices.numel() == 0:
         hist = None                       # an all-empty mask: the kernel must never dereference a 0-length buffer
     if n_splits <= 0:

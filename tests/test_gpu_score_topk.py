@@ -469,3 +469,13 @@ def test_small_catalogues_and_other_k(dev, K, nI, impl):
         ref = ops.topk_merge(ops.score_topk_keys(Ut, It, ut, K, head, pt, h, n_splits=1, impl="v1"), want="keys")
         got = ops.topk_merge(ops.score_topk_keys(Ut, It, ut, K, head, pt, h, n_splits=3), want="keys")
         assert torch.equal(ref, got), (K, nI, head, int((ref != got).sum()))
+
+
+def test_negative_popularity_is_rejected(dev):
+    from pda_amd import ops
+    U = torch.randn(8, 64, device=dev)
+    I = torch.randn(64, 64, device=dev)
+    pop = torch.rand(64, device=dev)
+    pop[3] = -0.1
+    with pytest.raises(ValueError):
+        ops.score_topk_keys(U, I, torch.arange(8, dtype=torch.int32, device=dev), 5, 1, pop)
