@@ -241,9 +241,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         raise ValueError("U and I_shard disagree on embed dim")
     if pop_shard is not None and pop_shard.numel() != nloc:
         raise ValueError("pop_shard must have one entry per local item row")
-    if head == HEAD_POP:
-        if pop_shard is None:
-            raise ValueError("HEAD_POP needs pop_shard")
+    if head == HEAD_POP and pop_shard is not None:       # (a missing pop_shard is the library's PDA_ERR_ARG)
         _check_pop(pop_shard)
     if hist is not None and hist.indices.numel() == 0:
         hist = None                       # an all-empty mask: the kernel must never dereference a 0-length buffer
