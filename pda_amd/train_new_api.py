@@ -191,7 +191,7 @@ class evaluation:
         self.data = data_ if data_ is not None else data
         self.Ks = list(Ks_ if Ks_ is not None else Ks)
         self.device = torch.device(device if device is not None else "cuda")
-        self.batch_size = block or (getattr(args, "eval_block", 65536) if args is not None else 65536)
+        self.batch_size = block or (getattr(args, "eval_block", 262144) if args is not None else 262144)
         self.testing_popularity = None
         self.eval_who = "test"
         self._hist = None
