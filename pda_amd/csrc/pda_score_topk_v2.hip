@@ -343,6 +343,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v2_kernel(ScoreArgs2 a
     auto hist_bits = [&](int t) __attribute__((always_inline)) -> uint32_t {
         if (!hist_on) return 0u;
         const int jg0 = a.item_offset + t * 32, jg1 = jg0 + 32;
+        if (!__any(nxt < jg1)) return 0u;      // no row of the wave has an entry in this tile (see pda_score_topk_v3.hip)
         nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
         const bool adv = nxt < jg1;
         uint32_t hb = (adv && (!ORD || nxt >= jg0)) ? (1u << ((nxt - jg0) & 31)) : 0u;

@@ -130,6 +130,10 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     auto hist_bits = [&](int t) __attribute__((always_inline)) -> uint64_t {
         if (!hist_on) return 0ull;
         const int jg0 = a.item_offset + t * TW, jg1 = jg0 + TW;
+        // most tiles hold no history entry of any of the wave's 32 rows (always so a few tiles into an ordered sweep): leave
+        // before the cursor bookkeeping.  A refill still in flight stays pending (flag and register untouched).  The loads
+        // below become conditional, which costs nothing here: the tile's own loads were consumed before this call.
+        if (!__any(nxt < jg1)) return 0ull;
         nxt2 = pend_flag ? (pend_ok ? pend_v : 0x7fffffff) : nxt2;
         const bool adv = nxt < jg1;
         uint64_t hb = (adv && (!ORD || nxt >= jg0)) ? (1ull << ((nxt - jg0) & (TW - 1))) : 0ull;
