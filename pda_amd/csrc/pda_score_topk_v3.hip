@@ -357,19 +357,17 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         }
     };
 
-    // ---- main loop (test of tile t-1 in the shadow of the MFMAs of tile t) -------------------------------------------------
+    // ---- main loop ---------------------------------------------------------------------------------------------------------
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 acc_prev[NB];
-    uint64_t hb_prev = 0, hb_cur = 0;
-    float pop_prev[NB], pop_cur[NB], ni_prev[NB], ni_cur[NB];
-    int id_prev[NB], id_cur[NB];
-    bool ok_prev[NB], ok_cur[NB];   // lane's item exists
+    uint64_t hb_cur = 0;
+    float pop_cur[NB], ni_cur[NB];
+    int id_cur[NB];
+    bool ok_cur[NB];   // lane's item exists
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
-        acc_prev[cb] = zero16;
-        pop_prev[cb] = pop_cur[cb] = ni_prev[cb] = ni_cur[cb] = 0.f;
-        id_prev[cb] = id_cur[cb] = 0;
-        ok_prev[cb] = ok_cur[cb] = false;
+        pop_cur[cb] = ni_cur[cb] = 0.f;
+        id_cur[cb] = 0;
+        ok_cur[cb] = false;
     }
 
     // ---- exact warm-up (ordered sweeps): the first kWarm tiles go through the fp32 matrix cores ---------------------------
@@ -482,6 +480,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     const uint16_t* bhrow = Bh + j * D;
     const int bsw = swzb<D>(j);
 
+    // One iteration = one tile: MFMAs, then the filter on THAT tile's scores (v1 / v2 test the previous tile in the shadow of
+    // the MFMA chain; with one MFMA per k-step the chain is ~15 % of the iteration, and carrying a second set of scores,
+    // item constants and history bits costs more registers and moves than the overlap returns).
     auto iteration = [&](int k, u32x4 (&cur_h)[NLD]) __attribute__((always_inline)) -> bool {
         const bool has_next = (k + 1) < nt;
         const int tn = tile_of(min(k + 1, nt - 1));
@@ -491,17 +492,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         lane_consts(tn, pop_next, ni_next, id_next);
         __builtin_amdgcn_sched_barrier(0);
 
-        // two independent accumulator chains: the two column blocks (NB = 2), or even / odd k-steps of the one block
-        f32x16 acc[2] = {zero16, zero16};
-        // Only the OR of the lane masks stays live (16 NB SGPR pairs would spill into VGPR lanes); the rare slow path
-        // recomputes them from acc_prev, which it needs anyway.
-        uint64_t many_c[NB];
-        float neg_eps[NB], ipop[NB], cc[NB];
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            many_c[cb] = 0;
-            test_consts(pop_prev[cb], ni_prev[cb], neg_eps[cb], ipop[cb], cc[cb]);
-        }
+        // independent accumulator chains: column block x even/odd k-step (NB = 2: four), even/odd k-step (NB = 1: two)
+        f32x16 acc[4] = {zero16, zero16, zero16, zero16};
 #pragma unroll
         for (int mm = 0; mm < NM; ++mm) {
             const int off = 8 * ((2 * mm + h) ^ bsw);
@@ -509,25 +501,27 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + cb * (32 * D) + off));
-                const int ai = NB == 2 ? cb : (mm & 1);
+                const int ai = NB == 2 ? 2 * cb + (mm & 1) : (mm & 1);
                 acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[ai], 0, 0, 0);
-#pragma unroll
-                for (int r = (16 * mm) / NM; r < (16 * (mm + 1)) / NM; ++r)
-                    many_c[cb] |= test_reg(acc_prev[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
             }
         }
-        f32x16 acc_new[NB];
+        f32x16 sc[NB];
         if constexpr (NB == 2) {
-            acc_new[0] = acc[0];
-            acc_new[NB - 1] = acc[1];
+            sc[0] = acc[0] + acc[1];
+            sc[NB - 1] = acc[2] + acc[3];
         } else {
-            acc_new[0] = acc[0] + acc[1];
+            sc[0] = acc[0] + acc[1];
         }
         uint64_t okm[NB], many = 0;
+        float neg_eps[NB], ipop[NB], cc[NB];
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            okm[cb] = __ballot(ok_prev[cb]);
-            many |= many_c[cb] & okm[cb];
+            test_consts(pop_cur[cb], ni_cur[cb], neg_eps[cb], ipop[cb], cc[cb]);
+            uint64_t mc = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mc |= test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+            okm[cb] = __ballot(ok_cur[cb]);
+            many |= mc & okm[cb];
         }
 
         // All four waves drain their rings in the SAME iteration (flag set by whichever wave is filling up): the
@@ -546,8 +540,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(acc_prev[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
-            push_masks(M, okm, hb_prev, id_prev);
+                for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+            push_masks(M, okm, hb_cur, id_cur);
         }
         bool stop = false;
         if constexpr (ORD) {
@@ -573,15 +567,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             if ((k & PDA_VOTE) == PDA_VOTE && has_next && aa.sufA != nullptr) stop = (votes[0] & votes[1] & votes[2] & votes[3]) != 0;
         }
 
-        hb_prev = hb_cur;
         hb_cur = hb_next;
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            acc_prev[cb] = acc_new[cb];
-            pop_prev[cb] = pop_cur[cb];
-            ni_prev[cb] = ni_cur[cb];
-            ok_prev[cb] = ok_cur[cb];
-            id_prev[cb] = id_cur[cb];
             pop_cur[cb] = pop_next[cb];
             ni_cur[cb] = ni_next[cb];
             id_cur[cb] = id_next[cb];
@@ -594,18 +582,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         if (iteration(k, pA_h)) break;
     }
     if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n32);
-    if (k0 < nt) {   // drain the last tile
-        uint64_t M[NB][16], okm[NB];
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            float neg_eps, ipop, cc;
-            test_consts(pop_prev[cb], ni_prev[cb], neg_eps, ipop, cc);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(acc_prev[cb][r], thr[r], neg_eps, ipop, cc);
-            okm[cb] = __ballot(ok_prev[cb]);
-        }
-        push_masks(M, okm, hb_prev, id_prev);
-    }
     if (ring_cnt > 0) process_ring();
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(aa.visited) - 1, n_cand);   // workspace + 4: u32 "pairs rescored"
 
