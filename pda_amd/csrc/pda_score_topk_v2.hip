@@ -884,10 +884,10 @@ int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void*
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
                   reinterpret_cast<unsigned long long*>(ws + 2)};
     // Which pre-filtered kernel: v3 (1 MFMA per k-step, candidate ring, exact lists, exact fp32-MFMA warm-up of the first
-    // tiles of an ordered sweep) everywhere except bf16 tables at d = 256, where v2 (approximate lists; one MFMA per k-step
-    // as well on bf16 tables) measures ~4 % (dense) / 20 % (early stop) faster -- v3 has no warm-up there (one 32-item block
-    // per tile).  PDA_SCORE_KERNEL=v2|v3 forces one (A/B measurements, cross-checks).
-    bool use_v3 = !(bf16 && d == 256);
+    // tiles of an ordered sweep) everywhere except the early-terminating sweep over bf16 tables at d = 256, where v3 has no
+    // room for the warm-up block and v2 (approximate lists; one MFMA per k-step as well on bf16 tables) measures 15 %
+    // faster.  PDA_SCORE_KERNEL=v2|v3 forces one (A/B measurements, cross-checks).
+    bool use_v3 = !(bf16 && d == 256 && ordered && early_stop);
     // v3 packs (row, item id) into 32-bit ring words and uses 32-bit plane offsets
     const bool v3_fits = (uint64_t)item_offset + (uint64_t)n_items_local <= (1ull << 27) && (uint64_t)n_items_local * (uint64_t)d < (1ull << 32);
     use_v3 = use_v3 && v3_fits;
