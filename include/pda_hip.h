@@ -47,6 +47,7 @@ extern "C" {
 #define PDA_UPD_SGD_FUSED 1  /* north_star: in-kernel row update, atomics on item rows                       */
 #define PDA_UPD_DENSE_GRAD 2 /* atomically sum gradients into dense gU/gI (feeds pda_adam_dense_sweep_f32)  */
 #define PDA_UPD_SGD_ITEMS 3  /* internal: what pda_bpr_step_shard_f32 runs (item rows updated, user grads out)   */
+#define PDA_UPD_DENSE_ITEMS 4 /* internal: pda_bpr_step_shard_f32 with gI_shard (item grads accumulated, user grads out) */
 
 #define PDA_MAX_K 64
 #define PDA_TOPK_CAP 60 /* per-user on-chip candidate slots (>= K) */
@@ -211,11 +212,14 @@ int pda_refresh_rows_bf16(const float* master, uint16_t* shadow, const int32_t* 
  * reg_div as in pda_bpr_step_f32; loss_acc receives this rank's share of (loss, mf, reg): their sum over ranks is the
  * loss of the global batch.  R shard steps + the apply equal one pda_bpr_step_f32(PDA_UPD_SGD_FUSED) on the concatenated
  * batch (tests/test_gpu_bpr_step.py).  g rows may be strided (g_stride floats, >= d) so that the packed exchange buffer
- * can be applied in place.  No reference counterpart (single device there). */
+ * can be applied in place.  gI_shard != NULL (f32, shape of I_shard) switches to the reference's optimiser: the item
+ * gradients are summed into gI_shard instead of applied, the gathered user gradients are summed into a dense gU with
+ * pda_apply_user_grads_f32(gU, .., lr = -1), and pda_adam_dense_sweep_f32 runs on U (identically on every rank) and on the
+ * rank's I_shard.  No reference counterpart (single device there). */
 int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_offset, const int32_t* users, const int32_t* pos,
                            const int32_t* neg, const float* pos_pop, const float* neg_pop, int B_local, int d, float regs,
-                           float reg_div, float mean_div, float lr, float* g_user, int g_stride, float* loss_acc,
-                           void* stream);
+                           float reg_div, float mean_div, float lr, float* g_user, int g_stride, float* gI_shard,
+                           float* loss_acc, void* stream);
 int pda_apply_user_grads_f32(float* U, const int32_t* users, const float* g, int n, int d, int g_stride, float lr,
                              void* stream);
 

@@ -63,7 +63,8 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
     const int t = blockIdx.x * TPB + g;
     const bool active = t < a.B;
     const bool with_pop = a.pos_pop != nullptr;
-    const bool scatter = a.mode == PDA_UPD_SGD_FUSED || a.mode == PDA_UPD_DENSE_GRAD || a.mode == PDA_UPD_SGD_ITEMS;
+    const bool scatter = a.mode == PDA_UPD_SGD_FUSED || a.mode == PDA_UPD_DENSE_GRAD || a.mode == PDA_UPD_SGD_ITEMS ||
+                         a.mode == PDA_UPD_DENSE_ITEMS;
 
     float maxi = 0.f, sq = 0.f;
     int p = -1;
@@ -120,6 +121,10 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
             atomic_add4(np_, dne * nlr);
             dpe = dpe * nlr;
             ptarget = pp;
+        } else if (a.mode == PDA_UPD_DENSE_ITEMS) {
+            // item-parallel Adam: item gradients summed into the shard's dense accumulator, user gradient out
+            atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
+            ptarget = a.gI + (size_t)p * D + 4 * e;
         } else if (a.mode == PDA_UPD_DENSE_GRAD) {
             atomic_add4(a.gU + (size_t)u * D + 4 * e, due);
             atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
@@ -416,13 +421,14 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
 extern "C" int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_offset, const int32_t* users, const int32_t* pos,
                                       const int32_t* neg, const float* pos_pop, const float* neg_pop, int B_local, int d,
                                       float regs, float reg_div, float mean_div, float lr, float* g_user, int g_stride,
-                                      float* loss_acc, void* stream) {
+                                      float* gI_shard, float* loss_acc, void* stream) {
     if (!U || !I_shard || !users || !pos || !neg || !g_user || B_local <= 0 || reg_div <= 0.f || mean_div <= 0.f || item_offset < 0)
         return PDA_ERR_ARG;
     if (g_stride < d || (g_stride & 3)) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
-    StepArgs a{const_cast<float*>(U), I_shard, users, pos, neg, pos_pop, neg_pop, g_user, nullptr, nullptr, nullptr, nullptr,
-               loss_acc, B_local, 1.0f / mean_div, regs / reg_div, lr, PDA_UPD_SGD_ITEMS, item_offset, g_stride, U, I_shard};
+    StepArgs a{const_cast<float*>(U), I_shard, users, pos, neg, pos_pop, neg_pop, g_user, nullptr, nullptr, nullptr, gI_shard,
+               loss_acc, B_local, 1.0f / mean_div, regs / reg_div, lr, gI_shard ? PDA_UPD_DENSE_ITEMS : PDA_UPD_SGD_ITEMS,
+               item_offset, g_stride, U, I_shard};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);

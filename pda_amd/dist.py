@@ -171,15 +171,28 @@ class ItemShardedBPR:
     `step_fn` / `apply_fn` default to the HIP entry points; tests inject doubles under gloo on CPU."""
 
     def __init__(self, U: torch.Tensor, I_shard: torch.Tensor, item_offset: int, *, regs: float, lr: float, global_batch: int,
-                 rank: int = 0, world: int = 1, group=None, step_fn: Optional[Callable] = None, apply_fn: Optional[Callable] = None):
+                 rank: int = 0, world: int = 1, group=None, step_fn: Optional[Callable] = None, apply_fn: Optional[Callable] = None,
+                 optimizer: str = "sgd", sweep_fn: Optional[Callable] = None):
         if step_fn is None or apply_fn is None:
             from . import ops
             step_fn = step_fn or ops.bpr_step_shard
             apply_fn = apply_fn or ops.apply_user_grads
+        if optimizer not in ("sgd", "adam"):
+            raise NotImplementedError("item-parallel optimizer must be sgd | adam")
         self.U, self.I_shard, self.item_offset = U, I_shard, item_offset
         self.regs, self.lr, self.global_batch = regs, lr, global_batch
         self.rank, self.world, self.group = rank, world, group
         self.step_fn, self.apply_fn = step_fn, apply_fn
+        self.optimizer, self._t, self._state = optimizer, 0, None
+        if optimizer == "adam":
+            # the reference's optimiser (TF-1.14 Adam, dense decay): U and its state are replicated and swept identically on
+            # every rank, the item slice and its state are swept by their owner
+            if sweep_fn is None:
+                from . import ops
+                sweep_fn = ops.adam_dense_sweep
+            z = torch.zeros_like
+            self._state = {"mU": z(U), "vU": z(U), "gU": z(U), "mI": z(I_shard), "vI": z(I_shard), "gI": z(I_shard)}
+        self.sweep_fn = sweep_fn
 
     def local_step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
         """This rank's kernel: updates the local item rows, returns the packed exchange buffer [B_local, d + 4] =
@@ -188,9 +201,10 @@ class ItemShardedBPR:
         if Bl * self.world != self.global_batch:
             raise ValueError("every rank must bring global_batch / world triplets")
         buf = torch.zeros((Bl, d + 4), dtype=torch.float32, device=users.device)
+        extra = {"gI_shard": self._state["gI"]} if self.optimizer == "adam" else {}
         self.step_fn(self.U, self.I_shard, self.item_offset, users, pos, neg, pos_pop, neg_pop, regs=self.regs,
                      reg_div=float(self.global_batch), mean_div=float(self.global_batch), lr=self.lr,
-                     g_user=buf[:, :d], loss_acc=buf[0, d + 1:d + 4])
+                     g_user=buf[:, :d], loss_acc=buf[0, d + 1:d + 4], **extra)
         buf[:, d].view(torch.int32).copy_(users)
         return buf
 
@@ -204,7 +218,16 @@ class ItemShardedBPR:
         """Applies every rank's user gradients to the local replica of U; returns the global (loss, mf, reg)."""
         d = self.U.shape[1]
         users_all = allb[:, d].view(torch.int32).contiguous()
-        self.apply_fn(self.U, users_all, allb[:, :d], self.lr)
+        if self.optimizer == "adam":
+            from .ops import adam_lr_t
+            st = self._state
+            self._t += 1
+            lr_t = adam_lr_t(self.lr, self._t)
+            self.apply_fn(st["gU"], users_all, allb[:, :d], -1.0)          # gU += every rank's user gradients
+            self.sweep_fn(self.U, st["mU"], st["vU"], st["gU"], lr_t)       # identical on every rank
+            self.sweep_fn(self.I_shard, st["mI"], st["vI"], st["gI"], lr_t) # this rank's slice
+        else:
+            self.apply_fn(self.U, users_all, allb[:, :d], self.lr)
         Bl = allb.shape[0] // self.world
         return allb.view(self.world, Bl, d + 4)[:, 0, d + 1:d + 4].sum(dim=0)
 

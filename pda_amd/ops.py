@@ -381,7 +381,8 @@ def refresh_rows_bf16(master, shadow, rows=None):
 
 
 def bpr_step_shard(U, I_shard, item_offset: int, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float,
-                   mean_div: float, lr: float, g_user: torch.Tensor, loss_acc: Optional[torch.Tensor] = None):
+                   mean_div: float, lr: float, g_user: torch.Tensor, loss_acc: Optional[torch.Tensor] = None,
+                   gI_shard: Optional[torch.Tensor] = None):
     """pda_bpr_step_shard_f32: one rank's part of an item-parallel SGD step.  pos/neg are GLOBAL ids inside
     [item_offset, item_offset + I_shard.shape[0]); g_user float32 [B_local, >=d] (row stride = g_user.stride(0))."""
     lib = _lib.load()
@@ -399,8 +400,10 @@ def bpr_step_shard(U, I_shard, item_offset: int, users, pos, neg, pos_pop=None, 
         raise ValueError("g_user must be float32 [B_local, d] with unit inner stride")
     check(lib.pda_bpr_step_shard_f32(ptr(U), ptr(I_shard), int(item_offset), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop),
                                      ptr(neg_pop), B, d, float(regs), float(reg_div), float(mean_div), float(lr),
-                                     ptr(g_user), g_user.stride(0), ptr(loss_acc), stream_ptr()), "pda_bpr_step_shard_f32")
-    mark_modified(I_shard)
+                                     ptr(g_user), g_user.stride(0), ptr(_need(gI_shard, torch.float32, "gI_shard", optional=True)),
+                                     ptr(loss_acc), stream_ptr()), "pda_bpr_step_shard_f32")
+    if gI_shard is None:
+        mark_modified(I_shard)
 
 
 def apply_user_grads(U, users, g, lr: float):

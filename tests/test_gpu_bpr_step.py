@@ -376,3 +376,38 @@ def test_group_triplets_by_pos(dev, B):
         outs.append(got)
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_item_parallel_adam_equals_the_reference_optimiser_on_the_concatenated_batch(dev):
+    """Item-parallel training with the REFERENCE's optimiser (TF-1.14 Adam, dense decay): four emulated ranks, each with its
+    own replica of U and the Adam state of its item slice; after two global steps every U replica and the union of the
+    slices equal two oracle Adam steps on the concatenated batches (dense decay: untouched rows move too)."""
+    from pda_amd import dist as pdist
+    rng = np.random.default_rng(2024)
+    R, nU, nI, d, Bl, regs, lr = 4, 3000, 512, 64, 256, 1e-2, 1e-2
+    Bg, per = R * Bl, nI // R
+    U = (rng.standard_normal((nU, d)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.2).astype(np.float32)
+    trainers = []
+    for r in range(R):
+        trainers.append(pdist.ItemShardedBPR(torch.from_numpy(U.copy()).to(dev), torch.from_numpy(I[r * per:(r + 1) * per].copy()).to(dev),
+                                             r * per, regs=regs, lr=lr, global_batch=Bg, rank=r, world=R, optimizer="adam"))
+    Uref, Iref, state = U, I, None
+    for step in range(1, 3):
+        users = rng.permutation(nU)[:Bg].astype(np.int32)
+        pos = np.concatenate([rng.integers(r * per, r * per + per // 4, Bl) for r in range(R)]).astype(np.int32)
+        neg = np.concatenate([rng.integers(r * per, (r + 1) * per, Bl) for r in range(R)]).astype(np.int32)
+        pp = (rng.uniform(0, 1, Bg) ** 0.22).astype(np.float32)
+        pn = (rng.uniform(0, 1, Bg) ** 0.22).astype(np.float32)
+        Uref, Iref, state, ref_loss = po.train_step(Uref, Iref, users, pos, neg, pp, pn, regs, Bg, lr, optimizer="adam", state=state, t=step)
+        bufs = []
+        for r, t in enumerate(trainers):
+            sl = slice(r * Bl, (r + 1) * Bl)
+            bufs.append(t.local_step(*to(dev, users[sl], pos[sl], neg[sl], pp[sl], pn[sl])))
+        allb = torch.cat(bufs)
+        losses = [t.apply(allb) for t in trainers]                       # what every rank does after the all-gather
+        np.testing.assert_allclose(losses[0].cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+        for t in trainers:
+            np.testing.assert_allclose(t.U.cpu().numpy(), Uref, atol=TOL)
+        np.testing.assert_allclose(torch.cat([t.I_shard for t in trainers]).cpu().numpy(), Iref, atol=TOL)
+    assert np.abs(Uref - U).max() > 1e-3
