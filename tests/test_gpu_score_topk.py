@@ -197,6 +197,15 @@ def test_item_shards_merge_equals_single_device(dev):
     np.testing.assert_array_equal(idx.cpu().numpy(), idx1)
     np.testing.assert_array_equal(val.cpu().numpy(), val1)
     check_against_oracle(idx1, val1, U, I, users, K, 1, pop, hist, exact=False)
+    # the all-to-all form (dist.ItemShardedTopK.topk_sharded): rank r merges only its slice of the users, from every
+    # shard's list for that slice -- the union of the slices is the same result
+    S, per_u = 3, nU // 3
+    for r in range(S):
+        lo, hi = r * per_u, (r + 1) * per_u
+        mine = torch.stack([p[lo:hi] for p in parts]).contiguous()
+        sidx, sval = ops.topk_merge(mine, ut[lo:hi].contiguous(), h)
+        np.testing.assert_array_equal(sidx.cpu().numpy(), idx1[lo:hi])
+        np.testing.assert_array_equal(sval.cpu().numpy(), val1[lo:hi])
 
 
 def test_merge_matches_numpy_oracle(dev):
