@@ -203,8 +203,9 @@ def bench_train(args, dev):
     from pda_amd import ops, synthetic
     W = synthetic.make_workload("c2" if args.workload != "tiny" else "tiny", dev)
     B, regs, lr, NB, G = 2048, 1e-2, 1e-2, 64, 64
+    # pre-staged batches, grouped by positive item (pda_group_triplets_by_pos): the step kernel then combines whole runs
     batches = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2020, step=s, n_pool=W.n_users,
-                                   train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+                                   train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train, sort_by_pos=True)
                for s in range(NB)]
     out = {"workload": "C2: synthetic %d users x %d items, d=%d, B=%d, PD/PDA (s_condition, gamma=%.2f)" %
                        (W.n_users, W.n_items, W.d, B, W.gamma), "graph_launches": G}
@@ -233,7 +234,14 @@ def bench_train(args, dev):
     U, I = W.U.clone(), W.I.clone()
     loss = torch.zeros(3, device=dev)
     out["sgd_fused"] = timed_graph(lambda i: ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, lr=lr,
-                                                          mode=ops.UPD_SGD_FUSED, loss_acc=loss), args.train_steps)
+                                                          mode=ops.UPD_SGD_FUSED, loss_acc=loss, grouped=True), args.train_steps)
+    U, I = W.U.clone(), W.I.clone()
+    raw_batches = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2020, step=s_, n_pool=W.n_users,
+                                       train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train, sort_by_pos=False)
+                   for s_ in range(NB)]
+    out["sgd_fused_batches_in_sampling_order"] = timed_graph(
+        lambda i: ops.bpr_step(U, I, *raw_batches[i % NB], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss),
+        args.train_steps)
     out["sgd_fused"]["bytes_per_triplet"] = 6 * W.d * 4 + 20
     out["sgd_fused"]["hbm_frac"] = out["sgd_fused"]["triplets_per_s"] * (6 * W.d * 4 + 20) / 1e9 / PEAK_HBM_GBS
 

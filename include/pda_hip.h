@@ -46,6 +46,8 @@ extern "C" {
 #define PDA_UPD_NONE 0       /* loss + per-occurrence gradients only (parity harness)                        */
 #define PDA_UPD_SGD_FUSED 1  /* north_star: in-kernel row update, atomics on item rows                       */
 #define PDA_UPD_DENSE_GRAD 2 /* atomically sum gradients into dense gU/gI (feeds pda_adam_dense_sweep_f32)  */
+#define PDA_UPD_ANY_ORDER 0x100 /* OR into update_mode when the batch is NOT grouped by positive: equal positives are then
+                                 * combined on chip wherever they sit in a workgroup (slightly slower on grouped batches) */
 #define PDA_UPD_SGD_ITEMS 3  /* internal: what pda_bpr_step_shard_f32 runs (item rows updated, user grads out)   */
 #define PDA_UPD_DENSE_ITEMS 4 /* internal: pda_bpr_step_shard_f32 with gI_shard (item grads accumulated, user grads out) */
 

@@ -36,6 +36,7 @@ struct StepArgs {
     int g_stride;      // floats between consecutive g_user rows (>= D)
     const void* Ufwd;  // tables the forward pass gathers from: U / I themselves (fp32) or their bf16 shadows
     const void* Ifwd;  // (pda_bpr_step_bf16: U / I are then the fp32 masters that take the update)
+    int any_order;     // PDA_UPD_ANY_ORDER: equal positives are combined wherever they sit in the workgroup
 };
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -139,7 +140,19 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
     }
     if (e == 0) s_pos[g] = p;
     __syncthreads();
-    if (scatter && active && (g == 0 || s_pos[g - 1] != p)) {   // first triplet of a run of equal positives
+    if (scatter && active && a.any_order) {
+        // batch in sampling order: the first triplet of the workgroup with this positive sums ALL the workgroup's
+        // contributions to it -- adjacent or not -- and leaves as one atomic per element (hot item: one atomic per
+        // workgroup instead of one per occurrence; 24.8 -> 12.9 us per 2048-triplet step at C2 without any sort)
+        bool leader = true;
+        for (int k = 0; k < g; ++k) leader = leader && (s_pos[k] != p);
+        if (leader) {
+            f32x4 sum = *reinterpret_cast<const f32x4*>(s_dpe + g * D + 4 * e);
+            for (int k = g + 1; k < TPB; ++k)
+                if (s_pos[k] == p) sum += *reinterpret_cast<const f32x4*>(s_dpe + k * D + 4 * e);
+            atomic_add4(ptarget, sum);
+        }
+    } else if (scatter && active && (g == 0 || s_pos[g - 1] != p)) {   // grouped batch: first triplet of a run of equal positives
         f32x4 sum = *reinterpret_cast<const f32x4*>(s_dpe + g * D + 4 * e);
         for (int k = g + 1; k < TPB && s_pos[k] == p; ++k) sum += *reinterpret_cast<const f32x4*>(s_dpe + k * D + 4 * e);
         atomic_add4(ptarget, sum);
@@ -403,11 +416,13 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
                                 float* gI, float* loss_acc, void* stream) {
     if (!U || !I || !users || !pos || !neg || B <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
+    update_mode &= ~PDA_UPD_ANY_ORDER;
     if (update_mode < PDA_UPD_NONE || update_mode > PDA_UPD_DENSE_GRAD) return PDA_ERR_ARG;
     if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
     if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
     StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
-               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I};
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I, any_order};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);
@@ -428,7 +443,7 @@ extern "C" int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_o
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     StepArgs a{const_cast<float*>(U), I_shard, users, pos, neg, pos_pop, neg_pop, g_user, nullptr, nullptr, nullptr, gI_shard,
                loss_acc, B_local, 1.0f / mean_div, regs / reg_div, lr, gI_shard ? PDA_UPD_DENSE_ITEMS : PDA_UPD_SGD_ITEMS,
-               item_offset, g_stride, U, I_shard};
+               item_offset, g_stride, U, I_shard, 1};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);
@@ -525,12 +540,14 @@ extern "C" int pda_bpr_step_bf16(const uint16_t* U_bf16, const uint16_t* I_bf16,
                                  float* g_user, float* g_pos, float* g_neg, float* gU, float* gI, float* loss_acc, void* stream) {
     if (!U_bf16 || !I_bf16 || !users || !pos || !neg || B <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
+    update_mode &= ~PDA_UPD_ANY_ORDER;
     if (update_mode < PDA_UPD_NONE || update_mode > PDA_UPD_DENSE_GRAD) return PDA_ERR_ARG;
     if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
     if (update_mode == PDA_UPD_SGD_FUSED && (!U_master || !I_master)) return PDA_ERR_ARG;   // bf16 rows take no atomics
     if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
     StepArgs a{U_master, I_master, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
-               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U_bf16, I_bf16};
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U_bf16, I_bf16, any_order};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32, true>(a, s);

@@ -8,7 +8,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import (HEAD_POP, HEAD_RAW, HIST_BY_BLOCK_ROW, HIST_BY_USER_ID, UPD_DENSE_GRAD, UPD_NONE,  # noqa: F401
+from ._lib import (HEAD_POP, HEAD_RAW, HIST_BY_BLOCK_ROW, HIST_BY_USER_ID, UPD_ANY_ORDER, UPD_DENSE_GRAD, UPD_NONE,  # noqa: F401
                    UPD_SGD_FUSED, check, ptr, stream_ptr)
 
 ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults (MF/model_api.py:83)
@@ -315,8 +315,10 @@ def recommend_topk(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist=
 
 
 def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float = 0.0,
-             mode: int = UPD_NONE, grads_out=None, gU=None, gI=None, loss_acc: Optional[torch.Tensor] = None):
-    """pda_bpr_step_f32.  grads_out = (g_user, g_pos, g_neg) float32 [B,d] or None."""
+             mode: int = UPD_NONE, grads_out=None, gU=None, gI=None, loss_acc: Optional[torch.Tensor] = None,
+             grouped: bool = False):
+    """pda_bpr_step_f32.  grads_out = (g_user, g_pos, g_neg) float32 [B,d] or None.  grouped: the batch went through
+    group_triplets_by_pos / sort_triplets_by_pos (equal positives adjacent); otherwise PDA_UPD_ANY_ORDER is set."""
     lib = _lib.load()
     U = _need(U, torch.float32, "U")
     I = _need(I, torch.float32, "I")
@@ -333,8 +335,8 @@ def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, 
     gI = _need(gI, torch.float32, "gI", optional=True)
     loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
     check(lib.pda_bpr_step_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), B, d,
-                               float(regs), float(reg_div), float(lr), mode, ptr(gu), ptr(gp), ptr(gn), ptr(gU),
-                               ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_f32")
+                               float(regs), float(reg_div), float(lr), mode | (0 if grouped else UPD_ANY_ORDER), ptr(gu), ptr(gp),
+                               ptr(gn), ptr(gU), ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_f32")
     if mode == UPD_SGD_FUSED:
         mark_modified(U, I)
 
@@ -359,7 +361,7 @@ def bpr_step_bf16(U16, I16, users, pos, neg, pos_pop=None, neg_pop=None, *, regs
     gI = _need(gI, torch.float32, "gI", optional=True)
     loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
     check(lib.pda_bpr_step_bf16(ptr(U16), ptr(I16), ptr(U_master), ptr(I_master), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop),
-                                ptr(neg_pop), B, d, float(regs), float(reg_div), float(lr), mode, ptr(gu), ptr(gp), ptr(gn),
+                                ptr(neg_pop), B, d, float(regs), float(reg_div), float(lr), mode | UPD_ANY_ORDER, ptr(gu), ptr(gp), ptr(gn),
                                 ptr(gU), ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_bf16")
     if mode == UPD_SGD_FUSED:
         mark_modified(U_master, I_master)
@@ -457,7 +459,7 @@ def metrics_sums(topk, tgt_indptr, tgt_indices, Ks, sums: Optional[torch.Tensor]
 
 
 def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int, users=None, user_pool=None,
-                    n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = True):
+                    n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = False):
     """pda_sample_triplets -> (users, pos, neg, pos_pop|None, neg_pop|None), all on device."""
     lib = _lib.load()
     dev = train_indptr.device
@@ -483,7 +485,7 @@ def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int
 
 
 def sample_triplets_into(out, train_indptr, train_indices, *, seed: int, step_dev: torch.Tensor, user_pool=None, n_pool: int = 0,
-                          train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = True, advance: bool = True):
+                          train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = False, advance: bool = True):
     """Graph-capturable sampler: writes one batch into the preallocated `out` = (users, pos, neg, pos_pop|None, neg_pop|None),
     taking the step from the device counter `step_dev` (int64[1]) and, with `advance`, incrementing it afterwards."""
     lib = _lib.load()

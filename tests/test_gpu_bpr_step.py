@@ -207,7 +207,8 @@ def test_hot_positive_runs_and_batch_sort(dev):
             o = np.argsort(got[:, 0]); o2 = np.argsort(users)
             np.testing.assert_array_equal(ppt.cpu().numpy()[o], pp[o2])            # pops moved with their triplets
         loss = torch.zeros(3, device=dev)
-        ops.bpr_step(Ut, It, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
+        # unsorted batch: PDA_UPD_ANY_ORDER (equal positives combined anywhere in a workgroup); sorted: run combining
+        ops.bpr_step(Ut, It, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss, grouped=sort)
         np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
         np.testing.assert_allclose(Ut.cpu().numpy(), U1, atol=TOL)
         np.testing.assert_allclose(It.cpu().numpy(), I1, atol=TOL)
