@@ -284,17 +284,18 @@ def bench_train(args, dev):
     # the same pipeline (sample -> sort by positive -> fused step) captured in HIP graphs: the batch counter lives in
     # device memory (pda_sample_triplets_dev + pda_counter_add), so every replayed step draws a NEW batch
     U, I = W.U.clone(), W.I.clone()
-    step_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+    step_dev = torch.zeros(2, dtype=torch.int64, device=dev)    # two slots: the sampler hands the counter on itself
     bufs = (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
             torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
             torch.empty(B, dtype=torch.float32, device=dev))
 
     def graph_sampled_body(i):
         ops.sample_triplets_into(bufs, W.hist_indptr, W.hist_indices, seed=7, step_dev=step_dev, n_pool=W.n_users,
-                                 train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+                                 train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train, parity=i & 1)
         ops.bpr_step(U, I, *bufs, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
     out["sgd_fused_with_device_sampler_graph"] = timed_graph(graph_sampled_body, max(256, args.train_steps // 2))
-    out["sgd_fused_with_device_sampler_graph"]["batches_drawn"] = int(step_dev.item())
+    out["sgd_fused_with_device_sampler_graph"]["batches_drawn"] = int(step_dev.max().item())
+
     return out, W, batches
 
 

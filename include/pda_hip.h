@@ -273,14 +273,17 @@ int pda_sample_triplets(int32_t* users, int gen_users, const int32_t* user_pool,
                         int neg_lo, int neg_hi, const float* pop_matrix, int n_slots, uint64_t seed, uint64_t step,
                         int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, void* stream);
 
-/* The same sampler with the step taken from DEVICE memory (*step_dev), so that sampler + sort + step can be captured in a
- * HIP graph and replayed: pda_counter_add(step_dev, 1, stream) inside the graph advances the stream of batches.
- * pda_sample_triplets_dev(.., seed, step_dev, ..) draws exactly what pda_sample_triplets(.., seed, *step_dev, ..) draws. */
+/* The same sampler with the step taken from DEVICE memory (*step_dev), so that sampler + step can be captured in a HIP
+ * graph and replayed with a new batch every time.  The stream of batches advances either with
+ * pda_counter_add(step_dev, 1, stream) inside the graph, or -- one launch less -- through step_next: the kernel stores
+ * *step_dev + 1 there (it must be a DIFFERENT location; alternate two slots from launch to launch, an even number of
+ * launches per graph).  pda_sample_triplets_dev(.., seed, step_dev, ..) draws exactly what
+ * pda_sample_triplets(.., seed, *step_dev, ..) draws. */
 int pda_sample_triplets_dev(int32_t* users, int gen_users, const int32_t* user_pool, int n_pool, int B,
                             const int64_t* train_indptr, const int32_t* train_indices, const int32_t* train_slots,
                             int neg_lo, int neg_hi, const float* pop_matrix, int n_slots, uint64_t seed,
-                            const uint64_t* step_dev, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop,
-                            void* stream);
+                            const uint64_t* step_dev, uint64_t* step_next, int32_t* pos, int32_t* neg, float* pos_pop,
+                            float* neg_pop, void* stream);
 int pda_counter_add(uint64_t* counter, uint64_t inc, void* stream);
 
 #ifdef __cplusplus

@@ -104,12 +104,17 @@ struct SampleArgs {
     uint64_t seed, step;
     int B, n_pool, gen_users, neg_lo, neg_hi, n_slots;
     const uint64_t* step_dev;   // optional device-resident step counter added to `step` (HIP-graph replay: pda_counter_add)
+    uint64_t* step_next;        // optional: receives *step_dev + 1 (a DIFFERENT location: no launch in between needed)
 };
 
 __global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= a.B) return;
-    if (a.step_dev) a.step += *a.step_dev;
+    if (a.step_dev) {
+        const uint64_t cur = *a.step_dev;
+        a.step += cur;
+        if (a.step_next && r == 0) *a.step_next = cur + 1;
+    }
     int u;
     if (a.gen_users) {
         const uint64_t key = mix64(a.seed ^ mix64(a.step));
@@ -185,7 +190,7 @@ extern "C" int pda_sample_triplets(int32_t* users, int gen_users, const int32_t*
     if (gen_users && n_pool <= 0) return PDA_ERR_ARG;
     if (pop_matrix && (!pos_pop || !neg_pop || n_slots <= 0)) return PDA_ERR_ARG;
     SampleArgs a{users, user_pool, train_indptr, train_indices, train_slots, pop_matrix, pos, neg, pos_pop, neg_pop,
-                 seed, step, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, nullptr};
+                 seed, step, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, nullptr, nullptr};
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     PDA_CHECK_LAUNCH();
@@ -199,13 +204,14 @@ __global__ void counter_add_kernel(uint64_t* c, uint64_t inc) { *c += inc; }
 extern "C" int pda_sample_triplets_dev(int32_t* users, int gen_users, const int32_t* user_pool, int n_pool, int B,
                                        const int64_t* train_indptr, const int32_t* train_indices,
                                        const int32_t* train_slots, int neg_lo, int neg_hi, const float* pop_matrix,
-                                       int n_slots, uint64_t seed, const uint64_t* step_dev, int32_t* pos, int32_t* neg,
-                                       float* pos_pop, float* neg_pop, void* stream) {
+                                       int n_slots, uint64_t seed, const uint64_t* step_dev, uint64_t* step_next, int32_t* pos,
+                                       int32_t* neg, float* pos_pop, float* neg_pop, void* stream) {
     if (!users || !train_indptr || !train_indices || !pos || !neg || !step_dev || B <= 0 || neg_hi <= neg_lo) return PDA_ERR_ARG;
+    if (step_next == step_dev) return PDA_ERR_ARG;      // other workgroups may still be reading *step_dev
     if (gen_users && n_pool <= 0) return PDA_ERR_ARG;
     if (pop_matrix && (!pos_pop || !neg_pop || n_slots <= 0)) return PDA_ERR_ARG;
     SampleArgs a{users, user_pool, train_indptr, train_indices, train_slots, pop_matrix, pos, neg, pos_pop, neg_pop,
-                 seed, 0, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, step_dev};
+                 seed, 0, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, step_dev, step_next};
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     PDA_CHECK_LAUNCH();

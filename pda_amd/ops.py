@@ -485,19 +485,28 @@ def sample_triplets(train_indptr, train_indices, B: int, *, seed: int, step: int
 
 
 def sample_triplets_into(out, train_indptr, train_indices, *, seed: int, step_dev: torch.Tensor, user_pool=None, n_pool: int = 0,
-                          train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = False, advance: bool = True):
+                          train_slots=None, neg_range=(0, 0), pop_matrix=None, sort_by_pos: bool = False, advance: bool = True,
+                          parity: Optional[int] = None):
     """Graph-capturable sampler: writes one batch into the preallocated `out` = (users, pos, neg, pos_pop|None, neg_pop|None),
-    taking the step from the device counter `step_dev` (int64[1]) and, with `advance`, incrementing it afterwards."""
+    taking the step from device memory.  step_dev int64[1]: read, and with `advance` incremented by a pda_counter_add launch.
+    step_dev int64[2] + parity p: the step is read from slot p and step + 1 stored to slot 1 - p by the sampler itself (no
+    extra launch); the caller alternates p from call to call (an even number of calls per captured graph)."""
     lib = _lib.load()
     users, pos, neg, pp, pn = out
     n_slots = pop_matrix.shape[1] if pop_matrix is not None else 0
+    if parity is None:
+        src, nxt = step_dev, None
+    else:
+        if step_dev.numel() != 2:
+            raise ValueError("parity mode needs a two-slot step counter")
+        src, nxt = step_dev[parity:parity + 1], step_dev[1 - parity:2 - parity]
     check(lib.pda_sample_triplets_dev(ptr(users), 1, ptr(user_pool), int(n_pool), users.numel(), ptr(train_indptr),
                                       ptr(train_indices), ptr(train_slots), int(neg_range[0]), int(neg_range[1]),
-                                      ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), ptr(step_dev), ptr(pos), ptr(neg), ptr(pp),
-                                      ptr(pn), stream_ptr()), "pda_sample_triplets_dev")
+                                      ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), ptr(src), ptr(nxt) if advance else None,
+                                      ptr(pos), ptr(neg), ptr(pp), ptr(pn), stream_ptr()), "pda_sample_triplets_dev")
     if sort_by_pos:
         group_triplets_by_pos(users, pos, neg, pp, pn)
-    if advance:
+    if advance and parity is None:
         check(lib.pda_counter_add(ptr(step_dev), 1, stream_ptr()), "pda_counter_add")
     return out
 

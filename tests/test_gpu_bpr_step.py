@@ -350,6 +350,16 @@ def test_device_counter_sampler_draws_the_same_batches(dev):
         for a, b in zip(bufs, ref):
             assert torch.equal(a, b)
     assert int(step_dev.item()) == 7
+    # two-slot form: the sampler itself stores step + 1 into the other slot (no counter launch)
+    two = torch.tensor([20, 0], dtype=torch.int64, device=dev)
+    for call, want_step in enumerate((20, 21, 22)):
+        ops.sample_triplets_into(bufs, W.hist_indptr, W.hist_indices, seed=11, step_dev=two, n_pool=W.n_users,
+                                 train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train, parity=call & 1)
+        ref = ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=11, step=want_step, n_pool=W.n_users,
+                                  train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+        for a, b in zip(bufs, ref):
+            assert torch.equal(a, b)
+    assert two.tolist() == [22, 23]
 
 
 @pytest.mark.parametrize("B", [1, 37, 2048, 4096])
