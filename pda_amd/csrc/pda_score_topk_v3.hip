@@ -56,7 +56,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     constexpr int NLD = (TW * CPR) / kThreads; // 16-byte loads per thread per tile
     static_assert(NLD >= 1, "v3 needs embed dim >= 64");
     uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);                                       // [TW][D] bf16, swizzled
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + TW * D * sizeof(uint16_t));        // [128][kCap3] EXACT keys
+    constexpr int kTileBytes = D <= 128 ? 64 * D * 2 : 32 * D * 2;   // d <= 128: room for the fp32 warm-up block (32 x D x 4)
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + kTileBytes);                       // [128][kCap3] EXACT keys
     int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * kCap3);                  // [128]
     float* taul = reinterpret_cast<float*>(cntl + kUserTile);                               // [128] exact K-th value (-inf until K entries)
     uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                        // [4][kRing]
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // v_mfma_f32_32x32x2_f32 in the k order of v1 gives the same bits as the fmaf chain (that is what v1 is), so these
     // tiles are scored exactly on the matrix cores and their keys go straight into the lists: 64 MFMAs of 64 cycles per
     // 32 items, paid for 2 tiles only.
-    constexpr int kWarm = (ORD && NB == 2) ? PDA_KWARM : 0;
+    constexpr int kWarm = D <= 128 ? (PDA_KWARM * 2) / NB : 0;    // 256 items
     int k0 = 0;          // first tile of the pre-filtered loop
     int n32 = 0;         // statistics: 32-item tiles scored
     if constexpr (kWarm > 0) {
@@ -409,7 +410,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
                     const int id = tid + kThreads * q;
                     const int jj = id / CPR4, ch = id % CPR4;
                     const int pos = min(t * TW + 32 * cb + jj, a.n_items_local - 1);
-                    const uint32_t item = (uint32_t)aa.order[pos];
+                    uint32_t item = (uint32_t)pos;
+                    if constexpr (ORD) item = (uint32_t)aa.order[pos];
                     *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pda_load4<BF>(a.I, (size_t)item * D + 4 * ch);
                 }
                 __syncthreads();
@@ -600,7 +602,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 
 template <int D, int HEAD, bool ORD, bool BF>
 int launch_v3(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = ((ORD && D <= 128) ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8 + 4) + 4 * kRing * sizeof(uint32_t) + 32;
+    const size_t smem = (D <= 128 ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8 + 4) + 4 * kRing * sizeof(uint32_t) + 32;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v3_kernel<D, HEAD, ORD, BF>),
