@@ -22,6 +22,9 @@
 #ifndef PDA_KWARM
 #define PDA_KWARM 4
 #endif
+#ifndef PDA_KWARM_NAT
+#define PDA_KWARM_NAT 16
+#endif
 #ifndef PDA_VOTE
 #define PDA_VOTE 3
 #endif
@@ -377,7 +380,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // v_mfma_f32_32x32x2_f32 in the k order of v1 gives the same bits as the fmaf chain (that is what v1 is), so these
     // tiles are scored exactly on the matrix cores and their keys go straight into the lists: 64 MFMAs of 64 cycles per
     // 32 items, paid for 2 tiles only.
-    constexpr int kWarm = D <= 128 ? (PDA_KWARM * 2) / NB : 0;    // 256 items
+    // visiting order: 256 items (more costs more than it saves -- the thresholds are already high after them); natural
+    // order: the record process K ln(n / K) is slower, 512 items pay (11.05 -> 9.9 ms at C3; 1024 items: the same)
+    constexpr int kWarm = D <= 128 ? (ORD ? (PDA_KWARM * 2) / NB : PDA_KWARM_NAT) : 0;
     int k0 = 0;          // first tile of the pre-filtered loop
     int n32 = 0;         // statistics: 32-item tiles scored
     if constexpr (kWarm > 0) {
