@@ -58,12 +58,14 @@ template <int D, bool BF>
 __global__ void __launch_bounds__(256) item_prep_kernel(const void* __restrict__ I, int n, uint16_t* __restrict__ hi,
                                                         uint16_t* __restrict__ lo, float* __restrict__ nrm, int* __restrict__ nrm_max_bits,
                                                         const int* __restrict__ order, const float* __restrict__ pop,
-                                                        float* __restrict__ pop_p, int* __restrict__ pos_of, int* __restrict__ bad) {
+                                                        float* __restrict__ pop_p, int* __restrict__ pos_of, int* __restrict__ bad,
+                                                        uint16_t* __restrict__ bex) {
     constexpr int TPR = D / 8;
     const int row = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
-    float ss = 0.f;
+    float ss = 0.f, popv = 1.0f;
     if (row < n) {
         int src = row;
+        if (pop) popv = pop[order ? min(max(order[row], 0), n - 1) : row];
         if (order) {                      // ordered prep: position `row` holds item order[row]
             src = order[row];
             if (src < 0 || src >= n) { if (e == 0) atomicOr(bad, 1); src = 0; }
@@ -92,6 +94,31 @@ __global__ void __launch_bounds__(256) item_prep_kernel(const void* __restrict__
         const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
         nrm[row] = v;
         atomicMax(nrm_max_bits, __float_as_int(v));   // v >= 0: integer order == float order
+        // The extra k-step of v3's folded test (pda_score_topk_v3.hip): with the A side holding the pieces of -threshold, -1
+        // and +eps_scale, one more MFMA turns the accumulator into  s~ - thr * (1/pop)' + (1 + eps)  -- "candidate" is then
+        // "accumulator > 0".  (1/pop)' is rounded DOWN and capped (conservative for thr > 0; thr <= 0 takes the kernel's
+        // pop > thr path), split into three bf16 pieces so that the eight products carry thr/pop to 2^-30.
+        uint32_t p1 = 0x3F80u, p2 = 0, p3 = 0, k1 = 0, k2 = 0;   // PDA_HEAD_RAW: 1/pop := 1, constant := +8e-6 slack
+        if (pop) {
+            float ip = (popv > 0.f) ? fminf((1.0f / popv) * 0.9999995f, 1.0e6f) : 1.0e6f;
+            bf16_split3(ip, p1, p2, p3);
+            k1 = 0x3F80u;
+            k2 = bf16_up(8.0e-6f);
+            if (!(popv == popv)) k1 = 0xFF61u;   // NaN popularity: never a candidate (the exact kernels' comparisons are false too)
+        } else {
+            k1 = bf16_up(8.0e-6f);
+        }
+        u32x4 lo4, hi4;
+        lo4[0] = p1 | (p2 << 16);
+        lo4[1] = p1 | (p2 << 16);
+        lo4[2] = p3 | (p1 << 16);
+        lo4[3] = p3 | (p2 << 16);
+        hi4[0] = k1 | (k2 << 16);
+        hi4[1] = bf16_up(v);
+        hi4[2] = 0;
+        hi4[3] = 0;
+        *reinterpret_cast<u32x4*>(bex + (size_t)row * 16) = lo4;
+        *reinterpret_cast<u32x4*>(bex + (size_t)row * 16 + 8) = hi4;
     }
 }
 
@@ -785,7 +812,7 @@ namespace {
 // [pos_of i32 n][sufA f32 n_tiles][sufB f32 n_tiles]; the bf16 planes come LAST (2 for fp32 tables, 0 / 1 for bf16
 // tables unordered / ordered) so that the offsets of the small arrays do not depend on the table type.
 struct PrepLayout {
-    size_t plane, hi, lo, norm, nmax, pop_p, order, pos_of, sufA, sufB, total;
+    size_t plane, hi, lo, norm, nmax, pop_p, order, pos_of, sufA, sufB, bex, total;
 };
 PrepLayout prep_layout(int n, int d, bool ordered, int n_planes) {
     PrepLayout L{};
@@ -802,6 +829,8 @@ PrepLayout prep_layout(int n, int d, bool ordered, int n_planes) {
         L.sufB = L.sufA + tiles;
         off = L.sufB + tiles;
     }
+    L.bex = off;
+    off += ((size_t)n * 32 + 255) & ~(size_t)255;
     L.hi = off;
     L.lo = off + L.plane;
     L.total = off + (size_t)n_planes * L.plane;
@@ -819,6 +848,7 @@ int run_item_prep(const void* I_shard, bool bf16, const float* pop, const int* o
     int* nmax = reinterpret_cast<int*>(pb + L.nmax);
     float* pop_p = ordered && pop ? reinterpret_cast<float*>(pb + L.pop_p) : nullptr;
     int* pos_of = ordered ? reinterpret_cast<int*>(pb + L.pos_of) : nullptr;
+    uint16_t* bex = reinterpret_cast<uint16_t*>(pb + L.bex);
     if (hipMemsetAsync(nmax, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
     if (ordered) {
         if (hipMemsetAsync(pos_of, 0xFF, (size_t)n * 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
@@ -828,8 +858,8 @@ int run_item_prep(const void* I_shard, bool bf16, const float* pop, const int* o
     case DD: {                                                                                               \
         constexpr int RPB = 256 / (DD / 8);                                                                  \
         const dim3 grid((unsigned)((n + RPB - 1) / RPB));                                                    \
-        if (bf16) hipLaunchKernelGGL((item_prep_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1); \
-        else hipLaunchKernelGGL((item_prep_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1); \
+        if (bf16) hipLaunchKernelGGL((item_prep_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1, bex); \
+        else hipLaunchKernelGGL((item_prep_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, n, hi, lo, nrm, nmax, order, pop, pop_p, pos_of, nmax + 1, bex); \
         break;                                                                                               \
     }
     switch (d) {
@@ -882,7 +912,8 @@ int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void*
                   ordered ? reinterpret_cast<const float*>(pb + L.pop_p) : nullptr,
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr,   // NULL: visit everything
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
-                  reinterpret_cast<unsigned long long*>(ws + 2)};
+                  reinterpret_cast<unsigned long long*>(ws + 2),
+                  reinterpret_cast<const uint16_t*>(pb + L.bex)};
     // Which pre-filtered kernel: v3 (1 MFMA per k-step, candidate ring, exact lists, exact fp32-MFMA warm-up of the first
     // tiles of an ordered sweep) everywhere except the early-terminating sweep over bf16 tables at d = 256, where v3 has no
     // room for the warm-up block and v2 (approximate lists; one MFMA per k-step as well on bf16 tables) measures 15 %

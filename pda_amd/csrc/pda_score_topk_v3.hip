@@ -56,6 +56,11 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // wider tile cost more than the bookkeeping saves (measured 12.2 vs 11.5 ms at C3).
     constexpr int NB = (ORD && D <= 128) ? 2 : 1;
     constexpr int TW = 32 * NB;
+    // Folded test: one extra MFMA k-step subtracts  thr / pop - 1 - eps  inside the matrix pipe (bf16 pieces prepared per
+    // item in I_bex, per row in `aex`), so that "candidate" is "accumulator > 0" and the 16 rows of a lane reduce with
+    // v_max3 before a single compare: 9 VALU per 32x32 block instead of 48 (max, fma, cmp per register).  The item side needs
+    // 1/pop at prep time: ordered sweeps of the PDA head, and raw-head sweeps (1/pop := 1) in natural order.
+    constexpr bool FOLD = (ORD && HEAD == PDA_HEAD_POP) || (!ORD && HEAD == PDA_HEAD_RAW);
     constexpr int NLD = (TW * CPR) / kThreads; // 16-byte loads per thread per tile
     static_assert(NLD >= 1, "v3 needs embed dim >= 64");
     uint16_t* Bh = reinterpret_cast<uint16_t*>(smem);                                       // [TW][D] bf16, swizzled
@@ -173,23 +178,51 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     if (tid < 4) votes[tid] = 0;
     if (lane < 32) unl[wave * 32 + lane] = nu_row;
     pda_wave_sync();
-    f32x16 thr;    // the rows' exact thresholds, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
-    auto refresh_thr = [&]() __attribute__((always_inline)) {
-        int hv = h;
-        asm volatile("" : "+v"(hv));
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float tq = taul[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv];
-            // strictly below tau (also for tau == 0): an item that TIES the K-th value must get through -- in visiting
-            // order it may carry the lower id and win
-            thr[r] = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
-        }
-    };
-    refresh_thr();
     float nu_max = nu_row;                     // ONE norm per wave (the largest): eps scale of the filter, and the
 #pragma unroll                                 // termination bound of the ordered sweep
     for (int o = 32; o > 0; o >>= 1) nu_max = fmaxf(nu_max, __shfl_xor(nu_max, o, 64));
     nu_max *= kEps * 1.001f;
+    // lowered threshold of row (r in accumulator layout of lane half hv); strictly below tau (also for tau == 0): an item
+    // that TIES the K-th value must get through -- in visiting order it may carry the lower id and win
+    auto thr_of = [&](int r, int hv) __attribute__((always_inline)) -> float {
+        const float tq = taul[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv];
+        return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
+    };
+    f32x16 thr;    // !FOLD: the rows' exact thresholds, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
+    // FOLD: the threshold of the lane's OWN row j (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative -- the last
+    // MFMA adds 11 products of magnitude up to |thr / pop| + 1 + eps to s~ in fp32 (<= 17 roundings of 2^-23 at that
+    // magnitude: 2^-18.9; the constant slot carries +5e-6, the eps slot +8 %) -- the wave's minimum, and the A operand of the
+    // extra k-step:  k 0..7 (lanes < 32): -(t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: +1, +1, +eps scale.
+    float thr_own = 0.f, thr_min = 0.f;
+    u32x4 aex = {0u, 0u, 0u, 0u};
+    auto refresh_thr = [&]() __attribute__((always_inline)) {
+        if constexpr (FOLD) {
+            const float tq = taul[wave * 32 + j];
+            float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
+            tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
+            thr_own = tf;
+            float m = tf;
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) m = fminf(m, __shfl_xor(m, o, 64));
+            thr_min = m;
+            uint32_t t1, t2, t3;
+            bf16_split3(tf, t1, t2, t3);
+            t1 ^= 0x8000u;
+            t2 ^= 0x8000u;
+            t3 ^= 0x8000u;
+            const uint32_t nnu = bf16_up(nu_max * 1.08f);
+            aex[0] = h ? 0x3F803F80u : (t1 | (t1 << 16));
+            aex[1] = h ? nnu : (t2 | (t2 << 16));
+            aex[2] = h ? 0u : (t1 | (t3 << 16));
+            aex[3] = h ? 0u : (t2 | (t3 << 16));
+        } else {
+            int hv = h;
+            asm volatile("" : "+v"(hv));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) thr[r] = thr_of(r, hv);
+        }
+    };
+    refresh_thr();
 
     uint64_t* my_lists = lists + (size_t)(wave * 32) * kCap3;
     uint32_t* ring = rings + wave * kRing;
@@ -215,11 +248,19 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             *reinterpret_cast<u32x4*>(Bh + jj * D + 8 * (ch ^ swzb<D>(jj))) = ph[q];
         }
     };
+    auto bex_load = [&](int t, u32x4 (&bx)[NB]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            const uint32_t it = (uint32_t)min(t * TW + 32 * cb + j, a.n_items_local - 1);
+            bx[cb] = *reinterpret_cast<const u32x4*>(aa.I_bex + (it * 16u + 8u * (uint32_t)h));
+        }
+    };
     auto lane_consts = [&](int t, float (&popv)[NB], float (&niv)[NB], int (&idv)[NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             const int it = min(t * TW + 32 * cb + j, a.n_items_local - 1);
-            niv[cb] = aa.I_norm[it];
+            niv[cb] = 0.f;
+            if constexpr (!FOLD) niv[cb] = aa.I_norm[it];
             popv[cb] = 1.0f;
             if constexpr (HEAD == PDA_HEAD_POP) popv[cb] = ORD ? aa.pop_p[it] : a.pop[it];
             if constexpr (ORD) idv[cb] = a.item_offset + aa.order[it];      // the ring keeps the item's real id
@@ -367,6 +408,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     float pop_cur[NB], ni_cur[NB];
     int id_cur[NB];
     bool ok_cur[NB];   // lane's item exists
+    u32x4 bex_cur[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
         pop_cur[cb] = ni_cur[cb] = 0.f;
@@ -477,6 +519,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         const int tk = tile_of(k0);
         tile_load(tk, pA_h);
         lane_consts(tk, pop_cur, ni_cur, id_cur);
+        if constexpr (FOLD) bex_load(tk, bex_cur);
         tile_store(pA_h);
         hb_cur = hist_bits(tk);
 #pragma unroll
@@ -497,36 +540,77 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         int id_next[NB];
         tile_load(tn, cur_h);
         lane_consts(tn, pop_next, ni_next, id_next);
+        u32x4 bex_next[NB];
+#ifndef PDA_X2
+        if constexpr (FOLD) bex_load(tn, bex_next);
+#else
+        for (int cb = 0; cb < NB; ++cb) bex_next[cb] = bex_cur[cb];
+#endif
         __builtin_amdgcn_sched_barrier(0);
 
-        // independent accumulator chains: column block x even/odd k-step (NB = 2: four), even/odd k-step (NB = 1: two)
-        f32x16 acc[4] = {zero16, zero16, zero16, zero16};
+        // One accumulator chain per column block (NB = 2) or per even/odd k-step (NB = 1), and the B operands of the next PF
+        // MFMAs always in flight: left to itself hipcc keeps a single B quad live and every MFMA waits a full LDS latency.
+        constexpr int S = NB * NM, PF = S < 8 ? S : 8;
+        auto b_load = [&](int s_) __attribute__((always_inline)) -> u32x4 {
+            const int cb = s_ / NM, mm = s_ % NM;
+            return *reinterpret_cast<const u32x4*>(bhrow + cb * (32 * D) + 8 * ((2 * mm + h) ^ bsw));
+        };
+        f32x16 acc[2] = {zero16, zero16};
+        u32x4 bq[PF];
 #pragma unroll
-        for (int mm = 0; mm < NM; ++mm) {
-            const int off = 8 * ((2 * mm + h) ^ bsw);
-            const bf16x8 xh = __builtin_bit_cast(bf16x8, ah[mm]);
+        for (int s_ = 0; s_ < PF; ++s_) bq[s_] = b_load(s_);
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
-                const bf16x8 bh = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(bhrow + cb * (32 * D) + off));
-                const int ai = NB == 2 ? 2 * cb + (mm & 1) : (mm & 1);
-                acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xh, bh, acc[ai], 0, 0, 0);
-            }
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int cb = s_ / NM, mm = s_ % NM;
+            const int ai = NB == 2 ? cb : (mm & 1);
+            acc[ai] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[mm]), __builtin_bit_cast(bf16x8, bq[s_ % PF]),
+                                                              acc[ai], 0, 0, 0);
+            if (s_ + PF < S) bq[s_ % PF] = b_load(s_ + PF);
         }
         f32x16 sc[NB];
         if constexpr (NB == 2) {
-            sc[0] = acc[0] + acc[1];
-            sc[NB - 1] = acc[2] + acc[3];
+            sc[0] = acc[0];
+            sc[NB - 1] = acc[1];
         } else {
             sc[0] = acc[0] + acc[1];
         }
         uint64_t okm[NB], many = 0;
         float neg_eps[NB], ipop[NB], cc[NB];
+        bool clampy[NB];
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
-            test_consts(pop_cur[cb], ni_cur[cb], neg_eps[cb], ipop[cb], cc[cb]);
             uint64_t mc = 0;
+            clampy[cb] = false;
+            if constexpr (FOLD) {
+#ifndef PDA_X3
+                sc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bex_cur[cb]),
+                                                                 sc[cb], 0, 0, 0);
+#endif
+                // (compiler-visible maxima, NOT inline asm: the hazard recogniser has to see the VALU read of the MFMA
+                // result -- an asm v_max3 right behind the MFMA read the accumulator before it was written)
+                // Integer maxima of the bit patterns: "some register is a positive float" == "the signed max is > 0", and
+                // v_max3_i32 needs no canonicalising pre-max of every MFMA result (fmaxf: +6 VALU per block).  A NaN with
+                // a clear sign bit counts as a candidate, which is the safe side.
+                int ma = max(__float_as_int(sc[cb][0]), __float_as_int(sc[cb][1])), mb = max(__float_as_int(sc[cb][2]), __float_as_int(sc[cb][3]));
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mc |= test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+                for (int r = 4; r < 16; r += 4) {
+                    ma = max(max(ma, __float_as_int(sc[cb][r])), __float_as_int(sc[cb][r + 1]));
+                    mb = max(max(mb, __float_as_int(sc[cb][r + 2])), __float_as_int(sc[cb][r + 3]));
+                }
+                mc = __ballot(max(ma, mb) > 0);
+                if constexpr (HEAD == PDA_HEAD_POP) {
+                    // s~ + eps < 0: the head is exp(.) pop <= pop -- such an item can only matter to rows with thr < pop.
+                    // Rare once the lists are warm (thr_min is the smallest threshold of the wave's rows).
+#ifndef PDA_X1
+                    clampy[cb] = __any(pop_cur[cb] > thr_min);
+#endif
+                    if (clampy[cb]) mc = ~0ull;
+                }
+            } else {
+                test_consts(pop_cur[cb], ni_cur[cb], neg_eps[cb], ipop[cb], cc[cb]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mc |= test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+            }
             okm[cb] = __ballot(ok_cur[cb]);
             many |= mc & okm[cb];
         }
@@ -545,9 +629,22 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         if (many) {
             uint64_t M[NB][16];
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb)
+            for (int cb = 0; cb < NB; ++cb) {
+                if constexpr (FOLD) {
+                    if (clampy[cb]) {
+                        int hv = h;
+                        asm volatile("" : "+v"(hv));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+                        for (int r = 0; r < 16; ++r) M[cb][r] = __ballot(sc[cb][r] > 0.f || pop_cur[cb] > thr_of(r, hv));
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) M[cb][r] = __ballot(sc[cb][r] > 0.f);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+                }
+            }
             push_masks(M, okm, hb_cur, id_cur);
         }
         bool stop = false;
@@ -557,12 +654,16 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             if ((k & PDA_VOTE) == PDA_VOTE && has_next && aa.sufA != nullptr) {
                 const float sa = aa.sufA[tn * NB], sb = aa.sufB[tn * NB];
                 bool dead = true;
-                int hv = h;
-                asm volatile("" : "+v"(hv));
+                if constexpr (FOLD) {
+                    dead = __builtin_fmaf(nu_row, sb, sa) * 1.000002f < thr_own;    // one row per lane (both halves hold row j)
+                } else {
+                    int hv = h;
+                    asm volatile("" : "+v"(hv));
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float ub = __builtin_fmaf(unl[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv], sb, sa) * 1.000002f;
-                    dead = dead && (ub < thr[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const float ub = __builtin_fmaf(unl[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv], sb, sa) * 1.000002f;
+                        dead = dead && (ub < thr[r]);
+                    }
                 }
                 const bool alldead = __all(dead);
                 if (lane == 0) votes[wave] = alldead ? 1 : 0;
@@ -579,6 +680,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         for (int cb = 0; cb < NB; ++cb) {
             pop_cur[cb] = pop_next[cb];
             ni_cur[cb] = ni_next[cb];
+            if constexpr (FOLD) bex_cur[cb] = bex_next[cb];
             id_cur[cb] = id_next[cb];
             ok_cur[cb] = has_next && (tn * TW + 32 * cb + j) < a.n_items_local;
         }

@@ -44,11 +44,28 @@ struct ScoreArgs2 {
     const float* sufA;      // [n_tiles] max over positions >= 32 t of |pop|            (1 for PDA_HEAD_RAW -> unused, 0)
     const float* sufB;      // [n_tiles] max over positions >= 32 t of |pop| * ||i||    (||i|| for PDA_HEAD_RAW)
     unsigned long long* visited;   // workspace: item tiles actually scored, summed over workgroups (statistics)
+    // v3 "folded test": 16 bf16 per item (one extra MFMA k-step) that subtract threshold/pop + 1 + eps inside the matrix pipe
+    const uint16_t* I_bex;  // [n_items_local][16]: k 0..7 pieces of 1/pop (1 for PDA_HEAD_RAW), k 8..10 constants and ||i||
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float x) {
     uint32_t u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+// x = t1 + t2 + t3 exactly, every piece a bf16 (truncation split; x finite).  Returned as bf16 bit patterns.
+__device__ __forceinline__ void bf16_split3(float x, uint32_t& t1, uint32_t& t2, uint32_t& t3) {
+    const uint32_t b1 = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(b1);                  // exact: <= 16 significant bits
+    const uint32_t b2 = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(b2);                 // exact: <= 8 significant bits, a bf16
+    t1 = b1 >> 16;
+    t2 = b2 >> 16;
+    t3 = __float_as_uint(r2) >> 16;
+}
+// smallest bf16 >= x  (x >= 0, finite)
+__device__ __forceinline__ uint32_t bf16_up(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u >> 16) + ((u & 0xFFFFu) ? 1u : 0u);
 }
 // split 8 floats into packed bf16 hi / lo words
 __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, u32x4& hi, u32x4& lo) {
