@@ -913,7 +913,7 @@ int run_score_prepped(const void* U, const void* I_shard, bool bf16, const void*
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr,   // NULL: visit everything
                   ordered && early_stop ? reinterpret_cast<const float*>(pb + L.sufB) : nullptr,
                   reinterpret_cast<unsigned long long*>(ws + 2),
-                  reinterpret_cast<const uint16_t*>(pb + L.bex)};
+                  reinterpret_cast<const uint16_t*>(pb + L.bex), hist_indices};
     // Which pre-filtered kernel: v3 (1 MFMA per k-step, candidate ring, exact lists, exact fp32-MFMA warm-up of the first
     // tiles of an ordered sweep) everywhere except the early-terminating sweep over bf16 tables at d = 256, where v3 has no
     // room for the warm-up block and v2 (approximate lists; one MFMA per k-step as well on bf16 tables) measures 15 %

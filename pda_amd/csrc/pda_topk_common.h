@@ -46,6 +46,7 @@ struct ScoreArgs2 {
     unsigned long long* visited;   // workspace: item tiles actually scored, summed over workgroups (statistics)
     // v3 "folded test": 16 bf16 per item (one extra MFMA k-step) that subtract threshold/pop + 1 + eps inside the matrix pipe
     const uint16_t* I_bex;  // [n_items_local][16]: k 0..7 pieces of 1/pop (1 for PDA_HEAD_RAW), k 8..10 constants and ||i||
+    const int32_t* hist_nat;   // the caller's history (item ids ascending per row) also for ordered sweeps: v3 masks at the candidate stage
 };
 
 __device__ __forceinline__ uint32_t bf16_rne(float x) {

@@ -104,6 +104,29 @@ def test_splits_and_k(dev, n_splits, K):
     check_against_oracle(idx, val, U, I, users, K, 0, None, hist, exact=True)
 
 
+@pytest.mark.parametrize("head", [0, 1])
+@pytest.mark.parametrize("d", [64, 128, 256])
+def test_history_holds_the_users_best_items(dev, d, head):
+    """Adversarial for the candidate-stage mask of the ordered sweeps: every train item of a user beats the user's K-th
+    unmasked score, so each one passes the pre-filter and the exact threshold and has to be thrown out by the history
+    lookup -- also behind the warm-up tiles, also when it ties with an unmasked item."""
+    rng = np.random.default_rng(900 + d + head)
+    nU, nI, K = 150, 3000, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d)
+    I[1500] = I[10]                                                   # an exact tie across the mask boundary
+    pop[1500] = pop[10]
+    sc = U.astype(np.float64) @ I.astype(np.float64).T
+    if head:
+        sc = np.where(sc > 0, sc + 1.0, np.exp(np.minimum(sc, 0))) * pop[None, :]
+    order = np.argsort(-sc, axis=1, kind="stable")
+    hist = [np.sort(order[u, ::2][: 20 + (u % 60)]).astype(np.int32) for u in range(nU)]     # every other item of the top
+    users = np.arange(nU, dtype=np.int32)
+    idx, val, _ = run_gpu(dev, U, I, users, K, head, pop if head else None, hist, by_user=True)
+    for u in range(nU):
+        assert not set(idx[u]) & set(hist[u])
+    check_against_oracle(idx, val, U, I, users, K, head, pop, hist, exact=(head == 0))
+
+
 def test_history_by_user_unsorted_with_duplicates(dev):
     from pda_amd import ops
     rng = np.random.default_rng(5)
