@@ -559,11 +559,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         tile_load(tn, cur_h);
         lane_consts(tn, pop_next, ni_next, id_next);
         u32x4 bex_next[NB];
-#ifndef PDA_X2
         if constexpr (FOLD) bex_load(tn, bex_next);
-#else
-        for (int cb = 0; cb < NB; ++cb) bex_next[cb] = bex_cur[cb];
-#endif
         __builtin_amdgcn_sched_barrier(0);
 
         // One accumulator chain per column block (NB = 2) or per even/odd k-step (NB = 1), and the B operands of the next PF
@@ -600,10 +596,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             uint64_t mc = 0;
             clampy[cb] = false;
             if constexpr (FOLD) {
-#ifndef PDA_X3
                 sc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bex_cur[cb]),
                                                                  sc[cb], 0, 0, 0);
-#endif
                 // (compiler-visible maxima, NOT inline asm: the hazard recogniser has to see the VALU read of the MFMA
                 // result -- an asm v_max3 right behind the MFMA read the accumulator before it was written)
                 // Integer maxima of the bit patterns: "some register is a positive float" == "the signed max is > 0", and
@@ -619,9 +613,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
                 if constexpr (HEAD == PDA_HEAD_POP) {
                     // s~ + eps < 0: the head is exp(.) pop <= pop -- such an item can only matter to rows with thr < pop.
                     // Rare once the lists are warm (thr_min is the smallest threshold of the wave's rows).
-#ifndef PDA_X1
                     clampy[cb] = __any(pop_cur[cb] > thr_min);
-#endif
                     if (clampy[cb]) mc = ~0ull;
                 }
             } else {
