@@ -345,6 +345,42 @@ def test_v2_prefilter_returns_exactly_the_v1_keys(dev, d, head, impl):
         assert torch.equal(k1, k2), (d, head, scale, int((k1 != k2).sum()))
 
 
+@pytest.mark.parametrize("case", ["pop_range", "tiny_pop", "huge_scores", "tiny_scores", "negative_scores", "constant"])
+def test_folded_threshold_test_survives_extreme_magnitudes(dev, case, impl):
+    """v3 folds  thr / pop - 1 - eps  into an extra MFMA k-step from bf16 pieces (pda_score_topk_v3.hip): popularities over
+    24 orders of magnitude and exact zeros (1/pop capped), thresholds that are huge, tiny or negative, lists that never
+    fill -- the keys must stay those of the exact kernel in every sweep mode."""
+    from pda_amd import ops
+    rng = np.random.default_rng(4242)
+    nU, nI, d, K = 200, 4000, 128, 50
+    U, I, pop, hist = make_case(rng, nU, nI, d)
+    head = 1
+    if case == "pop_range":
+        pop = (10.0 ** rng.uniform(-12, 12, nI)).astype(np.float32)
+        pop[rng.integers(0, nI, 50)] = 0.0
+    elif case == "tiny_pop":
+        pop = (rng.uniform(0, 1, nI) * 1e-20).astype(np.float32)
+    elif case == "huge_scores":
+        U *= 300.0
+        I *= 300.0
+    elif case == "tiny_scores":
+        U *= 1e-4
+        I *= 1e-4
+    elif case == "negative_scores":
+        head, U, I = 0, -np.abs(U), np.abs(I)                 # raw head: every score and every threshold below zero
+    elif case == "constant":
+        I[:] = I[0]                                            # every score of a user equal: ties everywhere
+        pop[:] = 0.5
+    users = np.arange(nU, dtype=np.int32)
+    ip, ix = csr(hist)
+    h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    args = (torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.from_numpy(users).to(dev), K, head,
+            torch.from_numpy(pop).to(dev) if head else None, h, 0)
+    k1 = ops.topk_merge(ops.score_topk_keys(*args, impl="v1"), want="keys")
+    k2 = ops.topk_merge(ops.score_topk_keys(*args, impl="v2"), want="keys")
+    assert torch.equal(k1, k2), (case, impl, int((k1 != k2).sum()))
+
+
 @pytest.mark.parametrize("head", [0, 1])
 @pytest.mark.parametrize("order_kind", ["default", "random", "reverse", "identity"])
 def test_ordered_sweep_is_exact_for_any_order_and_really_stops(dev, head, order_kind):
