@@ -52,9 +52,10 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // Item tile = NB blocks of 32 columns.  The loop is instruction-issue bound (PMC: ~260 instructions per wave and 32
     // items around 8 MFMAs), and roughly 60 % of them do not depend on the tile width (history cursor, staging addresses,
     // barriers, drain / stop flags, loop control): two blocks per tile halve that share.  d = 256: one block (LDS).
-    // Natural item order keeps one block: there the candidate-rich slow path dominates and the staler thresholds of a
-    // wider tile cost more than the bookkeeping saves (measured 12.2 vs 11.5 ms at C3).
-    constexpr int NB = (ORD && D <= 128) ? 2 : 1;
+    // Natural item order with the VALU test keeps one block: there the candidate-rich slow path dominates and the staler
+    // thresholds of a wider tile cost more than the bookkeeping saves (measured 12.2 vs 11.5 ms at C3); with the folded test
+    // (raw head) the wider tile wins again: 11.2 -> 10.1 ms.
+    constexpr int NB = ((ORD || HEAD == PDA_HEAD_RAW) && D <= 128) ? 2 : 1;
     constexpr int TW = 32 * NB;
     // Folded test: one extra MFMA k-step subtracts  thr / pop - 1 - eps  inside the matrix pipe (bf16 pieces prepared per
     // item in I_bex, per row in `aex`), so that "candidate" is "accumulator > 0" and the 16 rows of a lane reduce with
