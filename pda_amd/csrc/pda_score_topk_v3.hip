@@ -370,14 +370,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     };
 
     // ---- push the flagged lanes of the previous tile into the ring ------------------------------------------------------
-    // The fast test leaves one 64-bit lane mask per accumulator register in SGPRs; the per-lane bit mask is rebuilt here.
+    // m: the lane's flagged accumulator registers, bit 16 cb + 15 - r  <->  register r of column block cb.
     // Lane-parallel: every flagged lane pushes ITS OWN top flagged register per round (usually one round).
-    auto push_masks = [&](const uint64_t (&M)[NB][16], const uint64_t (&okm)[NB], uint64_t hb, const int (&item_id)[NB]) __attribute__((always_inline)) {
-        uint32_t m = 0;        // bit 16 cb + 15 - r  <->  accumulator register r of column block cb
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m |= (((M[cb][r] & okm[cb]) >> lane) & 1ull) ? (1u << (16 * cb + 15 - r)) : 0u;
+    auto push_masks = [&](uint32_t m, uint64_t hb, const int (&item_id)[NB]) __attribute__((always_inline)) {
         const bool any_hb = __any(hb != 0ull);
         while (__any(m != 0)) {
             const bool act = m != 0;
@@ -638,25 +633,38 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             if constexpr (!kHistAtCand) hb_next = hist_bits(tn);
         }
         if (many) {
-            uint64_t M[NB][16];
+            // The lane's own bit mask, built per lane: 32 wave-wide masks in SGPRs (spilled through VGPR lanes) and their
+            // per-lane extraction were most of what a natural-order sweep -- which takes this path on almost every tile --
+            // spent outside the MFMAs.
+            uint32_t m = 0;
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) {
+            for (int cb = NB - 1; cb >= 0; --cb) {
+                uint32_t mcb = 0;
                 if constexpr (FOLD) {
+                    // "register is a positive float" = sign bit of (0 - bits); one v_sub + one v_alignbit per register.
+                    // (-0.0 counts as positive: a false candidate at worst)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        mcb = __builtin_amdgcn_alignbit(mcb, 0u - (uint32_t)__float_as_int(sc[cb][r]), 31);
                     if (clampy[cb]) {
                         int hv = h;
                         asm volatile("" : "+v"(hv));
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) M[cb][r] = __ballot(sc[cb][r] > 0.f || pop_cur[cb] > thr_of(r, hv));
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) M[cb][r] = __ballot(sc[cb][r] > 0.f);
+                        for (int r = 0; r < 16; ++r) mcb |= (pop_cur[cb] > thr_of(r, hv)) ? (1u << (15 - r)) : 0u;
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) M[cb][r] = test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
+                    for (int r = 0; r < 16; ++r) {
+                        bool c;
+                        if constexpr (HEAD == PDA_HEAD_POP) c = fmaxf(sc[cb][r], neg_eps[cb]) > __builtin_fmaf(thr[r], ipop[cb], cc[cb]);
+                        else c = sc[cb][r] > thr[r] + neg_eps[cb];
+                        mcb |= c ? (1u << (15 - r)) : 0u;
+                    }
                 }
+                if (!ok_cur[cb]) mcb = 0;
+                m = (m << 16) | mcb;
             }
-            push_masks(M, okm, hb_cur, id_cur);
+            push_masks(m, hb_cur, id_cur);
         }
         bool stop = false;
         if constexpr (ORD) {
