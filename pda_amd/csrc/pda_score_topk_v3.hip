@@ -55,13 +55,12 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     // Natural item order with the VALU test keeps one block: there the candidate-rich slow path dominates and the staler
     // thresholds of a wider tile cost more than the bookkeeping saves (measured 12.2 vs 11.5 ms at C3); with the folded test
     // (raw head) the wider tile wins again: 11.2 -> 10.1 ms.
-    constexpr int NB = ((ORD || HEAD == PDA_HEAD_RAW) && D <= 128) ? 2 : 1;
+    constexpr int NB = D <= 128 ? 2 : 1;
     constexpr int TW = 32 * NB;
     // Folded test: one extra MFMA k-step subtracts  thr / pop - 1 - eps  inside the matrix pipe (bf16 pieces prepared per
     // item in I_bex, per row in `aex`), so that "candidate" is "accumulator > 0" and the 16 rows of a lane reduce with
     // v_max3 before a single compare: 9 VALU per 32x32 block instead of 48 (max, fma, cmp per register).  The item side needs
-    // 1/pop at prep time: ordered sweeps of the PDA head, and raw-head sweeps (1/pop := 1) in natural order.
-    constexpr bool FOLD = (ORD && HEAD == PDA_HEAD_POP) || (!ORD && HEAD == PDA_HEAD_RAW);
+    // 1/pop: ordered preps carry it; natural-order PDA-head sweeps rebuild the pieces per tile (~15 VALU per block).
     constexpr bool kHistAtCand = ORD;   // where the train-item mask is applied: see process_ring
     constexpr int NLD = (TW * CPR) / kThreads; // 16-byte loads per thread per tile
     static_assert(NLD >= 1, "v3 needs embed dim >= 64");
@@ -73,7 +72,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     uint32_t* rings = reinterpret_cast<uint32_t*>(taul + kUserTile);                        // [4][kRing]
     int* wgflag = reinterpret_cast<int*>(rings + 4 * kRing);                                // [2] "some wave wants to drain its ring"
     int* votes = wgflag + 2;                                                                // [4] ORD: wave w sees no use in going on
-    float* unl = reinterpret_cast<float*>(votes + 4) + 2;                                   // [128] ORD: padded row norms (termination bound)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -179,7 +177,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     }
     if (tid < 2) wgflag[tid] = 0;
     if (tid < 4) votes[tid] = 0;
-    if (lane < 32) unl[wave * 32 + lane] = nu_row;
     pda_wave_sync();
     float nu_max = nu_row;                     // ONE norm per wave (the largest): eps scale of the filter, and the
 #pragma unroll                                 // termination bound of the ordered sweep
@@ -191,15 +188,14 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         const float tq = taul[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv];
         return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
     };
-    f32x16 thr;    // !FOLD: the rows' exact thresholds, lowered by a 2^-20 relative margin (fp32 evaluation of the bound)
-    // FOLD: the threshold of the lane's OWN row j (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative -- the last
+    // The threshold of the lane's OWN row j (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative -- the last
     // MFMA adds 11 products of magnitude up to |thr / pop| + 1 + eps to s~ in fp32 (<= 17 roundings of 2^-23 at that
     // magnitude: 2^-18.9; the constant slot carries +5e-6, the eps slot +8 %) -- the wave's minimum, and the A operand of the
     // extra k-step:  k 0..7 (lanes < 32): -(t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: +1, +1, +eps scale.
     float thr_own = 0.f, thr_min = 0.f;
     u32x4 aex = {0u, 0u, 0u, 0u};
     auto refresh_thr = [&]() __attribute__((always_inline)) {
-        if constexpr (FOLD) {
+        {
             const float tq = taul[wave * 32 + j];
             float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
             tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
@@ -218,11 +214,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             aex[1] = h ? nnu : (t2 | (t2 << 16));
             aex[2] = h ? 0u : (t1 | (t3 << 16));
             aex[3] = h ? 0u : (t2 | (t3 << 16));
-        } else {
-            int hv = h;
-            asm volatile("" : "+v"(hv));
-#pragma unroll
-            for (int r = 0; r < 16; ++r) thr[r] = thr_of(r, hv);
         }
     };
     refresh_thr();
@@ -258,12 +249,10 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             bx[cb] = *reinterpret_cast<const u32x4*>(aa.I_bex + (it * 16u + 8u * (uint32_t)h));
         }
     };
-    auto lane_consts = [&](int t, float (&popv)[NB], float (&niv)[NB], int (&idv)[NB]) __attribute__((always_inline)) {
+    auto lane_consts = [&](int t, float (&popv)[NB], int (&idv)[NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             const int it = min(t * TW + 32 * cb + j, a.n_items_local - 1);
-            niv[cb] = 0.f;
-            if constexpr (!FOLD) niv[cb] = aa.I_norm[it];
             popv[cb] = 1.0f;
             if constexpr (HEAD == PDA_HEAD_POP) popv[cb] = ORD ? aa.pop_p[it] : a.pop[it];
             if constexpr (ORD) idv[cb] = a.item_offset + aa.order[it];      // the ring keeps the item's real id
@@ -395,37 +384,16 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             ring_cnt += __popcll(pm);
         }
     };
-    // the fast test of one accumulator register (see pda_score_topk_v2.hip):
-    //   PDA head:  (max(s~ + eps, 0) + 1) pop > T   <=>   max(s~, -eps) > T / pop - 1 - eps      raw head:  s~ + eps > T
-    auto test_reg = [&](float sacc, float t, float neg_eps, float ipop, float cc) __attribute__((always_inline)) -> uint64_t {
-        if constexpr (HEAD == PDA_HEAD_POP) {
-            float mx;      // plain v_max_f32: fmaxf() would first canonicalise the MFMA result with a second v_max (x, x)
-            asm("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(sacc), "v"(neg_eps));
-            return __ballot(mx > __builtin_fmaf(t, ipop, cc));
-        } else {
-            return __ballot(sacc > t + neg_eps);
-        }
-    };
-    auto test_consts = [&](float popv, float niv, float& neg_eps, float& ipop, float& cc) __attribute__((always_inline)) {
-        neg_eps = -(nu_max * niv + 3e-6f);
-        ipop = 0.f;
-        cc = 0.f;
-        if constexpr (HEAD == PDA_HEAD_POP) {
-            ipop = __builtin_amdgcn_rcpf(popv) * 0.9999995f;
-            cc = -1.0f + neg_eps;
-        }
-    };
-
     // ---- main loop ---------------------------------------------------------------------------------------------------------
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint64_t hb_cur = 0;
-    float pop_cur[NB], ni_cur[NB];
+    float pop_cur[NB];
     int id_cur[NB];
     bool ok_cur[NB];   // lane's item exists
     u32x4 bex_cur[NB];
 #pragma unroll
     for (int cb = 0; cb < NB; ++cb) {
-        pop_cur[cb] = ni_cur[cb] = 0.f;
+        pop_cur[cb] = 0.f;
         id_cur[cb] = 0;
         ok_cur[cb] = false;
     }
@@ -459,9 +427,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         for (int w = 0; w < nwarm; ++w) {
             const int t = tile_of(w);
             n32 += min(NB, (a.n_items_local - t * TW + 31) >> 5);
-            float popw[NB], niw[NB];
+            float popw[NB];
             int idw[NB];
-            lane_consts(t, popw, niw, idw);
+            lane_consts(t, popw, idw);
             const uint64_t hbw = hist_bits(t);
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
@@ -532,8 +500,8 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     if (k0 < nt) {
         const int tk = tile_of(k0);
         tile_load(tk, pA_h);
-        lane_consts(tk, pop_cur, ni_cur, id_cur);
-        if constexpr (FOLD) bex_load(tk, bex_cur);
+        lane_consts(tk, pop_cur, id_cur);
+        bex_load(tk, bex_cur);
         tile_store(pA_h);
         hb_cur = kHistAtCand ? 0ull : hist_bits(tk);      // ordered main loop: history is masked at the candidate stage
 #pragma unroll
@@ -550,12 +518,12 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
     auto iteration = [&](int k, u32x4 (&cur_h)[NLD]) __attribute__((always_inline)) -> bool {
         const bool has_next = (k + 1) < nt;
         const int tn = tile_of(min(k + 1, nt - 1));
-        float pop_next[NB], ni_next[NB];
+        float pop_next[NB];
         int id_next[NB];
         tile_load(tn, cur_h);
-        lane_consts(tn, pop_next, ni_next, id_next);
+        lane_consts(tn, pop_next, id_next);
         u32x4 bex_next[NB];
-        if constexpr (FOLD) bex_load(tn, bex_next);
+        bex_load(tn, bex_next);
         __builtin_amdgcn_sched_barrier(0);
 
         // One accumulator chain per column block (NB = 2) or per even/odd k-step (NB = 1), and the B operands of the next PF
@@ -585,15 +553,33 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             sc[0] = acc[0] + acc[1];
         }
         uint64_t okm[NB], many = 0;
-        float neg_eps[NB], ipop[NB], cc[NB];
         bool clampy[NB];
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             uint64_t mc = 0;
             clampy[cb] = false;
-            if constexpr (FOLD) {
-                sc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bex_cur[cb]),
-                                                                 sc[cb], 0, 0, 0);
+            {
+                u32x4 bx = bex_cur[cb];
+                if constexpr (HEAD == PDA_HEAD_POP && !ORD) {
+                    // natural order: the prep never saw the popularity (raw-type pieces) -- the 1/pop pieces and the constant
+                    // are rebuilt here, ~15 VALU per block (v_rcp is within 1 ulp; the 5e-7 lowering covers it)
+                    const float pv = pop_cur[cb];
+                    const float ip = (pv > 0.f) ? fminf(__builtin_amdgcn_rcpf(pv) * 0.9999995f, 1.0e6f) : 1.0e6f;
+                    uint32_t p1, p2, p3;
+                    bf16_split3(ip, p1, p2, p3);
+                    const uint32_t kk = ((pv == pv) ? 0x3F80u : 0xFF61u) | (bf16_up(8.0e-6f) << 16);
+                    bx[0] = h ? kk : (p1 | (p2 << 16));
+                    bx[1] = h ? bx[1] : (p1 | (p2 << 16));
+                    bx[2] = h ? 0u : (p3 | (p1 << 16));
+                    bx[3] = h ? 0u : (p3 | (p2 << 16));
+                } else if constexpr (HEAD == PDA_HEAD_RAW && ORD) {
+                    // ordered prep built with a popularity, raw head asked for: 1/pop := 1, constant := +8e-6
+                    bx[0] = h ? bf16_up(8.0e-6f) : 0x00003F80u;
+                    bx[1] = h ? bx[1] : 0x00003F80u;
+                    bx[2] = h ? 0u : 0x3F800000u;
+                    bx[3] = 0u;
+                }
+                sc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bx), sc[cb], 0, 0, 0);
                 // (compiler-visible maxima, NOT inline asm: the hazard recogniser has to see the VALU read of the MFMA
                 // result -- an asm v_max3 right behind the MFMA read the accumulator before it was written)
                 // Integer maxima of the bit patterns: "some register is a positive float" == "the signed max is > 0", and
@@ -612,10 +598,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
                     clampy[cb] = __any(pop_cur[cb] > thr_min);
                     if (clampy[cb]) mc = ~0ull;
                 }
-            } else {
-                test_consts(pop_cur[cb], ni_cur[cb], neg_eps[cb], ipop[cb], cc[cb]);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mc |= test_reg(sc[cb][r], thr[r], neg_eps[cb], ipop[cb], cc[cb]);
             }
             okm[cb] = __ballot(ok_cur[cb]);
             many |= mc & okm[cb];
@@ -640,7 +622,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 #pragma unroll
             for (int cb = NB - 1; cb >= 0; --cb) {
                 uint32_t mcb = 0;
-                if constexpr (FOLD) {
+                {
                     // "register is a positive float" = sign bit of (0 - bits); one v_sub + one v_alignbit per register.
                     // (-0.0 counts as positive: a false candidate at worst)
 #pragma unroll
@@ -651,14 +633,6 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
                         asm volatile("" : "+v"(hv));
 #pragma unroll
                         for (int r = 0; r < 16; ++r) mcb |= (pop_cur[cb] > thr_of(r, hv)) ? (1u << (15 - r)) : 0u;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        bool c;
-                        if constexpr (HEAD == PDA_HEAD_POP) c = fmaxf(sc[cb][r], neg_eps[cb]) > __builtin_fmaf(thr[r], ipop[cb], cc[cb]);
-                        else c = sc[cb][r] > thr[r] + neg_eps[cb];
-                        mcb |= c ? (1u << (15 - r)) : 0u;
                     }
                 }
                 if (!ok_cur[cb]) mcb = 0;
@@ -672,18 +646,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
             // row norms from LDS.)  Candidates still waiting in the ring can only raise thresholds.
             if ((k & PDA_VOTE) == PDA_VOTE && has_next && aa.sufA != nullptr) {
                 const float sa = aa.sufA[tn * NB], sb = aa.sufB[tn * NB];
-                bool dead = true;
-                if constexpr (FOLD) {
-                    dead = __builtin_fmaf(nu_row, sb, sa) * 1.000002f < thr_own;    // one row per lane (both halves hold row j)
-                } else {
-                    int hv = h;
-                    asm volatile("" : "+v"(hv));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float ub = __builtin_fmaf(unl[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * hv], sb, sa) * 1.000002f;
-                        dead = dead && (ub < thr[r]);
-                    }
-                }
+                const bool dead = __builtin_fmaf(nu_row, sb, sa) * 1.000002f < thr_own;    // one row per lane (both halves hold row j)
                 const bool alldead = __all(dead);
                 if (lane == 0) votes[wave] = alldead ? 1 : 0;
             }
@@ -698,8 +661,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 #pragma unroll
         for (int cb = 0; cb < NB; ++cb) {
             pop_cur[cb] = pop_next[cb];
-            ni_cur[cb] = ni_next[cb];
-            if constexpr (FOLD) bex_cur[cb] = bex_next[cb];
+            bex_cur[cb] = bex_next[cb];
             id_cur[cb] = id_next[cb];
             ok_cur[cb] = has_next && (tn * TW + 32 * cb + j) < a.n_items_local;
         }
@@ -728,7 +690,7 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
 
 template <int D, int HEAD, bool ORD, bool BF>
 int launch_v3(const ScoreArgs2& aa, hipStream_t stream) {
-    const size_t smem = (D <= 128 ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8 + 4) + 4 * kRing * sizeof(uint32_t) + 32;
+    const size_t smem = (D <= 128 ? 64 : 32) * D * sizeof(uint16_t) + (size_t)kUserTile * (kCap3 * sizeof(uint64_t) + 8) + 4 * kRing * sizeof(uint32_t) + 32;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&score_topk_v3_kernel<D, HEAD, ORD, BF>),
