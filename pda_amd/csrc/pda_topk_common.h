@@ -118,20 +118,25 @@ __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float
     const bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
     uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);  // fillers: unique, below any real key
     int rank;
+    // First compaction of a row (all <= 59 keys against each other): the keys to rank against come from LDS as broadcast
+    // reads, four in flight -- no SGPR round trip per key.  32 of these per wave were 40 % of the exact warm-up of a sweep.
     if (sorted_prefix) {
         rank = lane < K ? lane : 0;
         const uint64_t oldmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
         for (int jj = K; jj < c; ++jj) {
-            const uint64_t kj = pda_readlane_u64(key, jj);
+            const uint64_t kj = pda_readlane_u64(key, jj);      // (<= 9 keys: an LDS read per key would only add latency)
             rank += (kj > key) ? 1 : 0;
             const int olds_above = __popcll(__ballot(key > kj) & oldmask);
             rank += (lane == jj) ? olds_above : 0;
         }
     } else {
         rank = 0;
-        for (int jj = 0; jj < c; ++jj) {
-            const uint64_t kj = pda_readlane_u64(key, jj);
-            rank += (kj > key) ? 1 : 0;
+        for (int jj = 0; jj < c; jj += 4) {       // reads past c stay inside the workgroup's LDS and are masked
+            uint64_t k0 = buf[jj], k1 = buf[jj + 1], k2 = buf[jj + 2], k3 = buf[jj + 3];
+            k1 = jj + 1 < c ? k1 : 0ull;
+            k2 = jj + 2 < c ? k2 : 0ull;
+            k3 = jj + 3 < c ? k3 : 0ull;
+            rank += ((k0 > key) ? 1 : 0) + ((k1 > key) ? 1 : 0) + ((k2 > key) ? 1 : 0) + ((k3 > key) ? 1 : 0);
         }
     }
     pda_wave_sync();
