@@ -87,10 +87,12 @@ int pda_score_topk_f32(const float* U, const float* I_shard, const float* pop_sh
 /* Pre-filtered path: a bf16 MFMA pass scores every pair approximately with a rigorous error bound, only the pairs that
  * can still beat a user's running threshold are rescored with the exact fp32 chain; returns exactly the keys of
  * pda_score_topk_f32.  Two kernels sit behind these entry points and the library picks per call (PDA_SCORE_KERNEL=v2|v3
- * forces one): v3 (pda_score_topk_v3.hip: ONE bf16 MFMA per k-step, candidate ring, exact lists) for every sweep that
- * scores all tiles and for d = 256; v2 (pda_score_topk_v2.hip: hi/lo split = three MFMAs per k-step, approximate lists,
- * exact finish, exact-kernel recomputation of user tiles whose near-tie band overflows) for the early-terminating sweep.
- * The item shard is pre-split once per weight version into bf16 planes + padded row norms:
+ * forces one): v3 (pda_score_topk_v3.hip: ONE bf16 MFMA per k-step plus one k-step that carries the threshold test,
+ * candidate ring, exact lists) everywhere except the early-terminating sweep over bf16 tables at d = 256, which runs v2
+ * (pda_score_topk_v2.hip: hi/lo split = three MFMAs per k-step, approximate lists, exact finish, exact-kernel
+ * recomputation of user tiles whose near-tie band overflows).
+ * The item shard is pre-split once per weight version into bf16 planes, padded row norms and the 16 bf16 per item of the
+ * folded threshold test (the prep of an ordered sweep also holds the pieces of 1/pop: redo it when pop changes):
  *   pda_item_prep_bytes(n, d)  -> size of the caller-owned `prep` buffer (device)
  *   pda_item_prep_f32(I_shard, n, d, prep, stream)
  *   pda_score_topk_workspace_bytes(n_users_blk) -> size of the per-call scratch `workspace` (device; the call
@@ -123,10 +125,12 @@ int pda_score_topk_prepped_f32(const float* U, const float* I_shard, const void*
  *   pda_hist_reorder(prep, n, d, item_offset, hist_indptr, hist_indices, n_rows, out_indices, stream)
  *        out_indices i32 [nnz]: in-shard ids replaced by item_offset + position, every row sorted again
  *   pda_score_topk_ordered_f32(.. as pda_score_topk_prepped_f32, with hist_indices_ord after hist_indices ..)
- *        hist_indices stays the ORIGINAL (item-id) history: the exact-kernel recomputation of overflowed tiles uses it.
+ *        hist_indices stays the ORIGINAL (item-id) history, ascending per row: v3 walks hist_indices_ord over its exact
+ *        warm-up tiles only and masks later candidates by a binary search in hist_indices; v2's exact-kernel
+ *        recomputation of overflowed tiles uses it too.
  *        early_stop = 1: stop as described.  early_stop = 0: every tile is scored (a dense sweep) but still in visiting
  *        order -- strong items first raise the running thresholds quickly, which alone removes most of the candidate
- *        handling (C3: 10.4 ms instead of 14.6 ms per 65 536 users).
+ *        handling (C3: 4.2 ms instead of 8.7 ms per 65 536 users).
  * With n_splits > 1 the splits take interleaved tiles of the visiting order.
  * No reference counterpart: the reference scores the full [Bu, I] matrix (MF/train_new_api.py:594-612). */
 size_t pda_item_prep_ordered_bytes(int n_items_local, int d);
@@ -144,8 +148,8 @@ int pda_score_topk_ordered_f32(const float* U, const float* I_shard, const void*
 /* bf16 tables (BASELINE config 5: 10M x 2M, d=256 bf16).  U and I_shard hold bf16 bit patterns (uint16, row-major).
  * The score of a pair is DEFINED as the same fp32 fmaf chain applied to the widened values -- i.e. these entry points
  * return exactly the keys pda_score_topk_f32 returns on the tables converted to fp32 (tests/test_gpu_score_topk.py).
- * Products of two bf16 are exact in fp32, so the pre-filter needs ONE bf16 MFMA per k-step (fp32 tables: three) and no
- * hi/lo planes: the prep buffer holds the row norms only (plus, ordered, the rows gathered into visiting order).
+ * Products of two bf16 are exact in fp32, so the pre-filter's error bound is 2^-14 instead of 2^-8 ||u|| ||i|| and there are
+ * no hi/lo planes: the prep buffer holds the row norms and the test pieces (plus, ordered, the rows in visiting order).
  * d in {64,128,256}.  pda_item_prep_ordered_check / pda_hist_reorder serve both table types. */
 size_t pda_item_prep_bf16_bytes(int n_items_local, int d);
 int pda_item_prep_bf16(const uint16_t* I_shard, int n_items_local, int d, void* prep, void* stream);
