@@ -299,6 +299,23 @@ def bench_train(args, dev):
     out["sgd_fused_with_device_sampler_graph"] = timed_graph(graph_sampled_body, max(256, args.train_steps // 2))
     out["sgd_fused_with_device_sampler_graph"]["batches_drawn"] = int(step_dev.max().item())
 
+    # one launch per step: the step on batch t, the sampler of batch t + 1 in spare workgroups of the same kernel
+    # (pda_bpr_step_sample_f32) -- two sets of batch buffers, a new batch every replayed step
+    U, I = W.U.clone(), W.I.clone()
+    step_dev2 = torch.zeros(2, dtype=torch.int64, device=dev)
+    mk = lambda: (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                  torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.float32, device=dev),
+                  torch.empty(B, dtype=torch.float32, device=dev))
+    two = [mk(), mk()]
+    skw = dict(n_pool=W.n_users, train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+    ops.sample_triplets_into(two[0], W.hist_indptr, W.hist_indices, seed=7, step_dev=step_dev2, parity=0, **skw)
+
+    def fused_sampled_body(i):
+        ops.bpr_step_and_sample(U, I, *two[i & 1], regs=regs, reg_div=B, lr=lr, next_out=two[(i + 1) & 1], train_indptr=W.hist_indptr,
+                                train_indices=W.hist_indices, seed=7, step_dev=step_dev2, parity=(i + 1) & 1, loss_acc=loss, **skw)
+    out["sgd_fused_step_and_next_batch_sampler_one_launch_graph"] = timed_graph(fused_sampled_body, max(256, args.train_steps // 2))
+    out["sgd_fused_step_and_next_batch_sampler_one_launch_graph"]["batches_drawn"] = int(step_dev2.max().item())
+
     return out, W, batches
 
 

@@ -290,6 +290,24 @@ int pda_sample_triplets_dev(int32_t* users, int gen_users, const int32_t* user_p
                             float* neg_pop, void* stream);
 int pda_counter_add(uint64_t* counter, uint64_t inc, void* stream);
 
+/* Train step of batch t and sampler of batch t + 1 in ONE launch (spare workgroups of the step kernel draw the next
+ * batch): the two are independent and latency-bound, and as separate launches -- also on two captured streams -- they run
+ * back to back.  `next` (host memory, read during the call) = the arguments of pda_sample_triplets_dev; its output arrays
+ * must be a second set of batch buffers, not the ones this step reads.  Step arguments as pda_bpr_step_f32 restricted to
+ * PDA_UPD_SGD_FUSED / PDA_UPD_NONE (| PDA_UPD_ANY_ORDER).  Equivalent to pda_bpr_step_f32 followed by
+ * pda_sample_triplets_dev on the same stream.  Reference: the generator thread that samples while session.run trains
+ * (MF/train_new_api.py:178-220, 260-288). */
+typedef struct pda_sample_job {
+    int32_t* users; int gen_users; const int32_t* user_pool; int n_pool; int B;
+    const int64_t* train_indptr; const int32_t* train_indices; const int32_t* train_slots;
+    int neg_lo, neg_hi; const float* pop_matrix; int n_slots; uint64_t seed;
+    const uint64_t* step_dev; uint64_t* step_next;
+    int32_t* pos; int32_t* neg; float* pos_pop; float* neg_pop;
+} pda_sample_job;
+int pda_bpr_step_sample_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                            const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
+                            int update_mode, float* loss_acc, const pda_sample_job* next, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

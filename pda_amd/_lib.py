@@ -23,6 +23,15 @@ TOPK_CAP = 60
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
+class SampleJob(C.Structure):
+    """struct pda_sample_job of include/pda_hip.h (arguments of pda_sample_triplets_dev, for pda_bpr_step_sample_f32)."""
+    _fields_ = [("users", _vp), ("gen_users", _i), ("user_pool", _vp), ("n_pool", _i), ("B", _i),
+                ("train_indptr", _vp), ("train_indices", _vp), ("train_slots", _vp),
+                ("neg_lo", _i), ("neg_hi", _i), ("pop_matrix", _vp), ("n_slots", _i), ("seed", _u64),
+                ("step_dev", _vp), ("step_next", _vp),
+                ("pos", _vp), ("neg", _vp), ("pos_pop", _vp), ("neg_pop", _vp)]
+
+
 # name -> (restype, argtypes); exactly the declarations of include/pda_hip.h
 SIGNATURES = {
     "pda_abi_version": (_i, []),
@@ -57,6 +66,7 @@ SIGNATURES = {
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pda_sample_triplets_dev": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_counter_add": (_i, [_vp, _u64, _vp]),
+    "pda_bpr_step_sample_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp]),
     "pda_sample_triplets": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
 }
 

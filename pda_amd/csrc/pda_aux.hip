@@ -60,101 +60,12 @@ __global__ void __launch_bounds__(256) metrics_kernel(const int32_t* topk, int n
 // Sampler.  Counter-based RNG (splitmix64 of (seed, step, row, draw)); a keyed Feistel permutation
 // with cycle walking draws `B` distinct users per batch (rd.sample semantics) in O(B).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t mix64(uint64_t z) {
-    z += 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-__device__ __forceinline__ uint32_t draw(uint64_t seed, uint64_t step, uint32_t row, uint32_t k) {
-    return (uint32_t)(mix64(mix64(seed ^ (step * 0xD1B54A32D192ED03ull)) ^ (((uint64_t)row << 32) | k)) >> 32);
-}
-__device__ __forceinline__ uint32_t bounded(uint32_t r, uint32_t n) { return (uint32_t)(((uint64_t)r * n) >> 32); }
+}  // namespace
+#include "pda_sample.h"
+namespace {
 
-__device__ uint32_t feistel_perm(uint32_t x, uint32_t n, uint64_t key) {
-    int bits = 1;
-    while ((1ull << bits) < n) ++bits;
-    const int hb = (bits + 1) / 2;
-    const uint32_t hm = (1u << hb) - 1u;
-    do {
-        uint32_t l = x >> hb, r = x & hm;
-#pragma unroll
-        for (int round = 0; round < 4; ++round) {
-            const uint32_t f = (uint32_t)mix64(key ^ ((uint64_t)round << 40) ^ r) & hm;
-            const uint32_t nl = r;
-            r = l ^ f;
-            l = nl;
-        }
-        x = (l << hb) | r;
-    } while (x >= n);
-    return x;
-}
-
-struct SampleArgs {
-    int32_t* users;
-    const int32_t* user_pool;
-    const int64_t* indptr;
-    const int32_t* indices;
-    const int32_t* slots;
-    const float* pop;
-    int32_t* pos;
-    int32_t* neg;
-    float* pos_pop;
-    float* neg_pop;
-    uint64_t seed, step;
-    int B, n_pool, gen_users, neg_lo, neg_hi, n_slots;
-    const uint64_t* step_dev;   // optional device-resident step counter added to `step` (HIP-graph replay: pda_counter_add)
-    uint64_t* step_next;        // optional: receives *step_dev + 1 (a DIFFERENT location: no launch in between needed)
-};
-
-__global__ void __launch_bounds__(256) sample_kernel(SampleArgs a) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.B) return;
-    if (a.step_dev) {
-        const uint64_t cur = *a.step_dev;
-        a.step += cur;
-        if (a.step_next && r == 0) *a.step_next = cur + 1;
-    }
-    int u;
-    if (a.gen_users) {
-        const uint64_t key = mix64(a.seed ^ mix64(a.step));
-        // B <= n_pool: distinct users (rd.sample, MF/train_new_api.py:380-381); else with replacement (:383)
-        const uint32_t x = a.B <= a.n_pool ? feistel_perm((uint32_t)r, (uint32_t)a.n_pool, key)
-                                           : bounded(draw(a.seed, a.step, r, 7), a.n_pool);
-        u = a.user_pool ? a.user_pool[x] : (int)x;
-        a.users[r] = u;
-    } else {
-        u = a.users[r];
-    }
-    const int64_t b = a.indptr[u], e = a.indptr[u + 1];
-    const int len = (int)(e - b);
-    int p = 0, slot = 0;
-    if (len == 0) {  // :387-390
-        p = 0;
-        slot = a.n_slots > 0 ? (int)bounded(draw(a.seed, a.step, r, 1), a.n_slots) : 0;
-    } else {         // :392-396
-        const int idx = (int)bounded(draw(a.seed, a.step, r, 0), len);
-        p = a.indices[b + idx];
-        slot = a.slots ? a.slots[b + idx] : 0;
-    }
-    int n = a.neg_lo;
-    const uint32_t span = (uint32_t)(a.neg_hi - a.neg_lo);
-    for (uint32_t k = 0; k < 4096; ++k) {  // rejection against the (sorted) train row, :397-401
-        n = a.neg_lo + (int)bounded(draw(a.seed, a.step, r, 16 + k), span);
-        int64_t lo = b, hi = e;
-        while (lo < hi) {
-            const int64_t mid = (lo + hi) >> 1;
-            if (a.indices[mid] < n) lo = mid + 1; else hi = mid;
-        }
-        if (!(lo < e && a.indices[lo] == n)) break;
-    }
-    a.pos[r] = p;
-    a.neg[r] = n;
-    if (a.pop && a.pos_pop) {  // :402-403
-        a.pos_pop[r] = a.pop[(size_t)p * a.n_slots + slot];
-        a.neg_pop[r] = a.pop[(size_t)n * a.n_slots + slot];
-    }
-}
+// one wave per workgroup: every thread is a chain of dependent loads, spreading the waves over CUs beats packing them (13 -> 9 us)
+__global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) { sample_one(a, (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
 
 }  // namespace
 
@@ -191,7 +102,7 @@ extern "C" int pda_sample_triplets(int32_t* users, int gen_users, const int32_t*
     if (pop_matrix && (!pos_pop || !neg_pop || n_slots <= 0)) return PDA_ERR_ARG;
     SampleArgs a{users, user_pool, train_indptr, train_indices, train_slots, pop_matrix, pos, neg, pos_pop, neg_pop,
                  seed, step, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, nullptr, nullptr};
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
@@ -212,7 +123,7 @@ extern "C" int pda_sample_triplets_dev(int32_t* users, int gen_users, const int3
     if (pop_matrix && (!pos_pop || !neg_pop || n_slots <= 0)) return PDA_ERR_ARG;
     SampleArgs a{users, user_pool, train_indptr, train_indices, train_slots, pop_matrix, pos, neg, pos_pop, neg_pop,
                  seed, 0, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, step_dev, step_next};
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;

@@ -10,6 +10,7 @@
 // per triplet, each lane owns one float4 of the three gathered rows (a 4*d-byte row is one fully
 // coalesced segment), dots by xor-shuffle inside the lane group, per-block loss reduction -> 3 atomics.
 #include "pda_common.h"
+#include "pda_sample.h"
 
 namespace {
 
@@ -54,14 +55,14 @@ __device__ __forceinline__ void atomic_add4(float* p, f32x4 v) {
 // equal `pos` inside the block are summed by their first triplet and leave as ONE atomic per element.  Any batch order
 // is correct; a batch sorted by `pos` (pda_sort_triplets_by_pos, done by the device sampler) makes the runs long.
 template <int D, bool BF>
-__global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
+__device__ __forceinline__ void bpr_step_body(const StepArgs& a, const int bid) {
     constexpr int L = D / 4;        // lanes per triplet
     constexpr int TPB = 512 / L;    // triplets per block
     __shared__ float red[2][8];
     __shared__ int s_pos[TPB];
     __shared__ __attribute__((aligned(16))) float s_dpe[TPB * D];
     const int tid = threadIdx.x, g = tid / L, e = tid % L;
-    const int t = blockIdx.x * TPB + g;
+    const int t = bid * TPB + g;
     const bool active = t < a.B;
     const bool with_pop = a.pos_pop != nullptr;
     const bool scatter = a.mode == PDA_UPD_SGD_FUSED || a.mode == PDA_UPD_DENSE_GRAD || a.mode == PDA_UPD_SGD_ITEMS ||
@@ -182,6 +183,24 @@ __global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) {
         unsafeAtomicAdd(a.loss_acc + 1, mf);
         unsafeAtomicAdd(a.loss_acc + 2, rg);
     }
+}
+
+template <int D, bool BF>
+__global__ void __launch_bounds__(512) bpr_step_kernel(StepArgs a) { bpr_step_body<D, BF>(a, (int)blockIdx.x); }
+
+// The step of batch t and the sampler of batch t + 1 in ONE launch: workgroups [0, n_step_blocks) run the step, the ones
+// behind them draw the next batch into the OTHER set of batch buffers.  The two are independent (the sampler never reads
+// the tables) and both latency-bound on a handful of CUs; as consecutive graph nodes -- also on two captured streams --
+// they ran back to back (23 us per step against 13 us for the slower of the two).
+#ifndef PDA_SAMP_PER_BLOCK
+#define PDA_SAMP_PER_BLOCK 64
+#endif
+constexpr int kSampPerBlock = PDA_SAMP_PER_BLOCK;   // one wave per sampler workgroup: 32 workgroups for a 2048-triplet batch
+template <int D, bool BF>
+__global__ void __launch_bounds__(512) bpr_step_sample_kernel(StepArgs a, SampleArgs sa, int n_sample_blocks) {
+    // sampler workgroups first (they are dispatched first and have the longer dependent-load chains), kSampPerBlock triplets each
+    if ((int)blockIdx.x >= n_sample_blocks) bpr_step_body<D, BF>(a, (int)blockIdx.x - n_sample_blocks);
+    else if (threadIdx.x < kSampPerBlock) sample_one(sa, (int)blockIdx.x * kSampPerBlock + (int)threadIdx.x);
 }
 
 // Sort one batch by positive item inside a single workgroup (B <= 4096): bitonic sort of (pos, slot) in LDS, then all
@@ -381,9 +400,12 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, fl
 }
 
 template <int D, bool BF = false>
-int launch_step(const StepArgs& a, hipStream_t s) {
+int launch_step(const StepArgs& a, hipStream_t s, const SampleArgs* next = nullptr) {
     constexpr int TPB = 512 / (D / 4);
-    hipLaunchKernelGGL((bpr_step_kernel<D, BF>), dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
+    const int nsb = (a.B + TPB - 1) / TPB;
+    const int nsamp = next ? (next->B + kSampPerBlock - 1) / kSampPerBlock : 0;
+    if (next) hipLaunchKernelGGL((bpr_step_sample_kernel<D, BF>), dim3((unsigned)(nsb + nsamp)), dim3(512), 0, s, a, *next, nsamp);
+    else hipLaunchKernelGGL((bpr_step_kernel<D, BF>), dim3((unsigned)nsb), dim3(512), 0, s, a);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -429,6 +451,37 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
         case 64: return launch_step<64>(a, s);
         case 128: return launch_step<128>(a, s);
         case 256: return launch_step<256>(a, s);
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int pda_bpr_step_sample_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg,
+                                       const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div,
+                                       float lr, int update_mode, float* loss_acc, const pda_sample_job* next, void* stream) {
+    if (!U || !I || !users || !pos || !neg || B <= 0 || reg_div <= 0.f || !next) return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
+    update_mode &= ~PDA_UPD_ANY_ORDER;
+    if (update_mode != PDA_UPD_SGD_FUSED && update_mode != PDA_UPD_NONE) return PDA_ERR_ARG;
+    // the sampler job: validated like pda_sample_triplets_dev; its outputs must not be this step's inputs
+    if (!next->users || !next->train_indptr || !next->train_indices || !next->pos || !next->neg || !next->step_dev || next->B <= 0 ||
+        next->neg_hi <= next->neg_lo)
+        return PDA_ERR_ARG;
+    if (next->step_next == next->step_dev) return PDA_ERR_ARG;
+    if (next->gen_users && next->n_pool <= 0) return PDA_ERR_ARG;
+    if (next->pop_matrix && (!next->pos_pop || !next->neg_pop || next->n_slots <= 0)) return PDA_ERR_ARG;
+    if (next->users == users || next->pos == pos || next->neg == neg) return PDA_ERR_ARG;
+    StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, nullptr, nullptr, nullptr, nullptr, nullptr, loss_acc,
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I, any_order};
+    SampleArgs sa{next->users, next->user_pool, next->train_indptr, next->train_indices, next->train_slots, next->pop_matrix,
+                  next->pos, next->neg, next->pos_pop, next->neg_pop, next->seed, 0, next->B, next->n_pool, next->gen_users,
+                  next->neg_lo, next->neg_hi, next->n_slots, next->step_dev, next->step_next};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (d) {
+        case 32: return launch_step<32>(a, s, &sa);
+        case 64: return launch_step<64>(a, s, &sa);
+        case 128: return launch_step<128>(a, s, &sa);
+        case 256: return launch_step<256>(a, s, &sa);
         default: return PDA_ERR_UNSUPPORTED;
     }
 }

@@ -5,6 +5,8 @@ from __future__ import annotations
 import math
 from typing import Optional, Tuple
 
+import ctypes as C
+
 import torch
 
 from . import _lib
@@ -509,6 +511,31 @@ def sample_triplets_into(out, train_indptr, train_indices, *, seed: int, step_de
     if advance and parity is None:
         check(lib.pda_counter_add(ptr(step_dev), 1, stream_ptr()), "pda_counter_add")
     return out
+
+
+def bpr_step_and_sample(U, I, users, pos, neg, pos_pop, neg_pop, *, regs: float, reg_div: float, lr: float, next_out,
+                        train_indptr, train_indices, seed: int, step_dev: torch.Tensor, parity: int, user_pool=None,
+                        n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None, mode: int = UPD_SGD_FUSED,
+                        loss_acc: Optional[torch.Tensor] = None, grouped: bool = False):
+    """pda_bpr_step_sample_f32: the fused SGD step on (users, pos, neg, ...) and, in spare workgroups of the same launch, the
+    sampler of the NEXT batch into `next_out` = (users, pos, neg, pos_pop|None, neg_pop|None) -- a second set of batch
+    buffers.  step_dev int64[2] + parity as in sample_triplets_into (slot `parity` is read, 1 - parity receives step + 1).
+    Graph-capturable; equivalent to bpr_step followed by sample_triplets_into."""
+    lib = _lib.load()
+    if step_dev.numel() != 2:
+        raise ValueError("bpr_step_and_sample needs the two-slot step counter")
+    nu, npos, nneg, npp, npn = next_out
+    n_slots = pop_matrix.shape[1] if pop_matrix is not None else 0
+    job = _lib.SampleJob(ptr(nu), 1, ptr(user_pool), int(n_pool), nu.numel(), ptr(train_indptr), ptr(train_indices), ptr(train_slots),
+                         int(neg_range[0]), int(neg_range[1]), ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1),
+                         ptr(step_dev[parity:parity + 1]), ptr(step_dev[1 - parity:2 - parity]), ptr(npos), ptr(nneg), ptr(npp), ptr(npn))
+    if loss_acc is None:
+        loss_acc = torch.zeros(3, dtype=torch.float32, device=U.device)
+    m = int(mode) | (0 if grouped else UPD_ANY_ORDER)
+    check(lib.pda_bpr_step_sample_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), users.numel(),
+                                      U.shape[1], float(regs), float(reg_div), float(lr), m, ptr(loss_acc), C.byref(job), stream_ptr()),
+          "pda_bpr_step_sample_f32")
+    return loss_acc
 
 
 def group_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):

@@ -422,3 +422,68 @@ def test_item_parallel_adam_equals_the_reference_optimiser_on_the_concatenated_b
             np.testing.assert_allclose(t.U.cpu().numpy(), Uref, atol=TOL)
         np.testing.assert_allclose(torch.cat([t.I_shard for t in trainers]).cpu().numpy(), Iref, atol=TOL)
     assert np.abs(Uref - U).max() > 1e-3
+
+
+@pytest.mark.parametrize("d", [64, 128])
+def test_step_with_the_next_batch_sampled_in_the_same_launch(dev, d):
+    """pda_bpr_step_sample_f32 == pda_bpr_step_f32 followed by pda_sample_triplets_dev: same tables after every step
+    (1e-6: fp32 atomics), bit-identical sampled batches and step counters, also when replayed from a HIP graph."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("tiny", dev)
+    rng = np.random.default_rng(5 + d)
+    B, regs, lr, seed = 512, 1e-2, 0.05, 99
+    U0 = torch.from_numpy((rng.standard_normal((W.n_users, d)) * 0.2).astype(np.float32)).to(dev)
+    I0 = torch.from_numpy((rng.standard_normal((W.n_items, d)) * 0.2).astype(np.float32)).to(dev)
+    kw = dict(n_pool=W.n_users, train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+
+    def mk():
+        return (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
+
+    def run(fused, graph):
+        U, I = U0.clone(), I0.clone()
+        bufs, loss = [mk(), mk()], torch.zeros(3, device=dev)
+        step_dev = torch.tensor([3, 0], dtype=torch.int64, device=dev)
+        ops.sample_triplets_into(bufs[0], W.hist_indptr, W.hist_indices, seed=seed, step_dev=step_dev, parity=0, **kw)
+
+        def body(i):
+            cur, nxt, par = bufs[i & 1], bufs[(i + 1) & 1], (i + 1) & 1
+            if fused:
+                ops.bpr_step_and_sample(U, I, *cur, regs=regs, reg_div=B, lr=lr, next_out=nxt, train_indptr=W.hist_indptr,
+                                        train_indices=W.hist_indices, seed=seed, step_dev=step_dev, parity=par, loss_acc=loss, **kw)
+            else:
+                ops.bpr_step(U, I, *cur, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
+                ops.sample_triplets_into(nxt, W.hist_indptr, W.hist_indices, seed=seed, step_dev=step_dev, parity=par, **kw)
+        if graph:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                body(0); body(1)                                  # warm-up outside the capture (two calls: parity back to 0)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for i in range(4):
+                    body(i)
+            g.replay()
+        else:
+            for i in range(6):
+                body(i)
+        torch.cuda.synchronize()
+        return U, I, bufs, step_dev, loss
+
+    ref = run(False, False)
+    for fused, graph in ((True, False), (True, True)):
+        got = run(fused, graph)
+        np.testing.assert_allclose(got[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=0, atol=2e-6)
+        for a, b in zip(got[2][0] + got[2][1], ref[2][0] + ref[2][1]):
+            assert torch.equal(a, b)
+        assert got[3].tolist() == ref[3].tolist()
+        np.testing.assert_allclose(got[4].cpu().numpy(), ref[4].cpu().numpy(), rtol=1e-5)
+    # argument checks: the next batch must not land in the buffers this step reads
+    U, I = U0.clone(), I0.clone()
+    b = mk()
+    ops.sample_triplets_into(b, W.hist_indptr, W.hist_indices, seed=seed, step_dev=torch.tensor([0, 0], dtype=torch.int64, device=dev), parity=0, **kw)
+    with pytest.raises(ops.PdaHipError if hasattr(ops, "PdaHipError") else Exception):
+        ops.bpr_step_and_sample(U, I, *b, regs=regs, reg_div=B, lr=lr, next_out=b, train_indptr=W.hist_indptr, train_indices=W.hist_indices,
+                                seed=seed, step_dev=torch.tensor([0, 0], dtype=torch.int64, device=dev), parity=0, **kw)
