@@ -256,8 +256,7 @@ def bench_train(args, dev):
         tcount[0] += 1
         lr_t = ops.adam_lr_t(lr, min(tcount[0], 1000))       # host scalar frozen in the graph: fine for timing
         ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=st[2], gI=st[5], loss_acc=loss)
-        ops.adam_dense_sweep(U, st[0], st[1], st[2], lr_t)
-        ops.adam_dense_sweep(I, st[3], st[4], st[5], lr_t)
+        ops.adam_dense_sweep2(U, st[0], st[1], st[2], I, st[3], st[4], st[5], lr_t)
     out["adam_dense_reference_faithful"] = timed_graph(adam_body, max(256, args.train_steps // 4))
     sweep_bytes = 6 * (W.n_users + W.n_items) * W.d * 4
     r = out["adam_dense_reference_faithful"]

@@ -246,6 +246,11 @@ int pda_group_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float*
  * bias-corrected rate lr*sqrt(1-b2^t)/(1-b1^t) computed by the caller. */
 int pda_adam_dense_sweep_f32(float* var, float* m, float* v, float* g, size_t n, float lr_t, float beta1,
                              float beta2, float eps, void* stream);
+/* The same sweep over TWO tables (U and I of the model) in one launch; element for element the arithmetic of two
+ * pda_adam_dense_sweep_f32 calls. */
+int pda_adam_dense_sweep2_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t n_a, float* var_b, float* m_b,
+                              float* v_b, float* g_b, size_t n_b, float lr_t, float beta1, float beta2, float eps,
+                              void* stream);
 
 /* Lazy/sparse Adam on the touched rows only (declared deviation).  rows i32 [n_rows]
  * must be unique; g is the dense accumulator (reset on the touched rows). */

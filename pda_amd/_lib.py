@@ -62,6 +62,7 @@ SIGNATURES = {
     "pda_group_triplets_by_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_sort_triplets_by_pos": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_adam_dense_sweep_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
+    "pda_adam_dense_sweep2_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pda_sample_triplets_dev": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

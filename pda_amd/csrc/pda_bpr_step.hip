@@ -378,6 +378,40 @@ __global__ void __launch_bounds__(256) adam_dense_sweep_kernel(float* __restrict
     }
 }
 
+// Both tables of the model in one launch (the same arithmetic element by element): workgroups [0, blocks_a) sweep the first
+// table, the rest the second -- one launch and one tail less per training step.
+__global__ void __launch_bounds__(256) adam_dense_sweep2_kernel(float* __restrict__ var_a, float* __restrict__ m_a, float* __restrict__ v_a,
+                                                                float* __restrict__ g_a, size_t n4_a, float* __restrict__ var_b,
+                                                                float* __restrict__ m_b, float* __restrict__ v_b, float* __restrict__ g_b,
+                                                                size_t n4_b, unsigned blocks_a, float lr_t, float b1, float b2, float eps) {
+    const bool first = blockIdx.x < blocks_a;
+    float* var = first ? var_a : var_b;
+    float* m = first ? m_a : m_b;
+    float* v = first ? v_a : v_b;
+    float* g = first ? g_a : g_b;
+    const size_t n4 = first ? n4_a : n4_b;
+    const size_t blk = first ? blockIdx.x : blockIdx.x - blocks_a, nblk = first ? blocks_a : gridDim.x - blocks_a;
+    const size_t stride = nblk * blockDim.x;
+    for (size_t i = blk * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        f32x4 gg = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 xx = reinterpret_cast<f32x4*>(var)[i];
+        bool touched = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            touched |= gg[k] != 0.f;
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+            xx[k] = xx[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        }
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        reinterpret_cast<f32x4*>(var)[i] = xx;
+        if (touched) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, float* v, float* g, const int32_t* rows,
                                                         int n_rows, float lr_t, float b1, float b2, float eps) {
@@ -563,6 +597,21 @@ extern "C" int pda_adam_dense_sweep_f32(float* var, float* m, float* v, float* g
     const unsigned blocks = (unsigned)(want < 256u * 8u ? want : 256u * 8u);  // 8 blocks/CU, grid-stride
     hipLaunchKernelGGL(adam_dense_sweep_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), var, m,
                        v, g, n4, lr_t, beta1, beta2, eps);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_adam_dense_sweep2_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t n_a, float* var_b, float* m_b,
+                                         float* v_b, float* g_b, size_t n_b, float lr_t, float beta1, float beta2, float eps,
+                                         void* stream) {
+    if (!var_a || !m_a || !v_a || !g_a || !var_b || !m_b || !v_b || !g_b || n_a == 0 || n_b == 0 || ((n_a | n_b) & 3)) return PDA_ERR_ARG;
+    const size_t n4a = n_a / 4, n4b = n_b / 4, total = 256u * 8u;               // 8 blocks / CU in all, split by size
+    size_t ba = (size_t)((double)total * (double)n4a / (double)(n4a + n4b));
+    ba = ba < 1 ? 1 : (ba > total - 1 ? total - 1 : ba);
+    const size_t wa = (n4a + 255) / 256, wb = (n4b + 255) / 256;
+    const unsigned blocks_a = (unsigned)(wa < ba ? wa : ba), blocks_b = (unsigned)(wb < total - ba ? wb : total - ba);
+    hipLaunchKernelGGL(adam_dense_sweep2_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), var_a,
+                       m_a, v_a, g_a, n4a, var_b, m_b, v_b, g_b, n4b, blocks_a, lr_t, beta1, beta2, eps);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

@@ -110,8 +110,7 @@ class _MFBase:
         ops.bpr_step_bf16(U16, I16, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
                           mode=ops.UPD_DENSE_GRAD, gU=st["gU"], gI=st["gI"], loss_acc=self._loss)
         if self.optimizer == "adam":
-            ops.adam_dense_sweep(U, st["mU"], st["vU"], st["gU"], lr_t)
-            ops.adam_dense_sweep(I, st["mI"], st["vI"], st["gI"], lr_t)
+            ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
             ops.refresh_rows_bf16(U, U16)                      # dense decay moves every row
             ops.refresh_rows_bf16(I, I16)
         else:
@@ -144,8 +143,7 @@ class _MFBase:
         ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
                      mode=ops.UPD_DENSE_GRAD, gU=st["gU"], gI=st["gI"], loss_acc=self._loss)
         if self.optimizer == "adam":
-            ops.adam_dense_sweep(U, st["mU"], st["vU"], st["gU"], lr_t)
-            ops.adam_dense_sweep(I, st["mI"], st["vI"], st["gI"], lr_t)
+            ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
         else:
             ops.adam_rows(U, st["mU"], st["vU"], st["gU"], torch.unique(users).int(), lr_t)
             ops.adam_rows(I, st["mI"], st["vI"], st["gI"], torch.unique(torch.cat([pos, neg])).int(), lr_t)

@@ -429,6 +429,17 @@ def adam_lr_t(lr: float, t: int, beta1=ADAM_BETA1, beta2=ADAM_BETA2) -> float:
     return lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
 
 
+def adam_dense_sweep2(var_a, m_a, v_a, g_a, var_b, m_b, v_b, g_b, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+    """pda_adam_dense_sweep2_f32: the dense-decay Adam sweep over both tables of the model in one launch."""
+    lib = _lib.load()
+    for t in (var_a, m_a, v_a, g_a, var_b, m_b, v_b, g_b):
+        _need(t, torch.float32, "adam state")
+    check(lib.pda_adam_dense_sweep2_f32(ptr(var_a), ptr(m_a), ptr(v_a), ptr(g_a), var_a.numel(), ptr(var_b), ptr(m_b), ptr(v_b), ptr(g_b),
+                                        var_b.numel(), lr_t, beta1, beta2, eps, stream_ptr()), "pda_adam_dense_sweep2_f32")
+    mark_modified(var_a)
+    mark_modified(var_b)
+
+
 def adam_dense_sweep(var, m, v, g, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
     lib = _lib.load()
     for t, n in ((var, "var"), (m, "m"), (v, "v"), (g, "g")):

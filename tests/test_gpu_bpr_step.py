@@ -487,3 +487,24 @@ def test_step_with_the_next_batch_sampled_in_the_same_launch(dev, d):
     with pytest.raises(ops.PdaHipError if hasattr(ops, "PdaHipError") else Exception):
         ops.bpr_step_and_sample(U, I, *b, regs=regs, reg_div=B, lr=lr, next_out=b, train_indptr=W.hist_indptr, train_indices=W.hist_indices,
                                 seed=seed, step_dev=torch.tensor([0, 0], dtype=torch.int64, device=dev), parity=0, **kw)
+
+
+def test_two_table_adam_sweep_equals_two_sweeps(dev):
+    """pda_adam_dense_sweep2_f32 is the arithmetic of two pda_adam_dense_sweep_f32 calls, bit for bit (sizes that do not split
+    evenly over the workgroups, sparse gradients, the accumulators zeroed)."""
+    from pda_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    def state(n):
+        var = torch.randn(n, generator=g, device=dev)
+        m, v = torch.randn(n, generator=g, device=dev) * 0.01, torch.rand(n, generator=g, device=dev) * 0.01
+        gr = torch.randn(n, generator=g, device=dev) * (torch.rand(n, generator=g, device=dev) < 0.05)
+        return [var, m, v, gr]
+    for na, nb in ((50000 * 64, 20000 * 64), (1028, 7 * 4), (3 * 4, 999 * 64)):
+        a, b = state(na), state(nb)
+        a2, b2 = [t.clone() for t in a], [t.clone() for t in b]
+        ops.adam_dense_sweep(*a, 1e-3)
+        ops.adam_dense_sweep(*b, 1e-3)
+        ops.adam_dense_sweep2(*a2, *b2, 1e-3)
+        for x, y in zip(a + b, a2 + b2):
+            assert torch.equal(x, y)
+        assert float(a2[3].abs().max()) == 0.0 and float(b2[3].abs().max()) == 0.0
