@@ -42,7 +42,7 @@ def parse():
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--workload", default="c3", choices=["c2", "c3", "tiny"])
-    p.add_argument("--eval-block", type=int, default=65536, help="users per step")
+    p.add_argument("--eval-block", type=int, default=262144, help="users per step (the default of the product's --eval_block)")
     p.add_argument("--head", default="condition", choices=["main_branch", "condition"])
     p.add_argument("--K", type=int, default=50)
     p.add_argument("--no-train", action="store_true")
