@@ -166,6 +166,39 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
                                 int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys,
                                 void* workspace, void* stream);
 
+/* Generation 4 of the pre-filtered path (pda_score_topk_v4.hip): the same filter + exact rescoring (same keys again), with
+ * 64 user rows per matrix-core wave, separate rescoring waves and LDS-DMA tile streaming.  ONE entry point per table type
+ * covers the three sweep modes of the entry points above:
+ *   order == NULL in the prep            natural item order
+ *   order given, early_stop == 0         visiting order, every tile scored
+ *   order given, early_stop == 1         visiting order with exact early termination
+ * The prep holds the item rows padded to 2 d + 48 bytes in visiting order (bf16 row, the 16 bf16 of the folded threshold
+ * test, pop, local id, norm) plus the suffix bounds; redo it when the weights, pop or the order change:
+ *   pda_item_prep4_bytes(n, d)
+ *   pda_item_prep4_f32 / _bf16(I_shard, pop_shard|NULL, order|NULL, n, d, prep, stream)
+ *        pop_shard NULL: a prep for PDA_HEAD_RAW only; with pop_shard: PDA_HEAD_POP, and PDA_HEAD_RAW without early_stop
+ *   pda_item_prep4_check(prep, n, d, stream)   optional, synchronises: PDA_ERR_ARG if `order` was not a permutation
+ *   pda_score_topk4_auto_splits(n_users_blk, n_items_local, d)   the n_splits the call picks for n_splits <= 0
+ *   pda_score_topk4_f32 / _bf16(.. as pda_score_topk_ordered_*, without hist_indices_ord: train items are masked at the
+ *        candidate stage by a binary search in hist_indices ..)
+ * d in {64,128,256}; K <= 54; n_items_local <= 2^26; workspace as pda_score_topk_workspace_bytes.  out_keys doubles as the
+ * hand-over buffer between the exact warm-up kernel and the sweep.  PDA_ERR_UNSUPPORTED: use the entry points above. */
+size_t pda_item_prep4_bytes(int n_items_local, int d);
+int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,
+                       void* stream);
+int pda_item_prep4_bf16(const uint16_t* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,
+                        void* stream);
+int pda_item_prep4_check(const void* prep, int n_items_local, int d, void* stream);
+int pda_score_topk4_auto_splits(int n_users_blk, int n_items_local, int d);
+int pda_score_topk4_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
+                        int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                        const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
+                        uint64_t* out_keys, void* workspace, void* stream);
+int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
+                         int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                         const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
+                         uint64_t* out_keys, void* workspace, void* stream);
+
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0
  *   out_keys u64 [n_users_blk, K] or NULL;  out_idx i32 / out_val f32 [n_users_blk, K] or NULL.

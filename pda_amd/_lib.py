@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpda_hip.so")
+LIB_PATH = os.environ.get("PDA_HIP_LIB") or os.path.join(_HERE, "csrc", "libpda_hip.so")   # PDA_HIP_LIB: an A/B build of the same library (tools/)
 
 # Constants mirrored from include/pda_hip.h
 ABI_VERSION = 1
@@ -53,6 +53,13 @@ SIGNATURES = {
     "pda_item_prep_ordered_bf16_bytes": (_sz, [_i, _i]),
     "pda_item_prep_ordered_bf16": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pda_score_topk_ordered_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pda_item_prep4_bytes": (_sz, [_i, _i]),
+    "pda_item_prep4_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "pda_item_prep4_bf16": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "pda_item_prep4_check": (_i, [_vp, _i, _i, _vp]),
+    "pda_score_topk4_auto_splits": (_i, [_i, _i, _i]),
+    "pda_score_topk4_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pda_score_topk4_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_bpr_step_shard_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _i, _vp, _vp, _vp]),

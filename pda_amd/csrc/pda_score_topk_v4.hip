@@ -1,0 +1,972 @@
+// score + mask + top-K, generation 4: the v3 algorithm (ONE bf16 MFMA per k-step as a rigorous pre-filter, threshold test
+// folded into one extra k-step, exact fp32 rescoring of the few survivors, exact per-user lists) on a different machine
+// mapping.  Same packed keys as v1 / v3, bit for bit (tests/test_gpu_score_topk.py runs every case through all of them).
+//
+// What v3's profile said (profiles/round1k_pmc.txt): matrix pipe 39 % busy, ~11 non-MFMA instructions per MFMA, 35 % of
+// the wave cycles waiting -- every wave amortised its B reads, barriers and loop control over 32 user rows only, and every
+// ring drain (a chain of dependent gathers) stopped the MFMAs of its wave.  v4 therefore
+//   * gives each MFMA wave 64 user rows (UA = 2 A operands per B read: half the LDS reads, half the per-tile bookkeeping
+//     per MFMA; d = 256 keeps 32 rows -- its A operand alone is 128 VGPRs);
+//   * splits the workgroup into 4 MFMA waves and 4 RESCORING waves (wave w + 4 serves wave w: it owns the rows' lists,
+//     drains the candidate ring, gathers the exact rows, runs the fp32 fmaf chains, appends, compacts, publishes the
+//     thresholds).  The MFMA waves never wait for a gather: the latency-bound half of the algorithm runs beside them on the
+//     same SIMDs.  Results do not depend on the timing: a stale threshold is a LOWER threshold (more candidates, never
+//     fewer), every candidate is rescored exactly, and the lists keep the exact best K;
+//   * has no s_barrier in the loop (it would tie the rescoring waves to the tile cadence): the MFMA waves hand tiles to each
+//     other through one monotonic LDS counter -- "my share of tile i+1 has landed and I am done reading tile i" -- which
+//     orders both the RAW and the WAR side of the two tile buffers;
+//   * streams the tiles with global_load_lds (LDS-DMA, no staging registers, no ds_write pass) from a layout the prep
+//     kernel pads per item: [d bf16][16 bf16 test pieces][pop f32][local id i32][norm f32][0] = 2d + 48 bytes.  The row
+//     stride is an ODD number of 16-byte slots, so the B-operand ds_read_b128 of any 16 rows hits 16 different bank slots
+//     WITHOUT a swizzle: the LDS image is the global image, a tile is one contiguous run of whole 1 KiB DMA pieces, every
+//     LDS address in the loop is a per-lane base plus an immediate, and the test pieces, the popularity and the item id
+//     travel with the tile (no per-tile scalar-indexed side loads).  Tail tiles are padded with null items that can never
+//     become candidates, so the loop carries no "item exists" masks;
+//   * takes the exact warm-up out of the sweep: warm4_kernel scores the first tiles of every split exactly on the fp32
+//     matrix cores (the v1 k order = the fmaf chain of the oracle) and leaves sorted lists in out_keys; sweep4_kernel
+//     starts from them.  (Inside one kernel the warm-up block dictated the register allocation of the main loop.)
+//   * treats natural item order as the visiting order "identity": ONE kernel for all three sweep modes; train items are
+//     masked at the candidate stage for all of them (binary search in the caller's id-sorted history by the rescoring wave).
+//
+// Error bound of the filter, folded test, tie handling: pda_score_topk_v3.hip (unchanged).
+#include "pda_topk_common.h"
+#include <cstdlib>
+
+using namespace pda_topk;
+
+namespace {
+
+constexpr int kCap4 = 57;            // list slots per user (LDS budget at d = 128: 256 users x 57 x 8 B = 114 KiB)
+constexpr int kRing4 = 256;          // ring entries per MFMA wave (u32 each)
+constexpr int kWarmTiles = 4;        // 64-item tiles per split scored by warm4_kernel (256 items)
+constexpr int kMainWaves = 4;
+#ifndef PDA_V4_ABL
+#define PDA_V4_ABL 0      // timing-only ablations (results are wrong): 1 no filter, 2 no hand-over between MFMA waves, 4 no tile loads, 8 rescoring waves leave at once
+#endif
+constexpr unsigned kSpinMax = 1u << 26;   // every spin is bounded: a protocol error sets stats[0] and leaves instead of hanging the GPU
+
+__host__ __device__ constexpr int row_bytes(int d) { return 2 * d + 48; }
+__host__ __device__ constexpr int tile_bytes(int d) { return 64 * row_bytes(d); }
+
+struct Args4 {
+    const void* U;               // f32 or bf16 [n_users_total, d]
+    const void* I;               // f32 or bf16 [n_items_local, d]   (exact rescoring)
+    const float* pop;            // f32 [n_items_local] or NULL
+    const int32_t* users;
+    const int64_t* hist_indptr;
+    const int32_t* hist_indices; // GLOBAL ids, ascending per row
+    uint64_t* out_keys;          // [n_splits, n_users_blk, K]: warm4 writes, sweep4 reads and overwrites
+    const unsigned char* rows;   // prep: padded item rows in visiting order, whole 64-item tiles
+    const float* sufA;           // [n_tiles] suffix bounds per 64-item tile, or NULL: no early termination
+    const float* sufB;
+    const int* pos_of;           // [n_items_local] local id -> visiting position, or NULL: identity
+    unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
+    int n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, n_tiles;
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// prep: padded rows in visiting order
+// ---------------------------------------------------------------------------------------------------------------------
+struct Prep4Layout {
+    size_t hdr, pos_of, sufA, sufB, sufR, rows, total;
+    int n_tiles;
+};
+Prep4Layout prep4_layout(int n, int d) {
+    Prep4Layout L{};
+    L.n_tiles = (n + 63) / 64;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    L.hdr = 0;                                  // +0 int: "order is not a permutation"; +4 int: prep was built with a popularity
+    L.pos_of = 256;
+    L.sufA = L.pos_of + al((size_t)n * 4);
+    L.sufB = L.sufA + al((size_t)L.n_tiles * 4);
+    L.sufR = L.sufB + al((size_t)L.n_tiles * 4);
+    L.rows = L.sufR + al((size_t)L.n_tiles * 4);
+    L.total = L.rows + (size_t)L.n_tiles * tile_bytes(d);
+    return L;
+}
+
+// one row per D/8 threads.  pos >= n: a null item (zero vector, constant slot -3e38: never a candidate, pop NaN)
+template <int D, bool BF>
+__global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, const float* __restrict__ pop, const int* __restrict__ order,
+                                                    int n, int n_pad, unsigned char* __restrict__ rows, int* __restrict__ pos_of,
+                                                    int* __restrict__ hdr) {
+    constexpr int TPR = D / 8, RB = row_bytes(D);
+    const int pos = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
+    if (pos >= n_pad) return;
+    unsigned char* rp = rows + (size_t)pos * RB;
+    float ss = 0.f, popv = 1.0f;
+    int src = -1;
+    if (pos < n) {
+        src = pos;
+        if (order) {
+            src = order[pos];
+            if (src < 0 || src >= n) { if (e == 0) atomicOr(hdr, 1); src = 0; }
+            else if (e == 0 && atomicExch(&pos_of[src], pos) != -1) atomicOr(hdr, 1);   // not a permutation
+        } else if (e == 0) {
+            pos_of[pos] = pos;                      // natural order: the identity
+        }
+        if (pop) popv = pop[src];
+        const f32x4 a = pda_load4<BF>(I, (size_t)src * D + 8 * e);
+        const f32x4 b = pda_load4<BF>(I, (size_t)src * D + 8 * e + 4);
+        u32x4 hq, lq;
+        split8(a, b, hq, lq);                       // bf16 tables: the RNE of a bf16 value is itself
+        *reinterpret_cast<u32x4*>(rp + 16 * e) = hq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ss += a[k] * a[k] + b[k] * b[k];
+    } else {
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        *reinterpret_cast<u32x4*>(rp + 16 * e) = z;
+    }
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (e == 0) {
+        const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
+        // the B side of the extra k-step (see pda_score_topk_v2.hip:item_prep_kernel): k 0..7 pieces of (1/pop)' rounded
+        // down (1 for the raw head), k 8 the constant 1 (raw: 8e-6), k 9 8e-6 (raw: 0), k 10 the padded norm rounded up
+        uint32_t p1 = 0x3F80u, p2 = 0, p3 = 0, k1 = 0, k2 = 0;
+        if (pop) {
+            const float ip = (popv > 0.f) ? fminf((1.0f / popv) * 0.9999995f, 1.0e6f) : 1.0e6f;
+            bf16_split3(ip, p1, p2, p3);
+            k1 = 0x3F80u;
+            k2 = bf16_up(8.0e-6f);
+            if (!(popv == popv)) k1 = 0xFF61u;      // NaN popularity: never a candidate
+        } else {
+            k1 = bf16_up(8.0e-6f);
+        }
+        if (pos >= n) { k1 = 0xFF61u; k2 = 0; p1 = 0x3F80u; p2 = p3 = 0; }
+        u32x4 lo4, hi4;
+        lo4[0] = p1 | (p2 << 16);
+        lo4[1] = p1 | (p2 << 16);
+        lo4[2] = p3 | (p1 << 16);
+        lo4[3] = p3 | (p2 << 16);
+        hi4[0] = k1 | (k2 << 16);
+        hi4[1] = pos < n ? bf16_up(v) : 0u;
+        hi4[2] = 0;
+        hi4[3] = 0;
+        *reinterpret_cast<u32x4*>(rp + 2 * D) = lo4;
+        *reinterpret_cast<u32x4*>(rp + 2 * D + 16) = hi4;
+        u32x4 tail;
+        tail[0] = pos < n ? __float_as_uint(pop ? popv : 1.0f) : 0x7FC00000u;     // null item: NaN (no comparison is ever true)
+        tail[1] = (uint32_t)(pos < n ? src : 0);
+        tail[2] = __float_as_uint(pos < n ? v : 0.f);
+        tail[3] = 0;
+        *reinterpret_cast<u32x4*>(rp + 2 * D + 32) = tail;
+    }
+}
+
+// per-tile maxima of |pop|, |pop| ||i|| and ||i||, then suffix maxima (single workgroup)
+__global__ void __launch_bounds__(256) tile_bound4_kernel(const unsigned char* __restrict__ rows, int rb, int d2, int n_tiles, int has_pop,
+                                                          float* __restrict__ tA, float* __restrict__ tB, float* __restrict__ tR) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    float ma = 0.f, mb = 0.f, mr = 0.f;
+    for (int q = 0; q < 64; ++q) {
+        const float* tl = reinterpret_cast<const float*>(rows + ((size_t)t * 64 + q) * rb + d2 + 32);
+        const float p = tl[0], nr = tl[2];
+        if (p == p) {                       // null items and NaN popularities never rank
+            const float pa = has_pop ? fabsf(p) : 0.f;
+            ma = fmaxf(ma, pa);
+            mb = fmaxf(mb, pa * nr * 1.000001f);
+            mr = fmaxf(mr, nr);
+        }
+    }
+    tA[t] = ma;
+    tB[t] = mb;
+    tR[t] = mr;
+}
+__global__ void __launch_bounds__(1024) suffix_max4_kernel(float* __restrict__ tA, float* __restrict__ tB, float* __restrict__ tR, int n_tiles) {
+    __shared__ float sa[1024], sb[1024], sr[1024];
+    const int per = (n_tiles + 1023) / 1024, lo = threadIdx.x * per, hi = min(lo + per, n_tiles);
+    float ma = 0.f, mb = 0.f, mr = 0.f;
+    for (int t = lo; t < hi; ++t) { ma = fmaxf(ma, tA[t]); mb = fmaxf(mb, tB[t]); mr = fmaxf(mr, tR[t]); }
+    sa[threadIdx.x] = ma;
+    sb[threadIdx.x] = mb;
+    sr[threadIdx.x] = mr;
+    __syncthreads();
+    float ra = 0.f, rb = 0.f, rr = 0.f;
+    for (int q = threadIdx.x + 1; q < 1024; ++q) { ra = fmaxf(ra, sa[q]); rb = fmaxf(rb, sb[q]); rr = fmaxf(rr, sr[q]); }
+    for (int t = hi - 1; t >= lo; --t) {
+        ra = fmaxf(ra, tA[t]);
+        rb = fmaxf(rb, tB[t]);
+        rr = fmaxf(rr, tR[t]);
+        tA[t] = ra;
+        tB[t] = rb;
+        tR[t] = rr;
+    }
+}
+
+int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
+    if (d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
+    const Prep4Layout L = prep4_layout(n, d);
+    unsigned char* pb = reinterpret_cast<unsigned char*>(prep);
+    int* hdr = reinterpret_cast<int*>(pb + L.hdr);
+    int* pos_of = reinterpret_cast<int*>(pb + L.pos_of);
+    if (hipMemsetAsync(hdr, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (order && hipMemsetAsync(pos_of, 0xFF, (size_t)n * 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    const int n_pad = L.n_tiles * 64;
+#define PDA_P4(DD)                                                                                                              \
+    case DD: {                                                                                                                  \
+        constexpr int RPB = 256 / (DD / 8);                                                                                     \
+        const dim3 grid((unsigned)((n_pad + RPB - 1) / RPB));                                                                   \
+        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr); \
+        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr);    \
+        break;                                                                                                                  \
+    }
+    switch (d) { PDA_P4(64) PDA_P4(128) PDA_P4(256) }
+#undef PDA_P4
+    PDA_CHECK_LAUNCH();
+    float* tA = reinterpret_cast<float*>(pb + L.sufA);
+    float* tB = reinterpret_cast<float*>(pb + L.sufB);
+    float* tR = reinterpret_cast<float*>(pb + L.sufR);
+    hipLaunchKernelGGL(tile_bound4_kernel, dim3((unsigned)((L.n_tiles + 255) / 256)), dim3(256), 0, s, pb + L.rows, row_bytes(d), 2 * d,
+                       L.n_tiles, pop ? 1 : 0, tA, tB, tR);
+    PDA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(suffix_max4_kernel, dim3(1), dim3(1024), 0, s, tA, tB, tR, L.n_tiles);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// shared device pieces
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned lds_ld(const unsigned* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+#define PDA_CBAR() asm volatile("" ::: "memory")
+
+__device__ __forceinline__ f32x16 zero16v() {
+    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return z;
+}
+
+// the tiles of split s: s, s + S, s + 2 S, ...
+__device__ __forceinline__ int split_tiles(int n_tiles, int split, int n_splits) {
+    return split < n_tiles ? (n_tiles - split + n_splits - 1) / n_splits : 0;
+}
+
+// append one exact key per flagged lane to its row's list; compaction (whole wave) when a list is full.  Returns true
+// when a threshold may have changed.
+template <int CAP>
+__device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t key, uint64_t* lists, int* cntl, float* taul, int row0,
+                                            int n_rows, int K, int lane) {
+    bool changed = false;
+    for (;;) {
+        bool ov = false;
+        if (p) {
+            const int slot = atomicAdd(&cntl[lrow], 1);
+            if (slot < CAP) lists[(size_t)lrow * CAP + slot] = key;
+            else ov = true;
+        }
+        if (!__any(ov)) break;
+        pda_wave_sync();
+        uint64_t full = __ballot(lane < n_rows && cntl[row0 + (lane < n_rows ? lane : 0)] >= CAP);
+        while (full) {
+            const int rr = __builtin_ctzll(full);
+            full &= full - 1ull;
+            compact_list<CAP>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+        }
+        changed = true;
+        p = ov && (tt >= taul[lrow]);
+    }
+    return changed;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// warm-up: the first kWarmTiles tiles of every split, exact (fp32 matrix cores, k order of v1), lists -> out_keys
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int HEAD, bool BF>
+__global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Args4 g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RB = row_bytes(D);
+    constexpr int NC = D / 8;                 // k-chunks of 8
+    constexpr int CPR4 = D / 4;               // 16-byte chunks per fp32 row
+    constexpr int NLD4 = (32 * CPR4) / kThreads;
+    constexpr int CAP = kCap4;
+    float* Bt = reinterpret_cast<float*>(smem);                                              // [32][D] fp32, swizzled
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 32 * D * 4);                        // [128][CAP]
+    int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * CAP);                     // [128]
+    float* taul = reinterpret_cast<float*>(cntl + kUserTile);                                // [128]
+    unsigned* hmask = reinterpret_cast<unsigned*>(taul + kUserTile);                         // [128][2 kWarmTiles]
+    float* popw = reinterpret_cast<float*>(hmask + kUserTile * 2 * kWarmTiles);              // [32]
+    int* idw = reinterpret_cast<int*>(popw + 32);                                            // [32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    const int K = g.K;
+    const int nt = split_tiles(g.n_tiles, split, g.n_splits);
+    const int nwarm = min(kWarmTiles, nt);
+
+    const int row_blk = utile * kUserTile + wave * 32 + j;
+    const bool row_ok = row_blk < g.n_users_blk;
+    const int uid = row_ok ? g.users[row_blk] : 0;
+
+    if (lane < 32) {
+        cntl[wave * 32 + lane] = 0;
+        taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
+    }
+    for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = 0u;
+    __syncthreads();
+    // train items among the warm positions: two threads per row walk the row's history
+    if (g.hist_indptr != nullptr) {
+        const int r = tid >> 1, part = tid & 1;
+        const int rb = utile * kUserTile + r;
+        if (rb < g.n_users_blk) {
+            const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)g.users[rb] : (int64_t)rb;
+            const int64_t hb = g.hist_indptr[hr], he = g.hist_indptr[hr + 1];
+            for (int64_t e = hb + part; e < he; e += 2) {
+                const int loc = g.hist_indices[e] - g.item_offset;
+                if (loc < 0 || loc >= g.n_items_local) continue;
+                const int p = g.pos_of ? g.pos_of[loc] : loc;
+                const int T = p >> 6;
+                if (T % g.n_splits != split) continue;
+                const int q = (T - split) / g.n_splits;
+                if (q < nwarm) atomicOr(&hmask[r * (2 * kWarmTiles) + 2 * q + ((p & 63) >> 5)], 1u << (p & 31));
+            }
+        }
+    }
+    f32x4 areg[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row_ok) v = pda_load4<BF>(g.U, (size_t)uid * D + 4 * h + 8 * c);
+        areg[c] = v;
+    }
+    const float* brow = Bt + j * D;
+    const int bswz = swz<D>(j);
+    uint64_t* my_lists = lists + (size_t)(wave * 32) * CAP;
+    for (int w = 0; w < nwarm; ++w) {
+        const int t = split + w * g.n_splits;
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            __syncthreads();                  // the previous block has been read by everyone (and hmask is complete)
+            if (tid < 32) {
+                const float* tl = reinterpret_cast<const float*>(g.rows + ((size_t)t * 64 + 32 * cb + tid) * RB + 2 * D + 32);
+                popw[tid] = tl[0];
+                idw[tid] = reinterpret_cast<const int*>(tl)[1];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < NLD4; ++q) {
+                const int id = tid + kThreads * q;
+                const int jj = id / CPR4, ch = id % CPR4;
+                // (null items of a tail tile carry id 0: a valid row, masked by okw below)
+                *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pda_load4<BF>(g.I, (size_t)idw[jj] * D + 4 * ch);
+            }
+            __syncthreads();
+            f32x16 acc0 = zero16v(), acc1 = zero16v();
+#pragma unroll
+            for (int c = 0; c < NC; c += 2) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + h) ^ bswz));
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + 2 + h) ^ bswz));
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][q], b0[q], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c + 1][q], b1[q], acc1, 0, 0, 0);
+                }
+            }
+            const f32x16 accx = acc0 + acc1;
+            const bool okw = (t * 64 + 32 * cb + j) < g.n_items_local;
+            const float pv = popw[j];
+            const int item = g.item_offset + idw[j];
+            const unsigned hb_mine = hmask[(wave * 32 + j) * (2 * kWarmTiles) + 2 * w + cb];
+            const bool any_hb = __any(hb_mine != 0u);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int lrow = wave * 32 + row;
+                float sc = accx[r];
+                if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+                bool p = okw && (sc >= taul[lrow]);
+                if (any_hb) {
+                    const uint32_t hbr = (uint32_t)__shfl((int)hb_mine, row, 64);          // train items never enter
+                    if ((hbr >> j) & 1u) p = false;
+                }
+                const uint64_t key = pda_pack_key(sc, (uint32_t)item);
+                append_keys<CAP>(p, lrow, sc, key, lists, cntl, taul, wave * 32, 32, K, lane);
+            }
+        }
+    }
+    pda_wave_sync();
+    if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * nwarm));
+    for (int rr = 0; rr < 32; ++rr) {
+        uint64_t* buf = my_lists + rr * CAP;
+        compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+        const int c = cntl[wave * 32 + rr];
+        const int rb = utile * kUserTile + wave * 32 + rr;
+        if (rb < g.n_users_blk && lane < K) {
+            const uint64_t k = lane < c ? buf[lane] : 0ull;
+            g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the sweep
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D>
+struct Geo4 {
+    static constexpr int UA = D <= 128 ? 2 : 1;          // A operands (32 user rows each) per MFMA wave
+    static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
+    static constexpr int UT = kMainWaves * ROWS;         // user rows per workgroup
+    static constexpr int NB = 2;                         // 32-column blocks per tile
+    static constexpr int RB = row_bytes(D), TB = tile_bytes(D), NCH = TB / 1024;
+    static constexpr size_t lds_tiles = 2 * (size_t)TB;
+    static constexpr size_t lds_lists = (size_t)UT * kCap4 * 8;
+    static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 256;
+};
+
+template <int D, int HEAD, bool BF>
+__global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
+    using G = Geo4<D>;
+    constexpr int UA = G::UA, ROWS = G::ROWS, UT = G::UT, NB = G::NB, RB = G::RB, TB = G::TB, NCH = G::NCH;
+    constexpr int NM = D / 16;
+    constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tiles = smem;                                                             // 2 x TB
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + G::lds_tiles);                      // [UT][kCap4] exact keys
+    int* cntl = reinterpret_cast<int*>(lists + (size_t)UT * kCap4);                          // [UT]
+    float* taul = reinterpret_cast<float*>(cntl + UT);                                       // [UT] exact K-th value (-inf until K entries)
+    unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [4][kRing4]
+    unsigned* sync = rings + kMainWaves * kRing4;                                            // see below
+    unsigned* s_ready = sync;                 // [1]  monotonic: += 1 per MFMA wave and tile
+    unsigned* s_tail = sync + 4;              // [4]  ring write positions (MFMA wave w)
+    unsigned* s_head = sync + 8;              // [4]  ring read positions (rescoring wave w)
+    unsigned* s_tver = sync + 12;             // [4]  bumped by the rescoring wave whenever a threshold of its rows rose
+    unsigned* s_done = sync + 16;             // [4]  MFMA wave w has pushed its last candidate
+    unsigned* s_vote = sync + 20;             // [2][4]  early termination votes
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    const int K = g.K;
+    const int nt = split_tiles(g.n_tiles, split, g.n_splits);
+    const int n_it = max(0, nt - kWarmTiles);                    // tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
+    if (tid < 32) sync[tid] = 0u;
+
+    if (wave >= kMainWaves) {
+        // ============================== rescoring wave ==============================
+        const int w = wave - kMainWaves;
+        const int row0 = w * ROWS;
+        uint64_t* my_lists = lists + (size_t)row0 * kCap4;
+        // lane l <-> row l of the wave: user id, history range, initial list
+        const int rb_l = utile * UT + row0 + lane;
+        const bool rok_l = lane < ROWS && rb_l < g.n_users_blk;
+        const int uid = rok_l ? g.users[rb_l] : 0;
+        int64_t hbeg = 0, hend = 0;
+        const bool hist_on = g.hist_indptr != nullptr;
+        if (hist_on && rok_l) {
+            const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)rb_l;
+            hbeg = g.hist_indptr[hr];
+            hend = g.hist_indptr[hr + 1];
+        }
+        for (int rr = 0; rr < ROWS; ++rr) {
+            const int rb = utile * UT + row0 + rr;
+            uint64_t key = 0ull;
+            if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane];
+            const int c = __popcll(__ballot(key != 0ull));
+            if (lane < K) my_lists[(size_t)rr * kCap4 + lane] = key;
+            const uint64_t kth = pda_readlane_u64(key, K - 1);
+            if (lane == 0) {
+                cntl[row0 + rr] = c;
+                taul[row0 + rr] = rb < g.n_users_blk ? (c >= K ? pda_key_val(kth) : -INFINITY) : INFINITY;
+            }
+        }
+        __syncthreads();
+        unsigned head = 0, n_cand = 0, tver = 0;
+        unsigned* ring = rings + w * kRing4;
+        constexpr int LPC = D / 32;                 // lanes per candidate: each owns 32 consecutive k
+        constexpr int CPP = 64 / LPC;               // candidates per pass
+        const int q = lane % LPC, ci = lane / LPC;
+        unsigned idle = 0;
+        for (;;) {
+            if constexpr ((PDA_V4_ABL & 8) != 0) break;
+            const unsigned dn = lds_ld(&s_done[w]);
+            const unsigned tail = lds_ld(&s_tail[w]);
+            if (tail == head) {
+                if (dn) break;
+                if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            idle = 0;
+            PDA_CBAR();
+            const int n = min((int)(tail - head), CPP);
+            n_cand += (unsigned)n;
+            const bool valid = ci < n;
+            const unsigned word = valid ? ring[(head + (unsigned)ci) % kRing4] : 0u;
+            const int row = (int)(word >> 26);
+            const int loc = (int)(word & 0x3FFFFFFu);                               // local item id
+            const int urow = __shfl(uid, row, 64);
+            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)loc * D + q * 32;
+            f32x4 uu[8], ii[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
+                ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
+            }
+            float pv = 1.0f;
+            if constexpr (HEAD == PDA_HEAD_POP) pv = g.pop[loc];
+            float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < LPC; ++ph) {
+                o0 = c0;
+                o1 = c1;
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {      // chunk 4 q + cc of the row: even chunks feed chain 0, odd ones chain 1
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        if (cc & 1) {
+                            o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
+                            o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
+                        } else {
+                            o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
+                            o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
+                        }
+                    }
+                }
+                if (ph < LPC - 1) {
+                    const float r0 = __shfl_up(o0, 1, 64), r1 = __shfl_up(o1, 1, 64);
+                    if (q == ph + 1) {
+                        c0 = r0;
+                        c1 = r1;
+                    }
+                }
+            }
+            float sc = o0 + o1;                               // meaningful on the candidate's last lane
+            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+            const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
+            const int lrow = row0 + row;
+            const int item = g.item_offset + loc;
+            // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in
+            bool p = valid && q == LPC - 1 && (tt >= taul[lrow]);
+            if (hist_on) {
+                // train items are masked HERE: one binary search in the row's id-sorted history for a candidate that has
+                // passed the filter and the exact threshold
+                int64_t lo = __shfl(hbeg, row, 64), hi = __shfl(hend, row, 64);
+                const int64_t he = hi;
+                if (p) {
+                    while (lo < hi) {
+                        const int64_t mid = (lo + hi) >> 1;
+                        if (g.hist_indices[mid] < item) lo = mid + 1; else hi = mid;
+                    }
+                    if (lo < he && g.hist_indices[lo] == item) p = false;
+                }
+            }
+            const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+            const bool changed = append_keys<kCap4>(p, lrow, tt, key, lists, cntl, taul, row0, ROWS, K, lane);
+            head += (unsigned)n;
+            PDA_CBAR();
+            lds_st(&s_head[w], head);
+            if (changed) lds_st(&s_tver[w], ++tver);
+        }
+        if (lane == 0) atomicAdd(g.stats + 1, n_cand);
+        // finalise: the lists are exact; sort and emit
+        for (int rr = 0; rr < ROWS; ++rr) {
+            uint64_t* buf = my_lists + (size_t)rr * kCap4;
+            compact_list<kCap4>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+            const int c = cntl[row0 + rr];
+            const int rb = utile * UT + row0 + rr;
+            if (rb < g.n_users_blk && lane < K) {
+                const uint64_t k = lane < c ? buf[lane] : 0ull;
+                g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+            }
+        }
+        return;
+    }
+
+    // ================================== MFMA wave ==================================
+    const int w = wave;
+    const int j = lane & 31, h = lane >> 5;
+    const int row0 = w * ROWS;
+    // A operands: rows 32 ua + j of the wave (k = 16 m + 8 h .. + 7) rounded to bf16; padded row norms
+    u32x4 ah[UA][NM];
+    float nu_row[UA];
+#pragma unroll
+    for (int ua = 0; ua < UA; ++ua) {
+        const int rb = utile * UT + row0 + 32 * ua + j;
+        const bool ok = rb < g.n_users_blk;
+        const int uid = ok ? g.users[rb] : 0;
+        float ss = 0.f;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+            if (ok) {
+                x = pda_load4<BF>(g.U, (size_t)uid * D + 8 * h + 16 * m);
+                y = pda_load4<BF>(g.U, (size_t)uid * D + 8 * h + 16 * m + 4);
+            }
+            u32x4 lo_unused;
+            split8(x, y, ah[ua][m], lo_unused);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        nu_row[ua] = sqrtf(ss) * 1.0009765625f * 1.0001f;              // padded ||u||
+    }
+
+    // tile i of the loop -> LDS buffer i & 1.  This wave's share: the 1 KiB pieces w, w + 4, ...
+    // Issued through inline asm: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+    // s_waitcnt vmcnt(0) in front of the next ds_read of ANY address -- the tile load became synchronous (measured: 1.2 of
+    // 4.4 ms).  The asm statement is invisible to that bookkeeping; this wave waits for its own pieces explicitly
+    // (vmcnt(0) before its increment of the hand-over counter).  M0 = LDS byte address of the piece, saved and restored.
+    const unsigned lds_tiles0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
+    auto issue_tile = [&](int i) __attribute__((always_inline)) {
+        int t = split + (kWarmTiles + i) * g.n_splits;
+        if constexpr ((PDA_V4_ABL & 16) != 0) t &= 7;          // timing only: eight L2-resident tiles
+        [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * TB + lane * 16;
+        [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((i & 1) * TB);
+#pragma unroll
+        for (int c = 0; c < (NCH + kMainWaves - 1) / kMainWaves; ++c) {
+            const int piece = w + kMainWaves * c;
+            if (piece < NCH) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                unsigned keep;
+                const unsigned char* gsrc = src + (size_t)piece * 1024;
+                const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + (unsigned)piece * 1024u);
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+#endif
+            }
+        }
+    };
+    if (n_it > 0) issue_tile(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // lists, thresholds and sync words are initialised; tile 0 has landed
+
+    // thresholds of the lane's own rows (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative (the rounding of the
+    // extra k-step, pda_score_topk_v3.hip), as the A operand of the extra k-step:
+    //   k 0..7 (lanes < 32): -(t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: +1, +1, +eps scale of the row
+    float thr_own[UA], thr_min = 0.f;
+    u32x4 aex[UA];
+    auto refresh_thr = [&]() __attribute__((always_inline)) {
+        float mn = 1.0e30f;
+#pragma unroll
+        for (int ua = 0; ua < UA; ++ua) {
+            const float tq = taul[row0 + 32 * ua + j];
+            float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
+            tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
+            thr_own[ua] = tf;
+            mn = fminf(mn, tf);
+            uint32_t t1, t2, t3;
+            bf16_split3(tf, t1, t2, t3);
+            t1 ^= 0x8000u;
+            t2 ^= 0x8000u;
+            t3 ^= 0x8000u;
+            const uint32_t nnu = bf16_up(nu_row[ua] * (kEps * 1.001f * 1.08f));
+            aex[ua][0] = h ? 0x3F803F80u : (t1 | (t1 << 16));
+            aex[ua][1] = h ? nnu : (t2 | (t2 << 16));
+            aex[ua][2] = h ? 0u : (t1 | (t3 << 16));
+            aex[ua][3] = h ? 0u : (t2 | (t3 << 16));
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+        thr_min = mn;
+    };
+    // the exact threshold of accumulator register r (lane half hv, A operand ua), strictly below tau (ties must pass)
+    auto thr_of = [&](int r, int hv, int ua) __attribute__((always_inline)) -> float {
+        const float tq = taul[row0 + 32 * ua + (r & 3) + 8 * (r >> 2) + 4 * hv];
+        return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
+    };
+    refresh_thr();
+    unsigned tver_seen = 0;
+
+    unsigned* ring = rings + w * kRing4;
+    unsigned tail = 0, head_c = 0;          // wave-uniform
+    // push the flagged registers of A operand ua: m bit 16 cb + 15 - r <-> register r of column block cb
+    auto push_masks = [&](uint32_t m, int ua, int loc0, int loc1) __attribute__((always_inline)) {
+        while (__any(m != 0)) {
+            const bool act = m != 0;
+            const int bit = 31 - __builtin_clz(m | 1u);
+            const int cb = bit >> 4, r = 15 - (bit & 15);
+            const int row = 32 * ua + (r & 3) + 8 * (r >> 2) + 4 * h;
+            m &= ~(1u << bit);
+            const uint64_t pm = __ballot(act);
+            if (tail + 64u - head_c > (unsigned)kRing4) {      // ring full: publish what is there and wait for the rescoring wave
+                PDA_CBAR();
+                lds_st(&s_tail[w], tail);
+                unsigned spin = 0;
+                do {
+                    head_c = lds_ld(&s_head[w]);
+                    if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 2u; break; }
+                } while (tail + 64u - head_c > (unsigned)kRing4);
+            }
+            const unsigned slot = (tail + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))) % kRing4;
+            const int idsel = cb ? loc1 : loc0;
+            if (act) ring[slot] = ((uint32_t)row << 26) | (uint32_t)idsel;
+            tail += (unsigned)__popcll(pm);
+        }
+    };
+
+    const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment (cb, m) of buffer b: + b TB + cb 32 RB + 32 m
+    int n_done = 0;
+    bool stopped = false;
+    for (int i = 0; i < n_it && !stopped; ++i) {
+        if constexpr (!(PDA_V4_ABL & 4)) if (i + 1 < n_it) issue_tile(i + 1);
+        {   // thresholds: re-read when the rescoring wave has raised one
+            const unsigned tv = lds_ld(&s_tver[w]);
+            if (tv != tver_seen) {
+                tver_seen = tv;
+                refresh_thr();
+            }
+        }
+        const unsigned char* tb = lane_base + (i & 1) * TB;
+        f32x16 acc[UA][NB];
+        // S = NB NM B reads, each feeding UA MFMAs; PF reads in flight
+        constexpr int S = NB * NM, PF = S < 6 ? S : 6;
+        auto b_load = [&](int s_) __attribute__((always_inline)) -> u32x4 {
+            const int m = s_ / NB, cb = s_ % NB;
+            return *reinterpret_cast<const u32x4*>(tb + cb * (32 * RB) + 32 * m);
+        };
+        u32x4 bq[PF];
+#pragma unroll
+        for (int s_ = 0; s_ < PF; ++s_) bq[s_] = b_load(s_);
+#pragma unroll
+        for (int s_ = 0; s_ < S; ++s_) {
+            const int m = s_ / NB, cb = s_ % NB;
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua)
+                acc[ua][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[ua][m]), __builtin_bit_cast(bf16x8, bq[s_ % PF]),
+                                                                      m == 0 ? zero16v() : acc[ua][cb], 0, 0, 0);
+            if (s_ + PF < S) bq[s_ % PF] = b_load(s_ + PF);
+        }
+        float pop_cur[NB];
+        int loc_cur[NB];
+#pragma unroll
+        for (int cb = 0; cb < NB; ++cb) {
+            u32x4 bx = *reinterpret_cast<const u32x4*>(tb + cb * (32 * RB) + 2 * D);
+            const uint2 pi = *reinterpret_cast<const uint2*>(tb - 16 * h + cb * (32 * RB) + 2 * D + 32);
+            pop_cur[cb] = __uint_as_float(pi.x);
+            loc_cur[cb] = (int)pi.y;
+            if constexpr (HEAD == PDA_HEAD_RAW) {
+                // raw head on any prep: 1/pop := 1, constant := +8e-6 (a prep built with a popularity carries its pieces);
+                // null items keep their -3e38
+                const bool nul = !(pop_cur[cb] == pop_cur[cb]);
+                bx[0] = h ? (nul ? 0x0000FF61u : bf16_up(8.0e-6f)) : 0x00003F80u;
+                bx[1] = h ? bx[1] : 0x00003F80u;
+                bx[2] = h ? 0u : 0x3F800000u;
+                bx[3] = 0u;
+            }
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua)
+                acc[ua][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex[ua]), __builtin_bit_cast(bf16x8, bx), acc[ua][cb], 0, 0, 0);
+        }
+        // ---- early termination (every 4th tile): can anything at or behind the next tile still reach one of my rows?
+        // Candidates still waiting in the ring can only raise thresholds.  Bound: pda_score_topk_v2.hip.
+        const bool vote_now = g.sufA != nullptr && (i & 3) == 3 && (i + 1) < n_it;
+        if (vote_now) {
+            const int tn = split + (kWarmTiles + i + 1) * g.n_splits;
+            const float sa = g.sufA[tn], sb = g.sufB[tn];
+            bool dead = true;
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua) dead = dead && (__builtin_fmaf(nu_row[ua], sb, sa) * 1.000002f < thr_own[ua]);
+            const bool alldead = __all(dead);
+            if (lane == 0) lds_st(&s_vote[((i >> 2) & 1) * 4 + w], alldead ? 1u : 0u);
+        }
+        // my share of tile i + 1 has landed, and I am done reading tile i
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (!(PDA_V4_ABL & 2)) if (lane == 0) __hip_atomic_fetch_add(s_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+
+        // ---- the filter: "some register of the lane is a positive float" = the signed maximum of the bit patterns is > 0 ----
+        uint64_t mc[UA][NB], many = 0;
+        bool clampy[NB];
+        if constexpr ((PDA_V4_ABL & 1) != 0) {
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+                for (int ua = 0; ua < UA; ++ua) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("" ::"v"(acc[ua][cb]));
+#endif
+                }
+        }
+#pragma unroll
+        for (int cb = 0; (PDA_V4_ABL & 1) == 0 && cb < NB; ++cb) {
+            clampy[cb] = false;
+            if constexpr (HEAD == PDA_HEAD_POP) clampy[cb] = __any(pop_cur[cb] > thr_min);     // s~ + eps < 0: head <= pop; rare once the lists are warm
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua) {
+                const f32x16& sc = acc[ua][cb];
+                int ma = max(__float_as_int(sc[0]), __float_as_int(sc[1])), mb = max(__float_as_int(sc[2]), __float_as_int(sc[3]));
+#pragma unroll
+                for (int r = 4; r < 16; r += 4) {
+                    ma = max(max(ma, __float_as_int(sc[r])), __float_as_int(sc[r + 1]));
+                    mb = max(max(mb, __float_as_int(sc[r + 2])), __float_as_int(sc[r + 3]));
+                }
+                mc[ua][cb] = __ballot(max(ma, mb) > 0);
+                if (clampy[cb]) mc[ua][cb] = ~0ull;
+                many |= mc[ua][cb];
+            }
+        }
+        if (many) {
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua) {
+                uint32_t m = 0;
+#pragma unroll
+                for (int cb = NB - 1; cb >= 0; --cb) {
+                    uint32_t mcb = 0;
+                    if (mc[ua][cb]) {
+                        // "register is a positive float" = sign bit of (0 - bits); one v_sub + one v_alignbit per register
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            mcb = __builtin_amdgcn_alignbit(mcb, 0u - (uint32_t)__float_as_int(acc[ua][cb][r]), 31);
+                        if (clampy[cb]) {
+                            int hv = h;
+                            asm volatile("" : "+v"(hv));
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mcb |= (pop_cur[cb] > thr_of(r, hv, ua)) ? (1u << (15 - r)) : 0u;
+                        }
+                    }
+                    m = (m << 16) | mcb;
+                }
+                push_masks(m, ua, loc_cur[0], loc_cur[NB - 1]);
+            }
+            PDA_CBAR();
+            lds_st(&s_tail[w], tail);
+        }
+        ++n_done;
+        // ---- wait for the other MFMA waves: tile i + 1 complete, tile i released ----
+        {
+            const unsigned want = (unsigned)kMainWaves * (unsigned)(i + 1);
+            unsigned spin = 0;
+            if constexpr (!(PDA_V4_ABL & 2))
+                while (lds_ld(s_ready) < want) {
+                    if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 1u; stopped = true; break; }
+                }
+            PDA_CBAR();
+        }
+        // every wave stored its vote of this iteration before its increment: all four are visible now, and none is
+        // overwritten before every wave has passed this point (the next vote is four increments away)
+        if (vote_now) {
+            const unsigned* v = &s_vote[((i >> 2) & 1) * 4];
+            stopped = (lds_ld(&v[0]) & lds_ld(&v[1]) & lds_ld(&v[2]) & lds_ld(&v[3])) != 0u;
+        }
+    }
+    PDA_CBAR();
+    lds_st(&s_tail[w], tail);
+    PDA_CBAR();
+    lds_st(&s_done[w], 1u);
+    if (lane == 0 && w == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * n_done * (UT / kUserTile)));
+}
+
+template <int D, int HEAD, bool BF>
+int launch4(const Args4& g, hipStream_t stream) {
+    using G = Geo4<D>;
+    {
+        constexpr int CAP = kCap4;
+        const size_t smem = 32 * D * 4 + (size_t)kUserTile * (CAP * 8 + 8) + kUserTile * 2 * kWarmTiles * 4 + 256;
+        static int attr_set = 0;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&warm4_kernel<D, HEAD, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)smem) != hipSuccess)
+                return PDA_ERR_LAUNCH;
+            attr_set = 1;
+        }
+        const int utiles = (g.n_users_blk + kUserTile - 1) / kUserTile;
+        hipLaunchKernelGGL((warm4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(kThreads), smem, stream, g);
+        PDA_CHECK_LAUNCH();
+    }
+    if ((g.n_tiles + g.n_splits - 1) / g.n_splits <= kWarmTiles) return PDA_OK;      // every split ends inside its warm-up
+    {
+        static int attr_set = 0;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)G::lds_total) != hipSuccess)
+                return PDA_ERR_LAUNCH;
+            attr_set = 1;
+        }
+        const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(512), G::lds_total, stream, g);
+        PDA_CHECK_LAUNCH();
+    }
+    return PDA_OK;
+}
+
+int user_tile4(int d) { return d <= 128 ? 256 : 128; }
+
+int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
+               int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
+               int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s) {
+    if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
+    if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
+    if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
+    if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
+    if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
+    if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
+    if (d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
+    if (K > kCap4 - 3) return PDA_ERR_UNSUPPORTED;
+    if ((uint64_t)n_items_local > (1ull << 26)) return PDA_ERR_UNSUPPORTED;          // ring words: 6-bit row, 26-bit local item id
+    if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
+    const Prep4Layout L = prep4_layout(n_items_local, d);
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
+    if (hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
+    const float* sA = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufA : L.sufB));
+    const float* sB = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufB : L.sufR));
+    // raw head: bound = ||u|| max ||i||: sufA := 0 is not stored -- the raw-head vote uses (sufB' = sufR, sufA' = 0) through
+    // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
+    Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
+            early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
+            reinterpret_cast<unsigned*>(workspace), n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles};
+    if (head == PDA_HEAD_RAW) {
+        g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
+        g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;
+    }
+#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, s) : launch4<DD, PDA_HEAD_RAW, BFV>(g, s))
+    switch (d) {
+        case 64: return bf16 ? PDA_V4_(64, true) : PDA_V4_(64, false);
+        case 128: return bf16 ? PDA_V4_(128, true) : PDA_V4_(128, false);
+        case 256: return bf16 ? PDA_V4_(256, true) : PDA_V4_(256, false);
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_V4_
+}
+
+}  // namespace
+
+extern "C" int pda_score_topk4_auto_splits(int n_users_blk, int n_items_local, int d) {
+    if (n_users_blk <= 0 || n_items_local <= 0) return 1;
+    const int ut = user_tile4(d);
+    const int utiles = (n_users_blk + ut - 1) / ut;
+    const int n_tiles = (n_items_local + 63) / 64;
+    if (utiles >= 192) return 1;
+    int s = 8;                                    // multiples of 8: the workgroups of a split share an XCD's L2 (block b -> XCD b % 8)
+    while (utiles * s < 256 && s < 64) s *= 2;
+    while (s > 1 && n_tiles / s < 2 * kWarmTiles) s /= 2;
+    return s < 8 ? (n_tiles >= 4 * kWarmTiles && utiles < 128 ? 2 : 1) : s;
+}
+
+extern "C" size_t pda_item_prep4_bytes(int n_items_local, int d) { return n_items_local > 0 ? prep4_layout(n_items_local, d).total : 0; }
+
+extern "C" int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,
+                                  void* stream) {
+    if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_prep4(I_shard, false, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_item_prep4_bf16(const uint16_t* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,
+                                   void* stream) {
+    if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_prep4(I_shard, true, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_item_prep4_check(const void* prep, int n_items_local, int d, void* stream) {
+    if (!prep || n_items_local <= 0) return PDA_ERR_ARG;
+    int bad = 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(&bad, prep, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (hipStreamSynchronize(s) != hipSuccess) return PDA_ERR_LAUNCH;
+    return bad ? PDA_ERR_ARG : PDA_OK;
+}
+
+extern "C" int pda_score_topk4_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
+                                   int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                                   const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
+                                   uint64_t* out_keys, void* workspace, void* stream) {
+    return run_score4(U, I_shard, false, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices,
+                      hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace, reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
+                                    int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                                    const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
+                                    uint64_t* out_keys, void* workspace, void* stream) {
+    return run_score4(U, I_shard, true, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices,
+                      hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace, reinterpret_cast<hipStream_t>(stream));
+}

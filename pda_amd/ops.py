@@ -150,6 +150,49 @@ def item_prep_ordered(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], 
     return buf, order
 
 
+_PREP4_CACHE = {}      # id(I_shard) -> (weakref(I), I._version, order|None, pop weakref|None, pop _version, prep buffer)
+TOPK_K_V4 = 54         # pda_score_topk4_*: K <= 54 (57 list slots per user)
+
+
+def item_prep4(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], order: Optional[torch.Tensor]) -> torch.Tensor:
+    """pda_item_prep4_f32 / _bf16 (padded item rows in visiting order + suffix bounds), cached per (weight version, pop
+    version, order object).  order None = natural item order."""
+    lib = _lib.load()
+    n, d = I_shard.shape
+    hit = _PREP4_CACHE.get(id(I_shard))
+    buf = None
+    if hit is not None and hit[0]() is I_shard:
+        buf = hit[5]
+        same_pop = (hit[3] is None and pop_shard is None) or (hit[3] is not None and hit[3]() is pop_shard and hit[4] == pop_shard._version)
+        if hit[1] == I_shard._version and hit[2] is order and same_pop:
+            return buf
+    if buf is None:
+        buf = torch.empty(lib.pda_item_prep4_bytes(n, d), dtype=torch.uint8, device=I_shard.device)
+    if order is not None:
+        order = _need(order, torch.int32, "order")
+        if order.numel() != n:
+            raise ValueError("order must have one entry per local item row")
+    fn = lib.pda_item_prep4_bf16 if I_shard.dtype == torch.bfloat16 else lib.pda_item_prep4_f32
+    check(fn(ptr(I_shard), ptr(pop_shard), ptr(order), n, d, ptr(buf), stream_ptr()), "pda_item_prep4")
+    for k in [k for k, v in _PREP4_CACHE.items() if v[0]() is None]:
+        del _PREP4_CACHE[k]
+    _PREP4_CACHE[id(I_shard)] = (weakref.ref(I_shard), I_shard._version, order,
+                                 weakref.ref(pop_shard) if pop_shard is not None else None,
+                                 pop_shard._version if pop_shard is not None else 0, buf)
+    return buf
+
+
+def score_kernel(d: int, K: int, nloc: int) -> str:
+    """Which pre-filtered kernel generation serves a call: 'v4' (pda_score_topk_v4.hip) wherever it applies, else the v2/v3
+    entry points.  PDA_SCORE_KERNEL=v2|v3|v4 forces one (A/B measurements, cross-checks)."""
+    import os
+    forced = os.environ.get("PDA_SCORE_KERNEL", "")
+    fits = d in (64, 128, 256) and K <= TOPK_K_V4 and nloc <= (1 << 26)
+    if forced in ("v2", "v3", "old"):      # "old": whatever the v2/v3 entry points pick
+        return forced
+    return "v4" if fits else "v3"
+
+
 def check_order(prep_ord: torch.Tensor, n: int, d: int):
     """Synchronising: raises if the order given to item_prep_ordered was not a permutation of 0..n-1."""
     check(_lib.load().pda_item_prep_ordered_check(ptr(prep_ord), n, d, stream_ptr()), "pda_item_prep_ordered_check")
@@ -247,6 +290,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         _check_pop(pop_shard)
     if hist is not None and hist.indices.numel() == 0:
         hist = None                       # an all-empty mask: the kernel must never dereference a 0-length buffer
+    n_splits_auto = n_splits <= 0
+    out_given = out
     if n_splits <= 0:
         n_splits = lib.pda_score_topk_auto_splits(nu, nloc)
     if out is None:
@@ -256,6 +301,22 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     impl = impl or score_impl(d, K, item_offset + nloc)
     if prune is None:
         prune = prune_default(head)
+    if impl == "v2" and score_kernel(d, K, nloc) == "v4":
+        order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
+        prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
+        if n_splits_auto and out_given is None:
+            n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
+            out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
+        ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)
+        fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
+        check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+                 ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
+                 K, head, 1 if prune is True else 0, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
+        if stats is not None:
+            stats["tiles_scored"] = ws[8:16].view(torch.int64)
+            stats["pairs_rescored"] = ws[4:8].view(torch.int32)
+            stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)
+        return out
     if impl == "v2" and prune:
         prep, order = item_prep_ordered(I_shard, pop_shard if head == HEAD_POP else None)
         hist_ord = hist_reordered(hist, prep, order, item_offset, nloc, d) if hist else None
