@@ -31,6 +31,7 @@
 // Error bound of the filter, folded test, tie handling: pda_score_topk_v3.hip (unchanged).
 #include "pda_topk_common.h"
 #include <cstdlib>
+#include <type_traits>
 
 using namespace pda_topk;
 
@@ -42,6 +43,19 @@ constexpr int kWarmTiles = 4;        // 64-item tiles per split scored by warm4_
 constexpr int kMainWaves = 4;
 #ifndef PDA_V4_ABL
 #define PDA_V4_ABL 0      // timing-only ablations (results are wrong): 1 no filter, 2 no hand-over between MFMA waves, 4 no tile loads, 8 rescoring waves leave at once
+#endif
+#ifdef PDA_V4_PROF
+// profiling build only (tools/build_variant.sh prof -DPDA_V4_PROF): cycle counters summed over waves
+__device__ unsigned long long pda_prof4[16];
+#define PROF_T0(v) const long long v = __builtin_readcyclecounter()
+#define PROF_T1(v, slot) prof[slot] += (unsigned long long)(__builtin_readcyclecounter() - v)
+#define PROF_INC(slot, x) prof[slot] += (unsigned long long)(x)
+#define PROF_FLUSH(first, last) do { if (lane == 0) for (int pq = (first); pq <= (last); ++pq) atomicAdd(&pda_prof4[pq], prof[pq]); } while (0)
+#else
+#define PROF_T0(v) do {} while (0)
+#define PROF_T1(v, slot) do {} while (0)
+#define PROF_INC(slot, x) do {} while (0)
+#define PROF_FLUSH(first, last) do {} while (0)
 #endif
 constexpr unsigned kSpinMax = 1u << 26;   // every spin is bounded: a protocol error sets stats[0] and leaves instead of hanging the GPU
 
@@ -260,11 +274,13 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
         }
         if (!__any(ov)) break;
         pda_wave_sync();
-        uint64_t full = __ballot(lane < n_rows && cntl[row0 + (lane < n_rows ? lane : 0)] >= CAP);
-        while (full) {
-            const int rr = __builtin_ctzll(full);
-            full &= full - 1ull;
-            compact_list<CAP>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+        for (int base = 0; base < n_rows; base += 64) {
+            uint64_t full = __ballot(base + lane < n_rows && cntl[row0 + (base + lane < n_rows ? base + lane : 0)] >= CAP);
+            while (full) {
+                const int rr = base + __builtin_ctzll(full);
+                full &= full - 1ull;
+                compact_list<CAP>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+            }
         }
         changed = true;
         p = ov && (tt >= taul[lrow]);
@@ -405,37 +421,53 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // ---------------------------------------------------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------------------------------------------------
+constexpr int kLoaders = 2;          // waves 4, 5: LDS-DMA only
+constexpr int kRescorers = 2;        // waves 6, 7: rescoring wave r serves the MFMA waves 2 r and 2 r + 1
+
 template <int D>
 struct Geo4 {
     static constexpr int UA = D <= 128 ? 2 : 1;          // A operands (32 user rows each) per MFMA wave
     static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
     static constexpr int UT = kMainWaves * ROWS;         // user rows per workgroup
-    static constexpr int NB = 2;                         // 32-column blocks per tile
-    static constexpr int RB = row_bytes(D), TB = tile_bytes(D), NCH = TB / 1024;
-    static constexpr size_t lds_tiles = 2 * (size_t)TB;
+    static constexpr int RB = row_bytes(D), TB = tile_bytes(D);
+    static constexpr int HB = 32 * RB;                   // one 32-item half-tile = one column block = one ring slot
+    static constexpr int NP = (HB + 1023) / 1024;        // 1 KiB DMA pieces per half-tile; the last one covers HB % 1024 = 512 bytes (32 lanes)
+    static constexpr size_t lds_tiles = 4 * (size_t)HB;
     static constexpr size_t lds_lists = (size_t)UT * kCap4 * 8;
     static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 256;
 };
 
+// Workgroup = 8 waves, no s_barrier after the start:
+//   waves 0..3  MFMA waves: 32 UA user rows each; per half-tile (32 items) NM + 1 MFMAs per A operand.  The filter of half
+//               h - 1 (integer maxima over its accumulators) is issued between the MFMAs of half h.
+//   waves 4, 5  loaders: half-tile h goes into ring slot h & 3 as soon as every MFMA wave has released half h - 4.  An
+//               LDS-DMA piece costs its issuing wave ~100 cycles of issue time; in the MFMA waves those were 0.8 of 3.7 ms.
+//   waves 6, 7  rescoring waves (lists, exact rescoring, thresholds) of 2 ROWS user rows each.
+// Hand-over words in LDS (monotonic counters, relaxed LDS atomics; the LDS executes a wave's operations in order):
+//   landed    += 1 per loader and half-tile, after its pieces have landed (s_waitcnt vmcnt)
+//   released  += 1 per MFMA wave and half-tile, after its last LDS read of the slot
 template <int D, int HEAD, bool BF>
 __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
     using G = Geo4<D>;
-    constexpr int UA = G::UA, ROWS = G::ROWS, UT = G::UT, NB = G::NB, RB = G::RB, TB = G::TB, NCH = G::NCH;
+    constexpr int UA = G::UA, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, NP = G::NP;
     constexpr int NM = D / 16;
     constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* tiles = smem;                                                             // 2 x TB
+    unsigned char* tiles = smem;                                                             // 4 x HB
     uint64_t* lists = reinterpret_cast<uint64_t*>(smem + G::lds_tiles);                      // [UT][kCap4] exact keys
     int* cntl = reinterpret_cast<int*>(lists + (size_t)UT * kCap4);                          // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                                       // [UT] exact K-th value (-inf until K entries)
     unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [4][kRing4]
-    unsigned* sync = rings + kMainWaves * kRing4;                                            // see below
-    unsigned* s_ready = sync;                 // [1]  monotonic: += 1 per MFMA wave and tile
-    unsigned* s_tail = sync + 4;              // [4]  ring write positions (MFMA wave w)
-    unsigned* s_head = sync + 8;              // [4]  ring read positions (rescoring wave w)
-    unsigned* s_tver = sync + 12;             // [4]  bumped by the rescoring wave whenever a threshold of its rows rose
+    unsigned* sync = rings + kMainWaves * kRing4;
+    unsigned* s_landed = sync;                // [2]  per loader: half-tiles whose pieces (of that loader) have landed
+    unsigned* s_tver = sync + 36;             // [4]  per MFMA wave: bumped by its rescoring wave whenever a threshold of its rows rose
+    unsigned* s_stop = sync + 3;              // [1]  early termination: loaders leave
+    unsigned* s_released = sync + 4;          // [4]  per MFMA wave: half-tiles released (one word per writer: a sum would not
+                                              //      tell "everyone is past h" from "three are ahead, one is behind")
+    unsigned* s_tail = sync + 8;              // [4]  ring write positions (MFMA wave w)
+    unsigned* s_head = sync + 12;             // [4]  ring read positions
     unsigned* s_done = sync + 16;             // [4]  MFMA wave w has pushed its last candidate
-    unsigned* s_vote = sync + 20;             // [2][4]  early termination votes
+    unsigned* s_vote = sync + 20;             // [4][4]  early termination votes of checkpoint c & 3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -443,25 +475,35 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - kWarmTiles);                    // tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
-    if (tid < 32) sync[tid] = 0u;
+    const int n_half = 2 * n_it;
+    if (tid < 64) sync[tid] = 0u;
+#ifdef PDA_V4_PROF
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
-    if (wave >= kMainWaves) {
+    if (wave >= kMainWaves + kLoaders) {
         // ============================== rescoring wave ==============================
-        const int w = wave - kMainWaves;
-        const int row0 = w * ROWS;
+        constexpr int RR = 2 * ROWS;                         // rows of this wave
+        const int r = wave - kMainWaves - kLoaders;
+        const int row0 = r * RR;
         uint64_t* my_lists = lists + (size_t)row0 * kCap4;
-        // lane l <-> row l of the wave: user id, history range, initial list
-        const int rb_l = utile * UT + row0 + lane;
-        const bool rok_l = lane < ROWS && rb_l < g.n_users_blk;
-        const int uid = rok_l ? g.users[rb_l] : 0;
-        int64_t hbeg = 0, hend = 0;
+        // lane l <-> rows l and 64 + l of the wave: user id, history range
+        int uidv[2] = {0, 0};
+        int64_t hbv[2] = {0, 0}, hev[2] = {0, 0};
         const bool hist_on = g.hist_indptr != nullptr;
-        if (hist_on && rok_l) {
-            const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)rb_l;
-            hbeg = g.hist_indptr[hr];
-            hend = g.hist_indptr[hr + 1];
+#pragma unroll
+        for (int s2 = 0; s2 < (RR + 63) / 64; ++s2) {
+            const int rl = 64 * s2 + lane;
+            const int rb_l = utile * UT + row0 + rl;
+            const bool ok = rl < RR && rb_l < g.n_users_blk;
+            uidv[s2] = ok ? g.users[rb_l] : 0;
+            if (hist_on && ok) {
+                const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uidv[s2] : (int64_t)rb_l;
+                hbv[s2] = g.hist_indptr[hr];
+                hev[s2] = g.hist_indptr[hr + 1];
+            }
         }
-        for (int rr = 0; rr < ROWS; ++rr) {
+        for (int rr = 0; rr < RR; ++rr) {
             const int rb = utile * UT + row0 + rr;
             uint64_t key = 0ull;
             if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane];
@@ -474,40 +516,60 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             }
         }
         __syncthreads();
-        unsigned head = 0, n_cand = 0, tver = 0;
-        unsigned* ring = rings + w * kRing4;
+        unsigned head[2] = {0, 0}, n_cand = 0;
         constexpr int LPC = D / 32;                 // lanes per candidate: each owns 32 consecutive k
         constexpr int CPP = 64 / LPC;               // candidates per pass
         const int q = lane % LPC, ci = lane / LPC;
-        unsigned idle = 0;
-        for (;;) {
-            if constexpr ((PDA_V4_ABL & 8) != 0) break;
-            const unsigned dn = lds_ld(&s_done[w]);
-            const unsigned tail = lds_ld(&s_tail[w]);
-            if (tail == head) {
-                if (dn) break;
-                if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
-                __builtin_amdgcn_s_sleep(8);
-                continue;
-            }
-            idle = 0;
-            PDA_CBAR();
-            const int n = min((int)(tail - head), CPP);
-            n_cand += (unsigned)n;
-            const bool valid = ci < n;
-            const unsigned word = valid ? ring[(head + (unsigned)ci) % kRing4] : 0u;
-            const int row = (int)(word >> 26);
-            const int loc = (int)(word & 0x3FFFFFFu);                               // local item id
-            const int urow = __shfl(uid, row, 64);
-            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)loc * D + q * 32;
+        // Two passes in flight: the gathers of one pass are issued before the other pass is computed -- a pass is a chain of
+        // dependent latencies (ring word -> rows -> fmaf chain -> history lookup -> list), and the two rescoring waves of a
+        // workgroup have to keep up with four MFMA waves.
+        struct Pass {
             f32x4 uu[8], ii[8];
+            float pv;
+            int row, loc, n;
+            bool valid;
+        };
+        int sel = 0;                                // which of the two rings the next pass looks at first
+        bool all_done = false;
+        // stage A: claim up to CPP entries of one ring and issue their gathers
+        auto stage_a = [&](Pass& s) __attribute__((always_inline)) {
+            const unsigned dn0 = lds_ld(&s_done[2 * r]), dn1 = lds_ld(&s_done[2 * r + 1]);     // read BEFORE the tails
+            const unsigned tl0 = lds_ld(&s_tail[2 * r]), tl1 = lds_ld(&s_tail[2 * r + 1]);
+            const bool e0 = tl0 == head[0], e1 = tl1 == head[1];
+            s.n = 0;
+            s.valid = false;
+            if (e0 && e1) {
+                all_done = dn0 && dn1;
+                return;
+            }
+            sel = (sel == 0) ? (e1 ? 0 : 1) : (e0 ? 1 : 0);          // the ring looked at last time goes second
+            const unsigned tail = sel ? tl1 : tl0;
+            const unsigned hd = sel ? head[1] : head[0];
+            const unsigned* ring = rings + (2 * r + sel) * kRing4;
+            PDA_CBAR();
+            const int n = min((int)(tail - hd), CPP);
+            n_cand += (unsigned)n;
+            s.n = n;
+            s.valid = ci < n;
+            const unsigned word = s.valid ? ring[(hd + (unsigned)ci) % kRing4] : 0u;
+            s.row = sel * ROWS + (int)(word >> 26);                         // row of this wave
+            s.loc = (int)(word & 0x3FFFFFFu);                               // local item id
+            int urow = __shfl(uidv[0], s.row & 63, 64);
+            if constexpr (RR > 64) { const int u1 = __shfl(uidv[1], s.row & 63, 64); urow = s.row >= 64 ? u1 : urow; }
+            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)s.loc * D + q * 32;
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
-                ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
+                s.uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
+                s.ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
             }
-            float pv = 1.0f;
-            if constexpr (HEAD == PDA_HEAD_POP) pv = g.pop[loc];
+            s.pv = 1.0f;
+            if constexpr (HEAD == PDA_HEAD_POP) s.pv = g.pop[s.loc];
+            if (sel) head[1] += (unsigned)n; else head[0] += (unsigned)n;
+            PDA_CBAR();
+            lds_st(&s_head[2 * r + sel], sel ? head[1] : head[0]);          // the words are in registers: the slots are free
+        };
+        // stage B: exact score, threshold, history, list
+        auto stage_b = [&](Pass& s) __attribute__((always_inline)) {
             float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
             for (int ph = 0; ph < LPC; ++ph) {
@@ -518,11 +580,11 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
 #pragma unroll
                     for (int sidx = 0; sidx < 4; ++sidx) {
                         if (cc & 1) {
-                            o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
-                            o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
+                            o1 = __builtin_fmaf(s.uu[2 * cc][sidx], s.ii[2 * cc][sidx], o1);
+                            o1 = __builtin_fmaf(s.uu[2 * cc + 1][sidx], s.ii[2 * cc + 1][sidx], o1);
                         } else {
-                            o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
-                            o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
+                            o0 = __builtin_fmaf(s.uu[2 * cc][sidx], s.ii[2 * cc][sidx], o0);
+                            o0 = __builtin_fmaf(s.uu[2 * cc + 1][sidx], s.ii[2 * cc + 1][sidx], o0);
                         }
                     }
                 }
@@ -535,16 +597,22 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
                 }
             }
             float sc = o0 + o1;                               // meaningful on the candidate's last lane
-            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
-            const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
+            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * s.pv;
+            const float tt = (s.valid && q == LPC - 1) ? sc : -INFINITY;
+            const int row = s.row;
             const int lrow = row0 + row;
-            const int item = g.item_offset + loc;
+            const int item = g.item_offset + s.loc;
             // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in
-            bool p = valid && q == LPC - 1 && (tt >= taul[lrow]);
+            bool p = s.valid && q == LPC - 1 && (tt >= taul[lrow]);
             if (hist_on) {
                 // train items are masked HERE: one binary search in the row's id-sorted history for a candidate that has
                 // passed the filter and the exact threshold
-                int64_t lo = __shfl(hbeg, row, 64), hi = __shfl(hend, row, 64);
+                int64_t lo = __shfl(hbv[0], row & 63, 64), hi = __shfl(hev[0], row & 63, 64);
+                if constexpr (RR > 64) {
+                    const int64_t lo1 = __shfl(hbv[1], row & 63, 64), hi1 = __shfl(hev[1], row & 63, 64);
+                    lo = row >= 64 ? lo1 : lo;
+                    hi = row >= 64 ? hi1 : hi;
+                }
                 const int64_t he = hi;
                 if (p) {
                     while (lo < hi) {
@@ -555,15 +623,36 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
                 }
             }
             const uint64_t key = pda_pack_key(tt, (uint32_t)item);
-            const bool changed = append_keys<kCap4>(p, lrow, tt, key, lists, cntl, taul, row0, ROWS, K, lane);
-            head += (unsigned)n;
-            PDA_CBAR();
-            lds_st(&s_head[w], head);
-            if (changed) lds_st(&s_tver[w], ++tver);
+            const bool changed = append_keys<kCap4>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane);
+            if (changed && lane == 0) __hip_atomic_fetch_add(&s_tver[2 * r + (row >= ROWS ? 1 : 0)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        Pass s0, s1;
+        unsigned idle = 0;
+        if constexpr ((PDA_V4_ABL & 8) == 0) {
+            PROF_T0(tr0);
+            stage_a(s0);
+            for (;;) {
+                stage_a(s1);
+                if (s0.n) { PROF_INC(8, 1); stage_b(s0); }
+                stage_a(s0);
+                if (s1.n) { PROF_INC(8, 1); stage_b(s1); }
+                if (s0.n == 0 && s1.n == 0) {
+                    if (all_done) break;
+                    if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
+                    PROF_T0(ti);
+                    __builtin_amdgcn_s_sleep(8);
+                    PROF_T1(ti, 7);
+                } else {
+                    idle = 0;
+                }
+            }
+            PROF_T1(tr0, 6);
+            PROF_INC(9, n_cand);
+            PROF_FLUSH(6, 9);
         }
         if (lane == 0) atomicAdd(g.stats + 1, n_cand);
         // finalise: the lists are exact; sort and emit
-        for (int rr = 0; rr < ROWS; ++rr) {
+        for (int rr = 0; rr < RR; ++rr) {
             uint64_t* buf = my_lists + (size_t)rr * kCap4;
             compact_list<kCap4>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
             const int c = cntl[row0 + rr];
@@ -573,6 +662,62 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
                 g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
             }
         }
+        return;
+    }
+
+    if (wave >= kMainWaves) {
+        // ================================== loader ==================================
+        // Issued through inline asm: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+        // s_waitcnt vmcnt(0) in front of the next ds_read of ANY address (the hand-over polls): the loads would be
+        // synchronous.  M0 = LDS byte address of the piece, saved and restored inside the statement.
+        const int l = wave - kMainWaves;
+        const unsigned lds_tiles0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
+        __syncthreads();
+        constexpr int MYP = (NP + kLoaders - 1) / kLoaders;       // pieces per loader and half-tile (the last loader may have one less)
+        constexpr int MINP = NP / kLoaders;
+        bool stop = false;
+        PROF_T0(tl0);
+        for (int hf = 0; hf < n_half && !stop; ++hf) {
+            if (hf >= 4) {                                         // slot hf & 3 is free once every MFMA wave has released half hf - 4
+                const unsigned want = (unsigned)(hf - 3);
+                unsigned spin = 0;
+                PROF_T0(tw);
+                while (min(min(lds_ld(&s_released[0]), lds_ld(&s_released[1])), min(lds_ld(&s_released[2]), lds_ld(&s_released[3]))) < want) {
+                    if (lds_ld(s_stop)) { stop = true; break; }
+                    if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 4u; stop = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                PROF_T1(tw, 11);
+                if (stop) break;
+            }
+            const int t = split + (kWarmTiles + (hf >> 1)) * g.n_splits;
+            [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * G::TB + (size_t)(hf & 1) * HB + lane * 16;
+            [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((hf & 3) * HB);
+#pragma unroll
+            for (int c = 0; c < MYP; ++c) {
+                const int piece = l + kLoaders * c;
+                if (piece < NP && (piece < NP - 1 || lane < 32)) {           // the last piece is half a piece
+#if defined(__HIP_DEVICE_COMPILE__)
+                    unsigned keep;
+                    const unsigned char* gsrc = src + (size_t)piece * 1024;
+                    const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + (unsigned)piece * 1024u);
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+#endif
+                }
+            }
+            // the pieces of the PREVIOUS half have landed once at most this half's are outstanding (loads return in order)
+            if (hf > 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINP) : "memory");
+#endif
+                lds_st(&s_landed[l], (unsigned)hf);            // halves 0 .. hf - 1
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!stop && n_half > 0) lds_st(&s_landed[l], (unsigned)n_half);
+        PROF_T1(tl0, 10);
+        PROF_FLUSH(10, 11);
         return;
     }
 
@@ -598,45 +743,22 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             }
             u32x4 lo_unused;
             split8(x, y, ah[ua][m], lo_unused);
+            // The A side is NEGATED (all of it, the extra k-step too): the accumulators hold -(s~ - thr/pop + 1 + eps), and
+            // "candidate" is "negative", i.e. the SIGN BIT -- which one v_alignbit per register shifts into a per-lane mask.
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ah[ua][m][k] ^= 0x80008000u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
         }
         ss += __shfl_xor(ss, 32, 64);
         nu_row[ua] = sqrtf(ss) * 1.0009765625f * 1.0001f;              // padded ||u||
     }
-
-    // tile i of the loop -> LDS buffer i & 1.  This wave's share: the 1 KiB pieces w, w + 4, ...
-    // Issued through inline asm: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
-    // s_waitcnt vmcnt(0) in front of the next ds_read of ANY address -- the tile load became synchronous (measured: 1.2 of
-    // 4.4 ms).  The asm statement is invisible to that bookkeeping; this wave waits for its own pieces explicitly
-    // (vmcnt(0) before its increment of the hand-over counter).  M0 = LDS byte address of the piece, saved and restored.
-    const unsigned lds_tiles0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
-    auto issue_tile = [&](int i) __attribute__((always_inline)) {
-        int t = split + (kWarmTiles + i) * g.n_splits;
-        if constexpr ((PDA_V4_ABL & 16) != 0) t &= 7;          // timing only: eight L2-resident tiles
-        [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * TB + lane * 16;
-        [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((i & 1) * TB);
-#pragma unroll
-        for (int c = 0; c < (NCH + kMainWaves - 1) / kMainWaves; ++c) {
-            const int piece = w + kMainWaves * c;
-            if (piece < NCH) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                unsigned keep;
-                const unsigned char* gsrc = src + (size_t)piece * 1024;
-                const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + (unsigned)piece * 1024u);
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
-#endif
-            }
-        }
-    };
-    if (n_it > 0) issue_tile(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                       // lists, thresholds and sync words are initialised; tile 0 has landed
+    __syncthreads();                       // lists, thresholds and hand-over words are initialised
 
     // thresholds of the lane's own rows (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative (the rounding of the
     // extra k-step, pda_score_topk_v3.hip), as the A operand of the extra k-step:
-    //   k 0..7 (lanes < 32): -(t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: +1, +1, +eps scale of the row
+    //   k 0..7 (lanes < 32): (t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: -1, -1, -eps scale of the row
+    //   (negated like the rest of the A side: v3 carries the opposite signs)
     float thr_own[UA], thr_min = 0.f;
     u32x4 aex[UA];
     auto refresh_thr = [&]() __attribute__((always_inline)) {
@@ -650,11 +772,8 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             mn = fminf(mn, tf);
             uint32_t t1, t2, t3;
             bf16_split3(tf, t1, t2, t3);
-            t1 ^= 0x8000u;
-            t2 ^= 0x8000u;
-            t3 ^= 0x8000u;
-            const uint32_t nnu = bf16_up(nu_row[ua] * (kEps * 1.001f * 1.08f));
-            aex[ua][0] = h ? 0x3F803F80u : (t1 | (t1 << 16));
+            const uint32_t nnu = bf16_up(nu_row[ua] * (kEps * 1.001f * 1.08f)) | 0x8000u;
+            aex[ua][0] = h ? 0xBF80BF80u : (t1 | (t1 << 16));
             aex[ua][1] = h ? nnu : (t2 | (t2 << 16));
             aex[ua][2] = h ? 0u : (t1 | (t3 << 16));
             aex[ua][3] = h ? 0u : (t2 | (t3 << 16));
@@ -669,16 +788,16 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
         return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
     };
     refresh_thr();
-    unsigned tver_seen = 0;
+    unsigned tver_seen = 0, landed_c = 0;
 
     unsigned* ring = rings + w * kRing4;
     unsigned tail = 0, head_c = 0;          // wave-uniform
-    // push the flagged registers of A operand ua: m bit 16 cb + 15 - r <-> register r of column block cb
-    auto push_masks = [&](uint32_t m, int ua, int loc0, int loc1) __attribute__((always_inline)) {
+    // push the flagged registers (bit 15 - r <-> register r) of A operand ua
+    auto push_mask = [&](uint32_t m, int ua, int loc) __attribute__((always_inline)) {
         while (__any(m != 0)) {
             const bool act = m != 0;
             const int bit = 31 - __builtin_clz(m | 1u);
-            const int cb = bit >> 4, r = 15 - (bit & 15);
+            const int r = 15 - bit;
             const int row = 32 * ua + (r & 3) + 8 * (r >> 2) + 4 * h;
             m &= ~(1u << bit);
             const uint64_t pm = __ballot(act);
@@ -686,166 +805,243 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
                 PDA_CBAR();
                 lds_st(&s_tail[w], tail);
                 unsigned spin = 0;
+                PROF_T0(tq);
                 do {
                     head_c = lds_ld(&s_head[w]);
                     if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 2u; break; }
                 } while (tail + 64u - head_c > (unsigned)kRing4);
+                PROF_T1(tq, 2);
             }
             const unsigned slot = (tail + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))) % kRing4;
-            const int idsel = cb ? loc1 : loc0;
-            if (act) ring[slot] = ((uint32_t)row << 26) | (uint32_t)idsel;
+            if (act) ring[slot] = ((uint32_t)row << 26) | (uint32_t)loc;
             tail += (unsigned)__popcll(pm);
         }
     };
+    auto ensure_landed = [&](int hf) __attribute__((always_inline)) {
+        const unsigned want = (unsigned)(hf + 1);
+        if (landed_c < want) {
+            unsigned spin = 0;
+            PROF_T0(te);
+            do {
+                landed_c = min(lds_ld(&s_landed[0]), lds_ld(&s_landed[1]));
+                if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 1u; break; }
+            } while (landed_c < want);
+            PROF_T1(te, 1);
+            PDA_CBAR();
+        }
+    };
+    const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment m of ring slot s: + s HB + 32 m
 
-    const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment (cb, m) of buffer b: + b TB + cb 32 RB + 32 m
+    // one half-tile: NM + 1 MFMAs per A operand into acc; bq holds its first PF fragments on entry and those of the next
+    // half on exit (has_next; the next half must have landed)
+    constexpr int PF = NM < 4 ? NM : 4;
+    u32x4 bq[PF];
+    auto load_first = [&](int hf) __attribute__((always_inline)) {
+        const unsigned char* tb = lane_base + (hf & 3) * HB;
+#pragma unroll
+        for (int m = 0; m < PF; ++m) bq[m] = *reinterpret_cast<const u32x4*>(tb + 32 * m);
+    };
+    // One half-tile: NM + 1 MFMAs per A operand into acc.  bq holds its first PF fragments on entry and those of the next half on
+    // exit (the next half must have landed; behind the last half the reads hit a stale slot and are never used).
+    // TEST: the filter on the PREVIOUS half runs in the shadow of these MFMAs -- the lane's mask of negative accumulator
+    // registers (bit 15 - r <-> register r), one v_alignbit per register, 32 / NM of them behind every MFMA pair (pinned with
+    // sched_group_barrier: left alone hipcc puts all of them behind the last MFMA, 500 exposed cycles per tile).
+    auto mfma_half = [&](int hf, f32x16 (&acc)[UA], float& popv, int& locv, auto test_tag, const f32x16 (&prev)[UA],
+                         uint32_t (&msk)[UA]) __attribute__((always_inline)) {
+        constexpr bool TEST = decltype(test_tag)::value;
+        constexpr int RPS = 16 / NM > 0 ? 16 / NM : 1;          // accumulator registers of `prev` tested per k-step
+        const unsigned char* tb = lane_base + (hf & 3) * HB;
+        const unsigned char* tbn = lane_base + ((hf + 1) & 3) * HB;
+        u32x4 bx = *reinterpret_cast<const u32x4*>(tb + 2 * D);
+        const uint2 pi = *reinterpret_cast<const uint2*>(tb - 16 * h + 2 * D + 32);
+#pragma unroll
+        for (int ua = 0; ua < UA; ++ua) msk[ua] = 0u;
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua)
+                acc[ua] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[ua][m]), __builtin_bit_cast(bf16x8, bq[m % PF]),
+                                                                  m == 0 ? zero16v() : acc[ua], 0, 0, 0);
+            if (m + PF < NM) bq[m % PF] = *reinterpret_cast<const u32x4*>(tb + 32 * (m + PF));
+            else bq[m % PF] = *reinterpret_cast<const u32x4*>(tbn + 32 * (m + PF - NM));
+            if constexpr (TEST) {
+                // OR of the bit patterns: "some register of the lane is negative" is its sign bit.  (v_alignbit_b32 -- the exact
+                // per-register mask -- is a quarter-rate instruction: 64 of them per tile cost as much as the MFMAs; the exact
+                // mask is built in the slow path, for the rare half with a candidate.)
+                if (m * RPS < 16) {
+#pragma unroll
+                    for (int ua = 0; ua < UA; ++ua)
+#pragma unroll
+                        for (int r = m * RPS; r < (m + 1) * RPS; ++r) {
+                            if constexpr ((PDA_V4_ABL & 128) != 0) msk[ua] |= ah[ua][r % NM][r % 4] & 0x7fffffffu;      // timing only: not an MFMA result
+                            else msk[ua] |= (uint32_t)__float_as_int(prev[ua][r]);
+                        }
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_group_barrier(0x008, UA, 0);
+            if constexpr (TEST) __builtin_amdgcn_sched_group_barrier(0x002, (UA * RPS + 1) / 2, 0);      // v_or3_b32 takes two registers at a time
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // (two: the reads of the test pieces and of (pop, id) ride along)
+#endif
+        }
+        popv = __uint_as_float(pi.x);
+        locv = (int)pi.y;
+        if constexpr (HEAD == PDA_HEAD_RAW) {
+            // raw head on any prep: 1/pop := 1, constant := +8e-6 (a prep built with a popularity carries its pieces);
+            // null items keep their -3e38
+            const bool nul = !(popv == popv);
+            bx[0] = h ? (nul ? 0x0000FF61u : bf16_up(8.0e-6f)) : 0x00003F80u;
+            bx[1] = h ? bx[1] : 0x00003F80u;
+            bx[2] = h ? 0u : 0x3F800000u;
+            bx[3] = 0u;
+        }
+#pragma unroll
+        for (int ua = 0; ua < UA; ++ua)
+            acc[ua] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex[ua]), __builtin_bit_cast(bf16x8, bx), acc[ua], 0, 0, 0);
+        PDA_CBAR();
+        lds_st(&s_released[w], (unsigned)(hf + 1));
+        PDA_CBAR();
+    };
+    // what is left of the filter outside the MFMA shadow: "any lane flagged", and the clamp check of the popularity head
+    auto test_done = [&](const uint32_t (&msk)[UA], float popv, bool& clampy) __attribute__((always_inline)) -> bool {
+        bool many = false;
+        clampy = false;
+        if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv > thr_min);     // s~ + eps < 0: head <= pop; rare once the lists are warm
+#pragma unroll
+        for (int ua = 0; ua < UA; ++ua) many = many || __any((int)msk[ua] < 0);
+        return many || clampy;
+    };
+    // the same mask outside an MFMA block (the last half of the sweep)
+    auto test_plain = [&](const f32x16 (&acc)[UA], uint32_t (&msk)[UA]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ua = 0; ua < UA; ++ua) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m |= (uint32_t)__float_as_int(acc[ua][r]);
+            msk[ua] = m;
+        }
+    };
+    auto slow_half = [&](const f32x16 (&acc)[UA], float popv, int locv, const uint32_t (&msk)[UA], bool clampy) __attribute__((always_inline)) {
+        PROF_T0(ts);
+        PROF_INC(4, 1);
+        if (clampy) PROF_INC(14, 1);
+#pragma unroll
+        for (int ua = 0; ua < UA; ++ua) {
+            uint32_t mcb = 0;
+            if (__any((int)msk[ua] < 0)) {
+                // the exact mask: bit 15 - r <-> register r is negative (one v_alignbit per register shifts the sign bit in)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(acc[ua][r]), 31);
+            }
+            if (clampy) {
+                int hv = h;
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(hv));
+#endif
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mcb |= (popv > thr_of(r, hv, ua)) ? (1u << (15 - r)) : 0u;
+            }
+            if constexpr ((PDA_V4_ABL & 64) == 0) push_mask(mcb, ua, locv);
+        }
+        PDA_CBAR();
+        lds_st(&s_tail[w], tail);
+        PROF_T1(ts, 3);
+    };
+
+    PROF_T0(tm0);
+    f32x16 accA[UA], accB[UA];
+    float popA = 0.f, popB = 0.f;
+    int locA = 0, locB = 0;
+    uint32_t mkA[UA], mkB[UA];
+    [[maybe_unused]] uint32_t dummy = 0;
     int n_done = 0;
     bool stopped = false;
+    const std::true_type with_test{};
+    const std::false_type no_test{};
+    if (n_it > 0) {
+        ensure_landed(0);
+        load_first(0);
+        ensure_landed(1);
+        mfma_half(0, accA, popA, locA, no_test, accA, mkB);
+    }
     for (int i = 0; i < n_it && !stopped; ++i) {
-        if constexpr (!(PDA_V4_ABL & 4)) if (i + 1 < n_it) issue_tile(i + 1);
-        {   // thresholds: re-read when the rescoring wave has raised one
-            const unsigned tv = lds_ld(&s_tver[w]);
-            if (tv != tver_seen) {
-                tver_seen = tv;
-                refresh_thr();
+        const bool more = (i + 1) < n_it;
+        // the hand-over words, read here and used at the end of the iteration (the read is off the critical path)
+        const unsigned pr_l0 = lds_ld(&s_landed[0]), pr_l1 = lds_ld(&s_landed[1]), pr_tv = lds_ld(&s_tver[w]);
+        // ---- odd half of tile i -> accB, while the filter runs on accA (even half of tile i) ----
+        if (more) ensure_landed(2 * i + 2);
+        const float popT = popA;
+        const int locT = locA;
+        mfma_half(2 * i + 1, accB, popB, locB, with_test, accA, mkA);
+        if constexpr ((PDA_V4_ABL & 256) != 0) {
+            dummy |= mkA[0] | mkA[UA - 1];
+        } else if constexpr ((PDA_V4_ABL & 1) == 0) {
+            bool clampA;
+            if (test_done(mkA, popT, clampA)) slow_half(accA, popT, locT, mkA, clampA);
+        }
+        // ---- even half of tile i + 1 -> accA, while the filter runs on accB ----
+        if (more) {
+            ensure_landed(2 * i + 3);
+            const float popS = popB;
+            const int locS = locB;
+            mfma_half(2 * i + 2, accA, popA, locA, with_test, accB, mkB);
+            if constexpr ((PDA_V4_ABL & 256) != 0) {
+                dummy |= mkB[0] | mkB[UA - 1];
+            } else if constexpr ((PDA_V4_ABL & 1) == 0) {
+                bool clampB;
+                if (test_done(mkB, popS, clampB)) slow_half(accB, popS, locS, mkB, clampB);
             }
-        }
-        const unsigned char* tb = lane_base + (i & 1) * TB;
-        f32x16 acc[UA][NB];
-        // S = NB NM B reads, each feeding UA MFMAs; PF reads in flight
-        constexpr int S = NB * NM, PF = S < 6 ? S : 6;
-        auto b_load = [&](int s_) __attribute__((always_inline)) -> u32x4 {
-            const int m = s_ / NB, cb = s_ % NB;
-            return *reinterpret_cast<const u32x4*>(tb + cb * (32 * RB) + 32 * m);
-        };
-        u32x4 bq[PF];
-#pragma unroll
-        for (int s_ = 0; s_ < PF; ++s_) bq[s_] = b_load(s_);
-#pragma unroll
-        for (int s_ = 0; s_ < S; ++s_) {
-            const int m = s_ / NB, cb = s_ % NB;
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua)
-                acc[ua][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[ua][m]), __builtin_bit_cast(bf16x8, bq[s_ % PF]),
-                                                                      m == 0 ? zero16v() : acc[ua][cb], 0, 0, 0);
-            if (s_ + PF < S) bq[s_ % PF] = b_load(s_ + PF);
-        }
-        float pop_cur[NB];
-        int loc_cur[NB];
-#pragma unroll
-        for (int cb = 0; cb < NB; ++cb) {
-            u32x4 bx = *reinterpret_cast<const u32x4*>(tb + cb * (32 * RB) + 2 * D);
-            const uint2 pi = *reinterpret_cast<const uint2*>(tb - 16 * h + cb * (32 * RB) + 2 * D + 32);
-            pop_cur[cb] = __uint_as_float(pi.x);
-            loc_cur[cb] = (int)pi.y;
-            if constexpr (HEAD == PDA_HEAD_RAW) {
-                // raw head on any prep: 1/pop := 1, constant := +8e-6 (a prep built with a popularity carries its pieces);
-                // null items keep their -3e38
-                const bool nul = !(pop_cur[cb] == pop_cur[cb]);
-                bx[0] = h ? (nul ? 0x0000FF61u : bf16_up(8.0e-6f)) : 0x00003F80u;
-                bx[1] = h ? bx[1] : 0x00003F80u;
-                bx[2] = h ? 0u : 0x3F800000u;
-                bx[3] = 0u;
-            }
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua)
-                acc[ua][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex[ua]), __builtin_bit_cast(bf16x8, bx), acc[ua][cb], 0, 0, 0);
-        }
-        // ---- early termination (every 4th tile): can anything at or behind the next tile still reach one of my rows?
-        // Candidates still waiting in the ring can only raise thresholds.  Bound: pda_score_topk_v2.hip.
-        const bool vote_now = g.sufA != nullptr && (i & 3) == 3 && (i + 1) < n_it;
-        if (vote_now) {
-            const int tn = split + (kWarmTiles + i + 1) * g.n_splits;
-            const float sa = g.sufA[tn], sb = g.sufB[tn];
-            bool dead = true;
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua) dead = dead && (__builtin_fmaf(nu_row[ua], sb, sa) * 1.000002f < thr_own[ua]);
-            const bool alldead = __all(dead);
-            if (lane == 0) lds_st(&s_vote[((i >> 2) & 1) * 4 + w], alldead ? 1u : 0u);
-        }
-        // my share of tile i + 1 has landed, and I am done reading tile i
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if constexpr (!(PDA_V4_ABL & 2)) if (lane == 0) __hip_atomic_fetch_add(s_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-
-        // ---- the filter: "some register of the lane is a positive float" = the signed maximum of the bit patterns is > 0 ----
-        uint64_t mc[UA][NB], many = 0;
-        bool clampy[NB];
-        if constexpr ((PDA_V4_ABL & 1) != 0) {
-#pragma unroll
-            for (int cb = 0; cb < NB; ++cb)
-#pragma unroll
-                for (int ua = 0; ua < UA; ++ua) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                    asm volatile("" ::"v"(acc[ua][cb]));
-#endif
-                }
-        }
-#pragma unroll
-        for (int cb = 0; (PDA_V4_ABL & 1) == 0 && cb < NB; ++cb) {
-            clampy[cb] = false;
-            if constexpr (HEAD == PDA_HEAD_POP) clampy[cb] = __any(pop_cur[cb] > thr_min);     // s~ + eps < 0: head <= pop; rare once the lists are warm
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua) {
-                const f32x16& sc = acc[ua][cb];
-                int ma = max(__float_as_int(sc[0]), __float_as_int(sc[1])), mb = max(__float_as_int(sc[2]), __float_as_int(sc[3]));
-#pragma unroll
-                for (int r = 4; r < 16; r += 4) {
-                    ma = max(max(ma, __float_as_int(sc[r])), __float_as_int(sc[r + 1]));
-                    mb = max(max(mb, __float_as_int(sc[r + 2])), __float_as_int(sc[r + 3]));
-                }
-                mc[ua][cb] = __ballot(max(ma, mb) > 0);
-                if (clampy[cb]) mc[ua][cb] = ~0ull;
-                many |= mc[ua][cb];
-            }
-        }
-        if (many) {
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua) {
-                uint32_t m = 0;
-#pragma unroll
-                for (int cb = NB - 1; cb >= 0; --cb) {
-                    uint32_t mcb = 0;
-                    if (mc[ua][cb]) {
-                        // "register is a positive float" = sign bit of (0 - bits); one v_sub + one v_alignbit per register
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            mcb = __builtin_amdgcn_alignbit(mcb, 0u - (uint32_t)__float_as_int(acc[ua][cb][r]), 31);
-                        if (clampy[cb]) {
-                            int hv = h;
-                            asm volatile("" : "+v"(hv));
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) mcb |= (pop_cur[cb] > thr_of(r, hv, ua)) ? (1u << (15 - r)) : 0u;
-                        }
-                    }
-                    m = (m << 16) | mcb;
-                }
-                push_masks(m, ua, loc_cur[0], loc_cur[NB - 1]);
-            }
-            PDA_CBAR();
-            lds_st(&s_tail[w], tail);
+        } else if constexpr ((PDA_V4_ABL & 1) == 0) {
+            bool clampB;
+            test_plain(accB, mkB);
+            if (test_done(mkB, popB, clampB)) slow_half(accB, popB, locB, mkB, clampB);
         }
         ++n_done;
-        // ---- wait for the other MFMA waves: tile i + 1 complete, tile i released ----
+        landed_c = max(landed_c, min(pr_l0, pr_l1));
         {
-            const unsigned want = (unsigned)kMainWaves * (unsigned)(i + 1);
-            unsigned spin = 0;
-            if constexpr (!(PDA_V4_ABL & 2))
-                while (lds_ld(s_ready) < want) {
-                    if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 1u; stopped = true; break; }
-                }
-            PDA_CBAR();
+            const unsigned tv = pr_tv;
+            if (tv != tver_seen) {
+                tver_seen = tv;
+                PROF_T0(tf);
+                refresh_thr();
+                PROF_T1(tf, 12);
+                PROF_INC(5, 1);
+            }
         }
-        // every wave stored its vote of this iteration before its increment: all four are visible now, and none is
-        // overwritten before every wave has passed this point (the next vote is four increments away)
-        if (vote_now) {
-            const unsigned* v = &s_vote[((i >> 2) & 1) * 4];
-            stopped = (lds_ld(&v[0]) & lds_ld(&v[1]) & lds_ld(&v[2]) & lds_ld(&v[3])) != 0u;
+        // ---- early termination.  Checkpoint c = the end of tile 4 c + 3: vote "nothing at or behind tile 4 c + 8 can reach
+        // one of my rows" (candidates still in the ring can only raise thresholds); the votes of checkpoint c are read at
+        // checkpoint c + 1 -- the MFMA waves are never more than two tiles apart (a ring slot is refilled only when all four
+        // have released it), so all four votes are there and every wave takes the same decision.
+        if (g.sufA != nullptr && (i & 3) == 3) {
+            const int c = i >> 2;
+            if (c >= 1) {
+                const unsigned* v = &s_vote[((c - 1) & 3) * 4];
+                stopped = (lds_ld(&v[0]) & lds_ld(&v[1]) & lds_ld(&v[2]) & lds_ld(&v[3])) != 0u;
+            }
+            const int inext = i + 5;
+            bool alldead = false;
+            if (inext < n_it) {
+                const int tn = split + (kWarmTiles + inext) * g.n_splits;
+                const float sa = g.sufA[tn], sb = g.sufB[tn];
+                bool dead = true;
+#pragma unroll
+                for (int ua = 0; ua < UA; ++ua) dead = dead && (__builtin_fmaf(nu_row[ua], sb, sa) * 1.000002f < thr_own[ua]);
+                alldead = __all(dead);
+            }
+            if (lane == 0) lds_st(&s_vote[(c & 3) * 4 + w], alldead ? 1u : 0u);
         }
     }
+    if constexpr ((PDA_V4_ABL & 256) != 0) if (dummy == 0x12345u) g.stats[3] = dummy;
+    PROF_T1(tm0, 0);
+    PROF_INC(13, 1);
+    PROF_INC(15, tail);
+    PROF_FLUSH(0, 5);
+    PROF_FLUSH(12, 15);
     PDA_CBAR();
     lds_st(&s_tail[w], tail);
     PDA_CBAR();
     lds_st(&s_done[w], 1u);
+    if (stopped) lds_st(s_stop, 1u);
     if (lane == 0 && w == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * n_done * (UT / kUserTile)));
 }
 
@@ -922,6 +1118,14 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
 }
 
 }  // namespace
+
+#ifdef PDA_V4_PROF
+extern "C" int pda_debug_prof4(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pda_prof4), sizeof(unsigned long long) * 16) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pda_prof4), z, sizeof(z)) != hipSuccess) return PDA_ERR_LAUNCH; }
+    return PDA_OK;
+}
+#endif
 
 extern "C" int pda_score_topk4_auto_splits(int n_users_blk, int n_items_local, int d) {
     if (n_users_blk <= 0 || n_items_local <= 0) return 1;

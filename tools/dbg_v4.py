@@ -27,11 +27,11 @@ def case(d, head, mode, ns, nU=300, nI=1999, hist=True, K=50, seed=1):
         miss = sorted(set(ai[r]) - set(bi[r])); extra = sorted(set(bi[r]) - set(ai[r]))
         msg = " bad rows %d first %d missing %s extra %s" % (len(bad), r, miss[:6], extra[:6])
     print("d=%d head=%d mode=%s ns=%d hist=%d: %s%s cand=%d" % (d, head, mode, ns, hist, "OK" if ok else "MISMATCH", msg, int(st["pairs_rescored"][0])), flush=True)
-for d in (64, 128, 256):
-    for head in (0, 1):
-        for mode in (False, "order", True):
-            for ns in (1, 2):
-                case(d, head, mode, ns, hist=False)
-case(128, 1, "order", 0, nU=700, nI=9000)
-case(128, 1, True, 0, nU=700, nI=9000)
-case(64, 0, False, 0, nU=173)
+import itertools
+for d, nU, hist in itertools.product((64, 128), (173, 300), (False, True)):
+    case(d, 0, False, 0, nU=nU, hist=hist)
+    case(d, 0, False, 1, nU=nU, hist=hist)
+for head in (0, 1):
+    for mode in (False, "order"):
+        case(256, head, mode, 1, hist=False, nU=100)
+        case(256, head, mode, 1, hist=False, nU=300, nI=600)

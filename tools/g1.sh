@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_score_topk.py -x -q -m gpu -k "k4" --timeout 120 2>&1 | tail -8
+timeout 300 python tools/time_variants.py base,abl1,abl128,abl256 order 1 2>&1 | tail -4

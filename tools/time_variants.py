@@ -12,7 +12,7 @@ wl = sys.argv[5] if len(sys.argv) > 5 else "c3"
 nus = int(sys.argv[6]) if len(sys.argv) > 6 else 131072
 dev = torch.device('cuda')
 W = synthetic.make_workload(wl, dev, n_users=nus)
-hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+hist = None if os.environ.get('NOHIST') else ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in range(0, W.n_users - Bu + 1, Bu)][:4]
 os.environ["PDA_SCORE_KERNEL"] = os.environ.get("PDA_SCORE_KERNEL", "v4")
 here = os.path.dirname(os.path.abspath(_lib.__file__))
