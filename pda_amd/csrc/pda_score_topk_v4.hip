@@ -675,19 +675,16 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
         __syncthreads();
         constexpr int MYP = (NP + kLoaders - 1) / kLoaders;       // pieces per loader and half-tile (the last loader may have one less)
         constexpr int MINP = NP / kLoaders;
-        bool stop = false;
-        PROF_T0(tl0);
+        bool stop = (PDA_V4_ABL & 4) != 0;                      // timing only: no tile loads at all
         for (int hf = 0; hf < n_half && !stop; ++hf) {
-            if (hf >= 4) {                                         // slot hf & 3 is free once every MFMA wave has released half hf - 4
+            if ((PDA_V4_ABL & 2) == 0 && hf >= 4) {                // slot hf & 3 is free once every MFMA wave has released half hf - 4
                 const unsigned want = (unsigned)(hf - 3);
                 unsigned spin = 0;
-                PROF_T0(tw);
                 while (min(min(lds_ld(&s_released[0]), lds_ld(&s_released[1])), min(lds_ld(&s_released[2]), lds_ld(&s_released[3]))) < want) {
                     if (lds_ld(s_stop)) { stop = true; break; }
                     if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 4u; stop = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                PROF_T1(tw, 11);
                 if (stop) break;
             }
             const int t = split + (kWarmTiles + (hf >> 1)) * g.n_splits;
@@ -716,8 +713,6 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!stop && n_half > 0) lds_st(&s_landed[l], (unsigned)n_half);
-        PROF_T1(tl0, 10);
-        PROF_FLUSH(10, 11);
         return;
     }
 
@@ -819,6 +814,7 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
     };
     auto ensure_landed = [&](int hf) __attribute__((always_inline)) {
         const unsigned want = (unsigned)(hf + 1);
+        if constexpr ((PDA_V4_ABL & 2) != 0) return;
         if (landed_c < want) {
             unsigned spin = 0;
             PROF_T0(te);
@@ -834,7 +830,10 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
 
     // one half-tile: NM + 1 MFMAs per A operand into acc; bq holds its first PF fragments on entry and those of the next
     // half on exit (has_next; the next half must have landed)
-    constexpr int PF = NM < 4 ? NM : 4;
+#ifndef PDA_V4_PF
+#define PDA_V4_PF 4
+#endif
+    constexpr int PF = NM < PDA_V4_PF ? NM : PDA_V4_PF;
     u32x4 bq[PF];
     auto load_first = [&](int hf) __attribute__((always_inline)) {
         const unsigned char* tb = lane_base + (hf & 3) * HB;
@@ -949,53 +948,67 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
     };
 
     PROF_T0(tm0);
+    // MFMAs are issued far ahead of their execution (the matrix pipe queues them: measured, a 36-MFMA tile is issued in ~640
+    // cycles and executes in 1152).  A VALU read of an accumulator therefore stalls the wave until the pipe has worked its way
+    // up to that MFMA -- and with the wave stalled nothing new is queued: tested right behind its own MFMAs, the pipe runs dry
+    // once per tile (measured: 3.7 instead of 2.0 ms); tested BETWEEN the MFMAs of the next half-tile, the stall holds back the
+    // rest of that half-tile (3.6 ms).  So the filter of half-tile h runs after ALL MFMAs of half-tile h + 1 have been issued,
+    // on the other of two accumulator sets: it waits for h while h + 1 (576 cycles of pipe time) is queued behind.
     f32x16 accA[UA], accB[UA];
     float popA = 0.f, popB = 0.f;
     int locA = 0, locB = 0;
-    uint32_t mkA[UA], mkB[UA];
+    uint32_t mk[UA];
     [[maybe_unused]] uint32_t dummy = 0;
     int n_done = 0;
     bool stopped = false;
-    const std::true_type with_test{};
     const std::false_type no_test{};
+    auto filter_half = [&](const f32x16 (&acc)[UA], float popv, int locv) __attribute__((always_inline)) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr ((PDA_V4_ABL & 1) != 0) {      // timing only: no filter -- but the MFMAs must not be dead code
+#pragma unroll
+            for (int ua = 0; ua < UA; ++ua) asm volatile("" ::"v"(acc[ua]));
+        }
+#endif
+        if constexpr ((PDA_V4_ABL & 1) == 0) {
+            bool clamp;
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);      // hipcc would hoist these (independent) VALU reads between the MFMAs above
+#endif
+            PROF_T0(tt0);
+            test_plain(acc, mk);
+#ifdef PDA_V4_PROF
+            asm volatile("" ::"v"(mk[0]), "v"(mk[UA - 1]));
+#endif
+            PROF_T1(tt0, 11);
+            if constexpr ((PDA_V4_ABL & 256) != 0) {            // timing only: the ORs alone
+                dummy |= mk[0] | mk[UA - 1];
+            } else if constexpr ((PDA_V4_ABL & 2048) != 0) {    // timing only: ORs + the wave-wide "any" + a trivial branch
+                if (test_done(mk, popv, clamp)) tail += 1;
+            } else {
+                if (test_done(mk, popv, clamp)) slow_half(acc, popv, locv, mk, clamp);
+            }
+        }
+    };
     if (n_it > 0) {
         ensure_landed(0);
         load_first(0);
         ensure_landed(1);
-        mfma_half(0, accA, popA, locA, no_test, accA, mkB);
+        mfma_half(0, accA, popA, locA, no_test, accA, mk);
     }
     for (int i = 0; i < n_it && !stopped; ++i) {
         const bool more = (i + 1) < n_it;
         // the hand-over words, read here and used at the end of the iteration (the read is off the critical path)
         const unsigned pr_l0 = lds_ld(&s_landed[0]), pr_l1 = lds_ld(&s_landed[1]), pr_tv = lds_ld(&s_tver[w]);
-        // ---- odd half of tile i -> accB, while the filter runs on accA (even half of tile i) ----
         if (more) ensure_landed(2 * i + 2);
-        const float popT = popA;
-        const int locT = locA;
-        mfma_half(2 * i + 1, accB, popB, locB, with_test, accA, mkA);
-        if constexpr ((PDA_V4_ABL & 256) != 0) {
-            dummy |= mkA[0] | mkA[UA - 1];
-        } else if constexpr ((PDA_V4_ABL & 1) == 0) {
-            bool clampA;
-            if (test_done(mkA, popT, clampA)) slow_half(accA, popT, locT, mkA, clampA);
-        }
-        // ---- even half of tile i + 1 -> accA, while the filter runs on accB ----
+        PROF_T0(tb0);
+        mfma_half(2 * i + 1, accB, popB, locB, no_test, accB, mk);      // odd half of tile i
+        PROF_T1(tb0, 10);
+        filter_half(accA, popA, locA);                                  // even half of tile i
         if (more) {
             ensure_landed(2 * i + 3);
-            const float popS = popB;
-            const int locS = locB;
-            mfma_half(2 * i + 2, accA, popA, locA, with_test, accB, mkB);
-            if constexpr ((PDA_V4_ABL & 256) != 0) {
-                dummy |= mkB[0] | mkB[UA - 1];
-            } else if constexpr ((PDA_V4_ABL & 1) == 0) {
-                bool clampB;
-                if (test_done(mkB, popS, clampB)) slow_half(accB, popS, locS, mkB, clampB);
-            }
-        } else if constexpr ((PDA_V4_ABL & 1) == 0) {
-            bool clampB;
-            test_plain(accB, mkB);
-            if (test_done(mkB, popB, clampB)) slow_half(accB, popB, locB, mkB, clampB);
+            mfma_half(2 * i + 2, accA, popA, locA, no_test, accA, mk);  // even half of tile i + 1
         }
+        filter_half(accB, popB, locB);                                  // odd half of tile i
         ++n_done;
         landed_c = max(landed_c, min(pr_l0, pr_l1));
         {
@@ -1031,12 +1044,13 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             if (lane == 0) lds_st(&s_vote[(c & 3) * 4 + w], alldead ? 1u : 0u);
         }
     }
-    if constexpr ((PDA_V4_ABL & 256) != 0) if (dummy == 0x12345u) g.stats[3] = dummy;
+    if constexpr ((PDA_V4_ABL & (256 | 512 | 1024)) != 0) if (dummy == 0x12345u) g.stats[3] = dummy;
+    (void)dummy;
     PROF_T1(tm0, 0);
     PROF_INC(13, 1);
     PROF_INC(15, tail);
     PROF_FLUSH(0, 5);
-    PROF_FLUSH(12, 15);
+    PROF_FLUSH(10, 15);
     PDA_CBAR();
     lds_st(&s_tail[w], tail);
     PDA_CBAR();

@@ -2,7 +2,7 @@
 import os, sys, ctypes as C, torch
 sys.path.insert(0, '.')
 here = os.path.dirname(os.path.abspath(__file__))
-os.environ["PDA_HIP_LIB"] = os.path.join(here, "..", "pda_amd", "csrc", "variants", "libpda_hip_prof.so")
+os.environ["PDA_HIP_LIB"] = os.path.join(here, "..", "pda_amd", "csrc", "variants", os.environ.get("PROFLIB", "libpda_hip_prof.so"))
 os.environ["PDA_SCORE_KERNEL"] = "v4"
 from pda_amd import ops, synthetic, _lib
 mode = {"order": "order", "0": False, "1": True}[sys.argv[1] if len(sys.argv) > 1 else "order"]
@@ -28,4 +28,4 @@ print("launch %.3f ms; MFMA waves %d; cand/user %.1f" % (e0.elapsed_time(e1), nm
 print("per MFMA wave [kcycles]: total %.0f  wait-landed %.0f  ring-full %.0f  slow path %.0f (%.0f calls, %.0f clamp)  refresh %.0f (%.0f)  pushed %.0f"
       % (v[0] / nm / 1e3, v[1] / nm / 1e3, v[2] / nm / 1e3, v[3] / nm / 1e3, v[4] / nm, v[14] / nm, v[12] / nm / 1e3, v[5] / nm, v[15] / nm))
 print("per rescoring wave [kcycles]: total %.0f  idle %.0f  passes %.0f  cand %.0f" % (v[6] / nr / 1e3, v[7] / nr / 1e3, v[8] / nr, v[9] / nr))
-print("per loader [kcycles]: total %.0f  wait-release %.0f" % (v[10] / nl / 1e3, v[11] / nl / 1e3))
+print("per MFMA wave [kcycles]: MFMA blocks (issue) %.0f  filter %.0f" % (v[10] / nm / 1e3, v[11] / nm / 1e3))
