@@ -38,9 +38,9 @@ using namespace pda_topk;
 namespace {
 
 constexpr int kCap4 = 57;            // list slots per user (LDS budget at d = 128: 256 users x 57 x 8 B = 114 KiB)
-constexpr int kRing4 = 256;          // ring entries per MFMA wave (u32 each)
+constexpr int kRing4 = 128;          // ring entries per MFMA wave (u32 each); a push needs 64 free
 constexpr int kWarmTiles = 4;        // 64-item tiles per split scored by warm4_kernel (256 items)
-constexpr int kMainWaves = 4;
+constexpr int kMainWaves = 8;
 #ifndef PDA_V4_ABL
 #define PDA_V4_ABL 0      // timing-only ablations (results are wrong): 1 no filter, 2 no hand-over between MFMA waves, 4 no tile loads, 8 rescoring waves leave at once
 #endif
@@ -421,73 +421,84 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // ---------------------------------------------------------------------------------------------------------------------
 // the sweep
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int kLoaders = 2;          // waves 4, 5: LDS-DMA only
-constexpr int kRescorers = 2;        // waves 6, 7: rescoring wave r serves the MFMA waves 2 r and 2 r + 1
+// What the matrix pipe needs (tools/ubench/mfma_lds.hip, MI355X, random operands):
+//     1 wave per SIMD, 2 accumulator chains   1298 TFLOP/s      1 wave, 4 chains   1543      1 wave, 8 chains   1727
+//     2 waves per SIMD, 2 chains each         1994 TFLOP/s  (= the power-limited ceiling: 3 or 4 waves, more chains: the same)
+// i.e. back-to-back MFMAs on one accumulator do not fill the pipe; it takes >= 4 independent chains, best from two waves.
+// And (tools/ubench/mfma_valu*.hip, profiling build): a VALU read of an accumulator stalls its wave until the pipe has
+// worked its way up to that MFMA -- with one MFMA wave per SIMD nothing is queued meanwhile.  Hence:
+//   waves 0..7   MFMA waves, two per SIMD: 32 user rows each; per block (NB half-tiles of 32 items = NB chains) NB (NM + 1)
+//                MFMAs, then the filter on the block's own accumulators (sign bit of the OR of a lane's registers) while the
+//                other MFMA wave of the SIMD has the pipe;
+//   waves 8, 9   loaders (LDS-DMA only: a 1 KiB piece costs its issuing wave ~100 cycles of issue time -- in the MFMA waves
+//                that was 0.8 of 3.7 ms); block b goes into slot b & 1 once every MFMA wave has released block b - 2;
+//   waves 10, 11 rescoring waves (lists, exact rescoring, thresholds) of 128 user rows each.
+// No s_barrier after the start.  Hand-over words in LDS, one word per WRITER (a sum over writers cannot tell "everyone is
+// past b" from "some are ahead, one is behind"), relaxed LDS atomics; the LDS executes a wave's operations in order:
+//   landed[l]     blocks whose pieces (of loader l) have landed        released[w]   blocks MFMA wave w is done reading
+// d <= 128: the kernel needs <= 128 VGPRs -- four waves per SIMD: 8 MFMA waves + 4 loaders + 4 rescoring waves (two loaders
+// could not keep up: the MFMA waves waited 39 % of their time for tiles); d = 256 (168 VGPRs): 8 + 2 + 2.
 
 template <int D>
 struct Geo4 {
-    static constexpr int UA = D <= 128 ? 2 : 1;          // A operands (32 user rows each) per MFMA wave
-    static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
+    static constexpr int NB = D <= 128 ? 2 : 1;          // half-tiles (32 items, one accumulator chain each) per block
+    static constexpr int LOADERS = D <= 128 ? 4 : 2;
+    static constexpr int RESCORERS = D <= 128 ? 4 : 2;
+    static constexpr int MPR = kMainWaves / RESCORERS;   // MFMA waves per rescoring wave
+    static constexpr int WAVES = kMainWaves + LOADERS + RESCORERS;
+    static constexpr int ROWS = 32;                      // user rows per MFMA wave
     static constexpr int UT = kMainWaves * ROWS;         // user rows per workgroup
     static constexpr int RB = row_bytes(D), TB = tile_bytes(D);
-    static constexpr int HB = 32 * RB;                   // one 32-item half-tile = one column block = one ring slot
-    static constexpr int NP = (HB + 1023) / 1024;        // 1 KiB DMA pieces per half-tile; the last one covers HB % 1024 = 512 bytes (32 lanes)
-    static constexpr size_t lds_tiles = 4 * (size_t)HB;
+    static constexpr int HB = 32 * RB;                   // one half-tile
+    static constexpr int BB = NB * HB;                   // one block = one ring slot
+    static constexpr int NP = (BB + 1023) / 1024;        // 1 KiB DMA pieces per block; the last one may be half a piece (32 lanes)
+    static constexpr int LASTL = (BB % 1024) ? (BB % 1024) / 16 : 64;
+    static constexpr size_t lds_tiles = 2 * (size_t)BB;
     static constexpr size_t lds_lists = (size_t)UT * kCap4 * 8;
-    static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 256;
+    static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 512;
 };
 
-// Workgroup = 8 waves, no s_barrier after the start:
-//   waves 0..3  MFMA waves: 32 UA user rows each; per half-tile (32 items) NM + 1 MFMAs per A operand.  The filter of half
-//               h - 1 (integer maxima over its accumulators) is issued between the MFMAs of half h.
-//   waves 4, 5  loaders: half-tile h goes into ring slot h & 3 as soon as every MFMA wave has released half h - 4.  An
-//               LDS-DMA piece costs its issuing wave ~100 cycles of issue time; in the MFMA waves those were 0.8 of 3.7 ms.
-//   waves 6, 7  rescoring waves (lists, exact rescoring, thresholds) of 2 ROWS user rows each.
-// Hand-over words in LDS (monotonic counters, relaxed LDS atomics; the LDS executes a wave's operations in order):
-//   landed    += 1 per loader and half-tile, after its pieces have landed (s_waitcnt vmcnt)
-//   released  += 1 per MFMA wave and half-tile, after its last LDS read of the slot
 template <int D, int HEAD, bool BF>
-__global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
+__global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     using G = Geo4<D>;
-    constexpr int UA = G::UA, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, NP = G::NP;
+    constexpr int kLoaders = G::LOADERS, kMPR = G::MPR;
+    constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP;
     constexpr int NM = D / 16;
     constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* tiles = smem;                                                             // 4 x HB
+    unsigned char* tiles = smem;                                                             // 2 x BB
     uint64_t* lists = reinterpret_cast<uint64_t*>(smem + G::lds_tiles);                      // [UT][kCap4] exact keys
     int* cntl = reinterpret_cast<int*>(lists + (size_t)UT * kCap4);                          // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                                       // [UT] exact K-th value (-inf until K entries)
-    unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [4][kRing4]
+    unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [8][kRing4]
     unsigned* sync = rings + kMainWaves * kRing4;
-    unsigned* s_landed = sync;                // [2]  per loader: half-tiles whose pieces (of that loader) have landed
-    unsigned* s_tver = sync + 36;             // [4]  per MFMA wave: bumped by its rescoring wave whenever a threshold of its rows rose
-    unsigned* s_stop = sync + 3;              // [1]  early termination: loaders leave
-    unsigned* s_released = sync + 4;          // [4]  per MFMA wave: half-tiles released (one word per writer: a sum would not
-                                              //      tell "everyone is past h" from "three are ahead, one is behind")
-    unsigned* s_tail = sync + 8;              // [4]  ring write positions (MFMA wave w)
-    unsigned* s_head = sync + 12;             // [4]  ring read positions
-    unsigned* s_done = sync + 16;             // [4]  MFMA wave w has pushed its last candidate
-    unsigned* s_vote = sync + 20;             // [4][4]  early termination votes of checkpoint c & 3
+    unsigned* s_landed = sync;                // [4]
+    unsigned* s_stop = sync + 76;             // [1]  early termination: loaders leave
+    unsigned* s_released = sync + 4;          // [8]
+    unsigned* s_tail = sync + 12;             // [8]  ring write positions (MFMA wave w)
+    unsigned* s_head = sync + 20;             // [8]  ring read positions
+    unsigned* s_done = sync + 28;             // [8]  MFMA wave w has pushed its last candidate
+    unsigned* s_tver = sync + 36;             // [8]  bumped by the rescoring wave whenever a threshold of wave w's rows rose
+    unsigned* s_vote = sync + 44;             // [4][8]  early termination votes of checkpoint c & 3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
-    const int n_it = max(0, nt - kWarmTiles);                    // tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
-    const int n_half = 2 * n_it;
-    if (tid < 64) sync[tid] = 0u;
+    const int n_it = max(0, nt - kWarmTiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
+    const int n_blk = n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
+    if (tid < 128) sync[tid] = 0u;
 #ifdef PDA_V4_PROF
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
     if (wave >= kMainWaves + kLoaders) {
         // ============================== rescoring wave ==============================
-        constexpr int RR = 2 * ROWS;                         // rows of this wave
+        constexpr int RR = kMPR * ROWS;                      // rows of this wave (128: two per lane)
         const int r = wave - kMainWaves - kLoaders;
         const int row0 = r * RR;
         uint64_t* my_lists = lists + (size_t)row0 * kCap4;
-        // lane l <-> rows l and 64 + l of the wave: user id, history range
         int uidv[2] = {0, 0};
         int64_t hbv[2] = {0, 0}, hev[2] = {0, 0};
         const bool hist_on = g.hist_indptr != nullptr;
@@ -516,60 +527,67 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             }
         }
         __syncthreads();
-        unsigned head[2] = {0, 0}, n_cand = 0;
+        unsigned head[kMPR], n_cand = 0;
+#pragma unroll
+        for (int z = 0; z < kMPR; ++z) head[z] = 0;
         constexpr int LPC = D / 32;                 // lanes per candidate: each owns 32 consecutive k
         constexpr int CPP = 64 / LPC;               // candidates per pass
         const int q = lane % LPC, ci = lane / LPC;
-        // Two passes in flight: the gathers of one pass are issued before the other pass is computed -- a pass is a chain of
-        // dependent latencies (ring word -> rows -> fmaf chain -> history lookup -> list), and the two rescoring waves of a
-        // workgroup have to keep up with four MFMA waves.
-        struct Pass {
-            f32x4 uu[8], ii[8];
-            float pv;
-            int row, loc, n;
-            bool valid;
-        };
-        int sel = 0;                                // which of the two rings the next pass looks at first
-        bool all_done = false;
-        // stage A: claim up to CPP entries of one ring and issue their gathers
-        auto stage_a = [&](Pass& s) __attribute__((always_inline)) {
-            const unsigned dn0 = lds_ld(&s_done[2 * r]), dn1 = lds_ld(&s_done[2 * r + 1]);     // read BEFORE the tails
-            const unsigned tl0 = lds_ld(&s_tail[2 * r]), tl1 = lds_ld(&s_tail[2 * r + 1]);
-            const bool e0 = tl0 == head[0], e1 = tl1 == head[1];
-            s.n = 0;
-            s.valid = false;
-            if (e0 && e1) {
-                all_done = dn0 && dn1;
-                return;
+        int sel = 0;                                // the ring looked at last
+        unsigned idle = 0;
+        PROF_T0(tr0);
+        for (;;) {
+            if constexpr ((PDA_V4_ABL & 8) != 0) break;
+            unsigned dn = 1u, tl[kMPR];
+#pragma unroll
+            for (int z = 0; z < kMPR; ++z) dn &= lds_ld(&s_done[kMPR * r + z]);                 // read BEFORE the tails
+#pragma unroll
+            for (int z = 0; z < kMPR; ++z) tl[z] = lds_ld(&s_tail[kMPR * r + z]);
+            // the next non-empty ring behind the one looked at last time
+            int pick = -1;
+            unsigned tail = 0, hd = 0;
+#pragma unroll
+            for (int z = kMPR; z >= 1; --z) {
+                const int cand = (sel + z) % kMPR;
+                unsigned tz = 0, hz = 0;
+#pragma unroll
+                for (int y = 0; y < kMPR; ++y) { tz = cand == y ? tl[y] : tz; hz = cand == y ? head[y] : hz; }
+                if (tz != hz) { pick = cand; tail = tz; hd = hz; }
             }
-            sel = (sel == 0) ? (e1 ? 0 : 1) : (e0 ? 1 : 0);          // the ring looked at last time goes second
-            const unsigned tail = sel ? tl1 : tl0;
-            const unsigned hd = sel ? head[1] : head[0];
-            const unsigned* ring = rings + (2 * r + sel) * kRing4;
+            if (pick < 0) {
+                if (dn) break;
+                if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
+                PROF_T0(ti);
+                __builtin_amdgcn_s_sleep(8);
+                PROF_T1(ti, 7);
+                continue;
+            }
+            idle = 0;
+            sel = pick;
+            PROF_INC(8, 1);
+            const unsigned* ring = rings + (kMPR * r + sel) * kRing4;
             PDA_CBAR();
             const int n = min((int)(tail - hd), CPP);
             n_cand += (unsigned)n;
-            s.n = n;
-            s.valid = ci < n;
-            const unsigned word = s.valid ? ring[(hd + (unsigned)ci) % kRing4] : 0u;
-            s.row = sel * ROWS + (int)(word >> 26);                         // row of this wave
-            s.loc = (int)(word & 0x3FFFFFFu);                               // local item id
-            int urow = __shfl(uidv[0], s.row & 63, 64);
-            if constexpr (RR > 64) { const int u1 = __shfl(uidv[1], s.row & 63, 64); urow = s.row >= 64 ? u1 : urow; }
-            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)s.loc * D + q * 32;
+            const bool valid = ci < n;
+            const unsigned word = valid ? ring[(hd + (unsigned)ci) % kRing4] : 0u;
+            const int row = sel * ROWS + (int)(word >> 26);                         // row of this wave
+            const int loc = (int)(word & 0x3FFFFFFu);                               // local item id
+            int urow = __shfl(uidv[0], row & 63, 64);
+            if constexpr (RR > 64) { const int u1 = __shfl(uidv[1], row & 63, 64); urow = row >= 64 ? u1 : urow; }
+            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)loc * D + q * 32;
+            f32x4 uu[8], ii[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                s.uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
-                s.ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
+                uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
+                ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
             }
-            s.pv = 1.0f;
-            if constexpr (HEAD == PDA_HEAD_POP) s.pv = g.pop[s.loc];
-            if (sel) head[1] += (unsigned)n; else head[0] += (unsigned)n;
+            float pv = 1.0f;
+            if constexpr (HEAD == PDA_HEAD_POP) pv = g.pop[loc];
+#pragma unroll
+            for (int y = 0; y < kMPR; ++y) head[y] += sel == y ? (unsigned)n : 0u;
             PDA_CBAR();
-            lds_st(&s_head[2 * r + sel], sel ? head[1] : head[0]);          // the words are in registers: the slots are free
-        };
-        // stage B: exact score, threshold, history, list
-        auto stage_b = [&](Pass& s) __attribute__((always_inline)) {
+            lds_st(&s_head[kMPR * r + sel], hd + (unsigned)n);              // the words are in registers: the slots are free
             float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
             for (int ph = 0; ph < LPC; ++ph) {
@@ -580,11 +598,11 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
 #pragma unroll
                     for (int sidx = 0; sidx < 4; ++sidx) {
                         if (cc & 1) {
-                            o1 = __builtin_fmaf(s.uu[2 * cc][sidx], s.ii[2 * cc][sidx], o1);
-                            o1 = __builtin_fmaf(s.uu[2 * cc + 1][sidx], s.ii[2 * cc + 1][sidx], o1);
+                            o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
+                            o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
                         } else {
-                            o0 = __builtin_fmaf(s.uu[2 * cc][sidx], s.ii[2 * cc][sidx], o0);
-                            o0 = __builtin_fmaf(s.uu[2 * cc + 1][sidx], s.ii[2 * cc + 1][sidx], o0);
+                            o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
+                            o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
                         }
                     }
                 }
@@ -597,13 +615,12 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
                 }
             }
             float sc = o0 + o1;                               // meaningful on the candidate's last lane
-            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * s.pv;
-            const float tt = (s.valid && q == LPC - 1) ? sc : -INFINITY;
-            const int row = s.row;
+            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+            const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
             const int lrow = row0 + row;
-            const int item = g.item_offset + s.loc;
+            const int item = g.item_offset + loc;
             // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in
-            bool p = s.valid && q == LPC - 1 && (tt >= taul[lrow]);
+            bool p = valid && q == LPC - 1 && (tt >= taul[lrow]);
             if (hist_on) {
                 // train items are masked HERE: one binary search in the row's id-sorted history for a candidate that has
                 // passed the filter and the exact threshold
@@ -624,32 +641,11 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             }
             const uint64_t key = pda_pack_key(tt, (uint32_t)item);
             const bool changed = append_keys<kCap4>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane);
-            if (changed && lane == 0) __hip_atomic_fetch_add(&s_tver[2 * r + (row >= ROWS ? 1 : 0)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        };
-        Pass s0, s1;
-        unsigned idle = 0;
-        if constexpr ((PDA_V4_ABL & 8) == 0) {
-            PROF_T0(tr0);
-            stage_a(s0);
-            for (;;) {
-                stage_a(s1);
-                if (s0.n) { PROF_INC(8, 1); stage_b(s0); }
-                stage_a(s0);
-                if (s1.n) { PROF_INC(8, 1); stage_b(s1); }
-                if (s0.n == 0 && s1.n == 0) {
-                    if (all_done) break;
-                    if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
-                    PROF_T0(ti);
-                    __builtin_amdgcn_s_sleep(8);
-                    PROF_T1(ti, 7);
-                } else {
-                    idle = 0;
-                }
-            }
-            PROF_T1(tr0, 6);
-            PROF_INC(9, n_cand);
-            PROF_FLUSH(6, 9);
+            if (changed && lane == 0) __hip_atomic_fetch_add(&s_tver[kMPR * r + sel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        PROF_T1(tr0, 6);
+        PROF_INC(9, n_cand);
+        PROF_FLUSH(6, 9);
         if (lane == 0) atomicAdd(g.stats + 1, n_cand);
         // finalise: the lists are exact; sort and emit
         for (int rr = 0; rr < RR; ++rr) {
@@ -673,27 +669,33 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
         const int l = wave - kMainWaves;
         const unsigned lds_tiles0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
         __syncthreads();
-        constexpr int MYP = (NP + kLoaders - 1) / kLoaders;       // pieces per loader and half-tile (the last loader may have one less)
-        constexpr int MINP = NP / kLoaders;
-        bool stop = (PDA_V4_ABL & 4) != 0;                      // timing only: no tile loads at all
-        for (int hf = 0; hf < n_half && !stop; ++hf) {
-            if ((PDA_V4_ABL & 2) == 0 && hf >= 4) {                // slot hf & 3 is free once every MFMA wave has released half hf - 4
-                const unsigned want = (unsigned)(hf - 3);
+        constexpr int MYP = (NP + kLoaders - 1) / kLoaders;       // pieces per loader and block (the last loader may have one less)
+        bool stop = false;
+        for (int b = 0; b < n_blk && !stop; ++b) {
+            if (b >= 2) {                                          // slot b & 1 is free once every MFMA wave has released block b - 2
+                const unsigned want = (unsigned)(b - 1);
                 unsigned spin = 0;
-                while (min(min(lds_ld(&s_released[0]), lds_ld(&s_released[1])), min(lds_ld(&s_released[2]), lds_ld(&s_released[3]))) < want) {
+                auto min_released = [&]() __attribute__((always_inline)) -> unsigned {
+                    unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int z = 0; z < kMainWaves; ++z) mn = min(mn, lds_ld(&s_released[z]));
+                    return mn;
+                };
+                while (min_released() < want) {
                     if (lds_ld(s_stop)) { stop = true; break; }
                     if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 4u; stop = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 if (stop) break;
             }
-            const int t = split + (kWarmTiles + (hf >> 1)) * g.n_splits;
-            [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * G::TB + (size_t)(hf & 1) * HB + lane * 16;
-            [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((hf & 3) * HB);
+            const int hf0 = b * NB;                                // first half-tile of the block
+            const int t = split + (kWarmTiles + (hf0 >> 1)) * g.n_splits;
+            [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * G::TB + (size_t)(hf0 & 1) * HB + lane * 16;
+            [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((b & 1) * BB);
 #pragma unroll
             for (int c = 0; c < MYP; ++c) {
                 const int piece = l + kLoaders * c;
-                if (piece < NP && (piece < NP - 1 || lane < 32)) {           // the last piece is half a piece
+                if (piece < NP && (piece < NP - 1 || lane < G::LASTL)) {
 #if defined(__HIP_DEVICE_COMPILE__)
                     unsigned keep;
                     const unsigned char* gsrc = src + (size_t)piece * 1024;
@@ -703,16 +705,12 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
 #endif
                 }
             }
-            // the pieces of the PREVIOUS half have landed once at most this half's are outstanding (loads return in order)
-            if (hf > 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MINP) : "memory");
-#endif
-                lds_st(&s_landed[l], (unsigned)hf);            // halves 0 .. hf - 1
-            }
+            // With two slots there is nothing else to issue until block b - 1 is released: wait for THIS block to land and
+            // say so at once (publishing it only behind the issue of the next block -- a counted vmcnt -- made every MFMA
+            // wave wait for that issue: 39 % of its time).
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_st(&s_landed[l], (unsigned)(b + 1));            // blocks 0 .. b
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (!stop && n_half > 0) lds_st(&s_landed[l], (unsigned)n_half);
         return;
     }
 
@@ -720,12 +718,12 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
     const int w = wave;
     const int j = lane & 31, h = lane >> 5;
     const int row0 = w * ROWS;
-    // A operands: rows 32 ua + j of the wave (k = 16 m + 8 h .. + 7) rounded to bf16; padded row norms
-    u32x4 ah[UA][NM];
-    float nu_row[UA];
-#pragma unroll
-    for (int ua = 0; ua < UA; ++ua) {
-        const int rb = utile * UT + row0 + 32 * ua + j;
+    // A operand: row j of the wave (k = 16 m + 8 h .. + 7) rounded to bf16 and NEGATED (all of the A side, the extra k-step
+    // too): the accumulators hold -(s~ - thr/pop + 1 + eps), and "candidate" is "negative", i.e. the sign bit.
+    u32x4 ah[NM];
+    float nu_row;
+    {
+        const int rb = utile * UT + row0 + j;
         const bool ok = rb < g.n_users_blk;
         const int uid = ok ? g.users[rb] : 0;
         float ss = 0.f;
@@ -737,49 +735,43 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
                 y = pda_load4<BF>(g.U, (size_t)uid * D + 8 * h + 16 * m + 4);
             }
             u32x4 lo_unused;
-            split8(x, y, ah[ua][m], lo_unused);
-            // The A side is NEGATED (all of it, the extra k-step too): the accumulators hold -(s~ - thr/pop + 1 + eps), and
-            // "candidate" is "negative", i.e. the SIGN BIT -- which one v_alignbit per register shifts into a per-lane mask.
+            split8(x, y, ah[m], lo_unused);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ah[ua][m][k] ^= 0x80008000u;
+            for (int k = 0; k < 4; ++k) ah[m][k] ^= 0x80008000u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
         }
         ss += __shfl_xor(ss, 32, 64);
-        nu_row[ua] = sqrtf(ss) * 1.0009765625f * 1.0001f;              // padded ||u||
+        nu_row = sqrtf(ss) * 1.0009765625f * 1.0001f;              // padded ||u||
     }
     __syncthreads();                       // lists, thresholds and hand-over words are initialised
 
-    // thresholds of the lane's own rows (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative (the rounding of the
+    // threshold of the lane's own row (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative (the rounding of the
     // extra k-step, pda_score_topk_v3.hip), as the A operand of the extra k-step:
     //   k 0..7 (lanes < 32): (t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: -1, -1, -eps scale of the row
     //   (negated like the rest of the A side: v3 carries the opposite signs)
-    float thr_own[UA], thr_min = 0.f;
-    u32x4 aex[UA];
+    float thr_own = 0.f, thr_min = 0.f;
+    u32x4 aex = {0u, 0u, 0u, 0u};
     auto refresh_thr = [&]() __attribute__((always_inline)) {
-        float mn = 1.0e30f;
-#pragma unroll
-        for (int ua = 0; ua < UA; ++ua) {
-            const float tq = taul[row0 + 32 * ua + j];
-            float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
-            tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
-            thr_own[ua] = tf;
-            mn = fminf(mn, tf);
-            uint32_t t1, t2, t3;
-            bf16_split3(tf, t1, t2, t3);
-            const uint32_t nnu = bf16_up(nu_row[ua] * (kEps * 1.001f * 1.08f)) | 0x8000u;
-            aex[ua][0] = h ? 0xBF80BF80u : (t1 | (t1 << 16));
-            aex[ua][1] = h ? nnu : (t2 | (t2 << 16));
-            aex[ua][2] = h ? 0u : (t1 | (t3 << 16));
-            aex[ua][3] = h ? 0u : (t2 | (t3 << 16));
-        }
+        const float tq = taul[row0 + j];
+        float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
+        tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
+        thr_own = tf;
+        float mn = tf;
+        uint32_t t1, t2, t3;
+        bf16_split3(tf, t1, t2, t3);
+        const uint32_t nnu = bf16_up(nu_row * (kEps * 1.001f * 1.08f)) | 0x8000u;
+        aex[0] = h ? 0xBF80BF80u : (t1 | (t1 << 16));
+        aex[1] = h ? nnu : (t2 | (t2 << 16));
+        aex[2] = h ? 0u : (t1 | (t3 << 16));
+        aex[3] = h ? 0u : (t2 | (t3 << 16));
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
         thr_min = mn;
     };
-    // the exact threshold of accumulator register r (lane half hv, A operand ua), strictly below tau (ties must pass)
-    auto thr_of = [&](int r, int hv, int ua) __attribute__((always_inline)) -> float {
-        const float tq = taul[row0 + 32 * ua + (r & 3) + 8 * (r >> 2) + 4 * hv];
+    // the exact threshold of accumulator register r (lane half hv), strictly below tau (ties must pass)
+    auto thr_of = [&](int r, int hv) __attribute__((always_inline)) -> float {
+        const float tq = taul[row0 + (r & 3) + 8 * (r >> 2) + 4 * hv];
         return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
     };
     refresh_thr();
@@ -787,13 +779,13 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
 
     unsigned* ring = rings + w * kRing4;
     unsigned tail = 0, head_c = 0;          // wave-uniform
-    // push the flagged registers (bit 15 - r <-> register r) of A operand ua
-    auto push_mask = [&](uint32_t m, int ua, int loc) __attribute__((always_inline)) {
+    // push the flagged registers (bit 15 - r <-> register r)
+    auto push_mask = [&](uint32_t m, int loc) __attribute__((always_inline)) {
         while (__any(m != 0)) {
             const bool act = m != 0;
             const int bit = 31 - __builtin_clz(m | 1u);
             const int r = 15 - bit;
-            const int row = 32 * ua + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
             m &= ~(1u << bit);
             const uint64_t pm = __ballot(act);
             if (tail + 64u - head_c > (unsigned)kRing4) {      // ring full: publish what is there and wait for the rescoring wave
@@ -812,245 +804,151 @@ __global__ void __launch_bounds__(512, 2) sweep4_kernel(Args4 g) {
             tail += (unsigned)__popcll(pm);
         }
     };
-    auto ensure_landed = [&](int hf) __attribute__((always_inline)) {
-        const unsigned want = (unsigned)(hf + 1);
-        if constexpr ((PDA_V4_ABL & 2) != 0) return;
+    auto ensure_landed = [&](int b) __attribute__((always_inline)) {
+        const unsigned want = (unsigned)(b + 1);
         if (landed_c < want) {
             unsigned spin = 0;
             PROF_T0(te);
             do {
-                landed_c = min(lds_ld(&s_landed[0]), lds_ld(&s_landed[1]));
+                landed_c = 0xFFFFFFFFu;
+#pragma unroll
+                for (int z = 0; z < kLoaders; ++z) landed_c = min(landed_c, lds_ld(&s_landed[z]));
                 if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 1u; break; }
             } while (landed_c < want);
             PROF_T1(te, 1);
             PDA_CBAR();
         }
     };
-    const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment m of ring slot s: + s HB + 32 m
-
-    // one half-tile: NM + 1 MFMAs per A operand into acc; bq holds its first PF fragments on entry and those of the next
-    // half on exit (has_next; the next half must have landed)
-#ifndef PDA_V4_PF
-#define PDA_V4_PF 4
-#endif
-    constexpr int PF = NM < PDA_V4_PF ? NM : PDA_V4_PF;
-    u32x4 bq[PF];
-    auto load_first = [&](int hf) __attribute__((always_inline)) {
-        const unsigned char* tb = lane_base + (hf & 3) * HB;
-#pragma unroll
-        for (int m = 0; m < PF; ++m) bq[m] = *reinterpret_cast<const u32x4*>(tb + 32 * m);
-    };
-    // One half-tile: NM + 1 MFMAs per A operand into acc.  bq holds its first PF fragments on entry and those of the next half on
-    // exit (the next half must have landed; behind the last half the reads hit a stale slot and are never used).
-    // TEST: the filter on the PREVIOUS half runs in the shadow of these MFMAs -- the lane's mask of negative accumulator
-    // registers (bit 15 - r <-> register r), one v_alignbit per register, 32 / NM of them behind every MFMA pair (pinned with
-    // sched_group_barrier: left alone hipcc puts all of them behind the last MFMA, 500 exposed cycles per tile).
-    auto mfma_half = [&](int hf, f32x16 (&acc)[UA], float& popv, int& locv, auto test_tag, const f32x16 (&prev)[UA],
-                         uint32_t (&msk)[UA]) __attribute__((always_inline)) {
-        constexpr bool TEST = decltype(test_tag)::value;
-        constexpr int RPS = 16 / NM > 0 ? 16 / NM : 1;          // accumulator registers of `prev` tested per k-step
-        const unsigned char* tb = lane_base + (hf & 3) * HB;
-        const unsigned char* tbn = lane_base + ((hf + 1) & 3) * HB;
-        u32x4 bx = *reinterpret_cast<const u32x4*>(tb + 2 * D);
-        const uint2 pi = *reinterpret_cast<const uint2*>(tb - 16 * h + 2 * D + 32);
-#pragma unroll
-        for (int ua = 0; ua < UA; ++ua) msk[ua] = 0u;
-#pragma unroll
-        for (int m = 0; m < NM; ++m) {
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua)
-                acc[ua] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[ua][m]), __builtin_bit_cast(bf16x8, bq[m % PF]),
-                                                                  m == 0 ? zero16v() : acc[ua], 0, 0, 0);
-            if (m + PF < NM) bq[m % PF] = *reinterpret_cast<const u32x4*>(tb + 32 * (m + PF));
-            else bq[m % PF] = *reinterpret_cast<const u32x4*>(tbn + 32 * (m + PF - NM));
-            if constexpr (TEST) {
-                // OR of the bit patterns: "some register of the lane is negative" is its sign bit.  (v_alignbit_b32 -- the exact
-                // per-register mask -- is a quarter-rate instruction: 64 of them per tile cost as much as the MFMAs; the exact
-                // mask is built in the slow path, for the rare half with a candidate.)
-                if (m * RPS < 16) {
-#pragma unroll
-                    for (int ua = 0; ua < UA; ++ua)
-#pragma unroll
-                        for (int r = m * RPS; r < (m + 1) * RPS; ++r) {
-                            if constexpr ((PDA_V4_ABL & 128) != 0) msk[ua] |= ah[ua][r % NM][r % 4] & 0x7fffffffu;      // timing only: not an MFMA result
-                            else msk[ua] |= (uint32_t)__float_as_int(prev[ua][r]);
-                        }
-                }
-            }
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_group_barrier(0x008, UA, 0);
-            if constexpr (TEST) __builtin_amdgcn_sched_group_barrier(0x002, (UA * RPS + 1) / 2, 0);      // v_or3_b32 takes two registers at a time
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);     // (two: the reads of the test pieces and of (pop, id) ride along)
-#endif
-        }
-        popv = __uint_as_float(pi.x);
-        locv = (int)pi.y;
-        if constexpr (HEAD == PDA_HEAD_RAW) {
-            // raw head on any prep: 1/pop := 1, constant := +8e-6 (a prep built with a popularity carries its pieces);
-            // null items keep their -3e38
-            const bool nul = !(popv == popv);
-            bx[0] = h ? (nul ? 0x0000FF61u : bf16_up(8.0e-6f)) : 0x00003F80u;
-            bx[1] = h ? bx[1] : 0x00003F80u;
-            bx[2] = h ? 0u : 0x3F800000u;
-            bx[3] = 0u;
-        }
-#pragma unroll
-        for (int ua = 0; ua < UA; ++ua)
-            acc[ua] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex[ua]), __builtin_bit_cast(bf16x8, bx), acc[ua], 0, 0, 0);
-        PDA_CBAR();
-        lds_st(&s_released[w], (unsigned)(hf + 1));
-        PDA_CBAR();
-    };
-    // what is left of the filter outside the MFMA shadow: "any lane flagged", and the clamp check of the popularity head
-    auto test_done = [&](const uint32_t (&msk)[UA], float popv, bool& clampy) __attribute__((always_inline)) -> bool {
-        bool many = false;
-        clampy = false;
-        if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv > thr_min);     // s~ + eps < 0: head <= pop; rare once the lists are warm
-#pragma unroll
-        for (int ua = 0; ua < UA; ++ua) many = many || __any((int)msk[ua] < 0);
-        return many || clampy;
-    };
-    // the same mask outside an MFMA block (the last half of the sweep)
-    auto test_plain = [&](const f32x16 (&acc)[UA], uint32_t (&msk)[UA]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int ua = 0; ua < UA; ++ua) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m |= (uint32_t)__float_as_int(acc[ua][r]);
-            msk[ua] = m;
-        }
-    };
-    auto slow_half = [&](const f32x16 (&acc)[UA], float popv, int locv, const uint32_t (&msk)[UA], bool clampy) __attribute__((always_inline)) {
-        PROF_T0(ts);
-        PROF_INC(4, 1);
-        if (clampy) PROF_INC(14, 1);
-#pragma unroll
-        for (int ua = 0; ua < UA; ++ua) {
-            uint32_t mcb = 0;
-            if (__any((int)msk[ua] < 0)) {
-                // the exact mask: bit 15 - r <-> register r is negative (one v_alignbit per register shifts the sign bit in)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(acc[ua][r]), 31);
-            }
-            if (clampy) {
-                int hv = h;
-#if defined(__HIP_DEVICE_COMPILE__)
-                asm volatile("" : "+v"(hv));
-#endif
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mcb |= (popv > thr_of(r, hv, ua)) ? (1u << (15 - r)) : 0u;
-            }
-            if constexpr ((PDA_V4_ABL & 64) == 0) push_mask(mcb, ua, locv);
-        }
-        PDA_CBAR();
-        lds_st(&s_tail[w], tail);
-        PROF_T1(ts, 3);
-    };
+    const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment (cb, m) of slot s: + s BB + cb HB + 32 m
 
     PROF_T0(tm0);
-    // MFMAs are issued far ahead of their execution (the matrix pipe queues them: measured, a 36-MFMA tile is issued in ~640
-    // cycles and executes in 1152).  A VALU read of an accumulator therefore stalls the wave until the pipe has worked its way
-    // up to that MFMA -- and with the wave stalled nothing new is queued: tested right behind its own MFMAs, the pipe runs dry
-    // once per tile (measured: 3.7 instead of 2.0 ms); tested BETWEEN the MFMAs of the next half-tile, the stall holds back the
-    // rest of that half-tile (3.6 ms).  So the filter of half-tile h runs after ALL MFMAs of half-tile h + 1 have been issued,
-    // on the other of two accumulator sets: it waits for h while h + 1 (576 cycles of pipe time) is queued behind.
-    f32x16 accA[UA], accB[UA];
-    float popA = 0.f, popB = 0.f;
-    int locA = 0, locB = 0;
-    uint32_t mk[UA];
-    [[maybe_unused]] uint32_t dummy = 0;
     int n_done = 0;
     bool stopped = false;
-    const std::false_type no_test{};
-    auto filter_half = [&](const f32x16 (&acc)[UA], float popv, int locv) __attribute__((always_inline)) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        if constexpr ((PDA_V4_ABL & 1) != 0) {      // timing only: no filter -- but the MFMAs must not be dead code
-#pragma unroll
-            for (int ua = 0; ua < UA; ++ua) asm volatile("" ::"v"(acc[ua]));
-        }
-#endif
-        if constexpr ((PDA_V4_ABL & 1) == 0) {
-            bool clamp;
-#if defined(__HIP_DEVICE_COMPILE__)
-            __builtin_amdgcn_sched_barrier(0);      // hipcc would hoist these (independent) VALU reads between the MFMAs above
-#endif
-            PROF_T0(tt0);
-            test_plain(acc, mk);
-#ifdef PDA_V4_PROF
-            asm volatile("" ::"v"(mk[0]), "v"(mk[UA - 1]));
-#endif
-            PROF_T1(tt0, 11);
-            if constexpr ((PDA_V4_ABL & 256) != 0) {            // timing only: the ORs alone
-                dummy |= mk[0] | mk[UA - 1];
-            } else if constexpr ((PDA_V4_ABL & 2048) != 0) {    // timing only: ORs + the wave-wide "any" + a trivial branch
-                if (test_done(mk, popv, clamp)) tail += 1;
-            } else {
-                if (test_done(mk, popv, clamp)) slow_half(acc, popv, locv, mk, clamp);
-            }
-        }
-    };
-    if (n_it > 0) {
-        ensure_landed(0);
-        load_first(0);
-        ensure_landed(1);
-        mfma_half(0, accA, popA, locA, no_test, accA, mk);
-    }
-    for (int i = 0; i < n_it && !stopped; ++i) {
-        const bool more = (i + 1) < n_it;
-        // the hand-over words, read here and used at the end of the iteration (the read is off the critical path)
-        const unsigned pr_l0 = lds_ld(&s_landed[0]), pr_l1 = lds_ld(&s_landed[1]), pr_tv = lds_ld(&s_tver[w]);
-        if (more) ensure_landed(2 * i + 2);
-        PROF_T0(tb0);
-        mfma_half(2 * i + 1, accB, popB, locB, no_test, accB, mk);      // odd half of tile i
-        PROF_T1(tb0, 10);
-        filter_half(accA, popA, locA);                                  // even half of tile i
-        if (more) {
-            ensure_landed(2 * i + 3);
-            mfma_half(2 * i + 2, accA, popA, locA, no_test, accA, mk);  // even half of tile i + 1
-        }
-        filter_half(accB, popB, locB);                                  // odd half of tile i
-        ++n_done;
-        landed_c = max(landed_c, min(pr_l0, pr_l1));
+    for (int b = 0; b < n_blk && !stopped; ++b) {
+        const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
+        ensure_landed(b);
+        const unsigned char* tb = lane_base + (b & 1) * BB;
+        // ---- the block: NB chains, k-step major; S = NB NM B reads, PF in flight ----
+        f32x16 acc[NB];
+        float popv[NB];
+        int locv[NB];
         {
-            const unsigned tv = pr_tv;
-            if (tv != tver_seen) {
-                tver_seen = tv;
-                PROF_T0(tf);
-                refresh_thr();
-                PROF_T1(tf, 12);
-                PROF_INC(5, 1);
+            constexpr int S = NB * NM, PF = S < 8 ? S : 8;
+            auto b_load = [&](int s_) __attribute__((always_inline)) -> u32x4 {
+                const int m = s_ / NB, cb = s_ % NB;
+                return *reinterpret_cast<const u32x4*>(tb + cb * HB + 32 * m);
+            };
+            u32x4 bq[PF];
+#pragma unroll
+            for (int s_ = 0; s_ < PF; ++s_) bq[s_] = b_load(s_);
+            u32x4 bx[NB];
+            uint2 pi[NB];
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                bx[cb] = *reinterpret_cast<const u32x4*>(tb + cb * HB + 2 * D);
+                pi[cb] = *reinterpret_cast<const uint2*>(tb - 16 * h + cb * HB + 2 * D + 32);
+            }
+#pragma unroll
+            for (int s_ = 0; s_ < S; ++s_) {
+                const int m = s_ / NB, cb = s_ % NB;
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bq[s_ % PF]),
+                                                                  m == 0 ? zero16v() : acc[cb], 0, 0, 0);
+                if (s_ + PF < S) bq[s_ % PF] = b_load(s_ + PF);
+            }
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                popv[cb] = __uint_as_float(pi[cb].x);
+                locv[cb] = (int)pi[cb].y;
+                if constexpr (HEAD == PDA_HEAD_RAW) {
+                    // raw head on any prep: 1/pop := 1, constant := +8e-6 (a prep built with a popularity carries its pieces);
+                    // null items keep their -3e38
+                    const bool nul = !(popv[cb] == popv[cb]);
+                    bx[cb][0] = h ? (nul ? 0x0000FF61u : bf16_up(8.0e-6f)) : 0x00003F80u;
+                    bx[cb][1] = h ? bx[cb][1] : 0x00003F80u;
+                    bx[cb][2] = h ? 0u : 0x3F800000u;
+                    bx[cb][3] = 0u;
+                }
+                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bx[cb]), acc[cb], 0, 0, 0);
             }
         }
+        PDA_CBAR();
+        lds_st(&s_released[w], (unsigned)(b + 1));
+        PDA_CBAR();
+        // ---- the filter: "some register of the lane is negative" = the sign bit of the OR of the bit patterns.  (This stalls
+        // the wave until its MFMAs are through; the other MFMA wave of the SIMD has the matrix pipe meanwhile.) ----
+        if constexpr ((PDA_V4_ABL & 1) != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) asm volatile("" ::"v"(acc[cb]));       // timing only: no filter, but the MFMAs stay
+#endif
+        } else {
+#pragma unroll
+            for (int cb = 0; cb < NB; ++cb) {
+                uint32_t mo = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mo |= (uint32_t)__float_as_int(acc[cb][r]);
+                bool clampy = false;
+                if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv[cb] > thr_min);     // s~ + eps < 0: head <= pop; rare once the lists are warm
+                if (__any((int)mo < 0) || clampy) {
+                    PROF_T0(ts);
+                    PROF_INC(4, 1);
+                    uint32_t mcb = 0;
+                    if (__any((int)mo < 0)) {
+                        // the exact mask: bit 15 - r <-> register r is negative (v_alignbit shifts the sign bit in)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(acc[cb][r]), 31);
+                    }
+                    if (clampy) {
+                        int hv = h;
+#if defined(__HIP_DEVICE_COMPILE__)
+                        asm volatile("" : "+v"(hv));
+#endif
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mcb |= (popv[cb] > thr_of(r, hv)) ? (1u << (15 - r)) : 0u;
+                    }
+                    push_mask(mcb, locv[cb]);
+                    PDA_CBAR();
+                    lds_st(&s_tail[w], tail);
+                    PROF_T1(ts, 3);
+                }
+            }
+        }
+        if (pr_tv != tver_seen) {
+            tver_seen = pr_tv;
+            refresh_thr();
+            PROF_INC(5, 1);
+        }
+        if (NB == 1 && (b & 1) == 0) continue;
+        const int i = (b * NB) >> 1;           // 64-item tile i is complete
+        ++n_done;
         // ---- early termination.  Checkpoint c = the end of tile 4 c + 3: vote "nothing at or behind tile 4 c + 8 can reach
-        // one of my rows" (candidates still in the ring can only raise thresholds); the votes of checkpoint c are read at
-        // checkpoint c + 1 -- the MFMA waves are never more than two tiles apart (a ring slot is refilled only when all four
-        // have released it), so all four votes are there and every wave takes the same decision.
+        // my row" (candidates still in the ring can only raise thresholds); the votes of checkpoint c are read at checkpoint
+        // c + 1 -- the MFMA waves are never more than two blocks apart (a slot is refilled only when all of them have released
+        // it), so every vote is there and every wave takes the same decision.
         if (g.sufA != nullptr && (i & 3) == 3) {
             const int c = i >> 2;
             if (c >= 1) {
-                const unsigned* v = &s_vote[((c - 1) & 3) * 4];
-                stopped = (lds_ld(&v[0]) & lds_ld(&v[1]) & lds_ld(&v[2]) & lds_ld(&v[3])) != 0u;
+                const unsigned* v = &s_vote[((c - 1) & 3) * kMainWaves];
+                unsigned all = 1u;
+#pragma unroll
+                for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
+                stopped = all != 0u;
             }
             const int inext = i + 5;
             bool alldead = false;
             if (inext < n_it) {
                 const int tn = split + (kWarmTiles + inext) * g.n_splits;
                 const float sa = g.sufA[tn], sb = g.sufB[tn];
-                bool dead = true;
-#pragma unroll
-                for (int ua = 0; ua < UA; ++ua) dead = dead && (__builtin_fmaf(nu_row[ua], sb, sa) * 1.000002f < thr_own[ua]);
-                alldead = __all(dead);
+                alldead = __all(__builtin_fmaf(nu_row, sb, sa) * 1.000002f < thr_own);
             }
-            if (lane == 0) lds_st(&s_vote[(c & 3) * 4 + w], alldead ? 1u : 0u);
+            if (lane == 0) lds_st(&s_vote[(c & 3) * kMainWaves + w], alldead ? 1u : 0u);
         }
     }
-    if constexpr ((PDA_V4_ABL & (256 | 512 | 1024)) != 0) if (dummy == 0x12345u) g.stats[3] = dummy;
-    (void)dummy;
     PROF_T1(tm0, 0);
     PROF_INC(13, 1);
     PROF_INC(15, tail);
     PROF_FLUSH(0, 5);
-    PROF_FLUSH(10, 15);
+    PROF_FLUSH(13, 15);
     PDA_CBAR();
     lds_st(&s_tail[w], tail);
     PDA_CBAR();
@@ -1086,13 +984,13 @@ int launch4(const Args4& g, hipStream_t stream) {
             attr_set = 1;
         }
         const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(512), G::lds_total, stream, g);
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
         PDA_CHECK_LAUNCH();
     }
     return PDA_OK;
 }
 
-int user_tile4(int d) { return d <= 128 ? 256 : 128; }
+int user_tile4(int d) { (void)d; return kMainWaves * 32; }
 
 int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
                int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
