@@ -776,6 +776,9 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     };
     refresh_thr();
     unsigned tver_seen = 0, landed_c = 0;
+#ifdef PDA_V4_PRIO
+    if (w < 4) __builtin_amdgcn_s_setprio(PDA_V4_PRIO);     // experiment: the first-dispatched MFMA wave of every SIMD goes first
+#endif
 
     unsigned* ring = rings + w * kRing4;
     unsigned tail = 0, head_c = 0;          // wave-uniform

@@ -182,15 +182,20 @@ def item_prep4(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], order: 
     return buf
 
 
-def score_kernel(d: int, K: int, nloc: int) -> str:
-    """Which pre-filtered kernel generation serves a call: 'v4' (pda_score_topk_v4.hip) wherever it applies, else the v2/v3
-    entry points.  PDA_SCORE_KERNEL=v2|v3|v4 forces one (A/B measurements, cross-checks)."""
+def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
+    """Which pre-filtered kernel generation serves a call.  All of them return the same keys; the choice is by measured
+    speed (C3, 65 536 users per block): generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
+    waves) for sweeps with few candidates per user -- the dense sweep in visiting order, 3.5 vs 4.2 ms --; generation 3 for
+    the candidate-heavy natural-order sweeps (8.6 vs 11 ms) and, by a few per cent, for the early-terminating sweep.
+    PDA_SCORE_KERNEL=v2|v3|v4|old forces one (A/B measurements, cross-checks; "old" = whatever the v2/v3 entry points pick)."""
     import os
     forced = os.environ.get("PDA_SCORE_KERNEL", "")
     fits = d in (64, 128, 256) and K <= TOPK_K_V4 and nloc <= (1 << 26)
-    if forced in ("v2", "v3", "old"):      # "old": whatever the v2/v3 entry points pick
+    if forced in ("v2", "v3", "old"):
         return forced
-    return "v4" if fits else "v3"
+    if forced == "v4":
+        return "v4" if fits else "v3"
+    return "v4" if (fits and prune == "order" and d <= 128) else "v3"
 
 
 def check_order(prep_ord: torch.Tensor, n: int, d: int):
@@ -301,7 +306,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     impl = impl or score_impl(d, K, item_offset + nloc)
     if prune is None:
         prune = prune_default(head)
-    if impl == "v2" and score_kernel(d, K, nloc) == "v4":
+    if impl == "v2" and score_kernel(d, K, nloc, prune) == "v4":
         order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
         if n_splits_auto and out_given is None:

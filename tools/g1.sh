@@ -1,5 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python tools/dbg_v4.py 2>&1 | grep -c OK
-timeout 300 python tools/dbg_v4.py 2>&1 | grep -v OK | tail -3
-timeout 300 python tools/time_variants.py base,abl1 order 1 2>&1 | tail -2
-timeout 300 python tools/prof4.py order 1 2>&1 | tail -4
+timeout 600 python -m pytest tests/test_gpu_score_topk.py -x -q -m gpu -k "k4" --timeout 120 2>&1 | tail -4
+timeout 900 python tools/time_v4.py c3 65536 10 v3,v4 2>&1 | tail -12
