@@ -118,10 +118,13 @@ def bench_eval(args, rank, world, dev):
         del W.I                                           # every rank keeps only its shard of the item table
     sink = []
 
+    last = [None]
+
     def run(bl):
         # N > 1: the all-to-all exchange -- every rank merges and keeps the lists of its slice of the users
         for idx, val in ev.topk_blocks(bl, args.K, head, hist, sharded=world > 1):
             sink.append(idx[0, 0])                        # keep the result alive without a sync
+            last[0] = idx
 
     def timed_pass(prune):
         """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
@@ -156,7 +159,8 @@ def bench_eval(args, rank, world, dev):
         natural = {"value": Bu * args.steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / args.steps * 1e3, "kernel_ms": k_ms_n}
     dt, k_ms, st_d = timed_pass("order" if use_order else False)
     if use_order:
-        assert int(st_d["tiles_scored"][0]) == st_d["tiles_dense"], "the dense sweep must score every tile"
+        # (generation 4 counts whole 64-item tiles and whole 128-user tiles: >= the 32-item count)
+        assert int(st_d["tiles_scored"][0]) >= st_d["tiles_dense"], "the dense sweep must score every tile"
     # beside it: the product default for the PDA head -- ordered sweep WITH exact early termination (same keys).
     ordered = None
     if use_order and not args.headline_only:
@@ -167,6 +171,8 @@ def bench_eval(args, rank, world, dev):
                    "note": "pda_score_topk_ordered_f32: catalogue visited most-popular-first, a user block stops once "
                            "pop + ||u||*pop*||i|| of everything unvisited is below every user's running K-th value; "
                            "bit-identical keys (tests/test_gpu_score_topk.py); data-dependent, hence not the headline"}
+    if os.environ.get("PDA_BENCH_DUMP"):                  # tests/test_gpu_two_rank.py: the lists of the last step (this rank's rows)
+        torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_w%d_r%d.pt" % (world, rank)))
     n_local = ev.I_shard.shape[0]
     flops = 2.0 * Bu * n_local * W.d
     nnz_blk = float(W.n_train) * Bu / W.n_users

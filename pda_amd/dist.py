@@ -74,12 +74,29 @@ class ItemShardedTopK:
         return cls(U, I_full[lo:hi].contiguous(), lo, pop, rank, world, **kw)
 
     def set_popularity(self, pop_full: Optional[torch.Tensor]):
-        """evaluation.set_testing_popularity (MF/train_new_api.py:710): slice the new vector for this shard."""
+        """evaluation.set_testing_popularity (MF/train_new_api.py:710): slice the new vector for this shard.
+        The slice OBJECT is kept while the caller's vector is unchanged (same tensor, same version): the visiting order,
+        the item prep and the popularity check of ops are cached per tensor object, and recommend_device calls this once
+        per user block."""
         n = self.I_shard.shape[0]
-        self.pop_shard = None if pop_full is None else pop_full[self.item_offset:self.item_offset + n].contiguous()
+        if pop_full is None:
+            self.pop_shard, self._pop_src = None, None
+            return
+        src = getattr(self, "_pop_src", None)
+        if src is not None and src[0]() is pop_full and src[1] == pop_full._version and self.pop_shard is not None:
+            return
+        if pop_full.numel() < self.item_offset + n:
+            raise ValueError("popularity vector has %d entries, this shard needs items up to %d" % (pop_full.numel(), self.item_offset + n))
+        self.pop_shard = pop_full[self.item_offset:self.item_offset + n].contiguous()
+        import weakref
+        self._pop_src = (weakref.ref(pop_full), pop_full._version)
 
     # -- one block, blocking ---------------------------------------------------------------------
     def local_keys(self, users, K, head, hist):
+        if self.I_shard.shape[0] == 0:
+            # more ranks than 32-item tiles: this rank owns nothing and contributes empty lists (key 0 = empty slot), so that
+            # the collective of the other ranks does not wait for a call that would fail on a 0-row shard
+            return torch.zeros((users.numel(), K) if self.world > 1 else (1, users.numel(), K), dtype=torch.int64, device=users.device)
         keys = self.score_fn(self.U, self.I_shard, users, K, head, self.pop_shard if head else None, hist,
                              self.item_offset, 0)
         if self.world == 1:

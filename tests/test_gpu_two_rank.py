@@ -1,0 +1,41 @@
+"""The N > 1 path of bench.py with REAL kernels: two ranks under torch.distributed.run on the one GPU of the test box
+(PDA_BENCH_ONE_GPU=1: both ranks on cuda:0, gloo instead of RCCL -- RCCL refuses two ranks on one device).  Checks that
+the item-sharded evaluation starts, exchanges the partial lists (all-to-all orchestration of pda_amd.dist), prints the
+contract line -- and that the sharded result equals the single-rank result on the same users.  RCCL itself stays
+unexecuted until the driver's multi-GPU run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(cmd, env):
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
+    env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PDA_BENCH_DUMP=str(tmp_path))
+    one = _run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-train", "--no-cpu-baseline",
+                "--eval-block", "2048"], env)
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29517", "bench.py", "--gpus", "2", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                "--eval-block", "2048"], env)
+    for line, n in ((one, 1), (two, 2)):
+        assert line["n_gpus"] == n and line["unit"] == "users/s" and line["value"] > 0 and line["scaling"] == "strong"
+        assert line["roofline"]["bound"] == "mfma" and line["steps"] == 2
+    # the lists of the last step: rank r of the two-rank run holds the rows of ITS slice of the users
+    a = torch.load(os.path.join(tmp_path, "topk_w1_r0.pt"))
+    b = torch.cat([torch.load(os.path.join(tmp_path, "topk_w2_r%d.pt" % r)) for r in range(2)])
+    assert a.shape == b.shape == (2048, 50)
+    assert torch.equal(a, b)
