@@ -409,7 +409,7 @@ def main():
     if world != args.gpus and world == 1 and args.gpus > 1:
         print("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus, file=sys.stderr)
         sys.exit(2)
-    # PDA_BENCH_ONE_GPU=1 is a plumbing check only (tools/two_rank_smoke.sh): every rank on cuda:0 over gloo
+    # PDA_BENCH_ONE_GPU=1 is a plumbing check only (tests/test_gpu_two_rank.py): every rank on cuda:0 over gloo
     one_gpu = os.environ.get("PDA_BENCH_ONE_GPU") == "1"
     if one_gpu:
         local = 0

@@ -44,7 +44,7 @@ def _exchange_user_slices(keys: torch.Tensor, world: int, group=None) -> torch.T
     -- R times less than the all-gather -- and on the xGMI full mesh the R-1 transfers run on R-1 separate links."""
     Bu, K = keys.shape
     out = torch.empty((world, Bu // world, K), dtype=keys.dtype, device=keys.device)
-    if dist.get_backend(group) == "gloo" and keys.is_cuda:       # plumbing check on one GPU (tools/two_rank_smoke.sh)
+    if dist.get_backend(group) == "gloo" and keys.is_cuda:       # plumbing check on one GPU (tests/test_gpu_two_rank.py)
         parts = list(torch.empty((world, Bu, K), dtype=keys.dtype, device=keys.device).unbind(0))
         dist.all_gather(parts, keys.contiguous(), group=group)
         r = dist.get_rank(group)

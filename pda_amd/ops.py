@@ -187,15 +187,18 @@ def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
     speed (C3, 65 536 users per block): generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
     waves) for sweeps with few candidates per user -- the dense sweep in visiting order, 3.5 vs 4.2 ms --; generation 3 for
     the candidate-heavy natural-order sweeps (8.6 vs 11 ms) and, by a few per cent, for the early-terminating sweep.
-    PDA_SCORE_KERNEL=v2|v3|v4|old forces one (A/B measurements, cross-checks; "old" = whatever the v2/v3 entry points pick)."""
+    PDA_SCORE_KERNEL=v3|v4 forces one (A/B measurements, cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_KERNEL", "")
     fits = d in (64, 128, 256) and K <= TOPK_K_V4 and nloc <= (1 << 26)
-    if forced in ("v2", "v3", "old"):
-        return forced
+    if forced in ("v3", "old"):
+        return "v3"
     if forced == "v4":
         return "v4" if fits else "v3"
-    return "v4" if (fits and prune == "order" and d <= 128) else "v3"
+    if not (fits and prune):
+        return "v3"
+    # d = 256 (bf16 tables of config 5): generation 4 also wins the early-terminating sweep (3.5 vs 4.5 ms on a config-5 shard)
+    return "v4" if (prune == "order" or d == 256) else "v3"
 
 
 def check_order(prep_ord: torch.Tensor, n: int, d: int):
@@ -226,11 +229,12 @@ def mark_modified(*tensors):
 
 
 def score_impl(d: int, K: int, item_hi: int) -> str:
-    """'v2' = the pre-filtered kernels (bf16 MFMA filter + exact fp32 rescoring: pda_score_topk_v2.hip / _v3.hip) where they
-    apply, else 'v1' (exact fp32 MFMA).  Same results.  PDA_SCORE_IMPL=v1|v2 forces one (A/B measurements, cross-checks)."""
+    """'v2' = the pre-filtered kernels (bf16 MFMA filter + exact fp32 rescoring: pda_score_topk_v3.hip / _v4.hip; the label
+    is historical) where they apply, else 'v1' (exact fp32 MFMA).  Same results.  PDA_SCORE_IMPL=v1|v2 forces one (A/B
+    measurements, cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_IMPL", "")
-    ok = d in (64, 128, 256) and K <= TOPK_CAP_V2     # the library picks v2 or v3 inside (pda_score_topk_v2.hip, run_score_prepped)
+    ok = d in (64, 128, 256) and K <= TOPK_CAP_V2
     if forced == "v1" or not ok:
         return "v1"
     return "v2"

@@ -16,9 +16,15 @@ from typing import Optional
 import torch
 
 CONFIGS = {
-    # name: (n_users, n_items, embed, mean_hist)      BASELINE.json configs[1..3]
+    # name: (n_users, n_items, embed, mean_hist)      BASELINE.json configs[0..4]
+    # c1: the shape of the processed Douban data the reference trains on (README.md:41,69; ~6.7 M train pairs) -- the data
+    #     itself is a missing blob in the reference tree
+    "c1": (47_890, 26_047, 64, 140),
     "c2": (50_000, 20_000, 64, 150),
     "c3": (1_000_000, 200_000, 128, 50),
+    # c5shard: ONE rank's share of config 5 (10 M users x 2 M items, d = 256, bf16 tables, item-sharded over 8 GPUs):
+    #     250 000 item rows; the user table is replicated, 1 M of its 10 M rows are enough for any number of timed blocks
+    "c5shard": (1_000_000, 250_000, 256, 50),
     "tiny": (4_000, 3_000, 64, 30),
 }
 
@@ -48,7 +54,8 @@ def _gen(seed: int, device) -> torch.Generator:
 
 def make_workload(name: str = "c2", device="cuda", gamma: float = 0.22, n_slots: int = 10,
                   n_users: Optional[int] = None, n_items: Optional[int] = None, d: Optional[int] = None,
-                  mean_hist: Optional[int] = None) -> Workload:
+                  mean_hist: Optional[int] = None, table_dtype: torch.dtype = torch.float32) -> Workload:
+    """table_dtype=torch.bfloat16: U and I are returned as bf16 tables (config 5)."""
     cu, ci, cd, ch = CONFIGS[name]
     n_users, n_items, d, mean_hist = n_users or cu, n_items or ci, d or cd, mean_hist or ch
     dev = torch.device(device)
@@ -86,6 +93,8 @@ def make_workload(name: str = "c2", device="cuda", gamma: float = 0.22, n_slots:
     pop_all = pop.t().contiguous()                              # [I, T] like item_pop_seq_ori2.txt
     pop_train = pop_all[:, :-1].pow(gamma).float().contiguous()
     pop_last = pop_all[:, -2].pow(gamma).float().contiguous()
+    if table_dtype != torch.float32:
+        U, I = U.to(table_dtype), I.to(table_dtype)
     return Workload(name, n_users, n_items, d, gamma, U, I, indptr, items, slots, pop_train, pop_last, nnz)
 
 

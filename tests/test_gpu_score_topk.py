@@ -16,20 +16,19 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k2", "k3", "k4nat", "k4ord", "k4stop"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop"])
 def impl(request, monkeypatch):
-    """Every test runs against all scoring paths: v1 = exact fp32 MFMA, v2 = bf16x3 pre-filter + exact rescoring
-    (pda_score_topk_v2.hip), v2ord = v2 visiting the catalogue strongest-bound-first with early termination
-    (pda_score_topk_ordered_f32, forced on for BOTH heads here).  They must be indistinguishable."""
-    # k2 / k3 force ONE of the two pre-filtered kernels (approximate lists / candidate ring) for every sweep mode, so that
-    # each of them is checked in the modes the default policy would not give it
+    """Every test runs against all scoring paths: v1 = exact fp32 MFMA; v2 / v2ord / v2order_only = the pre-filtered path
+    (bf16 MFMA filter + exact rescoring) in natural order / visiting order with early termination / visiting order without
+    (forced on for BOTH heads here), each with generation 3 pinned; k3 = generation 3 again in its early-terminating mode
+    (historical duplicate of v2ord, kept for the parametrised ids); k4* = generation 4.  They must be indistinguishable."""
     monkeypatch.setenv("PDA_SCORE_IMPL", "v1" if request.param == "v1" else "v2")
     # k4*: the generation-4 kernel (pda_score_topk_v4.hip) in its three sweep modes; the older generations are pinned to v3
     # (v2 where the library picks it) so that they stay covered now that v4 is the default
-    monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order", "k2": "order", "k3": "1", "k4ord": "order",
+    monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order", "k3": "1", "k4ord": "order",
                                            "k4stop": "1"}.get(request.param, "0"))
-    if request.param in ("k2", "k3"):
-        monkeypatch.setenv("PDA_SCORE_KERNEL", "v2" if request.param == "k2" else "v3")
+    if request.param == "k3":
+        monkeypatch.setenv("PDA_SCORE_KERNEL", "v3")
     elif request.param.startswith("k4"):
         monkeypatch.setenv("PDA_SCORE_KERNEL", "v4")
     else:

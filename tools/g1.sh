@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_two_rank.py -x -q -m gpu 2>&1 | tail -5
+timeout 1500 python -m pytest tests/ -x -q -m gpu --timeout 300 2>&1 | tail -6

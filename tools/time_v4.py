@@ -8,7 +8,9 @@ Bu = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
 heads = [int(c) for c in (sys.argv[3] if len(sys.argv) > 3 else "10")]
 kernels = (sys.argv[4] if len(sys.argv) > 4 else "v3,v4").split(",")
 dev = torch.device('cuda')
-W = synthetic.make_workload(wl, dev)
+tdt = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == 'bf16') else torch.float32
+nus = int(sys.argv[6]) if len(sys.argv) > 6 else None
+W = synthetic.make_workload(wl, dev, table_dtype=tdt, n_users=nus)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 Bu = min(Bu, W.n_users)
 blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in range(0, min(W.n_users - Bu + 1, 4 * Bu), Bu)]
