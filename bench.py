@@ -41,7 +41,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
     p.add_argument("--warmup", type=int, default=3)
-    p.add_argument("--workload", default="c3", choices=["c2", "c3", "tiny"])
+    p.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5shard", "tiny"])
+    p.add_argument("--table-dtype", default="auto", choices=["auto", "f32", "bf16"],
+                   help="embedding table type (auto: bf16 for c5shard -- BASELINE config 5 --, f32 otherwise)")
+    p.add_argument("--no-per-config", action="store_true", help="skip the per_config block (C1, C2: evaluation and training beside the headline)")
     p.add_argument("--eval-block", type=int, default=262144, help="users per step (the default of the product's --eval_block)")
     p.add_argument("--head", default="condition", choices=["main_branch", "condition"])
     p.add_argument("--K", type=int, default=50)
@@ -101,17 +104,26 @@ class TimedScore:
         return sum(s.elapsed_time(e) for s, e in self.events) / max(1, len(self.events))
 
 
-def bench_eval(args, rank, world, dev):
+def table_dtype_of(args, workload):
+    td = args.table_dtype if args.table_dtype != "auto" else ("bf16" if workload == "c5shard" else "f32")
+    return td, (torch.bfloat16 if td == "bf16" else torch.float32)
+
+
+def bench_eval(args, rank, world, dev, workload=None, light=False):
+    """light: the per_config form -- headline sweep and early-terminating sweep only, a third of the steps."""
     import torch.distributed as dist
     from pda_amd import ops, synthetic
     from pda_amd.dist import ItemShardedTopK
-    W = synthetic.make_workload(args.workload, dev)
+    workload = workload or args.workload
+    td_name, td = table_dtype_of(args, workload)
+    steps = max(2, args.steps // 3) if light else args.steps
+    W = synthetic.make_workload(workload, dev, table_dtype=td)
     head = ops.HEAD_POP if args.head == "condition" else ops.HEAD_RAW
     timed = TimedScore()
     ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, rank, world, score_fn=timed)
     hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
     Bu = min(args.eval_block, W.n_users)
-    n_blocks = args.warmup + args.steps
+    n_blocks = args.warmup + steps
     starts = [(b * Bu) % max(1, W.n_users - Bu + 1) for b in range(n_blocks)]
     blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in starts]
     if world > 1:
@@ -154,9 +166,9 @@ def bench_eval(args, rank, world, dev):
     v2 = ops.score_impl(W.d, args.K, W.n_items) == "v2"
     use_order = head == ops.HEAD_POP and v2
     natural = None
-    if use_order and not args.headline_only:
+    if use_order and not args.headline_only and not light:
         dt_n, k_ms_n, _ = timed_pass(False)
-        natural = {"value": Bu * args.steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / args.steps * 1e3, "kernel_ms": k_ms_n}
+        natural = {"value": Bu * steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / steps * 1e3, "kernel_ms": k_ms_n}
     dt, k_ms, st_d = timed_pass("order" if use_order else False)
     if use_order:
         # (generation 4 counts whole 64-item tiles and whole 128-user tiles: >= the 32-item count)
@@ -166,7 +178,7 @@ def bench_eval(args, rank, world, dev):
     if use_order and not args.headline_only:
         dt_o, k_ms_o, st = timed_pass(True)
         frac = float(st["tiles_scored"][0]) / st["tiles_dense"] if "tiles_scored" in st else None
-        ordered = {"value": Bu * args.steps / dt_o, "unit": "users/s", "ms_per_step": dt_o / args.steps * 1e3,
+        ordered = {"value": Bu * steps / dt_o, "unit": "users/s", "ms_per_step": dt_o / steps * 1e3,
                    "kernel_ms": k_ms_o, "item_tiles_scored_frac": frac,
                    "note": "pda_score_topk_ordered_f32: catalogue visited most-popular-first, a user block stops once "
                            "pop + ||u||*pop*||i|| of everything unvisited is below every user's running K-th value; "
@@ -176,7 +188,8 @@ def bench_eval(args, rank, world, dev):
     n_local = ev.I_shard.shape[0]
     flops = 2.0 * Bu * n_local * W.d
     nnz_blk = float(W.n_train) * Bu / W.n_users
-    abytes = n_local * W.d * 4 + n_local * 4 + Bu * W.d * 4 + nnz_blk * 4 + (Bu + 1) * 8 + Bu * args.K * 8
+    esz = 2 if td_name == "bf16" else 4
+    abytes = n_local * W.d * esz + n_local * 4 + Bu * W.d * esz + nnz_blk * 4 + (Bu + 1) * 8 + Bu * args.K * 8
     impl = ops.score_impl(W.d, args.K, W.n_items)
     hd = "POP" if head else "RAW"
     alg_tf = flops / (k_ms * 1e-3) / 1e12
@@ -186,10 +199,12 @@ def bench_eval(args, rank, world, dev):
         # v2 = bf16x3 MFMA pre-filter (3 bf16 MFMAs per fp32 product) + exact fp32 rescoring of the survivors.
         # dense sweeps of fp32 tables run the v3 kernel: ONE bf16 MFMA per k-step as pre-filter (+ one k-step that carries
         # the threshold test), survivors rescored exactly in fp32.
-        roof = {"kernel": "score_topk_v3_kernel<%d,%s,%s>" % (W.d, hd, "ordered visiting, early_stop=0" if use_order else "natural order"),
+        gen = ops.score_kernel(W.d, args.K, n_local, "order" if use_order else False)
+        kname = ("sweep4_kernel" if gen == "v4" else "score_topk_v3_kernel")
+        roof = {"kernel": "%s<%d,%s,%s>%s" % (kname, W.d, hd, td_name, " visiting order, early_stop=0" if use_order else " natural order"),
                 "bound": "mfma", "achieved": alg_tf,
                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_BF16_MFMA_TFLOPS,
-                "traffic": profile_traffic("score_topk_v3"), "kernel_ms": k_ms, "flops_per_launch": flops,
+                "traffic": profile_traffic(kname), "kernel_ms": k_ms, "flops_per_launch": flops,
                 # the folded threshold test is one more MFMA k-step per tile (d/16 + 1 instead of d/16): executed > algorithmic
                 "executed": {"bf16_mfma_TFLOPs": alg_tf * (W.d / 16 + 1) / (W.d / 16),
                              "frac_of_bf16_peak": alg_tf * (W.d / 16 + 1) / (W.d / 16) / PEAK_BF16_MFMA_TFLOPS,
@@ -201,23 +216,52 @@ def bench_eval(args, rank, world, dev):
         roof = {"kernel": "score_topk_kernel<%d,%s>" % (W.d, hd), "bound": "mfma", "achieved": alg_tf,
                 "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_F32_MFMA_TFLOPS,
                 "traffic": profile_traffic("score_topk_kernel"), "kernel_ms": k_ms, "flops_per_launch": flops, "hbm": hbm}
-    res = {"users_per_s": Bu * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "Bu": Bu, "W": W,
-           "roofline": roof, "hist": hist, "ordered": ordered, "natural": natural}
+    # What one evaluation pass over ALL users costs right after a weight update: the item-side preparation (bf16 rows in
+    # visiting order + test pieces + bounds; the visiting order and the reordered history depend on pop only and survive)
+    # plus ceil(U / Bu) steps.
+    prep = None
+    if impl == "v2" and world == 1:
+        pop_h = ev.pop_shard if head == ops.HEAD_POP else None
+        order = ops.visiting_order(ev.I_shard, pop_h) if use_order else None
+        def do_prep():
+            ops.mark_modified(ev.I_shard)
+            if gen == "v4":
+                ops.item_prep4(ev.I_shard, pop_h, order)
+            elif use_order:
+                ops.item_prep_ordered(ev.I_shard, pop_h)
+            else:
+                ops.item_prep(ev.I_shard)
+        do_prep()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            do_prep()
+        e1.record()
+        torch.cuda.synchronize()
+        prep_ms = e0.elapsed_time(e1) / 5
+        n_steps_all = -(-W.n_users // Bu)
+        pass_ms = prep_ms + n_steps_all * dt / steps * 1e3
+        prep = {"prep_ms": prep_ms, "steps_per_pass": n_steps_all, "pass_ms_incl_prep": pass_ms,
+                "users_per_s_incl_prep": W.n_users / (pass_ms * 1e-3),
+                "note": "one pass over all %d users after a weight update = item prep + %d steps of the headline sweep" % (W.n_users, n_steps_all)}
+    res = {"users_per_s": Bu * steps / dt, "ms_per_step": dt / steps * 1e3, "Bu": Bu, "W": W, "steps": steps, "table_dtype": td_name,
+           "roofline": roof, "hist": hist, "ordered": ordered, "natural": natural, "prep": prep}
     return res
 
 
-def bench_train(args, dev):
+def bench_train(args, dev, workload=None, quick=False):
     """Fused BPR step on BASELINE config 2 (50k x 20k, d=64, B=2048, PD/PDA s_condition), batches pre-staged in HBM
-    by the device sampler; steps captured into HIP graphs of 64 launches (launch-bound regime)."""
+    by the device sampler; steps captured into HIP graphs of 64 launches (launch-bound regime).  quick: the per_config
+    form (pre-staged fused SGD, reference-faithful Adam, one-launch step + sampler)."""
     from pda_amd import ops, synthetic
-    W = synthetic.make_workload("c2" if args.workload != "tiny" else "tiny", dev)
+    W = synthetic.make_workload(workload or ("c2" if args.workload != "tiny" else "tiny"), dev)
     B, regs, lr, NB, G = 2048, 1e-2, 1e-2, 64, 64
     # pre-staged batches, grouped by positive item (pda_group_triplets_by_pos): the step kernel then combines whole runs
     batches = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2020, step=s, n_pool=W.n_users,
                                    train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train, sort_by_pos=True)
                for s in range(NB)]
-    out = {"workload": "C2: synthetic %d users x %d items, d=%d, B=%d, PD/PDA (s_condition, gamma=%.2f)" %
-                       (W.n_users, W.n_items, W.d, B, W.gamma), "graph_launches": G}
+    out = {"workload": "%s: synthetic %d users x %d items, d=%d, B=%d, PD/PDA (s_condition, gamma=%.2f)" %
+                       (W.name.upper(), W.n_users, W.n_items, W.d, B, W.gamma), "graph_launches": G}
 
     def timed_graph(body, n_steps):
         s = torch.cuda.Stream()
@@ -269,6 +313,8 @@ def bench_train(args, dev):
     r["algorithmic_bytes_per_step"] = sweep_bytes
     r["hbm_frac"] = sweep_bytes / (r["us_per_step"] * 1e-6) / 1e9 / PEAK_HBM_GBS
 
+    if quick:
+        return out, W, batches
     U, I = W.U.clone(), W.I.clone()
     stepc = [0]
 
@@ -356,16 +402,19 @@ def bench_train_sharded(args, rank, world, dev):
             "note": "eager; one all_gather_into_tensor per step; strong scaling of one 2048-triplet step"}
 
 
-def cpu_baseline(args, ev_res, train_pack):
-    """Reference op sequence on the host cores (torch CPU fp32), bounded sample.  kind = "port"."""
+def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
+    """Reference op sequence on the host cores (torch CPU fp32), bounded sample.  kind = "port".  Protocol of BASELINE.md
+    section 3: 3 warm-up blocks, median of up to 10 timed 2048-user blocks (fewer if the budget runs out).
+    full: also the single-thread figure, the native top-K variant and the training port."""
     from oracle import cpu_baseline as cb
+    budget = budget or args.cpu_budget
     W = ev_res["W"]
     cores = torch.get_num_threads()
-    U, pop = W.U.cpu(), W.pop_last.cpu()
-    I = W.I.cpu()
+    U, pop = W.U.float().cpu(), W.pop_last.cpu()
+    I = W.I.float().cpu()
     indptr, indices = W.hist_indptr.cpu(), W.hist_indices.cpu()
     blocks, coos = [], []
-    for b in range(64):
+    for b in range(13):
         s = (b * 2048) % max(1, W.n_users - 2048)
         users = torch.arange(s, min(s + 2048, W.n_users))
         lo, hi = int(indptr[users[0]]), int(indptr[users[-1] + 1])
@@ -373,8 +422,8 @@ def cpu_baseline(args, ev_res, train_pack):
         rows = torch.repeat_interleave(torch.arange(users.numel()), lens)
         blocks.append(users)
         coos.append((rows, indices[lo:hi].long()))
-    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, "condition" if args.head == "condition" else "main_branch",
-                           budget_s=args.cpu_budget)
+    rec = "condition" if args.head == "condition" else "main_branch"
+    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget)
     cpu_model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -383,19 +432,26 @@ def cpu_baseline(args, ev_res, train_pack):
                 break
     except OSError:
         pass
-    # also a single-thread figure (a short sample: one or two reference blocks)
-    torch.set_num_threads(1)
-    rate1, n1 = cb.time_eval(U, I, pop, blocks, coos, args.K, "condition" if args.head == "condition" else "main_branch",
-                             budget_s=min(4.0, args.cpu_budget / 4))
-    torch.set_num_threads(cores)
     out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
-           "single_thread": {"value": rate1, "unit": "users/s", "users": n1},
+           "protocol": "3 warm-up blocks, median of the timed 2048-user blocks (up to 10, bounded by the budget)",
            "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d (torch-CPU restatement of "
-                     "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk)" % (n, W.n_items, W.d)}
+                     "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk; NOT TensorFlow itself)" % (n, W.n_items, W.d)}
+    if not full:
+        return out
+    # BASELINE.md section 3 "CPU-native-topk": the same block with the selection by a from-scratch native top-K (a heap per row,
+    # rows over all OpenMP threads: the algorithm class of the reference's arg_topk.h)
+    rate_n, n_n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.6, block_fn=cb.eval_block_native_topk)
+    out["native_topk"] = {"value": rate_n, "unit": "users/s", "users": n_n, "threads": cores,
+                          "what": "matmul + head + mask as above, top-K by oracle_arg_topk_2d (per-row heap select, OpenMP over rows)"}
+    # also a single-thread figure (a short sample)
+    torch.set_num_threads(1)
+    rate1, n1 = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=min(6.0, budget / 3), warmups=1, reps=3)
+    torch.set_num_threads(cores)
+    out["single_thread"] = {"value": rate1, "unit": "users/s", "users": n1}
     if train_pack is not None:
         _, W2, batches = train_pack
         cpu_batches = [tuple(t.cpu().long() if t.dtype == torch.int32 else t.cpu() for t in b) for b in batches[:16]]
-        r, steps = cb.time_train(W2.U.cpu(), W2.I.cpu(), cpu_batches, 1e-2, 2048, 1e-2, budget_s=min(8.0, args.cpu_budget))
+        r, steps = cb.time_train(W2.U.cpu(), W2.I.cpu(), cpu_batches, 1e-2, 2048, 1e-2, budget_s=min(8.0, budget))
         out["train"] = {"value": r, "unit": "triplets/s", "steps": steps,
                         "sample": "C2 tables, B=2048, dense-decay Adam over both full tables (reference-faithful)"}
     return out
@@ -429,13 +485,43 @@ def main():
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, ev, train_pack)
+    # roofs measured on this box, beside the datasheet's (north_star: "measured roofline")
+    from pda_amd import ops as _ops
+    peaks = _ops.measured_peaks(dev) if rank == 0 else None
+    if peaks:
+        r = ev["roofline"]
+        r["peak_measured"] = peaks["bf16_mfma_TFLOPs"] if r["peak"] == PEAK_BF16_MFMA_TFLOPS else None
+        if r["peak_measured"]:
+            r["frac_of_measured"] = r["achieved"] / r["peak_measured"]
+        r["hbm"]["peak_measured_GBs"] = peaks["hbm_copy_GBs"]
+        r["peaks_measured"] = peaks
+    # the smaller BASELINE configs beside the headline: evaluation (headline sweep + early-terminating sweep) and training
+    per_config = None
+    if world == 1 and rank == 0 and not args.no_per_config and not args.headline_only and args.workload == "c3":
+        per_config = {}
+        for wl in ("c1", "c2"):
+            e = bench_eval(args, rank, world, dev, workload=wl, light=True)
+            entry = {"workload": "%s: %d users x %d items, d=%d" % (wl.upper(), e["W"].n_users, e["W"].n_items, e["W"].d),
+                     "eval": {"users_per_s": e["users_per_s"], "ms_per_step": e["ms_per_step"], "users_per_step": e["Bu"],
+                              "roofline_frac": e["roofline"]["frac"], "kernel": e["roofline"]["kernel"], "kernel_ms": e["roofline"]["kernel_ms"],
+                              "early_terminating_sweep": e["ordered"], "prep": e["prep"],
+                              "note": "a %d-item catalogue is %d tiles of 64: the fixed cost per user block (exact warm-up on the "
+                                      "first 256 items, list hand-over, launch) is a visible share of the step" % (e["W"].n_items, -(-e["W"].n_items // 64))}}
+            if not args.no_train:
+                t = bench_train(args, dev, workload=wl, quick=True)[0]
+                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful") if k in t}
+            if not args.no_cpu_baseline:
+                entry["cpu_baseline"] = cpu_baseline(args, e, None, budget=6.0, full=False)
+            per_config[wl] = entry
+            del e
+            torch.cuda.empty_cache()
     if rank == 0:
         W = ev["W"]
         line = {
             "metric": "users/sec full-catalogue top-K@%d (eval)" % args.K, "value": ev["users_per_s"], "unit": "users/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ev["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": ev["table_dtype"],
             "data": "synthetic",
             "config": {"workload": "%s: synthetic %d users x %d items, embed_dim=%d, %s head, history-masked top-K@%d"
                                    % (args.workload.upper(), W.n_users, W.n_items, W.d,
@@ -444,10 +530,12 @@ def main():
                        "users_per_step": ev["Bu"], "sharding": ("item-parallel x%d, one RCCL all-to-all of the partial top-K lists per step, result sharded by user slice" % world)
                                    if world > 1 else "single GPU",
                        "train_nnz": W.n_train,
-                       "arithmetic": "fp32 tables and fp32 results, bit-identical to the exact fp32-MFMA kernel; bf16 MFMA only as a "
-                                     "pre-filter with a rigorous error bound, every returned score recomputed in fp32"},
+                       "arithmetic": ("fp32 tables and fp32 results, bit-identical to the exact fp32-MFMA kernel; bf16 MFMA only as a "
+                                      "pre-filter with a rigorous error bound, every returned score recomputed in fp32") if ev["table_dtype"] == "f32" else
+                                     ("bf16 tables; scores = the fp32 fmaf chain on the widened values (exact products), bit-identical to the exact "
+                                      "kernel on the widened tables; the bf16 MFMA pass is a pre-filter with a rigorous error bound")},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "dense_natural_order": ev["natural"],
-            "ordered_sweep": ev["ordered"],
+            "ordered_sweep": ev["ordered"], "prep": ev["prep"], "per_config": per_config,
             "train": train_pack[0] if train_pack else ({"item_parallel_sgd": sharded_train} if sharded_train else None),
         }
         print(json.dumps(line))

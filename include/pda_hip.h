@@ -346,6 +346,17 @@ int pda_bpr_step_sample_f32(float* U, float* I, const int32_t* users, const int3
                             const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
                             int update_mode, float* loss_acc, const pda_sample_job* next, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Peaks measured on the box (no reference counterpart; BASELINE.md section 4 asks for measured roofs).
+ *   pda_peak_mfma_bf16: one launch of iters x 16 v_mfma_f32_32x32x16_bf16 per wave on 8192 waves (two per SIMD,
+ *        four accumulator chains each, register operands); the caller times it (HIP events) and divides
+ *        pda_peak_mfma_flops_per_launch(iters) by the duration.  sink: any 4 device bytes (never written).
+ *   pda_peak_copy: dst[0..n) = src[0..n), float4 grid-stride; 2 * 4 n bytes of HBM traffic per launch.
+ * ------------------------------------------------------------------------------------------------ */
+double pda_peak_mfma_flops_per_launch(int iters);
+int pda_peak_mfma_bf16(float* sink, int iters, void* stream);
+int pda_peak_copy(const float* src, float* dst, size_t n_floats, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,15 @@ def score_topk(U, I, users, K=50, mode=0, pop=None, hist_indptr=None, hist_indic
     return (idx, val, sc) if want_scores else (idx, val)
 
 
+def arg_topk_2d(ratings, K=50):
+    """oracle_arg_topk_2d: the native CPU top-K baseline (all OpenMP threads).  ratings float32 [rows, n] -> int32 [rows, K]."""
+    ratings = np.ascontiguousarray(ratings, dtype=np.float32)
+    rows, n = ratings.shape
+    out = np.empty((rows, K), dtype=np.int32)
+    lib().oracle_arg_topk_2d(_ptr(ratings, C.c_float), C.c_int(n), C.c_int(rows), C.c_int(K), _ptr(out, C.c_int32))
+    return out
+
+
 def scores_chain(U, I, users):
     U = np.ascontiguousarray(U, dtype=np.float32)
     I = np.ascontiguousarray(I, dtype=np.float32)

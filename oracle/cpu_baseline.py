@@ -25,16 +25,37 @@ def eval_block(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition")
     return torch.topk(R, K, dim=1, sorted=True).indices          # tf.nn.top_k, :598,604,609
 
 
-def time_eval(U, I, pop, users_blocks, coo_blocks, K=50, rec_type="condition", budget_s=20.0):
-    """Runs whole 2048-user reference blocks until `budget_s` of CPU time is used.  Returns (users/s, n_users)."""
-    done, t0 = 0, time.perf_counter()
-    for users, (rows, cols) in zip(users_blocks, coo_blocks):
-        eval_block(U, I, pop, users, rows, cols, K, rec_type)
-        done += users.numel()
-        if time.perf_counter() - t0 > budget_s:
+def eval_block_native_topk(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition"):
+    """The same block with the selection done by the native CPU top-K (oracle_arg_topk_2d: a heap per row, rows over all
+    OpenMP threads -- BASELINE.md section 3 "CPU-native-topk", the algorithm class of util/cython/include/arg_topk.h:15-45)."""
+    from . import c_oracle
+    R = U.index_select(0, users) @ I.t()
+    if rec_type != "main_branch":
+        R = (F.elu(R) + 1.0) * pop.unsqueeze(0)
+    R[coo_rows, coo_cols] = float("-inf")
+    return c_oracle.arg_topk_2d(R.numpy(), K)
+
+
+def time_eval(U, I, pop, users_blocks, coo_blocks, K=50, rec_type="condition", budget_s=20.0, warmups=3, reps=10, block_fn=None):
+    """BASELINE.md section 3 protocol: `warmups` untimed reference blocks, then the MEDIAN block time of up to `reps` timed
+    blocks (fewer when `budget_s` of wall time is used up first; at least one).  Returns (users/s, users timed)."""
+    import statistics
+    fn = block_fn or eval_block
+    t_start = time.perf_counter()
+    blocks = list(zip(users_blocks, coo_blocks))
+    for users, (rows, cols) in blocks[:warmups]:
+        fn(U, I, pop, users, rows, cols, K, rec_type)
+        if time.perf_counter() - t_start > budget_s * 0.4:
             break
-    dt = time.perf_counter() - t0
-    return done / dt, done
+    times, done = [], 0
+    for users, (rows, cols) in blocks[warmups:warmups + reps]:
+        t0 = time.perf_counter()
+        fn(U, I, pop, users, rows, cols, K, rec_type)
+        times.append((time.perf_counter() - t0) / users.numel())
+        done += users.numel()
+        if time.perf_counter() - t_start > budget_s:
+            break
+    return 1.0 / statistics.median(times), done
 
 
 class AdamDenseDecay:

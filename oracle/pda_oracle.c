@@ -128,6 +128,20 @@ int oracle_score_topk(const float* U, const float* I, const float* pop, const in
     return 0;
 }
 
+/* CPU-native top-K baseline ("CPU-native-topk"): per-row selection of the best K of a precomputed
+ * [rows, n_items] rating matrix (a K-sized heap per row: the algorithm class of the reference's per-row partial_sort of an
+ * index vector, util/cython/include/arg_topk.h:15-45), rows over OpenMP threads (the reference: a thread pool, :29-45).
+ * out_idx int32 [rows, K], best first, ties to the lower index. */
+void oracle_arg_topk_2d(const float* ratings, int n_items, int rows, int K, int32_t* out_idx) {
+#pragma omp parallel
+    {
+        float* hv = (float*)malloc(sizeof(float) * (size_t)K);
+#pragma omp for schedule(dynamic, 16)
+        for (int r = 0; r < rows; ++r) topk_row(ratings + (size_t)r * n_items, n_items, K, out_idx + (size_t)r * K, hv);
+        free(hv);
+    }
+}
+
 /* Scores only, chain order, for bit-exactness tests of the MFMA accumulation. */
 void oracle_scores_chain(const float* U, const float* I, const int32_t* users, int n_users_blk, int n_items, int d,
                          float* out) {

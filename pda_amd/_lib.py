@@ -60,6 +60,9 @@ SIGNATURES = {
     "pda_score_topk4_auto_splits": (_i, [_i, _i, _i]),
     "pda_score_topk4_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_score_topk4_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "pda_peak_mfma_flops_per_launch": (C.c_double, [_i]),
+    "pda_peak_mfma_bf16": (_i, [_vp, _i, _vp]),
+    "pda_peak_copy": (_i, [_vp, _vp, _sz, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_bpr_step_shard_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _i, _vp, _vp, _vp]),

@@ -135,3 +135,64 @@ extern "C" int pda_counter_add(uint64_t* counter, uint64_t inc, void* stream) {
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Peaks measured on the box ("Peaks must be measured"; bench.py reports them beside the datasheet
+// figures).  The matrix peak: 2 waves per SIMD x 4 independent accumulator chains of v_mfma_f32_32x32x16_bf16 on operands
+// held in registers -- the configuration that saturates the pipe (tools/ubench/mfma_lds.hip); operands are pseudo-random
+// bit patterns (zero-filled operands clock ~20 % higher: guides/MI355X_MICROARCH.md, DVFS).  The memory peak: a float4
+// copy, one pass, grid-stride.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace {
+typedef __bf16 peak_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned peak_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(512) peak_mfma_kernel(float* sink, int iters, unsigned seed) {
+    peak_u32x4 a[4], b[4];
+    unsigned x = seed ^ (threadIdx.x * 2654435761u) ^ (blockIdx.x * 40503u);
+    for (int q = 0; q < 4; ++q)
+        for (int k = 0; k < 4; ++k) {
+            x = x * 1664525u + 1013904223u;
+            a[q][k] = (x & 0x7FFF7FFFu) | 0x3C003C00u;        // bf16 pairs of moderate magnitude, random mantissas and signs cleared
+            a[q][k] ^= (x >> 3) & 0x80008000u;
+            x = x * 1664525u + 1013904223u;
+            b[q][k] = ((x & 0x7FFF7FFFu) | 0x3C003C00u) ^ ((x >> 5) & 0x80008000u);
+        }
+    f32x16 acc[4];
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(peak_bf16x8, a[(q + m) & 3]), __builtin_bit_cast(peak_bf16x8, b[q]),
+                                                                 acc[q], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int q = 0; q < 4; ++q)
+        for (int r = 0; r < 16; ++r) s += acc[q][r];
+    if (s == 12345.678f) sink[0] = s;                          // keeps the chains alive
+}
+
+__global__ void __launch_bounds__(256) peak_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+extern "C" double pda_peak_mfma_flops_per_launch(int iters) { return 256.0 * 4 * 8 * (double)iters * 16.0 * 2.0 * 32 * 32 * 16; }
+
+extern "C" int pda_peak_mfma_bf16(float* sink, int iters, void* stream) {
+    if (!sink || iters <= 0) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(peak_mfma_kernel, dim3(256 * 4), dim3(512), 0, reinterpret_cast<hipStream_t>(stream), sink, iters, 2021u);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_peak_copy(const float* src, float* dst, size_t n_floats, void* stream) {
+    if (!src || !dst || n_floats < 4) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       reinterpret_cast<const f32x4*>(src), reinterpret_cast<f32x4*>(dst), n_floats / 4);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}

@@ -637,6 +637,29 @@ def sort_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):
           "pda_sort_triplets_by_pos")
 
 
+def measured_peaks(device=None, mfma_iters: int = 4000, copy_mb: int = 1024) -> dict:
+    """pda_peak_mfma_bf16 / pda_peak_copy timed with HIP events (best of 3): the roofs of THIS box, beside the datasheet's."""
+    lib = _lib.load()
+    dev = device or torch.device("cuda")
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    n = copy_mb * (1 << 20) // 4
+    src, dst = torch.ones(n, dtype=torch.float32, device=dev), torch.empty(n, dtype=torch.float32, device=dev)
+    best_mfma = best_copy = float("inf")
+    for _ in range(4):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        check(lib.pda_peak_mfma_bf16(ptr(sink), mfma_iters, stream_ptr()), "pda_peak_mfma_bf16")
+        e[1].record()
+        check(lib.pda_peak_copy(ptr(src), ptr(dst), n, stream_ptr()), "pda_peak_copy")
+        e[2].record()
+        torch.cuda.synchronize()
+        best_mfma, best_copy = min(best_mfma, e[0].elapsed_time(e[1])), min(best_copy, e[1].elapsed_time(e[2]))
+    return {"bf16_mfma_TFLOPs": lib.pda_peak_mfma_flops_per_launch(mfma_iters) / (best_mfma * 1e-3) / 1e12,
+            "hbm_copy_GBs": 2.0 * 4.0 * n / (best_copy * 1e-3) / 1e9,
+            "note": "bf16 MFMA: 2 waves per SIMD x 4 accumulator chains, random register operands (power-limited clock); "
+                    "HBM: float4 copy of %d MiB, read + write bytes" % copy_mb}
+
+
 def unpack_keys(keys: torch.Tensor):
     """Host-side helper for tests: packed int64 keys -> (idx int64, val float32); empty (0) -> (-1, -inf)."""
     k = keys.cpu().numpy().view("uint64")

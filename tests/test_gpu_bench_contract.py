@@ -31,3 +31,20 @@ def test_bench_emits_one_contract_line(dev):
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     t = d["train"]
     assert t["sgd_fused"]["triplets_per_s"] > 0 and t["adam_dense_reference_faithful"]["triplets_per_s"] > 0
+    # round 2: what one pass costs after a weight update, roofs measured on the box, the native CPU top-K, the protocol
+    p = d["prep"]
+    assert p["prep_ms"] > 0 and p["users_per_s_incl_prep"] > 0 and p["steps_per_pass"] >= 1
+    assert r["peak_measured"] > 100 and abs(r["frac_of_measured"] - r["achieved"] / r["peak_measured"]) < 1e-9
+    assert r["hbm"]["peak_measured_GBs"] > 500
+    assert c["native_topk"]["value"] > 0 and c["native_topk"]["threads"] == c["cores"] and "median" in c["protocol"]
+    assert d["dtype"] == "f32"
+
+
+def test_bench_bf16_tables_line(dev):
+    """BASELINE config 5's table type through the same contract (tiny shapes: d = 64)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--table-dtype", "bf16", "--steps", "2",
+                          "--warmup", "1", "--eval-block", "1024", "--no-train", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["dtype"] == "bf16" and d["value"] > 0 and d["ordered_sweep"]["value"] > 0

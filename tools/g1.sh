@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/ -x -q -m gpu --timeout 300 2>&1 | tail -6
+timeout 900 python -m pytest tests/test_gpu_bench_contract.py -x -q -m gpu 2>&1 | tail -12
