@@ -176,7 +176,15 @@ __global__ void __launch_bounds__(512) peak_mfma_kernel(float* sink, int iters, 
 }
 
 __global__ void __launch_bounds__(256) peak_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+    // four 16-byte loads in flight per lane and pass; a block walks one contiguous 16 KiB chunk at a time
+    const size_t stride = (size_t)gridDim.x * 1024;
+    for (size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x; base < n4; base += stride) {
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = base + 256 * q < n4 ? __builtin_nontemporal_load(&src[base + 256 * q]) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (base + 256 * q < n4) __builtin_nontemporal_store(v[q], &dst[base + 256 * q]);
+    }
 }
 }  // namespace
 

@@ -10,7 +10,9 @@ kernels = (sys.argv[4] if len(sys.argv) > 4 else "v3,v4").split(",")
 dev = torch.device('cuda')
 tdt = torch.bfloat16 if (len(sys.argv) > 5 and sys.argv[5] == 'bf16') else torch.float32
 nus = int(sys.argv[6]) if len(sys.argv) > 6 else None
-W = synthetic.make_workload(wl, dev, table_dtype=tdt, n_users=nus)
+nit = int(sys.argv[7]) if len(sys.argv) > 7 else None
+mh = int(sys.argv[8]) if len(sys.argv) > 8 else None
+W = synthetic.make_workload(wl, dev, table_dtype=tdt, n_users=nus, n_items=nit, mean_hist=mh)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 Bu = min(Bu, W.n_users)
 blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in range(0, min(W.n_users - Bu + 1, 4 * Bu), Bu)]
@@ -31,7 +33,7 @@ def run(kern, prune, head, n=3):
     cand = float(st["pairs_rescored"][0]) / Bu if "pairs_rescored" in st else 0.0
     return ms, frac, cand, ops.topk_merge(k, want="keys")
 for head in heads:
-    for prune, name in (("order", "dense ordered"), (False, "dense natural"), (True, "early stop")):
+    for prune, name in ((("order", "dense ordered"),) if os.environ.get("ONLY_ORDER") else (("order", "dense ordered"), (False, "dense natural"), (True, "early stop"))):
         ref = None
         for kern in kernels:
             ms, frac, cand, keys = run(kern, prune, head)
