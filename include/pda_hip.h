@@ -44,7 +44,11 @@ extern "C" {
 
 /* Update modes of the fused triplet step. */
 #define PDA_UPD_NONE 0       /* loss + per-occurrence gradients only (parity harness)                        */
-#define PDA_UPD_SGD_FUSED 1  /* north_star: in-kernel row update, atomics on item rows                       */
+#define PDA_UPD_SGD_FUSED 1  /* north_star: in-kernel row update, atomics on item rows.  ASYNCHRONOUS inside a launch:
+                              * a workgroup may gather a row that another workgroup of the same launch has already
+                              * updated (hot positives, repeated users), so the result is a hogwild-style step -- equal
+                              * to the mini-batch step up to O(lr) cross terms, not bit-reproducible.  The exact
+                              * mini-batch step is PDA_UPD_NONE + pda_sgd_apply_f32 (two launches).              */
 #define PDA_UPD_DENSE_GRAD 2 /* atomically sum gradients into dense gU/gI (feeds pda_adam_dense_sweep_f32)  */
 #define PDA_UPD_ANY_ORDER 0x100 /* OR into update_mode when the batch is NOT grouped by positive: equal positives are then
                                  * combined on chip wherever they sit in a workgroup (slightly slower on grouped batches) */
@@ -226,6 +230,14 @@ int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* po
                      const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
                      int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU, float* gI,
                      float* loss_acc, void* stream);
+
+/* Apply phase of the EXACT mini-batch SGD step: after pda_bpr_step_f32(PDA_UPD_NONE, g_user, g_pos, g_neg) -- forward pass
+ * and per-occurrence gradients of the WHOLE batch against the unchanged tables -- this scatters
+ *   U[users[t]] -= lr g_user[t],  I[pos[t]] -= lr g_pos[t],  I[neg[t]] -= lr g_neg[t]      (fp32 atomics; rows may repeat).
+ * Together: one step of plain SGD on the batch loss (the reference's graph with tf.train.GradientDescentOptimizer in
+ * place of Adam, MF/model_api.py:83), deterministic up to the order of the fp32 additions. */
+int pda_sgd_apply_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg, const float* g_user,
+                      const float* g_pos, const float* g_neg, int B, int d, float lr, void* stream);
 
 /* bf16 tables (config 5): the forward pass gathers bf16 rows (U_bf16 / I_bf16, uint16 bit patterns) and computes in fp32
  * exactly as pda_bpr_step_f32 does on the widened rows; gradients are fp32.  bf16 rows cannot take atomic adds, so

@@ -564,6 +564,37 @@ extern "C" int pda_apply_user_grads_f32(float* U, const int32_t* users, const fl
     return PDA_OK;
 }
 
+namespace {
+// The apply phase of the exact mini-batch SGD step: U[users[t]] -= lr g_user[t], I[pos[t]] -= lr g_pos[t], I[neg[t]] -= lr g_neg[t]
+// (one float4 per thread, atomics: rows repeat inside a batch).  No table is READ for arithmetic here, so -- unlike the fused
+// in-kernel update -- no triplet can see another triplet's update of the same batch.
+__global__ void __launch_bounds__(256) sgd_apply_kernel(float* __restrict__ U, float* __restrict__ I, const int32_t* __restrict__ users,
+                                                       const int32_t* __restrict__ pos, const int32_t* __restrict__ neg,
+                                                       const float* __restrict__ gu, const float* __restrict__ gp,
+                                                       const float* __restrict__ gn, size_t n4, int d4, float nlr) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * n4) return;
+    const int which = (int)(i / n4);
+    const size_t k = i % n4, r = k / d4;
+    const int e = (int)(k % d4);
+    const float* g = which == 0 ? gu : (which == 1 ? gp : gn);
+    const int32_t row = which == 0 ? users[r] : (which == 1 ? pos[r] : neg[r]);
+    float* tab = which == 0 ? U : I;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(g + r * (size_t)(4 * d4) + 4 * e);
+    atomic_add4(tab + (size_t)row * (4 * d4) + 4 * e, v * nlr);
+}
+}  // namespace
+
+extern "C" int pda_sgd_apply_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg, const float* g_user,
+                                 const float* g_pos, const float* g_neg, int B, int d, float lr, void* stream) {
+    if (!U || !I || !users || !pos || !neg || !g_user || !g_pos || !g_neg || B <= 0 || d <= 0 || (d & 3)) return PDA_ERR_ARG;
+    const size_t n4 = (size_t)B * (d / 4);
+    hipLaunchKernelGGL(sgd_apply_kernel, dim3((unsigned)((3 * n4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), U, I,
+                       users, pos, neg, g_user, g_pos, g_neg, n4, d / 4, -lr);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
 extern "C" int pda_sort_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
                                         void* stream) {
     if (!users || !pos || !neg || B <= 0) return PDA_ERR_ARG;

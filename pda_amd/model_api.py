@@ -12,7 +12,11 @@ Optimisers (`args.optimizer`):
     adam       TF-1.14 AdamOptimizer semantics: m, v decayed and EVERY row updated each step [TF-ext]
                (= pda_bpr_step_f32(DENSE_GRAD) + pda_adam_dense_sweep_f32 on both tables).  Reference-faithful.
     lazy_adam  the same update restricted to the rows touched by the batch (declared deviation).
-    sgd        the north_star's fused in-kernel scatter update (declared deviation from MF/model_api.py:83).
+    sgd        plain mini-batch SGD, exact: gradients of the whole batch against the unchanged tables, then one scatter
+               (pda_bpr_step_f32(PDA_UPD_NONE) + pda_sgd_apply_f32; declared deviation from MF/model_api.py:83 = Adam).
+    sgd_fused  the north_star's fused in-kernel scatter update, ONE launch per step: asynchronous inside the launch (a row
+               gathered by one workgroup may already carry another triplet's update -- hogwild-style, equal to `sgd` up to
+               O(lr) cross terms, not bit-reproducible).  The throughput mode; `sgd` is the reference semantics.
 
 Table type (`args.table_dtype`, extension; BASELINE config 5): with "bf16" the forward pass and the evaluation read bf16
 copies of the tables (`score_tables()`), gradients stay fp32 and `weights[...]` are the fp32 masters that take the
@@ -56,8 +60,8 @@ class _MFBase:
         self.batch_size = args.batch_size            # the flag constant that divides the regulariser (:118)
         self.verbose = args.verbose
         self.optimizer = getattr(args, "optimizer", "adam")
-        if self.optimizer not in ("adam", "lazy_adam", "sgd"):
-            raise NotImplementedError("optimizer must be adam | lazy_adam | sgd")
+        if self.optimizer not in ("adam", "lazy_adam", "sgd", "sgd_fused"):
+            raise NotImplementedError("optimizer must be adam | lazy_adam | sgd | sgd_fused")
         self.table_dtype = getattr(args, "table_dtype", "f32")
         if self.table_dtype not in ("f32", "bf16"):
             raise NotImplementedError("table_dtype must be f32 | bf16")
@@ -100,7 +104,7 @@ class _MFBase:
     def _train_step_bf16(self, users, pos, neg, pos_pop, neg_pop):
         U, I = self.weights["user_embedding"], self.weights["item_embedding"]
         U16, I16 = self.tables16["user_embedding"], self.tables16["item_embedding"]
-        if self.optimizer == "sgd":
+        if self.optimizer in ("sgd", "sgd_fused"):      # (bf16 forward reads the shadow tables: no in-launch race either way)
             ops.bpr_step_bf16(U16, I16, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr,
                               mode=ops.UPD_SGD_FUSED, U_master=U, I_master=I, loss_acc=self._loss)
             return self._loss
@@ -133,9 +137,16 @@ class _MFBase:
         self._loss.zero_()
         if self.tables16 is not None:
             return self._train_step_bf16(users, pos, neg, pos_pop, neg_pop)
-        if self.optimizer == "sgd":
+        if self.optimizer == "sgd_fused":
             ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr,
                          mode=ops.UPD_SGD_FUSED, loss_acc=self._loss)
+            return self._loss
+        if self.optimizer == "sgd":
+            sc = getattr(self, "_sgd_scratch", None)
+            if sc is not None and sc[0].shape[0] != users.numel():
+                sc = None
+            self._sgd_scratch = ops.sgd_step_exact(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
+                                                   lr=self.lr, loss_acc=self._loss, scratch=sc)
             return self._loss
         st = self._opt_state()
         self._t += 1

@@ -413,6 +413,22 @@ def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, 
         mark_modified(U, I)
 
 
+def sgd_step_exact(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float,
+                   loss_acc: Optional[torch.Tensor] = None, scratch=None):
+    """The exact mini-batch SGD step: pda_bpr_step_f32(PDA_UPD_NONE) writes the per-occurrence gradients of the whole batch
+    against the unchanged tables, pda_sgd_apply_f32 scatters them.  `scratch` = (g_user, g_pos, g_neg) float32 [B, d] to
+    reuse between steps (allocated when None).  Returns the scratch tuple."""
+    lib = _lib.load()
+    B, d = users.numel(), U.shape[1]
+    if scratch is None:
+        scratch = tuple(torch.empty((B, d), dtype=torch.float32, device=U.device) for _ in range(3))
+    bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=regs, reg_div=reg_div, mode=UPD_NONE, grads_out=scratch, loss_acc=loss_acc)
+    check(lib.pda_sgd_apply_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(scratch[0]), ptr(scratch[1]), ptr(scratch[2]),
+                                B, d, float(lr), stream_ptr()), "pda_sgd_apply_f32")
+    mark_modified(U, I)
+    return scratch
+
+
 def bpr_step_bf16(U16, I16, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float = 0.0,
                   mode: int = UPD_NONE, U_master=None, I_master=None, grads_out=None, gU=None, gI=None,
                   loss_acc: Optional[torch.Tensor] = None, refresh: bool = True):

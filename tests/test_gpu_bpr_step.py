@@ -70,6 +70,45 @@ def test_sgd_fused_update_with_duplicate_items(dev, with_pop):
     np.testing.assert_allclose(It.cpu().numpy(), I1, atol=TOL)
 
 
+def _hot_batch(rng, nU, nI, B, hot_share=0.3):
+    """A batch in which one positive item carries `hot_share` of the triplets and users repeat (B > nU)."""
+    users = rng.integers(0, nU, B).astype(np.int32)
+    pos = rng.integers(0, nI, B).astype(np.int32)
+    pos[rng.random(B) < hot_share] = 7
+    neg = rng.integers(0, nI, B).astype(np.int32)
+    return users, pos, neg
+
+
+@pytest.mark.parametrize("lr", [0.05, 1.0, 5.0])
+def test_exact_sgd_step_on_a_hot_item_batch_at_realistic_lr(dev, lr):
+    """the fused in-kernel update is asynchronous inside a launch (hogwild).  The EXACT step -- gradients of the
+    whole batch against the unchanged tables, then one scatter -- must equal the oracle's mini-batch SGD step also with a
+    hot positive (30 % of the batch), repeated users and a large learning rate, where cross terms would show."""
+    from pda_amd import ops
+    rng = np.random.default_rng(31)
+    nU, nI, d, B, regs = 600, 300, 64, 2048, 1e-2
+    U = (rng.standard_normal((nU, d)) * 0.3).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.3).astype(np.float32)
+    users, pos, neg = _hot_batch(rng, nU, nI, B)
+    pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    U1, I1, _, ref_loss = po.train_step(U, I, users, pos, neg, pp, pn, regs, B, lr, optimizer="sgd")
+    Ut, It, ut, pt, nt, ppt, pnt = to(dev, U, I, users, pos, neg, pp, pn)
+    loss = torch.zeros(3, device=dev)
+    ops.sgd_step_exact(Ut, It, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, loss_acc=loss)
+    scale = max(1.0, lr)                                        # the hot row moves by O(lr): tolerance relative to that
+    np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+    np.testing.assert_allclose(Ut.cpu().numpy(), U1, atol=TOL * scale)
+    np.testing.assert_allclose(It.cpu().numpy(), I1, atol=TOL * scale)
+    # and the fused one-launch update is a DIFFERENT (asynchronous) step: the same loss -- the forward pass of the batch is
+    # taken before most updates land --, tables equal to the exact step up to O(lr^2) cross terms
+    Uf, If = to(dev, U, I)
+    lossf = torch.zeros(3, device=dev)
+    ops.bpr_step(Uf, If, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=lossf)
+    dev_f = float((If.cpu() - torch.from_numpy(I1)).abs().max())
+    assert dev_f <= 0.5 * lr * lr + 1e-4, dev_f                 # bounded by the cross terms, but NOT held to 1e-5
+
+
 def test_reference_faithful_adam_three_steps(dev):
     """TF-1.14 Adam: m,v decay and the variable update touch EVERY row each step [TF-ext]; three steps
     exercise that on rows that were touched once and then left alone."""
