@@ -74,7 +74,11 @@ class _MFBase:
             self.tables16 = {k: v.bfloat16() for k, v in self.weights.items()}
         self._t = 0
         self._state = None
-        self._loss = torch.zeros(3, dtype=torch.float32, device=self.device)
+        # loss buffers: a ring of 16 -- train_step returns the buffer of THIS step; it is overwritten 16 steps later, so a
+        # caller may keep a handful of returned tensors and sync once (no per-step clone launch, no per-step host sync)
+        self._loss_ring = torch.zeros((16, 3), dtype=torch.float32, device=self.device)
+        self._loss_i = 0
+        self._loss = self._loss_ring[0]
         self._statistics_params()
 
     # ---- parameters -----------------------------------------------------------------------------------
@@ -128,12 +132,15 @@ class _MFBase:
     # ---- one training step (A1-A5) --------------------------------------------------------------------
     def train_step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
         """Forward + loss + gradient + update on one batch of device tensors (int32 / float32).
-        Returns the float32[3] device tensor (loss, mf_loss, reg_loss) of THIS step (no host sync)."""
+        Returns the float32[3] device tensor (loss, mf_loss, reg_loss) of THIS step (no host sync): a view into a ring of
+        16 buffers -- valid until 16 further steps have been enqueued."""
         U, I = self.weights["user_embedding"], self.weights["item_embedding"]
         if not self.with_pop:
             pos_pop = neg_pop = None
         elif pos_pop is None or neg_pop is None:
             raise ValueError("PD/PDA needs pos_pop and neg_pop")
+        self._loss_i = (self._loss_i + 1) & 15
+        self._loss = self._loss_ring[self._loss_i]
         self._loss.zero_()
         if self.tables16 is not None:
             return self._train_step_bf16(users, pos, neg, pos_pop, neg_pop)
@@ -161,14 +168,33 @@ class _MFBase:
         return self._loss
 
     # ---- checkpoint (tf.train.Saver stand-in, MF/train_new_api.py:1014,1218-1228) ---------------------
+    CKPT_FORMAT = "pda_amd/2"     # torch.save pickle of this dict -- NOT a tf.train.Saver checkpoint (see README)
+
     def state_dict(self):
-        sd = {"user_embedding": self.weights["user_embedding"], "item_embedding": self.weights["item_embedding"],
+        sd = {"format": self.CKPT_FORMAT, "embed_size": self.emb_dim, "n_users": self.n_users, "n_items": self.n_items,
+              "optimizer": self.optimizer, "table_dtype": self.table_dtype,
+              "user_embedding": self.weights["user_embedding"], "item_embedding": self.weights["item_embedding"],
               "adam_t": self._t}
         if self._state is not None:
             sd.update({k: v for k, v in self._state.items() if k[0] in "mv"})
         return sd
 
     def load_state_dict(self, sd):
+        """Validates what the checkpoint was written for before touching the tables.  Files keep the reference's NAMES
+        (best_ckpt.ckpt ...) but are torch pickles: a TF checkpoint of the reference cannot be read here, nor the reverse."""
+        if not isinstance(sd, dict) or "user_embedding" not in sd:
+            raise ValueError("not a pda_amd checkpoint (a tf.train.Saver checkpoint of the reference cannot be loaded)")
+        for key, mine in (("embed_size", self.emb_dim), ("n_users", self.n_users), ("n_items", self.n_items)):
+            if key in sd and int(sd[key]) != int(mine):
+                raise ValueError("checkpoint %s = %s, model has %s" % (key, sd[key], mine))
+        if sd.get("table_dtype", self.table_dtype) != self.table_dtype:
+            raise ValueError("checkpoint written with table_dtype=%s, model runs %s" % (sd["table_dtype"], self.table_dtype))
+        if sd.get("optimizer", self.optimizer) != self.optimizer and ("mU" in sd) != (self.optimizer in ("adam", "lazy_adam")):
+            raise ValueError("checkpoint written with optimizer=%s (Adam state %s), model runs %s" %
+                             (sd["optimizer"], "present" if "mU" in sd else "absent", self.optimizer))
+        if tuple(sd["user_embedding"].shape) != tuple(self.weights["user_embedding"].shape) or \
+                tuple(sd["item_embedding"].shape) != tuple(self.weights["item_embedding"].shape):
+            raise ValueError("checkpoint tables do not have the model's shape")
         self.weights["user_embedding"].copy_(sd["user_embedding"])
         self.weights["item_embedding"].copy_(sd["item_embedding"])
         if self.tables16 is not None:
