@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--workload", default="c3", choices=["c1", "c2", "c3", "c5shard", "tiny"])
     p.add_argument("--table-dtype", default="auto", choices=["auto", "f32", "bf16"],
                    help="embedding table type (auto: bf16 for c5shard -- BASELINE config 5 --, f32 otherwise)")
+    p.add_argument("--user-groups", type=int, default=0,
+                   help="N > 1: user groups of the 2-D layout (0 = pda_amd.dist.default_user_groups: 2 from four GPUs on); "
+                        "inside a group the catalogue is item-sharded, the groups split the users of a block")
     p.add_argument("--no-per-config", action="store_true", help="skip the per_config block (C1, C2: evaluation and training beside the headline)")
     p.add_argument("--eval-block", type=int, default=262144, help="users per step (the default of the product's --eval_block)")
     p.add_argument("--head", default="condition", choices=["main_branch", "condition"])
@@ -120,13 +123,19 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
     W = synthetic.make_workload(workload, dev, table_dtype=td)
     head = ops.HEAD_POP if args.head == "condition" else ops.HEAD_RAW
     timed = TimedScore()
-    ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, rank, world, score_fn=timed)
+    # N > 1: `ugroups` user groups x (world / ugroups) item shards (pda_amd.dist.grid_layout)
+    from pda_amd.dist import default_user_groups, make_item_group
+    ugroups = (args.user_groups or default_user_groups(world)) if world > 1 else 1
+    gidx, grank, gsize, pgroup = make_item_group(rank, world, ugroups) if world > 1 else (0, 0, 1, None)
+    ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, grank, gsize, group=pgroup, score_fn=timed)
+    world_all, world = world, gsize                     # below, "world" is the item-shard group; world_all the whole job
     hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
     Bu = min(args.eval_block, W.n_users)
     n_blocks = args.warmup + steps
     starts = [(b * Bu) % max(1, W.n_users - Bu + 1) for b in range(n_blocks)]
-    blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in starts]
-    if world > 1:
+    per_g = Bu // ugroups                               # this group's users of every step
+    blocks = [torch.arange(s + gidx * per_g, s + (gidx + 1) * per_g if gidx < ugroups - 1 else s + Bu, dtype=torch.int32, device=dev) for s in starts]
+    if world_all > 1:
         del W.I                                           # every rank keeps only its shard of the item table
     sink = []
 
@@ -143,18 +152,18 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
         timed.prune, timed.enabled, timed.events, timed.stats = prune, False, [], {}
         run(blocks[:max(1, args.warmup)])
         torch.cuda.synchronize()
-        if world > 1:
+        if world_all > 1:
             dist.barrier()
         torch.cuda.synchronize()
         timed.enabled = True
         t0 = time.perf_counter()
         run(blocks[args.warmup:])
         torch.cuda.synchronize()
-        if world > 1:
+        if world_all > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        if world > 1:
+        if world_all > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
@@ -184,12 +193,13 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
                            "pop + ||u||*pop*||i|| of everything unvisited is below every user's running K-th value; "
                            "bit-identical keys (tests/test_gpu_score_topk.py); data-dependent, hence not the headline"}
     if os.environ.get("PDA_BENCH_DUMP"):                  # tests/test_gpu_two_rank.py: the lists of the last step (this rank's rows)
-        torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_w%d_r%d.pt" % (world, rank)))
+        torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_w%d_r%d.pt" % (world_all, rank)))
     n_local = ev.I_shard.shape[0]
-    flops = 2.0 * Bu * n_local * W.d
-    nnz_blk = float(W.n_train) * Bu / W.n_users
+    Bu_rank = blocks[0].numel()                           # users this rank scores per step (its group's share)
+    flops = 2.0 * Bu_rank * n_local * W.d
+    nnz_blk = float(W.n_train) * Bu_rank / W.n_users
     esz = 2 if td_name == "bf16" else 4
-    abytes = n_local * W.d * esz + n_local * 4 + Bu * W.d * esz + nnz_blk * 4 + (Bu + 1) * 8 + Bu * args.K * 8
+    abytes = n_local * W.d * esz + n_local * 4 + Bu_rank * W.d * esz + nnz_blk * 4 + (Bu_rank + 1) * 8 + Bu_rank * args.K * 8
     impl = ops.score_impl(W.d, args.K, W.n_items)
     hd = "POP" if head else "RAW"
     alg_tf = flops / (k_ms * 1e-3) / 1e12
@@ -220,7 +230,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
     # visiting order + test pieces + bounds; the visiting order and the reordered history depend on pop only and survive)
     # plus ceil(U / Bu) steps.
     prep = None
-    if impl == "v2" and world == 1:
+    if impl == "v2" and world_all == 1:
         pop_h = ev.pop_shard if head == ops.HEAD_POP else None
         order = ops.visiting_order(ev.I_shard, pop_h) if use_order else None
         def do_prep():
@@ -245,6 +255,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
                 "users_per_s_incl_prep": W.n_users / (pass_ms * 1e-3),
                 "note": "one pass over all %d users after a weight update = item prep + %d steps of the headline sweep" % (W.n_users, n_steps_all)}
     res = {"users_per_s": Bu * steps / dt, "ms_per_step": dt / steps * 1e3, "Bu": Bu, "W": W, "steps": steps, "table_dtype": td_name,
+           "layout": {"user_groups": ugroups, "item_shards": gsize, "users_per_rank_and_step": Bu_rank, "items_per_rank": n_local},
            "roofline": roof, "hist": hist, "ordered": ordered, "natural": natural, "prep": prep}
     return res
 
@@ -527,8 +538,11 @@ def main():
                                    % (args.workload.upper(), W.n_users, W.n_items, W.d,
                                       "PDA condition ((elu+1)*pop^%.2f)" % W.gamma if args.head == "condition" else "raw",
                                       args.K),
-                       "users_per_step": ev["Bu"], "sharding": ("item-parallel x%d, one RCCL all-to-all of the partial top-K lists per step, result sharded by user slice" % world)
-                                   if world > 1 else "single GPU",
+                       "users_per_step": ev["Bu"],
+                       "sharding": ("%d user group(s) x %d item shards: inside a group item-parallel (every rank owns an item slice), one RCCL "
+                                    "all-to-all of the partial top-K lists per step, result sharded by user slice; the groups split the users "
+                                    "of a step" % (ev["layout"]["user_groups"], ev["layout"]["item_shards"])) if world > 1 else "single GPU",
+                       "layout": ev["layout"],
                        "train_nnz": W.n_train,
                        "arithmetic": ("fp32 tables and fp32 results, bit-identical to the exact fp32-MFMA kernel; bf16 MFMA only as a "
                                       "pre-filter with a rigorous error bound, every returned score recomputed in fp32") if ev["table_dtype"] == "f32" else

@@ -124,6 +124,48 @@ def test_item_sharded_eval_two_ranks_gloo():
     assert o0 == 0 and o1 == n0 and n0 + n1 == 777 and n0 % 32 == 0
 
 
+def _worker_2d(rank, world, port, q):
+    """Four ranks as 2 user groups x 2 item shards (pda_amd.dist.grid_layout): a group scores ITS half of the users of a
+    block against its two item shards; the union over groups and ranks is the unsharded result."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pda_amd.dist import ItemShardedTopK, make_item_group
+    rng = np.random.default_rng(5)
+    nU, nI, d, K = 64, 500, 32, 20
+    U = (rng.standard_normal((nU, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.1).astype(np.float32)
+    pop = (rng.uniform(0, 1, nI) ** 0.22).astype(np.float32)
+    g, r, gsize, pg = make_item_group(rank, world, 2)
+    ev = ItemShardedTopK.from_full_tables(torch.from_numpy(U), torch.from_numpy(I), torch.from_numpy(pop), r, gsize, group=pg,
+                                          score_fn=score_double, merge_fn=merge_double)
+    users = torch.arange(g * 32, (g + 1) * 32, dtype=torch.int32)          # this group's half of the 64-user block
+    lo, hi = ev.user_slice(users.numel())
+    sidx, sval = ev.topk_sharded(users, K, 1, None)
+    ridx, rval = c_oracle.score_topk(U, I, users.numpy(), K, 1, pop, order=1)
+    ok = bool(np.array_equal(sidx.numpy(), ridx[lo:hi]) and np.array_equal(sval.numpy(), rval[lo:hi]))
+    q.put((rank, ok, g, r, gsize, ev.item_offset, int(users[lo]), int(users[hi - 1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_user_groups_of_two_item_shards_gloo():
+    world, port = 4, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_2d, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert [(r[2], r[3], r[4]) for r in res] == [(0, 0, 2), (0, 1, 2), (1, 0, 2), (1, 1, 2)]
+    assert res[0][5] == 0 and res[1][5] > 0 and res[2][5] == 0            # item offsets repeat per group
+    covered = sorted((r[6], r[7]) for r in res)                            # the four user slices tile the block
+    assert covered == [(0, 15), (16, 31), (32, 47), (48, 63)]
+
+
 # ---- item-parallel training step (ItemShardedBPR) -----------------------------------------------------------------
 
 def _global_batch(rng, R, nU, nI, Bl):

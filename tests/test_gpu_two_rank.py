@@ -39,3 +39,11 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
     b = torch.cat([torch.load(os.path.join(tmp_path, "topk_w2_r%d.pt" % r)) for r in range(2)])
     assert a.shape == b.shape == (2048, 50)
     assert torch.equal(a, b)
+    # four ranks = 2 user groups x 2 item shards (pda_amd.dist.grid_layout, the default from four GPUs on): rank order = user order
+    four = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                 "--master-port", "29519", "bench.py", "--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                 "--eval-block", "2048"], env)
+    assert four["n_gpus"] == 4 and four["config"]["layout"] == {"user_groups": 2, "item_shards": 2, "users_per_rank_and_step": 1024,
+                                                                 "items_per_rank": 1504}
+    c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w4_r%d.pt" % r)) for r in range(4)])
+    assert torch.equal(a, c)
