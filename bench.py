@@ -128,6 +128,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
     ugroups = (args.user_groups or default_user_groups(world)) if world > 1 else 1
     gidx, grank, gsize, pgroup = make_item_group(rank, world, ugroups) if world > 1 else (0, 0, 1, None)
     ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, grank, gsize, group=pgroup, score_fn=timed)
+    ev.seeded = True                                    # (the wrapper passes seed_reduce through)
     world_all, world = world, gsize                     # below, "world" is the item-shard group; world_all the whole job
     hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
     Bu = min(args.eval_block, W.n_users)
@@ -150,6 +151,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
     def timed_pass(prune):
         """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
         timed.prune, timed.enabled, timed.events, timed.stats = prune, False, [], {}
+        ev.prune = prune
         run(blocks[:max(1, args.warmup)])
         torch.cuda.synchronize()
         if world_all > 1:

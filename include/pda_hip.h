@@ -203,6 +203,32 @@ int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void*
                          const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
                          uint64_t* out_keys, void* workspace, void* stream);
 
+/* Item-sharded evaluation with exact early termination: the two phases of pda_score_topk4_* as separate calls and a seed.
+ *   phase 1  the exact warm-up only: out_keys holds every split's list of its first 64 warm_tiles visited items
+ *            (warm_tiles 1 .. 4, 0 = 4; the same value in both phases: with R shards the R warm-ups together cover
+ *            R x 64 warm_tiles items, so a sharded run wants fewer per shard)
+ *   pda_topk_kth_value(out_keys, n_splits, n_users_blk, K, pos, tau, stream)   tau f32 [n_users_blk]: the value at rank pos
+ *            (0-based) of a user's warm-up lists (max over the splits; -inf while no list is that long).  Two bounds of a
+ *            user's FINAL K-th value over R item shards: the MAXIMUM over the shards of their values at pos = K - 1, and the
+ *            MINIMUM over the shards of their values at pos = ceil(K / R) - 1 (R shards with ceil(K / R) items above it);
+ *            two all-reduces of 4 bytes per user, seed = the larger of the two
+ *   phase 2  the sweep, seed = that maximum (or NULL): pairs whose exact score is below the seed stay out of this shard's
+ *            list -- they cannot be in the merged top K -- and the early termination prunes against max(own K-th value, seed).
+ *            A shard's list may then end with fewer than K entries (empty slots = 0); the merge of the shards' lists is exactly
+ *            the top K of the whole catalogue.
+ * Without it every rank prunes against its own shard's K-th value only and scores 8 x 32 % instead of 3.9 % of the
+ * catalogue (config 3, eight shards).  n_splits must be the same (> 0) in both phases. */
+int pda_topk_kth_value(const uint64_t* keys, int n_splits, int n_users_blk, int K, int pos, float* out, void* stream);
+int pda_score_topk4_phase_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
+                              int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                              const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
+                              int phase, int warm_tiles, const float* seed, uint64_t* out_keys, void* workspace, void* stream);
+int pda_score_topk4_phase_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard,
+                               const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                               const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
+                               int early_stop, int n_splits, int phase, int warm_tiles, const float* seed, uint64_t* out_keys,
+                               void* workspace, void* stream);
+
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0
  *   out_keys u64 [n_users_blk, K] or NULL;  out_idx i32 / out_val f32 [n_users_blk, K] or NULL.

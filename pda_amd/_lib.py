@@ -63,6 +63,9 @@ SIGNATURES = {
     "pda_peak_mfma_flops_per_launch": (C.c_double, [_i]),
     "pda_peak_mfma_bf16": (_i, [_vp, _i, _vp]),
     "pda_peak_copy": (_i, [_vp, _vp, _sz, _vp]),
+    "pda_topk_kth_value": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "pda_score_topk4_phase_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pda_score_topk4_phase_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_sgd_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

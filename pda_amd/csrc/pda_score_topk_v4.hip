@@ -75,7 +75,9 @@ struct Args4 {
     const float* sufB;
     const int* pos_of;           // [n_items_local] local id -> visiting position, or NULL: identity
     unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
+    const float* seed;           // [n_users_blk] or NULL: an external LOWER bound of every user's final K-th value (other item shards)
     int n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, n_tiles;
+    int warm_tiles;              // 1 .. kWarmTiles: 64-item tiles per split scored exactly by warm4_kernel
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -312,7 +314,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
-    const int nwarm = min(kWarmTiles, nt);
+    const int nwarm = min(g.warm_tiles, nt);
 
     const int row_blk = utile * kUserTile + wave * 32 + j;
     const bool row_ok = row_blk < g.n_users_blk;
@@ -486,7 +488,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
-    const int n_it = max(0, nt - kWarmTiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
+    const int n_it = max(0, nt - g.warm_tiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
     const int n_blk = n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
     if (tid < 128) sync[tid] = 0u;
 #ifdef PDA_V4_PROF
@@ -500,6 +502,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         const int row0 = r * RR;
         uint64_t* my_lists = lists + (size_t)row0 * kCap4;
         int uidv[2] = {0, 0};
+        float seedv[2] = {-INFINITY, -INFINITY};
         int64_t hbv[2] = {0, 0}, hev[2] = {0, 0};
         const bool hist_on = g.hist_indptr != nullptr;
 #pragma unroll
@@ -508,6 +511,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             const int rb_l = utile * UT + row0 + rl;
             const bool ok = rl < RR && rb_l < g.n_users_blk;
             uidv[s2] = ok ? g.users[rb_l] : 0;
+            if (g.seed != nullptr && ok) seedv[s2] = g.seed[rb_l];
             if (hist_on && ok) {
                 const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uidv[s2] : (int64_t)rb_l;
                 hbv[s2] = g.hist_indptr[hr];
@@ -619,8 +623,12 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
             const int lrow = row0 + row;
             const int item = g.item_offset + loc;
-            // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in
-            bool p = valid && q == LPC - 1 && (tt >= taul[lrow]);
+            // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in.
+            // With a seed (item-sharded evaluation: the K-th values of the OTHER shards' warm-up lists) nothing below it can be
+            // in the merged top K: it stays out of this shard's list, which may then end shorter than K.
+            float sd = __shfl(seedv[0], row & 63, 64);
+            if constexpr (RR > 64) { const float s1 = __shfl(seedv[1], row & 63, 64); sd = row >= 64 ? s1 : sd; }
+            bool p = valid && q == LPC - 1 && (tt >= fmaxf(taul[lrow], sd));
             if (hist_on) {
                 // train items are masked HERE: one binary search in the row's id-sorted history for a candidate that has
                 // passed the filter and the exact threshold
@@ -689,7 +697,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 if (stop) break;
             }
             const int hf0 = b * NB;                                // first half-tile of the block
-            const int t = split + (kWarmTiles + (hf0 >> 1)) * g.n_splits;
+            const int t = split + (g.warm_tiles + (hf0 >> 1)) * g.n_splits;
             [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * G::TB + (size_t)(hf0 & 1) * HB + lane * 16;
             [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((b & 1) * BB);
 #pragma unroll
@@ -752,8 +760,13 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     //   (negated like the rest of the A side: v3 carries the opposite signs)
     float thr_own = 0.f, thr_min = 0.f;
     u32x4 aex = {0u, 0u, 0u, 0u};
+    float seed_own = -INFINITY;                 // external lower bound of the row's final K-th value (see the rescoring wave)
+    {
+        const int rb = utile * UT + row0 + j;
+        if (g.seed != nullptr && rb < g.n_users_blk) seed_own = g.seed[rb];
+    }
     auto refresh_thr = [&]() __attribute__((always_inline)) {
-        const float tq = taul[row0 + j];
+        const float tq = fmaxf(taul[row0 + j], seed_own);
         float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
         tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
         thr_own = tf;
@@ -771,7 +784,8 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     };
     // the exact threshold of accumulator register r (lane half hv), strictly below tau (ties must pass)
     auto thr_of = [&](int r, int hv) __attribute__((always_inline)) -> float {
-        const float tq = taul[row0 + (r & 3) + 8 * (r >> 2) + 4 * hv];
+        const int rw = (r & 3) + 8 * (r >> 2) + 4 * hv;
+        const float tq = fmaxf(taul[row0 + rw], __shfl(seed_own, rw, 64));
         return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
     };
     refresh_thr();
@@ -827,8 +841,36 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     PROF_T0(tm0);
     int n_done = 0;
     bool stopped = false;
+#ifndef PDA_V4_VOTE_EVERY
+#define PDA_V4_VOTE_EVERY 2
+#endif
+    constexpr int kVoteEvery = PDA_V4_VOTE_EVERY;      // a vote in front of every kVoteEvery-th tile (1, 2 or 4)
+    float sa_nx = 0.0f, sb_nx = 0.0f;          // suffix bounds at tile it + 2 of the coming vote
+    bool nx_ok = g.sufA != nullptr && kVoteEvery + 1 < n_it;
+    if (nx_ok) {
+        const int tn = split + (g.warm_tiles + kVoteEvery + 1) * g.n_splits;
+        sa_nx = g.sufA[tn];
+        sb_nx = g.sufB[tn];
+    }
     for (int b = 0; b < n_blk && !stopped; ++b) {
         const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
+        // ---- early termination.  In front of the last block of tile i every wave votes "nothing at or behind tile i + 2 can
+        // reach my rows" (candidates still in the ring can only raise thresholds) -- BEFORE it releases that block.  Once the
+        // first block of tile i + 2 has landed, every wave has released the block two before it, which is not earlier than
+        // the one the votes were stored in front of: the votes are complete, every wave reads the same eight words (while
+        // the MFMAs of that block run) and, if they all agree, leaves behind that block.
+        const int it = (b * NB) >> 1;
+        const bool tile_first = NB == 2 || (b & 1) == 0, tile_last = NB == 2 || (b & 1) == 1;
+        if (g.sufA != nullptr && tile_last && (it & (kVoteEvery - 1)) == kVoteEvery - 1) {
+            const bool alldead = nx_ok && __all(__builtin_fmaf(nu_row, sb_nx, sa_nx) * 1.000002f < thr_own);
+            if (lane == 0) lds_st(&s_vote[(it & 3) * kMainWaves + w], alldead ? 1u : 0u);
+            // the bounds of the next vote: loaded a tile ahead
+            const int inx = it + kVoteEvery + 2;
+            const int tn = split + (g.warm_tiles + min(inx, max(n_it - 1, 0))) * g.n_splits;
+            sa_nx = g.sufA[tn];               // (no use before the next vote: the loads stay in flight over the block)
+            sb_nx = g.sufB[tn];
+            nx_ok = inx < n_it;
+        }
         ensure_landed(b);
         const unsigned char* tb = lane_base + (b & 1) * BB;
         // ---- the block: NB chains, k-step major; S = NB NM B reads, PF in flight ----
@@ -873,6 +915,15 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 }
                 acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bx[cb]), acc[cb], 0, 0, 0);
             }
+        }
+        // (the votes about this tile, read while the MFMAs run and BEFORE the release -- a wave that sees it may store its vote
+        // four tiles on into the same words; the block is finished either way)
+        if (g.sufA != nullptr && tile_first && it >= 2 && ((it - 2) & (kVoteEvery - 1)) == kVoteEvery - 1) {
+            const unsigned* v = &s_vote[((it - 2) & 3) * kMainWaves];
+            unsigned all = 1u;
+#pragma unroll
+            for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
+            stopped = all != 0u;
         }
         PDA_CBAR();
         lds_st(&s_released[w], (unsigned)(b + 1));
@@ -922,30 +973,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             PROF_INC(5, 1);
         }
         if (NB == 1 && (b & 1) == 0) continue;
-        const int i = (b * NB) >> 1;           // 64-item tile i is complete
-        ++n_done;
-        // ---- early termination.  Checkpoint c = the end of tile 4 c + 3: vote "nothing at or behind tile 4 c + 8 can reach
-        // my row" (candidates still in the ring can only raise thresholds); the votes of checkpoint c are read at checkpoint
-        // c + 1 -- the MFMA waves are never more than two blocks apart (a slot is refilled only when all of them have released
-        // it), so every vote is there and every wave takes the same decision.
-        if (g.sufA != nullptr && (i & 3) == 3) {
-            const int c = i >> 2;
-            if (c >= 1) {
-                const unsigned* v = &s_vote[((c - 1) & 3) * kMainWaves];
-                unsigned all = 1u;
-#pragma unroll
-                for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
-                stopped = all != 0u;
-            }
-            const int inext = i + 5;
-            bool alldead = false;
-            if (inext < n_it) {
-                const int tn = split + (kWarmTiles + inext) * g.n_splits;
-                const float sa = g.sufA[tn], sb = g.sufB[tn];
-                alldead = __all(__builtin_fmaf(nu_row, sb, sa) * 1.000002f < thr_own);
-            }
-            if (lane == 0) lds_st(&s_vote[(c & 3) * kMainWaves + w], alldead ? 1u : 0u);
-        }
+        ++n_done;                              // a 64-item tile is complete
     }
     PROF_T1(tm0, 0);
     PROF_INC(13, 1);
@@ -961,9 +989,9 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 }
 
 template <int D, int HEAD, bool BF>
-int launch4(const Args4& g, hipStream_t stream) {
+int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = warm-up only, 2 = sweep only, 3 = both
     using G = Geo4<D>;
-    {
+    if (phase & 1) {
         constexpr int CAP = kCap4;
         const size_t smem = 32 * D * 4 + (size_t)kUserTile * (CAP * 8 + 8) + kUserTile * 2 * kWarmTiles * 4 + 256;
         static int attr_set = 0;
@@ -977,8 +1005,8 @@ int launch4(const Args4& g, hipStream_t stream) {
         hipLaunchKernelGGL((warm4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(kThreads), smem, stream, g);
         PDA_CHECK_LAUNCH();
     }
-    if ((g.n_tiles + g.n_splits - 1) / g.n_splits <= kWarmTiles) return PDA_OK;      // every split ends inside its warm-up
-    {
+    if ((g.n_tiles + g.n_splits - 1) / g.n_splits <= g.warm_tiles) return PDA_OK;      // every split ends inside its warm-up
+    if (phase & 2) {
         static int attr_set = 0;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -997,7 +1025,8 @@ int user_tile4(int d) { (void)d; return kMainWaves * 32; }
 
 int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
                int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
-               int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s) {
+               int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s,
+               int phase = 3, const float* seed = nullptr, int warm_tiles = 0) {
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
@@ -1007,22 +1036,24 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
     if (K > kCap4 - 3) return PDA_ERR_UNSUPPORTED;
     if ((uint64_t)n_items_local > (1ull << 26)) return PDA_ERR_UNSUPPORTED;          // ring words: 6-bit row, 26-bit local item id
+    if (warm_tiles < 0 || warm_tiles > kWarmTiles) return PDA_ERR_ARG;
+    if (warm_tiles == 0) warm_tiles = kWarmTiles;
     if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
     const Prep4Layout L = prep4_layout(n_items_local, d);
     const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
-    if (hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if ((phase & 1) && hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
     const float* sA = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufA : L.sufB));
     const float* sB = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufB : L.sufR));
     // raw head: bound = ||u|| max ||i||: sufA := 0 is not stored -- the raw-head vote uses (sufB' = sufR, sufA' = 0) through
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles};
+            reinterpret_cast<unsigned*>(workspace), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles};
     if (head == PDA_HEAD_RAW) {
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;
     }
-#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, s) : launch4<DD, PDA_HEAD_RAW, BFV>(g, s))
+#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, phase, s) : launch4<DD, PDA_HEAD_RAW, BFV>(g, phase, s))
     switch (d) {
         case 64: return bf16 ? PDA_V4_(64, true) : PDA_V4_(64, false);
         case 128: return bf16 ? PDA_V4_(128, true) : PDA_V4_(128, false);
@@ -1030,6 +1061,19 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
         default: return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_V4_
+}
+
+// the value at rank `pos` (0-based) of every user's (sorted, best first) partial lists: the largest over the item splits,
+// -inf when no list is that long
+__global__ void __launch_bounds__(256) kth_value_kernel(const uint64_t* __restrict__ keys, int S, int n_users, int K, int pos, float* __restrict__ out) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    float best = -INFINITY;
+    for (int sp = 0; sp < S; ++sp) {
+        const uint64_t k = keys[((size_t)sp * n_users + u) * K + pos];
+        if (k != 0ull) best = fmaxf(best, pda_key_val(k));
+    }
+    out[u] = best;
 }
 
 }  // namespace
@@ -1074,6 +1118,37 @@ extern "C" int pda_item_prep4_check(const void* prep, int n_items_local, int d, 
     if (hipMemcpyAsync(&bad, prep, 4, hipMemcpyDeviceToHost, s) != hipSuccess) return PDA_ERR_LAUNCH;
     if (hipStreamSynchronize(s) != hipSuccess) return PDA_ERR_LAUNCH;
     return bad ? PDA_ERR_ARG : PDA_OK;
+}
+
+extern "C" int pda_topk_kth_value(const uint64_t* keys, int n_splits, int n_users_blk, int K, int pos, float* out, void* stream) {
+    if (!keys || !out || n_splits < 1 || n_users_blk < 1 || K < 1 || pos < 0 || pos >= K) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(kth_value_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys,
+                       n_splits, n_users_blk, K, pos, out);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+// The two phases of pda_score_topk4_* as separate calls, for the item-sharded evaluation with exact early termination: every
+// rank runs the warm-up, the ranks exchange two values per user of their warm-up lists (pda_topk_kth_value: the K-th -- the
+// maximum over the ranks bounds the final K-th value from below -- and the ceil(K / R)-th -- R ranks with ceil(K / R) items
+// above the MINIMUM over the ranks make K items above it: with the popular items spread over the shards this is the bound
+// of a single GPU's warm-up), and the sweep takes the larger of the two as `seed`.
+extern "C" int pda_score_topk4_phase_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
+                                         int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
+                                         const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
+                                         int phase, int warm_tiles, const float* seed, uint64_t* out_keys, void* workspace, void* stream) {
+    if (phase != 1 && phase != 2) return PDA_ERR_ARG;
+    return run_score4(U, I_shard, false, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices,
+                      hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace, reinterpret_cast<hipStream_t>(stream), phase, seed, warm_tiles);
+}
+extern "C" int pda_score_topk4_phase_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const float* pop_shard,
+                                          const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                                          const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
+                                          int early_stop, int n_splits, int phase, int warm_tiles, const float* seed, uint64_t* out_keys,
+                                          void* workspace, void* stream) {
+    if (phase != 1 && phase != 2) return PDA_ERR_ARG;
+    return run_score4(U, I_shard, true, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices,
+                      hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace, reinterpret_cast<hipStream_t>(stream), phase, seed, warm_tiles);
 }
 
 extern "C" int pda_score_topk4_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,

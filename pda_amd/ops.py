@@ -3,6 +3,7 @@ stream-ordered on torch's current HIP stream.  No arithmetic happens here."""
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Tuple
 
 import ctypes as C
@@ -201,6 +202,14 @@ def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
     return "v4" if (prune == "order" or d == 256) else "v3"
 
 
+def seed_exchange_applies(d: int, K: int, head: int, prune=None, impl: Optional[str] = None) -> bool:
+    """Does score_topk_keys(seed_reduce=...) call seed_reduce for these arguments?  A function of arguments that are the same
+    on every rank, so that ranks which cannot score (an empty item shard) still know whether to join the two all-reduces."""
+    if prune is None:
+        prune = prune_default(head)
+    return (impl or score_impl(d, K, 0)) == "v2" and prune is True and d in (64, 128, 256) and K <= TOPK_K_V4
+
+
 def check_order(prep_ord: torch.Tensor, n: int, d: int):
     """Synchronising: raises if the order given to item_prep_ordered was not a permutation of 0..n-1."""
     check(_lib.load().pda_item_prep_ordered_check(ptr(prep_ord), n, d, stream_ptr()), "pda_item_prep_ordered_check")
@@ -277,7 +286,12 @@ def prune_default(head: int):
 
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
                     item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None,
-                    prune=None, stats: Optional[dict] = None) -> torch.Tensor:
+                    prune=None, stats: Optional[dict] = None, seed_reduce=None, seed_shards: int = 1) -> torch.Tensor:
+    """seed_reduce (item-sharded evaluation over `seed_shards` shards, early-terminating sweep): a callable (tau_k, tau_m)
+    that receives this shard's float32 [Bu] vectors of warm-up list values at rank K and at rank ceil(K / seed_shards) and
+    turns them IN PLACE into the maximum resp. the minimum over all shards (two dist.all_reduce).  The sweep prunes against
+    the larger of the two (pda_score_topk4_phase_*); the shard's lists may end shorter than K -- merge them with the other
+    shards' lists."""
     """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 -> packed keys
     int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All three return the same keys."""
     lib = _lib.load()
@@ -310,17 +324,36 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     impl = impl or score_impl(d, K, item_offset + nloc)
     if prune is None:
         prune = prune_default(head)
-    if impl == "v2" and score_kernel(d, K, nloc, prune) == "v4":
+    seeded = seed_reduce is not None and seed_exchange_applies(d, K, head, prune, impl)
+    if seeded and nloc > (1 << 26):
+        raise ValueError("seeded item-sharded evaluation: at most 2^26 item rows per shard")
+    if impl == "v2" and (seeded or score_kernel(d, K, nloc, prune) == "v4"):
         order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
         if n_splits_auto and out_given is None:
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)
-        fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
-        check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
-                 ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
-                 K, head, 1 if prune is True else 0, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
+        if seeded:
+            # warm-up -> K-th values -> maximum over the shards -> seeded sweep
+            fnp = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32
+            common = (ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+                      ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head, 1, n_splits)
+            # R shards warm up R x 64 warm_tiles items between them: two tiles each on 2 shards, one from 4 shards on
+            wt = int(os.environ.get("PDA_WARM_TILES", "0")) or max(1, 4 // max(1, seed_shards))
+            check(fnp(*common, 1, wt, None, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (warm-up)")
+            tau = torch.empty((2, nu), dtype=torch.float32, device=U.device)
+            m = -(-K // max(1, seed_shards))
+            check(lib.pda_topk_kth_value(ptr(out), n_splits, nu, K, K - 1, ptr(tau[0]), stream_ptr()), "pda_topk_kth_value")
+            check(lib.pda_topk_kth_value(ptr(out), n_splits, nu, K, m - 1, ptr(tau[1]), stream_ptr()), "pda_topk_kth_value")
+            seed_reduce(tau[0], tau[1])
+            seed = torch.maximum(tau[0], tau[1])
+            check(fnp(*common, 2, wt, ptr(seed), ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (sweep)")
+        else:
+            fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
+            check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+                     ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
+                     K, head, 1 if prune is True else 0, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
         if stats is not None:
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["pairs_rescored"] = ws[4:8].view(torch.int32)

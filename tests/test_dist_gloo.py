@@ -243,3 +243,69 @@ def test_item_parallel_training_two_ranks_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert all(all(r[1]) for r in res), res
+
+
+def score_double_seeded(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_reduce=None, seed_shards=1, prune=None):
+    """The seeded contract of ops.score_topk_keys on the CPU: warm-up lists of the shard's first 16 items -> the values at
+    rank K and at rank ceil(K / R) -> seed_reduce (MAX resp. MIN over the shards, in place) -> the shard's list WITHOUT the
+    entries below the larger of the two bounds (empty slots = key 0)."""
+    full = score_double(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits)
+    if seed_reduce is None:
+        return full
+    warm = score_double(U, I_shard[:16], users, K, head, None if pop_shard is None else pop_shard[:16], hist, item_offset, n_splits)
+    wv, wi = _unpack(warm.numpy()[0])
+    wv = np.where(wi >= 0, wv, -np.inf).astype(np.float32)
+    m = -(-K // seed_shards)
+    tau = torch.from_numpy(np.stack([wv[:, K - 1], wv[:, m - 1]]))
+    seed_reduce(tau[0], tau[1])
+    seed = torch.maximum(tau[0], tau[1]).numpy()
+    v, i = _unpack(full.numpy()[0])
+    keys = full.numpy()[0].copy()
+    keys[(v < seed[:, None]) | (i < 0)] = 0
+    return torch.from_numpy(keys)[None], float((keys == 0).mean())
+
+
+def _worker_seeded(rank, world, port, q):
+    """Three ranks, 60 items = two 32-item tiles: rank 2 owns NOTHING and must still join the two seed all-reduces."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pda_amd.dist import ItemShardedTopK
+    rng = np.random.default_rng(11)
+    nU, nI, d, K = 48, 60, 64, 10
+    U = rng.standard_normal((nU, d), dtype=np.float32) * 0.3
+    I = rng.standard_normal((nI, d), dtype=np.float32) * 0.3
+    pop = (rng.uniform(0, 1, nI) ** 3).astype(np.float32)
+    pop[:32] += 1.0                            # shard 0 holds the popular items: its K-th value prunes shard 1's list
+    dropped = []
+
+    def fn(*a, **k):
+        keys, frac = score_double_seeded(*a, **k)
+        dropped.append(frac)
+        return keys
+    ev = ItemShardedTopK.from_full_tables(torch.from_numpy(U), torch.from_numpy(I), torch.from_numpy(pop), rank, world,
+                                          score_fn=fn, merge_fn=merge_double)
+    assert ev.seeded is False
+    ev.seeded = True
+    users = torch.arange(nU, dtype=torch.int32)
+    idx, val = ev.topk(users, K, 1, None)
+    ridx, rval = c_oracle.score_topk(U, I, users.numpy(), K, 1, pop, order=1)
+    ok = bool(np.array_equal(idx.numpy(), ridx) and np.array_equal(val.numpy(), rval))
+    q.put((rank, ok, ev.I_shard.shape[0], max(dropped) if dropped else -1.0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_seeded_item_shards_with_an_empty_shard_gloo():
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_seeded, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=90) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert [r[2] for r in res] == [32, 28, 0]
+    assert res[1][3] > 0 and res[2][3] == -1.0         # the seed did drop entries of shard 1; rank 2 never scored

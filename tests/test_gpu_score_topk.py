@@ -4,6 +4,8 @@ Bar: bit-exact fp32 scores and exact top-K lists for the raw head (the kernel's 
 by oracle order=1); for the popularity head the kernel uses the hardware exp, so scores must agree to
 1e-5 (the north_star tolerance) and any list disagreement must be a near-tie within that tolerance.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -576,3 +578,97 @@ def test_full_size_c3_sweep_modes_agree(dev, impl):
     assert torch.equal(exact, out["natural"][:2048])
     idx, val = ops.unpack_keys(out["stop"][:64])
     assert (np.diff(val, axis=1) <= 0).all() and (idx >= 0).all() and (idx < W.n_items).all()
+
+
+def test_full_size_c5_shard_bf16(dev, impl):
+    """One rank's share of BASELINE config 5 at full size (250 000 item rows x d = 256, bf16 tables, 1M-user replica of the
+    user table, 50M-entry history CSR): the three sweep modes of both kernel generations return identical merged keys for
+    8 192 users; a 256-user sample equals the oracle on the widened tables (popularity head: 1e-5 + near-tie rule); lists
+    are sorted, in range and free of train items."""
+    if impl != "v2":
+        pytest.skip("sweep modes are chosen explicitly in this test")
+    import os
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("c5shard", dev, table_dtype=torch.bfloat16)
+    assert W.U.dtype == torch.bfloat16 and W.I.shape == (250_000, 256)
+    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+    users = torch.arange(300_000, 300_000 + 8192, dtype=torch.int32, device=dev)
+    out = {}
+    old = os.environ.get("PDA_SCORE_KERNEL")
+    try:
+        for kern in ("v3", "v4"):
+            os.environ["PDA_SCORE_KERNEL"] = kern
+            for name, prune in (("natural", False), ("order", "order"), ("stop", True)):
+                st = {}
+                keys = ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune, stats=st)
+                out[kern + name] = ops.topk_merge(keys, want="keys")
+                if name == "stop":
+                    assert float(st["tiles_scored"][0]) < st["tiles_dense"]          # (8 192 users are few user tiles: many item splits, each stopping on its own)
+    finally:
+        if old is None:
+            os.environ.pop("PDA_SCORE_KERNEL", None)
+        else:
+            os.environ["PDA_SCORE_KERNEL"] = old
+    ref = out["v3natural"]
+    for k, v in out.items():
+        assert torch.equal(ref, v), k
+    idx, val = ops.unpack_keys(ref)
+    assert (np.diff(val, axis=1) <= 0).all() and (idx >= 0).all() and (idx < W.n_items).all()
+    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
+    for r in range(0, 8192, 512):
+        u = 300_000 + r
+        assert not set(idx[r]) & set(ix[ip[u]:ip[u + 1]])
+    # oracle sample on the widened tables
+    sub = users[:256].cpu().numpy()
+    Uw, Iw = W.U[users[:256].long()].float().cpu().numpy(), W.I.float().cpu().numpy()
+    rows = [ix[ip[u]:ip[u + 1]] for u in sub]
+    bip, bix = csr(rows)
+    ridx, rval, sc = c_oracle.score_topk(Uw, Iw, np.arange(256, dtype=np.int32), 50, 1, W.pop_last.cpu().numpy(), bip, bix, order=1,
+                                         want_scores=True)
+    np.testing.assert_allclose(val[:256], rval, rtol=TOL, atol=TOL)
+    bad = np.argwhere(idx[:256] != ridx)
+    for r, k in bad:
+        a, b = idx[r, k], ridx[r, k]
+        assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b)
+
+
+@pytest.mark.parametrize("R,head", [(2, 1), (8, 1), (4, 0)])
+def test_seeded_item_shards_equal_one_shard(dev, impl, R, head):
+    """Item-sharded evaluation with exact early termination (pda_score_topk4_phase_*): R emulated shards of config 2, every
+    shard's sweep seeded with the two cross-shard bounds of the users' K-th values (maximum of the shards' K-th warm-up
+    values, minimum of their ceil(K / R)-th).  The shards' lists -- some shorter than K -- merge to exactly the one-shard
+    lists, and the shards score fewer tiles between them than with their own thresholds only."""
+    if impl != "v2":
+        pytest.skip("one kernel generation has the phase entry points")
+    from pda_amd import ops, synthetic
+    from pda_amd.dist import shard_range
+    W = synthetic.make_workload("c2", dev, n_users=16384)
+    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+    users = torch.arange(16384, dtype=torch.int32, device=dev)
+    pop = W.pop_last
+    ref = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, head, pop if head else None, hist, prune=False), want="keys")
+    shards = [(lo, W.I[lo:hi].contiguous(), pop[lo:hi].contiguous() if head else None) for lo, hi in (shard_range(W.n_items, r, R) for r in range(R))]
+    tk, tm = [], []
+    for lo, I_s, pop_s in shards:           # the all-reduces, emulated: the warm-up values of every shard first
+        ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1,
+                            seed_reduce=lambda a, b: (tk.append(a.clone()), tm.append(b.clone())), seed_shards=R)
+    seed_k, seed_m = torch.stack(tk).max(0).values, torch.stack(tm).min(0).values
+    tiles, short = {}, 0
+    for seeded in (False, True):
+        parts, tot = [], 0.0
+        for lo, I_s, pop_s in shards:
+            st = {}
+            kw = {"seed_reduce": (lambda a, b: (a.copy_(seed_k), b.copy_(seed_m))), "seed_shards": R} if seeded else {}
+            os.environ["PDA_SCORE_KERNEL"] = "v4"
+            try:
+                k = ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1, stats=st, **kw)
+            finally:
+                os.environ.pop("PDA_SCORE_KERNEL", None)
+            tot += float(st["tiles_scored"][0])
+            parts.append(ops.topk_merge(k, want="keys"))
+            short += int((parts[-1][:, -1] == 0).sum()) if seeded else 0
+        assert torch.equal(ops.topk_merge(torch.stack(parts), want="keys"), ref), (R, head, seeded)
+        tiles[seeded] = tot
+    # (raw head on i.i.d. norms: the suffix bounds are too loose to stop anything early, with or without a seed)
+    assert tiles[True] < tiles[False] if head else tiles[True] <= tiles[False], tiles
+    assert short > 0 or not head            # (popularity head) the seed did keep entries out of some shard's list
