@@ -41,6 +41,9 @@ constexpr int kCap4 = 57;            // list slots per user (LDS budget at d = 1
 constexpr int kRing4 = 128;          // ring entries per MFMA wave (u32 each); a push needs 64 free
 constexpr int kWarmTiles = 4;        // 64-item tiles per split scored by warm4_kernel (256 items)
 constexpr int kMainWaves = 8;
+#ifndef PDA_W4_ABL
+#define PDA_W4_ABL 0      // warm-up timing ablations (results are wrong): 1 no history walk, 2 no appends, 4 no final sort, 8 no MFMA, 16 no gather
+#endif
 #ifndef PDA_V4_ABL
 #define PDA_V4_ABL 0      // timing-only ablations (results are wrong): 1 no filter, 2 no hand-over between MFMA waves, 4 no tile loads, 8 rescoring waves leave at once
 #endif
@@ -326,21 +329,53 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     }
     for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = 0u;
     __syncthreads();
-    // train items among the warm positions: two threads per row walk the row's history
-    if (g.hist_indptr != nullptr) {
-        const int r = tid >> 1, part = tid & 1;
-        const int rb = utile * kUserTile + r;
-        if (rb < g.n_users_blk) {
-            const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)g.users[rb] : (int64_t)rb;
-            const int64_t hb = g.hist_indptr[hr], he = g.hist_indptr[hr + 1];
-            for (int64_t e = hb + part; e < he; e += 2) {
-                const int loc = g.hist_indices[e] - g.item_offset;
-                if (loc < 0 || loc >= g.n_items_local) continue;
-                const int p = g.pos_of ? g.pos_of[loc] : loc;
-                const int T = p >> 6;
-                if (T % g.n_splits != split) continue;
-                const int q = (T - split) / g.n_splits;
-                if (q < nwarm) atomicOr(&hmask[r * (2 * kWarmTiles) + 2 * q + ((p & 63) >> 5)], 1u << (p & 31));
+    // train items among the warm positions: a wave walks the histories of its 32 rows, 64 entries of a row per step and four
+    // rows in flight (two dependent loads per entry: the id, its visiting position)
+    if (g.hist_indptr != nullptr && !(PDA_W4_ABL & 1)) {
+        long long hb_l = 0, he_l = 0;
+        {
+            const int rb = utile * kUserTile + wave * 32 + (lane & 31);
+            if (rb < g.n_users_blk) {
+                const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)g.users[rb] : (int64_t)rb;
+                hb_l = g.hist_indptr[hr];
+                he_l = g.hist_indptr[hr + 1];
+            }
+        }
+        auto mark = [&](int r, int loc) __attribute__((always_inline)) {
+            const int pp = g.pos_of ? g.pos_of[loc] : loc;
+            const int T = pp >> 6;
+            if (T % g.n_splits != split) return;
+            const int q = (T - split) / g.n_splits;
+            if (q < nwarm) atomicOr(&hmask[r * (2 * kWarmTiles) + 2 * q + ((pp & 63) >> 5)], 1u << (pp & 31));
+        };
+        for (int r0 = 0; r0 < 32; r0 += 4) {
+            long long hb[4], he[4];
+            int loc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                hb[u] = __shfl(hb_l, r0 + u, 64);
+                he[u] = __shfl(he_l, r0 + u, 64);
+                loc[u] = hb[u] + lane < he[u] ? g.hist_indices[hb[u] + lane] - g.item_offset : -1;
+            }
+            int pp[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = loc[u] >= 0 && loc[u] < g.n_items_local;
+                pp[u] = in ? (g.pos_of ? g.pos_of[loc[u]] : loc[u]) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (pp[u] >= 0) {
+                    const int T = pp[u] >> 6;
+                    if (T % g.n_splits == split) {
+                        const int q = (T - split) / g.n_splits;
+                        if (q < nwarm) atomicOr(&hmask[(wave * 32 + r0 + u) * (2 * kWarmTiles) + 2 * q + ((pp[u] & 63) >> 5)], 1u << (pp[u] & 31));
+                    }
+                }
+                for (long long e = hb[u] + 64 + lane; e < he[u]; e += 64) {          // rows with more than 64 train items
+                    const int l2 = g.hist_indices[e] - g.item_offset;
+                    if (l2 >= 0 && l2 < g.n_items_local) mark(wave * 32 + r0 + u, l2);
+                }
             }
         }
     }
@@ -354,62 +389,155 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     const float* brow = Bt + j * D;
     const int bswz = swz<D>(j);
     uint64_t* my_lists = lists + (size_t)(wave * 32) * CAP;
-    for (int w = 0; w < nwarm; ++w) {
+    // All scores of the warm-up stay in registers (ordered-uint form, 0 = not a candidate: beyond the shard, a train item,
+    // NaN), newest half-tile first.
+    constexpr int NHT = 2 * kWarmTiles;
+    static_assert(NHT == 8, "eight named half-tile registers below");
+    typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+    // (separate vector values shifted by assignment: an array shifted in a rolled loop ends up in scratch memory)
+    u32x16 o0 = 0u, o1 = 0u, o2 = 0u, o3 = 0u, o4 = 0u, o5 = 0u, o6 = 0u, o7 = 0u;
+    int i0 = 0, i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+#pragma unroll 1
+    for (int ht = 0; ht < 2 * nwarm; ++ht) {
+        const int w = ht >> 1, cb = ht & 1;
         const int t = split + w * g.n_splits;
+        __syncthreads();                  // the previous block has been read by everyone (and hmask is complete)
+        if (tid < 32) {
+            const float* tl = reinterpret_cast<const float*>(g.rows + ((size_t)t * 64 + 32 * cb + tid) * RB + 2 * D + 32);
+            popw[tid] = tl[0];
+            idw[tid] = reinterpret_cast<const int*>(tl)[1];
+        }
+        __syncthreads();
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            __syncthreads();                  // the previous block has been read by everyone (and hmask is complete)
-            if (tid < 32) {
-                const float* tl = reinterpret_cast<const float*>(g.rows + ((size_t)t * 64 + 32 * cb + tid) * RB + 2 * D + 32);
-                popw[tid] = tl[0];
-                idw[tid] = reinterpret_cast<const int*>(tl)[1];
+        for (int q = 0; q < NLD4; ++q) {
+            if constexpr ((PDA_W4_ABL & 16) != 0) break;
+            const int id = tid + kThreads * q;
+            const int jj = id / CPR4, ch = id % CPR4;
+            // (null items of a tail tile carry id 0: a valid row, masked by okw below)
+            *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pda_load4<BF>(g.I, (size_t)idw[jj] * D + 4 * ch);
+        }
+        __syncthreads();
+        f32x16 acc0 = zero16v(), acc1 = zero16v();
+#pragma unroll
+        for (int c = 0; c < NC; c += 2) {
+            if constexpr ((PDA_W4_ABL & 8) != 0) break;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + h) ^ bswz));
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + 2 + h) ^ bswz));
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][q], b0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c + 1][q], b1[q], acc1, 0, 0, 0);
             }
-            __syncthreads();
+        }
+        const f32x16 accx = acc0 + acc1;
+        const bool okw = (t * 64 + 32 * cb + j) < g.n_items_local;
+        const float pv = popw[j];
+        const unsigned hb_mine = hmask[(wave * 32 + j) * (2 * kWarmTiles) + 2 * w + cb];
+        const bool any_hb = __any(hb_mine != 0u);
+        o7 = o6; o6 = o5; o5 = o4; o4 = o3; o3 = o2; o2 = o1; o1 = o0;
+        i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;
+        i0 = g.item_offset + idw[j];
 #pragma unroll
-            for (int q = 0; q < NLD4; ++q) {
-                const int id = tid + kThreads * q;
-                const int jj = id / CPR4, ch = id % CPR4;
-                // (null items of a tail tile carry id 0: a valid row, masked by okw below)
-                *reinterpret_cast<f32x4*>(Bt + jj * D + 4 * (ch ^ swz<D>(jj))) = pda_load4<BF>(g.I, (size_t)idw[jj] * D + 4 * ch);
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            float sc = accx[r];
+            if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+            bool p = okw && (sc >= -INFINITY);                                             // (NaN never ranks)
+            if (any_hb) {
+                const uint32_t hbr = (uint32_t)__shfl((int)hb_mine, row, 64);              // train items never enter
+                if ((hbr >> j) & 1u) p = false;
             }
-            __syncthreads();
-            f32x16 acc0 = zero16v(), acc1 = zero16v();
+            o0[r] = p ? pda_ordf(sc + 0.0f) : 0u;
+        }
+    }
+    const u32x16 ordv[NHT] = {o0, o1, o2, o3, o4, o5, o6, o7};
+    const int itemv[NHT] = {i0, i1, i2, i3, i4, i5, i6, i7};
+    // Per row (two at a time: one per half-wave) a threshold t with K <= #(scores >= t) <= CAP by bitwise descent over the
+    // ordered-uint scores (counts = ballots over the register file), then the survivors go to their list slots directly.
+    // More than CAP survivors at the exact K-th value (ties): the general append path with its compactions.
 #pragma unroll
-            for (int c = 0; c < NC; c += 2) {
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + h) ^ bswz));
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4 * ((2 * c + 2 + h) ^ bswz));
+    for (int r = 0; r < 16; ++r) {
+        if constexpr ((PDA_W4_ABL & 2) != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c][q], b0[q], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[c + 1][q], b1[q], acc1, 0, 0, 0);
+            for (int k = 0; k < NHT; ++k) asm volatile("" ::"v"(ordv[k][r]));
+#endif
+            continue;
+        }
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int lrow = wave * 32 + row;
+        auto count_ge = [&](uint32_t cand) __attribute__((always_inline)) -> int {
+            int lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < NHT; ++k) {
+                const uint64_t bm = __ballot(ordv[k][r] >= cand);
+                lo += __popc((uint32_t)bm);
+                hi += __popc((uint32_t)(bm >> 32));
+            }
+            return h ? hi : lo;
+        };
+        int c_t = count_ge(1u);
+        uint32_t t = 1u;
+        const bool need = c_t > CAP;
+        if (__any(need)) {
+            // bisection between the row's smallest and largest score in the ordered-uint domain (~ the log domain for
+            // positive scores: a handful of steps for smooth or heavy-tailed scores, <= 32 always); invariant:
+            // #(>= t) = c_t >= K, #(>= hi) < K
+            uint32_t mx = 0u, mn = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < NHT; ++k) {
+                const uint32_t v = ordv[k][r];
+                mx = max(mx, v);
+                mn = min(mn, v != 0u ? v : 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {                      // (xor < 32: stays inside the half-wave)
+                mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+                mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            }
+            uint32_t hi = mx + 1u;                                   // (mx < 0xFFFFFFFF: NaNs are not candidates)
+            if (need) t = mn;
+            for (int it = 0; it < 40; ++it) {
+                const bool open = need && c_t > CAP && hi - t > 1u;
+                if (!__any(open)) break;
+                const uint32_t mid = open ? t + ((hi - t) >> 1) : t;
+                const int cnt = count_ge(mid);
+                if (open) {
+                    if (cnt >= K) {
+                        t = mid;
+                        c_t = cnt;
+                    } else {
+                        hi = mid;
+                    }
                 }
             }
-            const f32x16 accx = acc0 + acc1;
-            const bool okw = (t * 64 + 32 * cb + j) < g.n_items_local;
-            const float pv = popw[j];
-            const int item = g.item_offset + idw[j];
-            const unsigned hb_mine = hmask[(wave * 32 + j) * (2 * kWarmTiles) + 2 * w + cb];
-            const bool any_hb = __any(hb_mine != 0u);
+        }
+        if (__any(c_t > CAP)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int lrow = wave * 32 + row;
-                float sc = accx[r];
-                if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
-                bool p = okw && (sc >= taul[lrow]);
-                if (any_hb) {
-                    const uint32_t hbr = (uint32_t)__shfl((int)hb_mine, row, 64);          // train items never enter
-                    if ((hbr >> j) & 1u) p = false;
-                }
-                const uint64_t key = pda_pack_key(sc, (uint32_t)item);
-                append_keys<CAP>(p, lrow, sc, key, lists, cntl, taul, wave * 32, 32, K, lane);
+            for (int k = 0; k < NHT; ++k) {
+                const bool p = ordv[k][r] >= t;
+                const uint64_t key = ((uint64_t)ordv[k][r] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)itemv[k]);
+                append_keys<CAP>(p, lrow, pda_unordf(ordv[k][r]), key, lists, cntl, taul, wave * 32, 32, K, lane);
             }
+        } else {
+            int run = 0;
+#pragma unroll
+            for (int k = 0; k < NHT; ++k) {
+                const bool p = ordv[k][r] >= t;
+                const uint64_t bm = __ballot(p);
+                const uint32_t bh = h ? (uint32_t)(bm >> 32) : (uint32_t)bm;
+                const int slot = run + __popc(bh & ((1u << j) - 1u));
+                if (p) lists[(size_t)lrow * CAP + slot] = ((uint64_t)ordv[k][r] << 32) | (uint64_t)(0xFFFFFFFFu - (uint32_t)itemv[k]);
+                run += __popc(bh);
+            }
+            if (j == 0) cntl[lrow] = run;
         }
     }
     pda_wave_sync();
     if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * nwarm));
     for (int rr = 0; rr < 32; ++rr) {
         uint64_t* buf = my_lists + rr * CAP;
+        if constexpr ((PDA_W4_ABL & 4) == 0)
         compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
         const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
@@ -1037,7 +1165,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (K > kCap4 - 3) return PDA_ERR_UNSUPPORTED;
     if ((uint64_t)n_items_local > (1ull << 26)) return PDA_ERR_UNSUPPORTED;          // ring words: 6-bit row, 26-bit local item id
     if (warm_tiles < 0 || warm_tiles > kWarmTiles) return PDA_ERR_ARG;
-    if (warm_tiles == 0) warm_tiles = kWarmTiles;
+    if (warm_tiles == 0) {
+        const char* e = getenv("PDA_V4_WARM");
+        warm_tiles = e ? atoi(e) : kWarmTiles;
+    }
     if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
     const Prep4Layout L = prep4_layout(n_items_local, d);
     const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);

@@ -185,10 +185,11 @@ def item_prep4(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], order: 
 
 def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
     """Which pre-filtered kernel generation serves a call.  All of them return the same keys; the choice is by measured
-    speed (C3, 65 536 users per block): generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
-    waves) for sweeps with few candidates per user -- the dense sweep in visiting order, 3.5 vs 4.2 ms --; generation 3 for
-    the candidate-heavy natural-order sweeps (8.6 vs 11 ms) and, by a few per cent, for the early-terminating sweep.
-    PDA_SCORE_KERNEL=v3|v4 forces one (A/B measurements, cross-checks)."""
+    speed (65 536 users per block).  Generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
+    waves, register-resident exact warm-up) for every sweep in visiting order -- C3 dense 3.40 vs 4.61 ms, early-terminating
+    0.42 vs 0.49 ms; C1/C2 0.31 vs 0.60 ms; a config-5 shard 3.2 vs 4.5 ms --; generation 3 for the candidate-heavy
+    natural-order sweeps (C3: 8.8 vs 10.7 ms; a tie at d = 64).  PDA_SCORE_KERNEL=v3|v4 forces one (A/B measurements,
+    cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_KERNEL", "")
     fits = d in (64, 128, 256) and K <= TOPK_K_V4 and nloc <= (1 << 26)
@@ -198,8 +199,7 @@ def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
         return "v4" if fits else "v3"
     if not (fits and prune):
         return "v3"
-    # d = 256 (bf16 tables of config 5): generation 4 also wins the early-terminating sweep (3.5 vs 4.5 ms on a config-5 shard)
-    return "v4" if (prune == "order" or d == 256) else "v3"
+    return "v4"
 
 
 def seed_exchange_applies(d: int, K: int, head: int, prune=None, impl: Optional[str] = None) -> bool:

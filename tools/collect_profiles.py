@@ -23,8 +23,8 @@ if os.path.exists(hl):
 pat = sys.argv[3] if len(sys.argv) > 3 else "score_topk"
 pm = "# kernel pattern: %s\n" % pat + subprocess.check_output([sys.executable, "tools/pmc_summary.py", src, pat]).decode()
 open(os.path.join(dst, name + "_pmc.txt"), "w").write(
-    "# rocprofv3 --pmc passes (separate runs) of: python bench.py --steps 3 --warmup 1 --no-train --no-cpu-baseline\n"
-    "# mean counter value per dispatch of score_topk_kernel, summed over the 8 XCDs; FETCH_SIZE/WRITE_SIZE in KiB\n"
+    "# rocprofv3 --pmc passes (separate runs, tools/profile_round.sh) of: python bench.py [workload] --steps 3 --warmup 1 --no-train --no-cpu-baseline --headline-only\n"
+    "# mean counter value per dispatch of the kernel named below, summed over the 8 XCDs; FETCH_SIZE/WRITE_SIZE in KiB\n"
     "# (gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x -- guides/MI355X_MICROARCH.md, HBM section)\n" + pm)
 line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
 open(os.path.join(dst, name + "_bench.json"), "w").write(line + "\n")
