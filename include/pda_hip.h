@@ -185,7 +185,10 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *   pda_score_topk4_auto_splits(n_users_blk, n_items_local, d)   the n_splits the call picks for n_splits <= 0
  *   pda_score_topk4_f32 / _bf16(.. as pda_score_topk_ordered_*, without hist_indices_ord: train items are masked at the
  *        candidate stage by a binary search in hist_indices ..)
- * d in {64,128,256}; K <= 54; n_items_local <= 2^26; workspace as pda_score_topk_workspace_bytes.  out_keys doubles as the
+ *   pda_score_topk4_workspace_bytes(n_users_blk, n_items_local, d, n_splits)   the workspace of these calls (n_splits as
+ *        passed to the call, <= 0 = automatic): the counters, and for d <= 128 -- workgroups of 512 users, whose exact lists
+ *        do not fit the LDS -- 57 list slots of 8 bytes per user and item split (120 MB at 262 144 users)
+ * d in {64,128,256}; K <= 54; n_items_local <= 2^26.  out_keys doubles as the
  * hand-over buffer between the exact warm-up kernel and the sweep.  PDA_ERR_UNSUPPORTED: use the entry points above. */
 size_t pda_item_prep4_bytes(int n_items_local, int d);
 int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,
@@ -194,6 +197,7 @@ int pda_item_prep4_bf16(const uint16_t* I_shard, const float* pop_shard, const i
                         void* stream);
 int pda_item_prep4_check(const void* prep, int n_items_local, int d, void* stream);
 int pda_score_topk4_auto_splits(int n_users_blk, int n_items_local, int d);
+size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits);
 int pda_score_topk4_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
                         int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
                         const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,

@@ -41,6 +41,7 @@ SIGNATURES = {
     "pda_item_prep_bytes": (_sz, [_i, _i]),
     "pda_item_prep_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "pda_score_topk_workspace_bytes": (_sz, [_i]),
+    "pda_score_topk4_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pda_score_topk_prepped_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_item_prep_ordered_bytes": (_sz, [_i, _i]),
     "pda_item_prep_ordered_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),

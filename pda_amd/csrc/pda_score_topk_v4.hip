@@ -78,6 +78,7 @@ struct Args4 {
     const float* sufB;
     const int* pos_of;           // [n_items_local] local id -> visiting position, or NULL: identity
     unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
+    uint64_t* lists_ws;          // list slots of the workgroups whose lists live in HBM (Geo4::GL): [workgroup][UT][kCap4]
     const float* seed;           // [n_users_blk] or NULL: an external LOWER bound of every user's final K-th value (other item shards)
     int n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, n_tiles;
     int warm_tiles;              // 1 .. kWarmTiles: 64-item tiles per split scored exactly by warm4_kernel
@@ -266,7 +267,7 @@ __device__ __forceinline__ int split_tiles(int n_tiles, int split, int n_splits)
 
 // append one exact key per flagged lane to its row's list; compaction (whole wave) when a list is full.  Returns true
 // when a threshold may have changed.
-template <int CAP>
+template <int CAP, bool GLB = false>
 __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t key, uint64_t* lists, int* cntl, float* taul, int row0,
                                             int n_rows, int K, int lane) {
     bool changed = false;
@@ -278,13 +279,13 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
             else ov = true;
         }
         if (!__any(ov)) break;
-        pda_wave_sync();
+        list_sync<GLB>();
         for (int base = 0; base < n_rows; base += 64) {
             uint64_t full = __ballot(base + lane < n_rows && cntl[row0 + (base + lane < n_rows ? base + lane : 0)] >= CAP);
             while (full) {
                 const int rr = base + __builtin_ctzll(full);
                 full &= full - 1ull;
-                compact_list<CAP>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+                compact_list<CAP, GLB>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
             }
         }
         changed = true;
@@ -569,47 +570,68 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // d <= 128: the kernel needs <= 128 VGPRs -- four waves per SIMD: 8 MFMA waves + 4 loaders + 4 rescoring waves (two loaders
 // could not keep up: the MFMA waves waited 39 % of their time for tiles); d = 256 (168 VGPRs): 8 + 2 + 2.
 
+#ifndef PDA_V4_UA
+#define PDA_V4_UA 1       // d <= 128: A operands (32 user rows each) per MFMA wave and B read.  2 = 512-user workgroups with
+                          // half the LDS reads per MFMA and the lists in HBM: measured, no faster on the large dense sweep (the
+                          // kernel runs at the chip's power limit either way) and 2 x slower on 65 536-user blocks and on the
+                          // candidate-heavy sweeps -- kept as a build option (tools/build_variant.sh)
+#endif
+#ifndef PDA_V4_GL
+#define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
+#endif
+#ifndef PDA_V4_NSLOT
+#define PDA_V4_NSLOT 4    // tile slots in LDS when the lists live in HBM (<= 5: the vote words of the early termination)
+#endif
 template <int D>
 struct Geo4 {
-    static constexpr int NB = D <= 128 ? 2 : 1;          // half-tiles (32 items, one accumulator chain each) per block
-    static constexpr int LOADERS = D <= 128 ? 4 : 2;
-    static constexpr int RESCORERS = D <= 128 ? 4 : 2;
+    static constexpr int UA = D <= 128 ? PDA_V4_UA : 1;  // A operands per B read: 32 UA user rows per MFMA wave
+    // the exact lists in HBM (workspace) free the LDS for four tile slots (d = 256: 8.1 instead of 9.0 ms on a config-5 shard);
+    // 512 users x 57 x 8 B would not fit the LDS anyway
+    static constexpr bool GL = PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0;
+    static constexpr int NB = (D <= 128 && UA == 1) ? 2 : 1;          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
+    static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : 2;
+    static constexpr int RESCORERS = (D <= 128 && UA == 1) ? 4 : 2;
     static constexpr int MPR = kMainWaves / RESCORERS;   // MFMA waves per rescoring wave
     static constexpr int WAVES = kMainWaves + LOADERS + RESCORERS;
-    static constexpr int ROWS = 32;                      // user rows per MFMA wave
+    static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
     static constexpr int UT = kMainWaves * ROWS;         // user rows per workgroup
     static constexpr int RB = row_bytes(D), TB = tile_bytes(D);
     static constexpr int HB = 32 * RB;                   // one half-tile
     static constexpr int BB = NB * HB;                   // one block = one ring slot
     static constexpr int NP = (BB + 1023) / 1024;        // 1 KiB DMA pieces per block; the last one may be half a piece (32 lanes)
     static constexpr int LASTL = (BB % 1024) ? (BB % 1024) / 16 : 64;
-    static constexpr size_t lds_tiles = 2 * (size_t)BB;
-    static constexpr size_t lds_lists = (size_t)UT * kCap4 * 8;
+    static constexpr int NSLOT = GL ? PDA_V4_NSLOT : 2;
+    static constexpr size_t lds_tiles = NSLOT * (size_t)BB;
+    static constexpr size_t lds_lists = GL ? 0 : (size_t)UT * kCap4 * 8;
     static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 512;
+    static_assert(NSLOT >= 2 && NSLOT <= 5, "vote timing of the early termination");
+    static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
 };
 
 template <int D, int HEAD, bool BF>
 __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     using G = Geo4<D>;
     constexpr int kLoaders = G::LOADERS, kMPR = G::MPR;
-    constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP;
+    constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP, UA = G::UA, NSLOT = G::NSLOT;
+    constexpr bool GL = G::GL;
     constexpr int NM = D / 16;
     constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* tiles = smem;                                                             // 2 x BB
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + G::lds_tiles);                      // [UT][kCap4] exact keys
-    int* cntl = reinterpret_cast<int*>(lists + (size_t)UT * kCap4);                          // [UT]
+    unsigned char* tiles = smem;                                                             // NSLOT x BB
+    uint64_t* lists = GL ? g.lists_ws + (size_t)blockIdx.x * UT * kCap4                      // [UT][kCap4] exact keys
+                         : reinterpret_cast<uint64_t*>(smem + G::lds_tiles);
+    int* cntl = reinterpret_cast<int*>(smem + G::lds_tiles + G::lds_lists);                  // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                                       // [UT] exact K-th value (-inf until K entries)
     unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [8][kRing4]
     unsigned* sync = rings + kMainWaves * kRing4;
     unsigned* s_landed = sync;                // [4]
-    unsigned* s_stop = sync + 76;             // [1]  early termination: loaders leave
+    unsigned* s_stop = sync + 108;            // [1]  early termination: loaders leave
     unsigned* s_released = sync + 4;          // [8]
     unsigned* s_tail = sync + 12;             // [8]  ring write positions (MFMA wave w)
     unsigned* s_head = sync + 20;             // [8]  ring read positions
     unsigned* s_done = sync + 28;             // [8]  MFMA wave w has pushed its last candidate
     unsigned* s_tver = sync + 36;             // [8]  bumped by the rescoring wave whenever a threshold of wave w's rows rose
-    unsigned* s_vote = sync + 44;             // [4][8]  early termination votes of checkpoint c & 3
+    unsigned* s_vote = sync + 44;             // [8][8]  early termination votes about tile it & 7
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -629,12 +651,34 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         const int r = wave - kMainWaves - kLoaders;
         const int row0 = r * RR;
         uint64_t* my_lists = lists + (size_t)row0 * kCap4;
-        int uidv[2] = {0, 0};
-        float seedv[2] = {-INFINITY, -INFINITY};
-        int64_t hbv[2] = {0, 0}, hev[2] = {0, 0};
+        constexpr int NRL = (RR + 63) / 64;                  // rows per lane
+        int uidv[NRL];
+        float seedv[NRL];
+        long long hbv[NRL], hev[NRL];
+#pragma unroll
+        for (int s2 = 0; s2 < NRL; ++s2) { uidv[s2] = 0; seedv[s2] = -INFINITY; hbv[s2] = 0; hev[s2] = 0; }
+        // row `row` of this wave: entry row / 64 of lane row % 64
+        auto row_i = [&](const int (&a)[NRL], int row) __attribute__((always_inline)) -> int {
+            int v = __shfl(a[0], row & 63, 64);
+#pragma unroll
+            for (int s2 = 1; s2 < NRL; ++s2) { const int t = __shfl(a[s2], row & 63, 64); v = (row >> 6) == s2 ? t : v; }
+            return v;
+        };
+        auto row_f = [&](const float (&a)[NRL], int row) __attribute__((always_inline)) -> float {
+            float v = __shfl(a[0], row & 63, 64);
+#pragma unroll
+            for (int s2 = 1; s2 < NRL; ++s2) { const float t = __shfl(a[s2], row & 63, 64); v = (row >> 6) == s2 ? t : v; }
+            return v;
+        };
+        auto row_l = [&](const long long (&a)[NRL], int row) __attribute__((always_inline)) -> long long {
+            long long v = __shfl(a[0], row & 63, 64);
+#pragma unroll
+            for (int s2 = 1; s2 < NRL; ++s2) { const long long t = __shfl(a[s2], row & 63, 64); v = (row >> 6) == s2 ? t : v; }
+            return v;
+        };
         const bool hist_on = g.hist_indptr != nullptr;
 #pragma unroll
-        for (int s2 = 0; s2 < (RR + 63) / 64; ++s2) {
+        for (int s2 = 0; s2 < NRL; ++s2) {
             const int rl = 64 * s2 + lane;
             const int rb_l = utile * UT + row0 + rl;
             const bool ok = rl < RR && rb_l < g.n_users_blk;
@@ -658,6 +702,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 taul[row0 + rr] = rb < g.n_users_blk ? (c >= K ? pda_key_val(kth) : -INFINITY) : INFINITY;
             }
         }
+        if constexpr (GL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         unsigned head[kMPR], n_cand = 0;
 #pragma unroll
@@ -705,8 +750,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             const unsigned word = valid ? ring[(hd + (unsigned)ci) % kRing4] : 0u;
             const int row = sel * ROWS + (int)(word >> 26);                         // row of this wave
             const int loc = (int)(word & 0x3FFFFFFu);                               // local item id
-            int urow = __shfl(uidv[0], row & 63, 64);
-            if constexpr (RR > 64) { const int u1 = __shfl(uidv[1], row & 63, 64); urow = row >= 64 ? u1 : urow; }
+            const int urow = row_i(uidv, row);
             const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)loc * D + q * 32;
             f32x4 uu[8], ii[8];
 #pragma unroll
@@ -754,29 +798,23 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in.
             // With a seed (item-sharded evaluation: the K-th values of the OTHER shards' warm-up lists) nothing below it can be
             // in the merged top K: it stays out of this shard's list, which may then end shorter than K.
-            float sd = __shfl(seedv[0], row & 63, 64);
-            if constexpr (RR > 64) { const float s1 = __shfl(seedv[1], row & 63, 64); sd = row >= 64 ? s1 : sd; }
+            const float sd = row_f(seedv, row);
             bool p = valid && q == LPC - 1 && (tt >= fmaxf(taul[lrow], sd));
             if (hist_on) {
                 // train items are masked HERE: one binary search in the row's id-sorted history for a candidate that has
                 // passed the filter and the exact threshold
-                int64_t lo = __shfl(hbv[0], row & 63, 64), hi = __shfl(hev[0], row & 63, 64);
-                if constexpr (RR > 64) {
-                    const int64_t lo1 = __shfl(hbv[1], row & 63, 64), hi1 = __shfl(hev[1], row & 63, 64);
-                    lo = row >= 64 ? lo1 : lo;
-                    hi = row >= 64 ? hi1 : hi;
-                }
-                const int64_t he = hi;
+                long long lo = row_l(hbv, row), hi = row_l(hev, row);
+                const long long he = hi;
                 if (p) {
                     while (lo < hi) {
-                        const int64_t mid = (lo + hi) >> 1;
+                        const long long mid = (lo + hi) >> 1;
                         if (g.hist_indices[mid] < item) lo = mid + 1; else hi = mid;
                     }
                     if (lo < he && g.hist_indices[lo] == item) p = false;
                 }
             }
             const uint64_t key = pda_pack_key(tt, (uint32_t)item);
-            const bool changed = append_keys<kCap4>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane);
+            const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane);
             if (changed && lane == 0) __hip_atomic_fetch_add(&s_tver[kMPR * r + sel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         PROF_T1(tr0, 6);
@@ -786,7 +824,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         // finalise: the lists are exact; sort and emit
         for (int rr = 0; rr < RR; ++rr) {
             uint64_t* buf = my_lists + (size_t)rr * kCap4;
-            compact_list<kCap4>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+            compact_list<kCap4, GL>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
             const int c = cntl[row0 + rr];
             const int rb = utile * UT + row0 + rr;
             if (rb < g.n_users_blk && lane < K) {
@@ -805,11 +843,17 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         const int l = wave - kMainWaves;
         const unsigned lds_tiles0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
         __syncthreads();
+        // Three or more slots: a loader keeps TWO blocks in flight -- it announces block b - 1 behind the issue of its pieces
+        // of block b (a counted vmcnt), so a block is delivered per issue time, not per issue time + latency (2 500 cycles
+        // against the 1 600 of a block's MFMAs).  Two slots: nothing to issue ahead; wait for the block and say so at once.
+        constexpr bool PIPE = NSLOT >= 3;
         constexpr int MYP = (NP + kLoaders - 1) / kLoaders;       // pieces per loader and block (the last loader may have one less)
+        const int my_pieces = (NP - l + kLoaders - 1) / kLoaders;
         bool stop = false;
         for (int b = 0; b < n_blk && !stop; ++b) {
-            if (b >= 2) {                                          // slot b & 1 is free once every MFMA wave has released block b - 2
-                const unsigned want = (unsigned)(b - 1);
+            PROF_T0(tl0);
+            if (b >= NSLOT && !(PDA_V4_ABL & 2)) {                 // slot b % NSLOT is free once every MFMA wave has released block b - NSLOT
+                const unsigned want = (unsigned)(b - NSLOT + 1);
                 unsigned spin = 0;
                 auto min_released = [&]() __attribute__((always_inline)) -> unsigned {
                     unsigned mn = 0xFFFFFFFFu;
@@ -824,14 +868,16 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 }
                 if (stop) break;
             }
+            PROF_T1(tl0, 10);
+            PROF_T0(tl1);
             const int hf0 = b * NB;                                // first half-tile of the block
             const int t = split + (g.warm_tiles + (hf0 >> 1)) * g.n_splits;
             [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * G::TB + (size_t)(hf0 & 1) * HB + lane * 16;
-            [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((b & 1) * BB);
+            [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((b % NSLOT) * BB);
 #pragma unroll
             for (int c = 0; c < MYP; ++c) {
                 const int piece = l + kLoaders * c;
-                if (piece < NP && (piece < NP - 1 || lane < G::LASTL)) {
+                if (piece < NP && (piece < NP - 1 || lane < G::LASTL) && !(PDA_V4_ABL & 4)) {
 #if defined(__HIP_DEVICE_COMPILE__)
                     unsigned keep;
                     const unsigned char* gsrc = src + (size_t)piece * 1024;
@@ -841,12 +887,25 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 #endif
                 }
             }
-            // With two slots there is nothing else to issue until block b - 1 is released: wait for THIS block to land and
-            // say so at once (publishing it only behind the issue of the next block -- a counted vmcnt -- made every MFMA
-            // wave wait for that issue: 39 % of its time).
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            lds_st(&s_landed[l], (unsigned)(b + 1));            // blocks 0 .. b
+            PROF_T1(tl1, 11);
+            PROF_T0(tl2);
+            if constexpr (PIPE) {
+                if (b >= 1) {
+                    if (my_pieces == MYP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP > 0 ? MYP - 1 : 0) : "memory");
+                    lds_st(&s_landed[l], (unsigned)b);              // blocks 0 .. b - 1
+                }
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                lds_st(&s_landed[l], (unsigned)(b + 1));            // blocks 0 .. b
+            }
+            PROF_T1(tl2, 12);
         }
+        if constexpr (PIPE) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (!stop) lds_st(&s_landed[l], (unsigned)n_blk);
+        }
+        PROF_FLUSH(10, 12);
         return;
     }
 
@@ -856,10 +915,11 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     const int row0 = w * ROWS;
     // A operand: row j of the wave (k = 16 m + 8 h .. + 7) rounded to bf16 and NEGATED (all of the A side, the extra k-step
     // too): the accumulators hold -(s~ - thr/pop + 1 + eps), and "candidate" is "negative", i.e. the sign bit.
-    u32x4 ah[NM];
-    float nu_row;
-    {
-        const int rb = utile * UT + row0 + j;
+    u32x4 ah[UA][NM];
+    float nu_row[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int rb = utile * UT + row0 + 32 * u + j;
         const bool ok = rb < g.n_users_blk;
         const int uid = ok ? g.users[rb] : 0;
         float ss = 0.f;
@@ -871,14 +931,14 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 y = pda_load4<BF>(g.U, (size_t)uid * D + 8 * h + 16 * m + 4);
             }
             u32x4 lo_unused;
-            split8(x, y, ah[m], lo_unused);
+            split8(x, y, ah[u][m], lo_unused);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ah[m][k] ^= 0x80008000u;
+            for (int k = 0; k < 4; ++k) ah[u][m][k] ^= 0x80008000u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
         }
         ss += __shfl_xor(ss, 32, 64);
-        nu_row = sqrtf(ss) * 1.0009765625f * 1.0001f;              // padded ||u||
+        nu_row[u] = sqrtf(ss) * 1.0009765625f * 1.0001f;           // padded ||u||
     }
     __syncthreads();                       // lists, thresholds and hand-over words are initialised
 
@@ -886,34 +946,38 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     // extra k-step, pda_score_topk_v3.hip), as the A operand of the extra k-step:
     //   k 0..7 (lanes < 32): (t1,t1,t2,t2,t1,t3,t2,t3), thr = t1 + t2 + t3 exactly;  k 8..10: -1, -1, -eps scale of the row
     //   (negated like the rest of the A side: v3 carries the opposite signs)
-    float thr_own = 0.f, thr_min = 0.f;
-    u32x4 aex = {0u, 0u, 0u, 0u};
-    float seed_own = -INFINITY;                 // external lower bound of the row's final K-th value (see the rescoring wave)
-    {
-        const int rb = utile * UT + row0 + j;
-        if (g.seed != nullptr && rb < g.n_users_blk) seed_own = g.seed[rb];
+    float thr_own[UA], thr_min[UA];
+    u32x4 aex[UA];
+    float seed_own[UA];                         // external lower bound of the row's final K-th value (see the rescoring wave)
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+        const int rb = utile * UT + row0 + 32 * u + j;
+        seed_own[u] = (g.seed != nullptr && rb < g.n_users_blk) ? g.seed[rb] : -INFINITY;
     }
     auto refresh_thr = [&]() __attribute__((always_inline)) {
-        const float tq = fmaxf(taul[row0 + j], seed_own);
-        float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
-        tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
-        thr_own = tf;
-        float mn = tf;
-        uint32_t t1, t2, t3;
-        bf16_split3(tf, t1, t2, t3);
-        const uint32_t nnu = bf16_up(nu_row * (kEps * 1.001f * 1.08f)) | 0x8000u;
-        aex[0] = h ? 0xBF80BF80u : (t1 | (t1 << 16));
-        aex[1] = h ? nnu : (t2 | (t2 << 16));
-        aex[2] = h ? 0u : (t1 | (t3 << 16));
-        aex[3] = h ? 0u : (t2 | (t3 << 16));
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
-        thr_min = mn;
+        for (int u = 0; u < UA; ++u) {
+            const float tq = fmaxf(taul[row0 + 32 * u + j], seed_own[u]);
+            float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
+            tf = fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
+            thr_own[u] = tf;
+            float mn = tf;
+            uint32_t t1, t2, t3;
+            bf16_split3(tf, t1, t2, t3);
+            const uint32_t nnu = bf16_up(nu_row[u] * (kEps * 1.001f * 1.08f)) | 0x8000u;
+            aex[u][0] = h ? 0xBF80BF80u : (t1 | (t1 << 16));
+            aex[u][1] = h ? nnu : (t2 | (t2 << 16));
+            aex[u][2] = h ? 0u : (t1 | (t3 << 16));
+            aex[u][3] = h ? 0u : (t2 | (t3 << 16));
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) mn = fminf(mn, __shfl_xor(mn, o, 64));
+            thr_min[u] = mn;
+        }
     };
-    // the exact threshold of accumulator register r (lane half hv), strictly below tau (ties must pass)
-    auto thr_of = [&](int r, int hv) __attribute__((always_inline)) -> float {
+    // the exact threshold of accumulator register r (lane half hv) of row set u, strictly below tau (ties must pass)
+    auto thr_of = [&](int r, int hv, int u) __attribute__((always_inline)) -> float {
         const int rw = (r & 3) + 8 * (r >> 2) + 4 * hv;
-        const float tq = fmaxf(taul[row0 + rw], __shfl(seed_own, rw, 64));
+        const float tq = fmaxf(taul[row0 + 32 * u + rw], __shfl(seed_own[u], rw, 64));
         return (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 9.5367431640625e-7f - 1e-30f;
     };
     refresh_thr();
@@ -925,12 +989,12 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     unsigned* ring = rings + w * kRing4;
     unsigned tail = 0, head_c = 0;          // wave-uniform
     // push the flagged registers (bit 15 - r <-> register r)
-    auto push_mask = [&](uint32_t m, int loc) __attribute__((always_inline)) {
+    auto push_mask = [&](uint32_t m, int loc, int u) __attribute__((always_inline)) {
         while (__any(m != 0)) {
             const bool act = m != 0;
             const int bit = 31 - __builtin_clz(m | 1u);
             const int r = 15 - bit;
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
             m &= ~(1u << bit);
             const uint64_t pm = __ballot(act);
             if (tail + 64u - head_c > (unsigned)kRing4) {      // ring full: publish what is there and wait for the rescoring wave
@@ -951,7 +1015,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     };
     auto ensure_landed = [&](int b) __attribute__((always_inline)) {
         const unsigned want = (unsigned)(b + 1);
-        if (landed_c < want) {
+        if (landed_c < want && !(PDA_V4_ABL & 2)) {
             unsigned spin = 0;
             PROF_T0(te);
             do {
@@ -966,6 +1030,15 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     };
     const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment (cb, m) of slot s: + s BB + cb HB + 32 m
 
+#ifndef PDA_V4_PF
+#define PDA_V4_PF 4       // B fragments in flight per MFMA wave (the compiler keeps fewer when registers are short)
+#endif
+#ifndef PDA_V4_STAGGER
+#define PDA_V4_STAGGER 0
+#endif
+    // The two MFMA waves of a SIMD (w and w + 4) half a block apart: while one waits for its last MFMA and tests the
+    // accumulators, the other one's MFMAs keep the pipe busy.
+    if (PDA_V4_STAGGER > 0 && w >= 4) __builtin_amdgcn_s_sleep(PDA_V4_STAGGER);
     PROF_T0(tm0);
     int n_done = 0;
     bool stopped = false;
@@ -973,47 +1046,69 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 #define PDA_V4_VOTE_EVERY 2
 #endif
     constexpr int kVoteEvery = PDA_V4_VOTE_EVERY;      // a vote in front of every kVoteEvery-th tile (1, 2 or 4)
-    float sa_nx = 0.0f, sb_nx = 0.0f;          // suffix bounds at tile it + 2 of the coming vote
-    bool nx_ok = g.sufA != nullptr && kVoteEvery + 1 < n_it;
+    constexpr int kVL = (NSLOT + 2) / 2;               // a vote is about the tile kVL behind the one it is stored in front of
+    float sa_nx = 0.0f, sb_nx = 0.0f;          // suffix bounds at tile it + kVL of the coming vote
+    bool nx_ok = g.sufA != nullptr && kVoteEvery - 1 + kVL < n_it;
     if (nx_ok) {
-        const int tn = split + (g.warm_tiles + kVoteEvery + 1) * g.n_splits;
+        const int tn = split + (g.warm_tiles + kVoteEvery - 1 + kVL) * g.n_splits;
         sa_nx = g.sufA[tn];
         sb_nx = g.sufB[tn];
     }
+    constexpr int S = NB * NM, PF = S < PDA_V4_PF ? S : PDA_V4_PF;
+    constexpr bool PFX = NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
+    u32x4 bq[PF];
     for (int b = 0; b < n_blk && !stopped; ++b) {
         const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
-        // ---- early termination.  In front of the last block of tile i every wave votes "nothing at or behind tile i + 2 can
-        // reach my rows" (candidates still in the ring can only raise thresholds) -- BEFORE it releases that block.  Once the
-        // first block of tile i + 2 has landed, every wave has released the block two before it, which is not earlier than
-        // the one the votes were stored in front of: the votes are complete, every wave reads the same eight words (while
-        // the MFMAs of that block run) and, if they all agree, leaves behind that block.
+        // ---- early termination.  In front of the last block of tile i every wave votes "nothing at or behind tile i + kVL
+        // can reach my rows" (candidates still in the ring can only raise thresholds) -- BEFORE it releases that block.  Once
+        // the first block of tile i + kVL has landed, every wave has released the block NSLOT before it, which is not earlier
+        // than the one the votes were stored in front of (2 kVL - 1 >= NSLOT): the votes are complete, every wave reads the
+        // same eight words (while the MFMAs of that block run) and, if they all agree, leaves behind that block.  The words
+        // of tile i are written again for tile i + 8: by then every wave has released block 2 i + 17 - NSLOT, far behind.
         const int it = (b * NB) >> 1;
         const bool tile_first = NB == 2 || (b & 1) == 0, tile_last = NB == 2 || (b & 1) == 1;
         if (g.sufA != nullptr && tile_last && (it & (kVoteEvery - 1)) == kVoteEvery - 1) {
-            const bool alldead = nx_ok && __all(__builtin_fmaf(nu_row, sb_nx, sa_nx) * 1.000002f < thr_own);
-            if (lane == 0) lds_st(&s_vote[(it & 3) * kMainWaves + w], alldead ? 1u : 0u);
+            bool dead = nx_ok;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) dead = dead && (__builtin_fmaf(nu_row[u], sb_nx, sa_nx) * 1.000002f < thr_own[u]);
+            const bool alldead = __all(dead);
+            if (lane == 0) lds_st(&s_vote[(it & 7) * kMainWaves + w], alldead ? 1u : 0u);
             // the bounds of the next vote: loaded a tile ahead
-            const int inx = it + kVoteEvery + 2;
+            const int inx = it + kVoteEvery + kVL;
             const int tn = split + (g.warm_tiles + min(inx, max(n_it - 1, 0))) * g.n_splits;
             sa_nx = g.sufA[tn];               // (no use before the next vote: the loads stay in flight over the block)
             sb_nx = g.sufB[tn];
             nx_ok = inx < n_it;
         }
-        ensure_landed(b);
-        const unsigned char* tb = lane_base + (b & 1) * BB;
-        // ---- the block: NB chains, k-step major; S = NB NM B reads, PF in flight ----
-        f32x16 acc[NB];
+        // With three slots the first B fragments of block b + 1 are read while the MFMAs of block b are still being issued: the
+        // wave comes back from the accumulator test of block b with its operands in registers.
+        const bool has_next = PFX && b + 1 < n_blk;
+        if (b == 0 || !PFX) ensure_landed(b);
+        // "has block b + 1 landed?" is asked here and looked at half a block later, in front of the first read of block b + 1:
+        // a synchronous poll costs an LDS round trip per block (440 cycles of a block's 1 600 on a busy LDS)
+        unsigned lnd[kLoaders];
+        if (has_next && landed_c < (unsigned)(b + 2)) {
+#pragma unroll
+            for (int z = 0; z < kLoaders; ++z) lnd[z] = lds_ld(&s_landed[z]);
+        } else {
+#pragma unroll
+            for (int z = 0; z < kLoaders; ++z) lnd[z] = 0xFFFFFFFFu;
+        }
+        const unsigned char* tb = lane_base + (b % NSLOT) * BB;
+        [[maybe_unused]] const unsigned char* tbn = lane_base + ((b + 1) % NSLOT) * BB;
+        // ---- the block: NB UA chains, k-step major; S = NB NM B reads, PF in flight ----
+        f32x16 acc[UA][NB];
         float popv[NB];
         int locv[NB];
         {
-            constexpr int S = NB * NM, PF = S < 8 ? S : 8;
-            auto b_load = [&](int s_) __attribute__((always_inline)) -> u32x4 {
+            auto b_load = [&](const unsigned char* base, int s_) __attribute__((always_inline)) -> u32x4 {
                 const int m = s_ / NB, cb = s_ % NB;
-                return *reinterpret_cast<const u32x4*>(tb + cb * HB + 32 * m);
+                return *reinterpret_cast<const u32x4*>(base + cb * HB + 32 * m);
             };
-            u32x4 bq[PF];
+            if (!PFX || b == 0) {
 #pragma unroll
-            for (int s_ = 0; s_ < PF; ++s_) bq[s_] = b_load(s_);
+                for (int s_ = 0; s_ < PF; ++s_) bq[s_] = b_load(tb, s_);
+            }
             u32x4 bx[NB];
             uint2 pi[NB];
 #pragma unroll
@@ -1024,9 +1119,25 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 #pragma unroll
             for (int s_ = 0; s_ < S; ++s_) {
                 const int m = s_ / NB, cb = s_ % NB;
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[m]), __builtin_bit_cast(bf16x8, bq[s_ % PF]),
-                                                                  m == 0 ? zero16v() : acc[cb], 0, 0, 0);
-                if (s_ + PF < S) bq[s_ % PF] = b_load(s_ + PF);
+#pragma unroll
+                for (int u = 0; u < UA; ++u)
+                    acc[u][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[u][m]), __builtin_bit_cast(bf16x8, bq[s_ % PF]),
+                                                                         m == 0 ? zero16v() : acc[u][cb], 0, 0, 0);
+                if (s_ + PF < S) {
+                    bq[s_ % PF] = b_load(tb, s_ + PF);
+                } else if (has_next) {
+                    if (s_ + PF == S) {
+                        unsigned mn = landed_c;
+                        if (mn < (unsigned)(b + 2)) {
+                            mn = 0xFFFFFFFFu;
+#pragma unroll
+                            for (int z = 0; z < kLoaders; ++z) mn = min(mn, lnd[z]);
+                            landed_c = mn;
+                        }
+                        ensure_landed(b + 1);
+                    }
+                    bq[s_ % PF] = b_load(tbn, s_ + PF - S);
+                }
             }
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
@@ -1041,13 +1152,15 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                     bx[cb][2] = h ? 0u : 0x3F800000u;
                     bx[cb][3] = 0u;
                 }
-                acc[cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex), __builtin_bit_cast(bf16x8, bx[cb]), acc[cb], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < UA; ++u)
+                    acc[u][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aex[u]), __builtin_bit_cast(bf16x8, bx[cb]), acc[u][cb], 0, 0, 0);
             }
         }
         // (the votes about this tile, read while the MFMAs run and BEFORE the release -- a wave that sees it may store its vote
         // four tiles on into the same words; the block is finished either way)
-        if (g.sufA != nullptr && tile_first && it >= 2 && ((it - 2) & (kVoteEvery - 1)) == kVoteEvery - 1) {
-            const unsigned* v = &s_vote[((it - 2) & 3) * kMainWaves];
+        if (g.sufA != nullptr && tile_first && it >= kVL && ((it - kVL) & (kVoteEvery - 1)) == kVoteEvery - 1) {
+            const unsigned* v = &s_vote[((it - kVL) & 7) * kMainWaves];
             unsigned all = 1u;
 #pragma unroll
             for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
@@ -1061,37 +1174,41 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         if constexpr ((PDA_V4_ABL & 1) != 0) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-            for (int cb = 0; cb < NB; ++cb) asm volatile("" ::"v"(acc[cb]));       // timing only: no filter, but the MFMAs stay
+            for (int cb = 0; cb < NB; ++cb)
+                for (int u = 0; u < UA; ++u) asm volatile("" ::"v"(acc[u][cb]));       // timing only: no filter, but the MFMAs stay
 #endif
         } else {
 #pragma unroll
             for (int cb = 0; cb < NB; ++cb) {
-                uint32_t mo = 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mo |= (uint32_t)__float_as_int(acc[cb][r]);
-                bool clampy = false;
-                if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv[cb] > thr_min);     // s~ + eps < 0: head <= pop; rare once the lists are warm
-                if (__any((int)mo < 0) || clampy) {
-                    PROF_T0(ts);
-                    PROF_INC(4, 1);
-                    uint32_t mcb = 0;
-                    if (__any((int)mo < 0)) {
-                        // the exact mask: bit 15 - r <-> register r is negative (v_alignbit shifts the sign bit in)
+                for (int u = 0; u < UA; ++u) {
+                    uint32_t mo = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(acc[cb][r]), 31);
-                    }
-                    if (clampy) {
-                        int hv = h;
+                    for (int r = 0; r < 16; ++r) mo |= (uint32_t)__float_as_int(acc[u][cb][r]);
+                    bool clampy = false;
+                    if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv[cb] > thr_min[u]);     // s~ + eps < 0: head <= pop; rare once the lists are warm
+                    if (__any((int)mo < 0) || clampy) {
+                        PROF_T0(ts);
+                        PROF_INC(4, 1);
+                        uint32_t mcb = 0;
+                        if (__any((int)mo < 0)) {
+                            // the exact mask: bit 15 - r <-> register r is negative (v_alignbit shifts the sign bit in)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(acc[u][cb][r]), 31);
+                        }
+                        if (clampy) {
+                            int hv = h;
 #if defined(__HIP_DEVICE_COMPILE__)
-                        asm volatile("" : "+v"(hv));
+                            asm volatile("" : "+v"(hv));
 #endif
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) mcb |= (popv[cb] > thr_of(r, hv)) ? (1u << (15 - r)) : 0u;
+                            for (int r = 0; r < 16; ++r) mcb |= (popv[cb] > thr_of(r, hv, u)) ? (1u << (15 - r)) : 0u;
+                        }
+                        push_mask(mcb, locv[cb], u);
+                        PDA_CBAR();
+                        lds_st(&s_tail[w], tail);
+                        PROF_T1(ts, 3);
                     }
-                    push_mask(mcb, locv[cb]);
-                    PDA_CBAR();
-                    lds_st(&s_tail[w], tail);
-                    PROF_T1(ts, 3);
                 }
             }
         }
@@ -1149,7 +1266,21 @@ int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = 
     return PDA_OK;
 }
 
-int user_tile4(int d) { (void)d; return kMainWaves * 32; }
+int user_tile4(int d) { return d == 64 ? Geo4<64>::UT : d == 128 ? Geo4<128>::UT : Geo4<256>::UT; }
+static bool lists_in_hbm4(int d) { return d == 64 ? Geo4<64>::GL : d == 128 ? Geo4<128>::GL : Geo4<256>::GL; }
+// the workspace of the pda_score_topk4_* calls: the counters of pda_score_topk_workspace_bytes, then (workgroups of 512 users:
+// d <= 128) the list slots of every workgroup
+static size_t lists_offset4(int n_users_blk) { return (pda_score_topk_workspace_bytes(n_users_blk) + 255) & ~(size_t)255; }
+extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
+    if (n_users_blk <= 0 || n_items_local <= 0 || (d != 64 && d != 128 && d != 256)) return 0;
+    if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
+    size_t b = lists_offset4(n_users_blk);
+    if (lists_in_hbm4(d)) {
+        const size_t ut = (size_t)user_tile4(d);
+        b += ((size_t)n_users_blk + ut - 1) / ut * (size_t)n_splits * ut * kCap4 * 8 + 256;
+    }
+    return b;
+}
 
 int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
                int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
@@ -1179,7 +1310,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles};
+            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) + lists_offset4(n_users_blk)), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles};
     if (head == PDA_HEAD_RAW) {
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;

@@ -111,9 +111,21 @@ __device__ __forceinline__ int swz(int row) {
 // After the first compaction buf[0..K) is already sorted, so only the (<= kCap-K) appended keys need ranking:
 // rank(old i) = i + #new greater; rank(new) = #old greater (one ballot) + #new greater.  ~4x cheaper than the
 // generic all-pairs rank sort, which remains for the first compaction and the final sort.
-template <int CAP = kCap>
+// GLB: the list lives in HBM (generation 4, 512-user workgroups): the wave's own stores must have reached the cache
+// before other lanes read them back -- a workgroup-scope fence (waits for the outstanding stores; the L1 is the CU's).
+template <bool GLB>
+__device__ __forceinline__ void list_sync() {
+    if constexpr (GLB) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        list_sync<GLB>();
+    }
+}
+
+template <int CAP = kCap, bool GLB = false>
 __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane) {
-    pda_wave_sync();
+    list_sync<GLB>();
     const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), CAP);   // failed appends may have pushed it past kCap
     const bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
     uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);  // fillers: unique, below any real key
@@ -139,7 +151,7 @@ __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float
             rank += ((k0 > key) ? 1 : 0) + ((k1 > key) ? 1 : 0) + ((k2 > key) ? 1 : 0) + ((k3 > key) ? 1 : 0);
         }
     }
-    pda_wave_sync();
+    list_sync<GLB>();
     if (lane < c && rank < K) buf[rank] = key;
     if (c >= K) {
         uint64_t mk = __ballot(lane < c && rank == K - 1);
@@ -152,7 +164,7 @@ __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float
     } else if (lane == 0) {
         *cnt_slot = c;
     }
-    pda_wave_sync();
+    list_sync<GLB>();
 }
 
 

@@ -183,13 +183,14 @@ def item_prep4(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], order: 
     return buf
 
 
-def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
+def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) -> str:
     """Which pre-filtered kernel generation serves a call.  All of them return the same keys; the choice is by measured
     speed (65 536 users per block).  Generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
     waves, register-resident exact warm-up) for every sweep in visiting order -- C3 dense 3.40 vs 4.61 ms, early-terminating
     0.42 vs 0.49 ms; C1/C2 0.31 vs 0.60 ms; a config-5 shard 3.2 vs 4.5 ms --; generation 3 for the candidate-heavy
-    natural-order sweeps (C3: 8.8 vs 10.7 ms; a tie at d = 64).  PDA_SCORE_KERNEL=v3|v4 forces one (A/B measurements,
-    cross-checks)."""
+    natural-order sweeps (C3: 8.8 vs 10.7 ms; a tie at d = 64) and for the raw head at d = 256, whose visiting order by norm
+    leaves 300+ candidates per user (19.6 vs 29.3 ms: generation 4 keeps the d = 256 lists in HBM).  PDA_SCORE_KERNEL=v3|v4
+    forces one (A/B measurements, cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_KERNEL", "")
     fits = d in (64, 128, 256) and K <= TOPK_K_V4 and nloc <= (1 << 26)
@@ -197,7 +198,7 @@ def score_kernel(d: int, K: int, nloc: int, prune=None) -> str:
         return "v3"
     if forced == "v4":
         return "v4" if fits else "v3"
-    if not (fits and prune):
+    if not (fits and prune) or (d == 256 and head == HEAD_RAW):
         return "v3"
     return "v4"
 
@@ -327,13 +328,13 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     seeded = seed_reduce is not None and seed_exchange_applies(d, K, head, prune, impl)
     if seeded and nloc > (1 << 26):
         raise ValueError("seeded item-sharded evaluation: at most 2^26 item rows per shard")
-    if impl == "v2" and (seeded or score_kernel(d, K, nloc, prune) == "v4"):
+    if impl == "v2" and (seeded or score_kernel(d, K, nloc, prune, head) == "v4"):
         order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
         if n_splits_auto and out_given is None:
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
-        ws = torch.empty(lib.pda_score_topk_workspace_bytes(nu), dtype=torch.uint8, device=U.device)
+        ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
         if seeded:
             # warm-up -> K-th values -> maximum over the shards -> seeded sweep
             fnp = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32

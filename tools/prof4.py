@@ -28,4 +28,5 @@ print("launch %.3f ms; MFMA waves %d; cand/user %.1f" % (e0.elapsed_time(e1), nm
 print("per MFMA wave [kcycles]: total %.0f  wait-landed %.0f  ring-full %.0f  slow path %.0f (%.0f calls, %.0f clamp)  refresh %.0f (%.0f)  pushed %.0f"
       % (v[0] / nm / 1e3, v[1] / nm / 1e3, v[2] / nm / 1e3, v[3] / nm / 1e3, v[4] / nm, v[14] / nm, v[12] / nm / 1e3, v[5] / nm, v[15] / nm))
 print("per rescoring wave [kcycles]: total %.0f  idle %.0f  passes %.0f  cand %.0f" % (v[6] / nr / 1e3, v[7] / nr / 1e3, v[8] / nr, v[9] / nr))
-print("per MFMA wave [kcycles]: MFMA blocks (issue) %.0f  filter %.0f" % (v[10] / nm / 1e3, v[11] / nm / 1e3))
+nl = max(nm // 4, 1)
+print("per loader wave [kcycles] (two per workgroup): wait for a free slot %.0f  issue %.0f  wait for the loads %.0f" % (v[10] / nl / 1e3, v[11] / nl / 1e3, v[12] / nl / 1e3))

@@ -15,7 +15,7 @@ order = ops.visiting_order(W.I, W.pop_last)
 prep = ops.item_prep4(W.I, W.pop_last, order)
 ns = lib.pda_score_topk4_auto_splits(Bu, W.n_items, W.d)
 out = torch.empty((ns, Bu, 50), dtype=torch.int64, device=dev)
-ws = torch.empty(lib.pda_score_topk_workspace_bytes(Bu), dtype=torch.uint8, device=dev)
+ws = torch.empty(lib.pda_score_topk4_workspace_bytes(Bu, W.n_items, W.d, ns), dtype=torch.uint8, device=dev)
 fn = lib.pda_score_topk4_phase_bf16 if td == torch.bfloat16 else lib.pda_score_topk4_phase_f32
 def run():
     check(fn(ptr(W.U), ptr(W.I), ptr(prep), ptr(W.pop_last), ptr(users), Bu, 0, W.n_items, W.d, ptr(hist.indptr), ptr(hist.indices), hist.mode,
