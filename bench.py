@@ -383,6 +383,63 @@ def bench_train(args, dev, workload=None, quick=False):
     return out, W, batches
 
 
+def bench_adam_big_tables(args, dev, workload):
+    """The reference's optimiser (TF-1.14 Adam, dense decay) on the HEADLINE workload's tables, B = 2048: one sweep over both
+    tables per step vs the same arithmetic without the sweep (pda_adam_lazy_f32: idle rows replay their decay when next
+    needed).  Eager launches, the step counter advancing (a captured graph would freeze it); 512 distinct device-sampled
+    batches, so a user row comes back after ~n_users / B steps as in training; the final sync is timed separately."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload(workload, dev)
+    B, regs, lr = 2048, 1e-2, 1e-2
+    NBt = 512 if workload != "tiny" else 32
+    batches = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2021, step=s, n_pool=W.n_users, train_slots=W.hist_slots,
+                                   neg_range=(0, W.n_items), pop_matrix=W.pop_train) for s in range(NBt)]
+    out = {"workload": "%s tables (%d + %d rows x %d), B=%d" % (W.name.upper(), W.n_users, W.n_items, W.d, B)}
+    loss = torch.zeros(3, device=dev)
+    z = torch.zeros_like
+
+    def run(lazy, steps):
+        U, I = W.U.float().clone(), W.I.float().clone()
+        st = [z(U), z(U), z(U), z(I), z(I), z(I)]
+        lz = ops.LazyAdamState(W.n_users, W.n_items, lr, dev) if lazy else None
+        t = 0
+
+        def step():
+            nonlocal t
+            t += 1
+            b = batches[(t - 1) % NBt]
+            if lazy:
+                ops.adam_lazy(0, lz, U, st[0], st[1], st[2], I, st[3], st[4], st[5], b[0], b[1], b[2], t)
+            ops.bpr_step(U, I, *b, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=st[2], gI=st[5], loss_acc=loss)
+            if lazy:
+                ops.adam_lazy(1, lz, U, st[0], st[1], st[2], I, st[3], st[4], st[5], b[0], b[1], b[2], t)
+            else:
+                ops.adam_dense_sweep2(U, st[0], st[1], st[2], I, st[3], st[4], st[5], ops.adam_lr_t(lr, t))
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        r = {"triplets_per_s": steps * B / dt, "us_per_step": dt / steps * 1e6, "steps": steps}
+        if lazy:
+            t1 = time.perf_counter()
+            ops.adam_lazy_sync(lz, U, st[0], st[1], I, st[3], st[4], t)
+            torch.cuda.synchronize()
+            r["final_sync_ms"] = (time.perf_counter() - t1) * 1e3
+        return r
+    out["dense_sweep"] = run(False, 24 if workload != "tiny" else 8)
+    sweep_bytes = 6 * (W.n_users + W.n_items) * W.d * 4
+    out["dense_sweep"]["algorithmic_bytes_per_step"] = sweep_bytes
+    out["dense_sweep"]["hbm_frac"] = sweep_bytes / (out["dense_sweep"]["us_per_step"] * 1e-6) / 1e9 / PEAK_HBM_GBS
+    out["replay"] = run(True, 1536 if workload != "tiny" else 64)
+    out["replay"]["note"] = ("pda_adam_lazy_f32: bit-identical tables after the sync (tests/test_gpu_bpr_step.py); three launches per step, "
+                             "traffic = the batch rows")
+    return out
+
+
 def bench_train_sharded(args, rank, world, dev):
     """Item-parallel SGD on BASELINE config 2 across `world` ranks: global batch 2048, B_local = 2048 / world, positives
     and negatives inside the rank's item slice, ONE all-gather of (user grads, ids, loss shares) per step."""
@@ -495,6 +552,8 @@ def main():
     train_pack = None
     if world == 1 and not args.no_train:
         train_pack = bench_train(args, dev)
+        if not args.headline_only and args.workload in ("c3", "tiny"):
+            train_pack[0]["adam_on_headline_tables"] = bench_adam_big_tables(args, dev, args.workload)
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, ev, train_pack)

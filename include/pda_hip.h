@@ -332,6 +332,23 @@ int pda_adam_dense_sweep2_f32(float* var_a, float* m_a, float* v_a, float* g_a, 
 int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const int32_t* rows, int n_rows, int d, float lr_t,
                       float beta1, float beta2, float eps, void* stream);
 
+/* The SAME optimiser without the sweep (exact, not the lazy deviation above): a row whose gradient is zero at step k only
+ * decays -- m <- b1 m, v <- b2 v, x <- x - lr_k m / (sqrt(v) + eps), the arithmetic of pda_adam_dense_sweep_f32 with g = 0 --
+ * so it may skip its idle steps and replay them in registers when it is next needed.  last i32 [rows]: the step a row is
+ * current for (0 at the start); lr_tab f32 [>= t + 1]: lr_tab[k] = the bias-corrected rate of step k (index 0 unused).
+ * Per training step t (1-based), around pda_bpr_step_f32(PDA_UPD_DENSE_GRAD, gU, gI):
+ *   pda_adam_lazy_f32(phase = 0, ...)   before it: every row of the batch (users, pos, neg; repeats allowed) is brought to t - 1
+ *   pda_adam_lazy_f32(phase = 1, ...)   after it: every row of the batch takes step t with its summed gradient; its
+ *                                       accumulator row is cleared
+ *   pda_adam_lazy_sync_f32(table, t)    every row of a table up to step t: before an evaluation or a checkpoint
+ * After the sync the tables and moments equal those of t dense sweeps bit for bit (tests/test_gpu_bpr_step.py).  Traffic
+ * per step: the batch rows, instead of 3.7 GB (config 3) or 74 GB (config 5). */
+int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI,
+                      float* gI, int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d, int t,
+                      const float* lr_tab, float beta1, float beta2, float eps, void* stream);
+int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
+                           float beta1, float beta2, float eps, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Ranking metrics (A8; replaces get_performance + the Pool(5) reduction, MF/used_metric.py:4-80,
  * MF/train_new_api.py:741-778).   topk i32 [n_rows, k_cols]; targets as CSR by block row;

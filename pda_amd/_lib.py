@@ -79,6 +79,8 @@ SIGNATURES = {
     "pda_adam_dense_sweep_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_dense_sweep2_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
+    "pda_adam_lazy_f32": (_i, [_i] + [_vp] * 13 + [_i, _i, _i, _vp, _f, _f, _f, _vp]),
+    "pda_adam_lazy_sync_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _f, _f, _vp]),
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pda_sample_triplets_dev": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_counter_add": (_i, [_vp, _u64, _vp]),

@@ -433,6 +433,116 @@ __global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, fl
     *reinterpret_cast<f32x4*>(g + off) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Exact lazy dense-decay Adam.  A row whose gradient is zero at step k only decays: m <- b1 m, v <- b2 v,
+// x <- x - lr_k m / (sqrt(v) + eps) -- a function of the row and of k alone (the arithmetic of adam_dense_sweep_kernel with
+// g = 0, operation for operation).  So a row may skip its idle steps and replay them in registers when it is next needed:
+// last[row] = the step the row is current for, lr_tab[k] = the bias-corrected rate of step k.  Per training step t:
+//   phase 0  every row of the batch is brought to step t - 1 (the forward pass of step t reads it);
+//   (pda_bpr_step_f32, PDA_UPD_DENSE_GRAD: gradients into the dense accumulators)
+//   phase 1  every row of the batch takes step t with its summed gradient; the accumulator row is cleared.
+// Rows may repeat inside the lists (an item that is positive for one user and negative for another): the first group of
+// threads to raise last[row] owns the row, the others leave.  Traffic per step: the batch rows -- not the 3.7 GB (config 3)
+// or 74 GB (config 5) of the dense sweep.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LazyAdamArgs {
+    float *U, *mU, *vU, *gU;
+    int32_t* lastU;
+    float *I, *mI, *vI, *gI;
+    int32_t* lastI;
+    const int32_t *users, *pos, *neg;
+    const float* lr_tab;
+    int B, t, phase;
+    float b1, b2, eps;
+};
+
+// Steps from .. upto of an idle row, in registers.  The update lr_k m / (sqrt(v) + eps) shrinks by at least 0.905 per step (m by
+// 0.9, the denominator by no more than sqrt(0.999), lr_k grows by less than 0.5 % per step), so once a step leaves all four
+// x unchanged -- the update is below half an ulp -- every later step does too: from there on only m and v decay (two
+// multiplications per element and step instead of a square root and a division).  Same results, bit for bit.
+template <int D>
+__device__ __forceinline__ void adam_replay(f32x4& xx, f32x4& mm, f32x4& vv, int from, int upto, const float* __restrict__ lr_tab, float b1,
+                                            float b2, float eps) {
+    int k = from;
+    for (; k <= upto; ++k) {
+        const float lr_k = lr_tab[k];
+        bool moved = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mm[q] = b1 * mm[q] + (1.f - b1) * 0.f;
+            vv[q] = b2 * vv[q] + (1.f - b2) * 0.f * 0.f;
+            const float xn = xx[q] - lr_k * mm[q] / (sqrtf(vv[q]) + eps);
+            moved |= xn != xx[q];
+            xx[q] = xn;
+        }
+        if (!moved) { ++k; break; }
+    }
+    for (; k <= upto; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mm[q] = b1 * mm[q] + (1.f - b1) * 0.f;
+            vv[q] = b2 * vv[q] + (1.f - b2) * 0.f * 0.f;
+        }
+    }
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) adam_lazy_kernel(LazyAdamArgs a) {
+    constexpr int L = D / 4, RPB = 256 / L;
+    const int ridx = blockIdx.x * RPB + threadIdx.x / L, e = threadIdx.x % L;
+    if (ridx >= 3 * a.B) return;
+    const int which = ridx / a.B, i = ridx - which * a.B;
+    const bool user = which == 0;
+    const int row = user ? a.users[i] : (which == 1 ? a.pos[i] : a.neg[i]);
+    float* var = user ? a.U : a.I;
+    float* m = user ? a.mU : a.mI;
+    float* v = user ? a.vU : a.vI;
+    float* g = user ? a.gU : a.gI;
+    int32_t* last = user ? a.lastU : a.lastI;
+    const int target = a.phase == 0 ? a.t - 1 : a.t;
+    int old = 0;
+    if (e == 0) old = atomicMax(&last[row], target);
+    old = __shfl(old, (int)((threadIdx.x & 63) / L) * L, 64);
+    if (old >= target) return;                                       // current already, or another group of this launch owns the row
+    const size_t off = (size_t)row * D + 4 * e;
+    f32x4 mm = *reinterpret_cast<f32x4*>(m + off), vv = *reinterpret_cast<f32x4*>(v + off), xx = *reinterpret_cast<f32x4*>(var + off);
+    adam_replay<D>(xx, mm, vv, old + 1, a.t - 1, a.lr_tab, a.b1, a.b2, a.eps);
+    if (a.phase == 1) {
+        const f32x4 gg = *reinterpret_cast<f32x4*>(g + off);
+        const float lr_t = a.lr_tab[a.t];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mm[q] = a.b1 * mm[q] + (1.f - a.b1) * gg[q];
+            vv[q] = a.b2 * vv[q] + (1.f - a.b2) * gg[q] * gg[q];
+            xx[q] = xx[q] - lr_t * mm[q] / (sqrtf(vv[q]) + a.eps);
+        }
+        *reinterpret_cast<f32x4*>(g + off) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    *reinterpret_cast<f32x4*>(m + off) = mm;
+    *reinterpret_cast<f32x4*>(v + off) = vv;
+    *reinterpret_cast<f32x4*>(var + off) = xx;
+}
+
+// every row of a table up to step t (before an evaluation, a checkpoint, a switch of optimiser)
+template <int D>
+__global__ void __launch_bounds__(256) adam_lazy_sync_kernel(float* var, float* m, float* v, int32_t* last, size_t n_rows, int t,
+                                                             const float* __restrict__ lr_tab, float b1, float b2, float eps) {
+    constexpr int L = D / 4, RPB = 256 / L;
+    const int e = threadIdx.x % L;
+    for (size_t row = (size_t)blockIdx.x * RPB + threadIdx.x / L; row < n_rows; row += (size_t)gridDim.x * RPB) {
+        const int old = last[row];
+        if (old >= t) continue;
+        const size_t off = row * D + 4 * e;
+        f32x4 mm = *reinterpret_cast<f32x4*>(m + off), vv = *reinterpret_cast<f32x4*>(v + off), xx = *reinterpret_cast<f32x4*>(var + off);
+        adam_replay<D>(xx, mm, vv, old + 1, t, lr_tab, b1, b2, eps);
+        *reinterpret_cast<f32x4*>(m + off) = mm;
+        *reinterpret_cast<f32x4*>(v + off) = vv;
+        *reinterpret_cast<f32x4*>(var + off) = xx;
+        __builtin_amdgcn_wave_barrier();
+        if (e == 0) last[row] = t;
+    }
+}
+
 template <int D, bool BF = false>
 int launch_step(const StepArgs& a, hipStream_t s, const SampleArgs* next = nullptr) {
     constexpr int TPB = 512 / (D / 4);
@@ -663,6 +773,49 @@ extern "C" int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const
         default: return PDA_ERR_UNSUPPORTED;
     }
 #undef PDA_ROWS
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI,
+                                 float* gI, int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d, int t,
+                                 const float* lr_tab, float beta1, float beta2, float eps, void* stream) {
+    if (!U || !mU || !vU || !gU || !lastU || !I || !mI || !vI || !gI || !lastI || !users || !pos || !neg || !lr_tab) return PDA_ERR_ARG;
+    if (B <= 0 || t < 1 || (phase != 0 && phase != 1)) return PDA_ERR_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const LazyAdamArgs a{U, mU, vU, gU, lastU, I, mI, vI, gI, lastI, users, pos, neg, lr_tab, B, t, phase, beta1, beta2, eps};
+#define PDA_LAZY(DD)                                                                                                   \
+    case DD: {                                                                                                         \
+        constexpr int RPB = 256 / (DD / 4);                                                                            \
+        hipLaunchKernelGGL(adam_lazy_kernel<DD>, dim3((unsigned)((3 * (size_t)B + RPB - 1) / RPB)), dim3(256), 0, s, a); \
+        break;                                                                                                         \
+    }
+    switch (d) {
+        PDA_LAZY(32) PDA_LAZY(64) PDA_LAZY(128) PDA_LAZY(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_LAZY
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
+                                      float beta1, float beta2, float eps, void* stream) {
+    if (!var || !m || !v || !last || !lr_tab || n_rows == 0 || t < 0) return PDA_ERR_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define PDA_LSYNC(DD)                                                                                                  \
+    case DD: {                                                                                                         \
+        constexpr int RPB = 256 / (DD / 4);                                                                            \
+        const size_t nb = (n_rows + RPB - 1) / RPB;                                                                    \
+        hipLaunchKernelGGL(adam_lazy_sync_kernel<DD>, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, var, m, v, last, n_rows, \
+                           t, lr_tab, beta1, beta2, eps);                                                              \
+        break;                                                                                                         \
+    }
+    switch (d) {
+        PDA_LSYNC(32) PDA_LSYNC(64) PDA_LSYNC(128) PDA_LSYNC(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_LSYNC
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

@@ -49,6 +49,7 @@ def xavier_uniform_(t: torch.Tensor, gen: torch.Generator):
 
 class _MFBase:
     with_pop = False
+    ADAM_SWEEP_MAX_BYTES = 64 << 20      # C1/C2 (12 .. 18 MB of tables) sweep; config 3 (614 MB) and up replay
 
     def __init__(self, args, data_config, use_dataset_api=False, users_api=None, pos_items_api=None,
                  neg_items_api=None, pos_pop_api=None, neg_pop_api=None, device=None, seed=2021):
@@ -74,6 +75,18 @@ class _MFBase:
             self.tables16 = {k: v.bfloat16() for k, v in self.weights.items()}
         self._t = 0
         self._state = None
+        # optimizer == "adam": the reference's dense-decay Adam either as a sweep over both tables per step (small tables) or
+        # EXACTLY the same arithmetic without the sweep (ops.adam_lazy: idle rows replay their decay when next needed) once the
+        # tables outgrow ADAM_SWEEP_MAX_BYTES; args.adam_exact_lazy = True | False forces one
+        forced = getattr(args, "adam_exact_lazy", None)
+        mode = getattr(args, "adam_sweep", "auto")
+        if mode not in ("auto", "sweep", "replay"):
+            raise NotImplementedError("adam_sweep must be auto | sweep | replay")
+        if forced is None and mode != "auto":
+            forced = mode == "replay"
+        table_bytes = (self.n_users + self.n_items) * self.emb_dim * 4
+        self.adam_exact_lazy = (table_bytes > self.ADAM_SWEEP_MAX_BYTES) if forced is None else bool(forced)
+        self._lazy = None
         # loss buffers: a ring of 16 -- train_step returns the buffer of THIS step; it is overwritten 16 steps later, so a
         # caller may keep a handful of returned tensors and sync once (no per-step clone launch, no per-step host sync)
         self._loss_ring = torch.zeros((16, 3), dtype=torch.float32, device=self.device)
@@ -100,8 +113,29 @@ class _MFBase:
             self._state = {"mU": z(U), "vU": z(U), "gU": z(U), "mI": z(I), "vI": z(I), "gI": z(I)}
         return self._state
 
+    def sync_optimizer(self):
+        """Exact lazy Adam: bring every row (and its moments) to the current step -- before anything reads whole tables
+        (evaluation, checkpoint).  A no-op for the other optimisers and when nothing is behind."""
+        if self._lazy is not None and self._lazy.synced < self._t:
+            st = self._state
+            ops.adam_lazy_sync(self._lazy, self.weights["user_embedding"], st["mU"], st["vU"], self.weights["item_embedding"], st["mI"],
+                               st["vI"], self._t)
+            if self.tables16 is not None:
+                ops.refresh_rows_bf16(self.weights["user_embedding"], self.tables16["user_embedding"])
+                ops.refresh_rows_bf16(self.weights["item_embedding"], self.tables16["item_embedding"])
+
+    def _lazy_state(self):
+        if self._lazy is None:
+            self._lazy = ops.LazyAdamState(self.n_users, self.n_items, self.lr, self.device)
+            self._lazy.synced = self._t - 1 if self._t > 0 else 0      # (rows are current for everything before this step)
+            if self._t > 1:
+                self._lazy.lastU.fill_(self._t - 1)
+                self._lazy.lastI.fill_(self._t - 1)
+        return self._lazy
+
     def score_tables(self):
         """(U, I) the evaluation kernels read: the weights, or their bf16 copies when table_dtype == 'bf16'."""
+        self.sync_optimizer()
         t = self.tables16 if self.tables16 is not None else self.weights
         return t["user_embedding"], t["item_embedding"]
 
@@ -115,9 +149,22 @@ class _MFBase:
         st = self._opt_state()
         self._t += 1
         lr_t = ops.adam_lr_t(self.lr, self._t)
+        lazy = self.optimizer == "adam" and self.adam_exact_lazy
+        if lazy:
+            lz = self._lazy_state()
+            ops.adam_lazy(0, lz, U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], users, pos, neg, self._t)
+            for rows in (users,):
+                ops.refresh_rows_bf16(U, U16, rows)
+            for rows in (pos, neg):
+                ops.refresh_rows_bf16(I, I16, rows)
         ops.bpr_step_bf16(U16, I16, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
                           mode=ops.UPD_DENSE_GRAD, gU=st["gU"], gI=st["gI"], loss_acc=self._loss)
-        if self.optimizer == "adam":
+        if lazy:
+            ops.adam_lazy(1, lz, U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], users, pos, neg, self._t)
+            ops.refresh_rows_bf16(U, U16, users)
+            ops.refresh_rows_bf16(I, I16, pos)
+            ops.refresh_rows_bf16(I, I16, neg)
+        elif self.optimizer == "adam":
             ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
             ops.refresh_rows_bf16(U, U16)                      # dense decay moves every row
             ops.refresh_rows_bf16(I, I16)
@@ -158,9 +205,14 @@ class _MFBase:
         st = self._opt_state()
         self._t += 1
         lr_t = ops.adam_lr_t(self.lr, self._t)
+        lazy = self.optimizer == "adam" and self.adam_exact_lazy
+        if lazy:        # the batch rows up to step t - 1: the forward pass reads them
+            ops.adam_lazy(0, self._lazy_state(), U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], users, pos, neg, self._t)
         ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
                      mode=ops.UPD_DENSE_GRAD, gU=st["gU"], gI=st["gI"], loss_acc=self._loss)
-        if self.optimizer == "adam":
+        if lazy:
+            ops.adam_lazy(1, self._lazy, U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], users, pos, neg, self._t)
+        elif self.optimizer == "adam":
             ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
         else:
             ops.adam_rows(U, st["mU"], st["vU"], st["gU"], torch.unique(users).int(), lr_t)
@@ -171,6 +223,7 @@ class _MFBase:
     CKPT_FORMAT = "pda_amd/2"     # torch.save pickle of this dict -- NOT a tf.train.Saver checkpoint (see README)
 
     def state_dict(self):
+        self.sync_optimizer()
         sd = {"format": self.CKPT_FORMAT, "embed_size": self.emb_dim, "n_users": self.n_users, "n_items": self.n_items,
               "optimizer": self.optimizer, "table_dtype": self.table_dtype,
               "user_embedding": self.weights["user_embedding"], "item_embedding": self.weights["item_embedding"],
@@ -201,6 +254,7 @@ class _MFBase:
             for k in self.tables16:
                 ops.refresh_rows_bf16(self.weights[k], self.tables16[k])
         self._t = int(sd.get("adam_t", 0))
+        self._lazy = None                     # (a checkpoint holds synced tables: every row is current for adam_t)
         if "mU" in sd:
             st = self._opt_state()
             for k in ("mU", "vU", "mI", "vI"):

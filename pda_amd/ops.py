@@ -577,6 +577,56 @@ def adam_rows(var, m, v, g, rows, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA
     mark_modified(var)
 
 
+class LazyAdamState:
+    """The bookkeeping of the exact lazy dense-decay Adam (pda_adam_lazy_f32): per-row `last` steps and the device table of
+    bias-corrected rates lr_tab[k] = float32(adam_lr_t(lr, k)) -- the value the dense sweep receives as its lr_t argument."""
+
+    def __init__(self, n_users: int, n_items: int, lr: float, device, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+        self.lastU = torch.zeros(n_users, dtype=torch.int32, device=device)
+        self.lastI = torch.zeros(n_items, dtype=torch.int32, device=device)
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.lr_tab = torch.zeros(0, dtype=torch.float32, device=device)
+        self.synced = 0                     # the step every row is known to be current for
+
+    def rates(self, t: int) -> torch.Tensor:
+        """lr_tab with at least t + 1 entries (grown geometrically; computed in float64 like adam_lr_t, rounded once)."""
+        if self.lr_tab.numel() < t + 1:
+            # the very doubles the dense path passes as lr_t (adam_lr_t), rounded to float32 once -- as the ctypes call does
+            n = max(1024, 2 * (t + 1))
+            tab = [0.0] + [adam_lr_t(self.lr, k, self.beta1, self.beta2) for k in range(1, n)]
+            self.lr_tab = torch.tensor(tab, dtype=torch.float64).to(torch.float32).to(self.lastU.device)
+        return self.lr_tab
+
+
+def adam_lazy(phase: int, st: LazyAdamState, U, mU, vU, gU, I, mI, vI, gI, users, pos, neg, t: int):
+    """pda_adam_lazy_f32: phase 0 = the batch rows up to step t - 1 (before the forward pass of step t), phase 1 = step t on
+    the batch rows with their summed gradients (after pda_bpr_step_f32 in PDA_UPD_DENSE_GRAD mode)."""
+    lib = _lib.load()
+    for x in (U, mU, vU, gU, I, mI, vI, gI):
+        _need(x, torch.float32, "adam state")
+    for x in (users, pos, neg):
+        _need(x, torch.int32, "batch rows")
+    tab = st.rates(t)
+    check(lib.pda_adam_lazy_f32(phase, ptr(U), ptr(mU), ptr(vU), ptr(gU), ptr(st.lastU), ptr(I), ptr(mI), ptr(vI), ptr(gI), ptr(st.lastI),
+                                ptr(users), ptr(pos), ptr(neg), users.numel(), U.shape[1], t, ptr(tab), st.beta1, st.beta2, st.eps,
+                                stream_ptr()), "pda_adam_lazy_f32")
+    mark_modified(U)
+    mark_modified(I)
+
+
+def adam_lazy_sync(st: LazyAdamState, U, mU, vU, I, mI, vI, t: int):
+    """pda_adam_lazy_sync_f32 on both tables: every row current for step t (a no-op when nothing is behind)."""
+    if st.synced >= t:
+        return
+    lib = _lib.load()
+    tab = st.rates(t)
+    for var, m, v, last in ((U, mU, vU, st.lastU), (I, mI, vI, st.lastI)):
+        check(lib.pda_adam_lazy_sync_f32(ptr(var), ptr(m), ptr(v), ptr(last), var.shape[0], var.shape[1], t, ptr(tab), st.beta1, st.beta2,
+                                         st.eps, stream_ptr()), "pda_adam_lazy_sync_f32")
+        mark_modified(var)
+    st.synced = t
+
+
 def metrics_sums(topk, tgt_indptr, tgt_indices, Ks, sums: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pda_metrics: float64 [4, len(Ks)] sums of precision, recall, ndcg, hit over the rows (added to `sums`)."""
     lib = _lib.load()

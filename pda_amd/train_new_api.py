@@ -156,6 +156,7 @@ class DatasetApi_Model:
     def testing(self, sess, batch_users, items, model_type, pos_pop=None):
         """Dense scores f32 [B, len(items)] (:642-669).  Compatibility surface for the NeuRec evaluators (which the
         reference imports and never calls); NOT on the hot path and deliberately plain torch."""
+        self.Recommender.sync_optimizer()
         U = self.Recommender.weights["user_embedding"]
         users = torch.as_tensor(np.asarray(batch_users, dtype=np.int64), device=self.device)
         I, _ = self._tables(items)

@@ -31,6 +31,8 @@ def test_bench_emits_one_contract_line(dev):
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     t = d["train"]
     assert t["sgd_fused"]["triplets_per_s"] > 0 and t["adam_dense_reference_faithful"]["triplets_per_s"] > 0
+    a = t["adam_on_headline_tables"]         # the reference's optimiser on the headline tables: with and without the sweep
+    assert a["dense_sweep"]["triplets_per_s"] > 0 and a["replay"]["triplets_per_s"] > 0 and a["replay"]["final_sync_ms"] > 0
     # round 2: what one pass costs after a weight update, roofs measured on the box, the native CPU top-K, the protocol
     p = d["prep"]
     assert p["prep_ms"] > 0 and p["users_per_s_incl_prep"] > 0 and p["steps_per_pass"] >= 1

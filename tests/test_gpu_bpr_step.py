@@ -139,6 +139,98 @@ def test_reference_faithful_adam_three_steps(dev):
     np.testing.assert_allclose(st["vI"].cpu().numpy(), state["vI"], atol=TOL)
 
 
+@pytest.mark.parametrize("repeats", [False, True])
+def test_exact_lazy_adam_equals_the_dense_sweep_bit_for_bit(dev, repeats):
+    """pda_adam_lazy_f32 / pda_adam_lazy_sync_f32: the reference's dense-decay Adam WITHOUT the sweep.  Twelve steps on small
+    batches (most rows idle most of the time, item rows repeated inside a batch, one batch replayed after a long idle gap);
+    after the final sync every element of U, I, m, v equals the dense-sweep path bit for bit, and the oracle's dense-decay
+    Adam (po.train_step) to 1e-5 -- including rows touched once and then left alone."""
+    from pda_amd import ops
+    rng = np.random.default_rng(41)
+    nU, nI, d, B, regs, lr, N = 900, 400, 64, 96, 1e-2, 1e-2, 12
+    assert 2 * B <= nI
+    U = (rng.standard_normal((nU, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.1).astype(np.float32)
+    Ud, Id = to(dev, U, I)                        # dense sweeps
+    Ul, Il = to(dev, U, I)                        # lazy
+    z = torch.zeros_like
+    sd = {k: z(t) for k, t in (("mU", Ud), ("vU", Ud), ("gU", Ud), ("mI", Id), ("vI", Id), ("gI", Id))}
+    sl = {k: z(t) for k, t in (("mU", Ul), ("vU", Ul), ("gU", Ul), ("mI", Il), ("vI", Il), ("gI", Il))}
+    lz = ops.LazyAdamState(nU, nI, lr, dev)
+    Ur, Ir, state = U.astype(np.float64), I.astype(np.float64), None
+    first = None
+    for t in range(1, N + 1):
+        users = rng.permutation(nU)[:B].astype(np.int32)
+        if repeats:
+            pos = rng.integers(0, 40 if t % 3 else nI, B).astype(np.int32)      # a hot head of items: repeats inside the batch
+            neg = rng.integers(0, nI, B).astype(np.int32)
+        else:
+            pi = rng.permutation(nI).astype(np.int32)                            # every item row at most once per batch
+            pos, neg = pi[:B], pi[B:2 * B]
+        if first is None:
+            first = (users, pos, neg)
+        if t == N:
+            users, pos, neg = first                                              # rows idle since step 1 come back
+        pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+        pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+        Ur, Ir, state, ref_loss = po.train_step(Ur, Ir, users, pos, neg, pp, pn, regs, B, lr, "adam", state, t)
+        args = to(dev, users, pos, neg, pp, pn)
+        ld, ll = torch.zeros(3, device=dev), torch.zeros(3, device=dev)
+        ops.bpr_step(Ud, Id, *args, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sd["gU"], gI=sd["gI"], loss_acc=ld)
+        ops.adam_dense_sweep2(Ud, sd["mU"], sd["vU"], sd["gU"], Id, sd["mI"], sd["vI"], sd["gI"], ops.adam_lr_t(lr, t))
+        ops.adam_lazy(0, lz, Ul, sl["mU"], sl["vU"], sl["gU"], Il, sl["mI"], sl["vI"], sl["gI"], *args[:3], t)
+        ops.bpr_step(Ul, Il, *args, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sl["gU"], gI=sl["gI"], loss_acc=ll)
+        ops.adam_lazy(1, lz, Ul, sl["mU"], sl["vU"], sl["gU"], Il, sl["mI"], sl["vI"], sl["gI"], *args[:3], t)
+        np.testing.assert_allclose(ll.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+        assert float(sl["gU"].abs().max()) == 0.0 and float(sl["gI"].abs().max()) == 0.0
+    idle = int((lz.lastU < N).sum()) + int((lz.lastI < N).sum())
+    assert idle > 300                              # most rows have NOT been touched by the last step: the sync has work to do
+    assert not torch.equal(Ul, Ud)
+    ops.adam_lazy_sync(lz, Ul, sl["mU"], sl["vU"], Il, sl["mI"], sl["vI"], N)
+    assert int(lz.lastU.min()) == N and int(lz.lastI.min()) == N
+    # (the summed gradient of a repeated row is an atomic sum whose order differs between two launches: with repeats the two
+    # runs agree to rounding only, without them bit for bit)
+    for a, b, ref in ((Ul, Ud, Ur), (Il, Id, Ir), (sl["mU"], sd["mU"], state["mU"]), (sl["vU"], sd["vU"], state["vU"]),
+                      (sl["mI"], sd["mI"], state["mI"]), (sl["vI"], sd["vI"], state["vI"])):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-7, rtol=1e-5)
+        # against the float64 oracle: 1e-5, except where a gradient component is itself of the size of Adam's epsilon
+        # (1e-8: lr m / (sqrt(v) + eps) then turns the fp32 rounding of g into 1e-5 .. 1e-4 of x -- the dense sweep, which is
+        # the arithmetic compared bit for bit above, differs from the oracle in exactly the same elements)
+        err = np.abs(a.cpu().numpy() - ref)
+        assert (err > TOL).mean() < 1e-3 and err.max() < 2e-4, ((err > TOL).mean(), err.max())
+        if not repeats:
+            assert torch.equal(a, b)
+    Uc = Ul.clone()
+    ops.adam_lazy_sync(lz, Ul, sl["mU"], sl["vU"], Il, sl["mI"], sl["vI"], N)      # idempotent
+    assert torch.equal(Ul, Uc)
+
+
+def test_exact_lazy_adam_long_idle_gap(dev):
+    """3 000 idle steps replayed in one go (the update falls below half an ulp after ~150 steps; from there only m and v
+    decay) == 3 000 dense sweeps with zero gradient, bit for bit -- also for rows whose x is tiny or zero (they keep moving
+    for longer) and for zero moments."""
+    from pda_amd import ops
+    rng = np.random.default_rng(43)
+    n, d, T, lr = 96, 64, 3000, 1e-2
+    var = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    m = (rng.standard_normal((n, d)) * 1e-3).astype(np.float32)
+    v = (rng.uniform(0, 1, (n, d)) ** 4 * 1e-5).astype(np.float32)
+    var[0] = 0.0
+    var[1] *= 1e-20
+    m[2] = 0.0
+    v[3] = 0.0
+    vd, md, vvd = to(dev, var, m, v)
+    vl, ml, vvl = to(dev, var, m, v)
+    g = torch.zeros_like(vd)
+    for t in range(1, T + 1):
+        ops.adam_dense_sweep(vd, md, vvd, g, ops.adam_lr_t(lr, t))
+    lz = ops.LazyAdamState(n, n, lr, dev)
+    dummy = [x.clone() for x in (vl, ml, vvl)]
+    ops.adam_lazy_sync(lz, vl, ml, vvl, *dummy, T)
+    assert torch.equal(vl, vd) and torch.equal(ml, md) and torch.equal(vvl, vvd)
+    assert not torch.equal(vl, torch.from_numpy(var).to(dev))
+
+
 def test_lazy_adam_rows_matches_dense_on_touched_rows(dev):
     from pda_amd import ops
     rng = np.random.default_rng(29)

@@ -28,6 +28,8 @@ def _argv(toy, save, train, extra=()):
 @pytest.mark.parametrize("train,extra", [("s_condition", ()), ("normal", ("--sampler", "host")),
                                          ("s_condition", ("--optimizer", "sgd", "--lr", "0.05")),
                                          ("s_condition", ("--optimizer", "lazy_adam")),
+                                         ("s_condition", ("--adam_sweep", "replay")),                    # exact dense decay without the sweep
+                                         ("s_condition", ("--adam_sweep", "replay", "--table_dtype", "bf16")),
                                          ("s_condition", ("--table_dtype", "bf16")),                     # bf16 tables, faithful Adam on the masters
                                          ("normal", ("--table_dtype", "bf16", "--optimizer", "sgd", "--lr", "0.05"))])
 def test_main_runs_like_the_reference_script(dev, toy, tmp_path, capsys, train, extra):
@@ -110,6 +112,44 @@ def test_training_reduces_the_loss_and_beats_random_ranking(dev, toy, tmp_path):
     rec.weights["user_embedding"].zero_()
     rec.load_state_dict(sd)
     assert torch.equal(rec.weights["user_embedding"], sd["user_embedding"])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_adam_without_the_sweep_trains_the_same_model(dev, toy, tmp_path, dtype):
+    """--adam_sweep replay vs sweep through the drop-in trainer: same seed, same device-sampled batches, two epochs; the tables
+    the evaluation reads (after the implicit sync) and the moments in the checkpoint agree to rounding (item rows repeat
+    inside a batch: their atomic gradient sums differ in order between two runs), the recommendations agree."""
+    from pda_amd import train_new_api as t
+    from pda_amd.sampler import DeviceSampler
+    res = []
+    for mode in ("sweep", "replay"):
+        t.configure(_argv(toy, str(tmp_path) + "/", "s_condition", ("--adam_sweep", mode, "--table_dtype", dtype)))
+        a, d = t.args, t.data
+        pop_all = t.load_popularity(a)
+        d.add_expo_popularity(np.power(t.get_popularity_from_load(pop_all), a.pop_exp))
+        model = t.DatasetApi_Model(a, {"n_users": d.n_users, "n_items": d.n_items}, 256, DeviceSampler(d, dev, True), dev)
+        sess = t.Session(model)
+        rec = model.Recommender
+        assert rec.adam_exact_lazy == (mode == "replay")
+        for epoch in range(2):
+            model.switch_to_training_or_reinitsampler(sess)
+            try:
+                while True:
+                    sess.run([rec.opt_pop_global, rec.loss_pop_global])
+            except t.OutOfRangeError:
+                pass
+        if mode == "replay":
+            assert int((rec._lazy.lastU < rec._t).sum()) > 0          # rows are behind until something reads the tables
+        U, I = (x.float().clone() for x in rec.score_tables())
+        sd = rec.state_dict()
+        res.append((U, I, sd["mU"].clone(), sd["vI"].clone(), sd["adam_t"]))
+        if mode == "replay":
+            assert int(rec._lazy.lastU.min()) == rec._t and int(rec._lazy.lastI.min()) == rec._t
+    (U0, I0, m0, v0, t0), (U1, I1, m1, v1, t1) = res
+    assert t0 == t1 and t0 > 10
+    tol = dict(atol=2e-2, rtol=0) if dtype == "bf16" else dict(atol=1e-5, rtol=1e-4)
+    for x, y in ((U0, U1), (I0, I1), (m0, m1), (v0, v1)):
+        torch.testing.assert_close(x, y, **tol)
 
 
 def test_eval_user_without_train_rows_raises_keyerror_under_data2(dev, toy, tmp_path):
