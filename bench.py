@@ -326,6 +326,36 @@ def bench_train(args, dev, workload=None, quick=False):
     r["algorithmic_bytes_per_step"] = sweep_bytes
     r["hbm_frac"] = sweep_bytes / (r["us_per_step"] * 1e-6) / 1e9 / PEAK_HBM_GBS
 
+    # the whole loop on the device: one launch per `chunk` steps, a fresh device-sampled batch every step
+    def loop_one_launch(Bl, chunk, n_chunks):
+        U, I = W.U.clone(), W.I.clone()
+        mk = lambda: (torch.empty(Bl, dtype=torch.int32, device=dev), torch.empty(Bl, dtype=torch.int32, device=dev),
+                      torch.empty(Bl, dtype=torch.int32, device=dev), torch.empty(Bl, device=dev), torch.empty(Bl, device=dev))
+        bufs = [mk(), mk()]
+        ctr = torch.tensor([1], dtype=torch.int64, device=dev)
+        kw = dict(n_pool=W.n_users, train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+        ops.sample_triplets_into(bufs[1], W.hist_indptr, W.hist_indices, seed=7, step_dev=ctr, advance=False, **kw)
+        ops.sample_triplets_into(bufs[0], W.hist_indptr, W.hist_indices, seed=7, step_dev=ctr, **kw)
+        ws = torch.zeros(2, dtype=torch.int32, device=dev)
+
+        def go():
+            ops.bpr_train_steps(U, I, bufs, chunk, regs=regs, reg_div=Bl, lr=lr, train_indptr=W.hist_indptr, train_indices=W.hist_indices,
+                                seed=7, step_ctr=ctr, loss_acc=loss, barrier_ws=ws, **kw)
+        go()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_chunks):
+            go()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert int(ws[1]) == 0, "the training loop kernel was not resident as a whole"
+        n = chunk * n_chunks
+        return {"triplets_per_s": n * Bl / dt, "us_per_step": dt / n * 1e6, "steps": n, "steps_per_launch": chunk, "B": Bl}
+    chunk = 256 if W.name != "tiny" else 32          # (even: the buffer sets are back in place after every launch)
+    out["sgd_fused_loop_one_launch"] = loop_one_launch(B, chunk, max(2, args.train_steps // chunk))
+    out["sgd_fused_loop_one_launch"]["note"] = ("pda_bpr_train_steps_f32: a resident grid loops over the steps, the sampler one batch ahead, a "
+                                                 "grid barrier between steps; fresh batch every step")
+    out["sgd_fused_loop_one_launch"]["hbm_frac"] = out["sgd_fused_loop_one_launch"]["triplets_per_s"] * (6 * W.d * 4 + 20) / 1e9 / PEAK_HBM_GBS
     if quick:
         return out, W, batches
     U, I = W.U.clone(), W.I.clone()
@@ -581,7 +611,7 @@ def main():
                                       "first 256 items, list hand-over, launch) is a visible share of the step" % (e["W"].n_items, -(-e["W"].n_items // 64))}}
             if not args.no_train:
                 t = bench_train(args, dev, workload=wl, quick=True)[0]
-                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful") if k in t}
+                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_fused_loop_one_launch", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful") if k in t}
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(args, e, None, budget=6.0, full=False)
             per_config[wl] = entry

@@ -405,6 +405,20 @@ int pda_bpr_step_sample_f32(float* U, float* I, const int32_t* users, const int3
                             const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
                             int update_mode, float* loss_acc, const pda_sample_job* next, void* stream);
 
+/* n_steps fused SGD steps in ONE launch (the session.run loop of MF/train_new_api.py:1078-1096 with the generator thread
+ * sampling ahead): a resident grid loops on the device; iteration i steps on the batch in buffer set i & 1 while spare
+ * workgroups draw the next batch into set (i + 1) & 1; a grid barrier separates the iterations.  set0 / set1: the two sets of
+ * batch buffers with the sampler's configuration (step_dev / step_next unused); set0 must hold the first batch on entry, and
+ * after the call set (n_steps & 1) holds the batch of the next step.  step_ctr u64 (device): the sampler step of the first
+ * batch drawn here, advanced by n_steps.  loss_steps f32 [n_steps][3] (NULL: everything is summed into loss_acc [3]).
+ * barrier_ws: 8 device bytes; barrier_ws[1] (u32) != 0 afterwards: the grid was not resident as a whole (another kernel held
+ * CUs) and the loop was abandoned.  update_mode: PDA_UPD_SGD_FUSED (| PDA_UPD_ANY_ORDER).  Equals n_steps x
+ * (pda_bpr_step_f32, pda_sample_triplets_dev) on one stream (fp32 atomics: 1e-6).  The grid is at most 384 + 64
+ * workgroups, striding over larger batches. */
+int pda_bpr_train_steps_f32(float* U, float* I, int d, float regs, float reg_div, float lr, int update_mode,
+                            const pda_sample_job* set0, const pda_sample_job* set1, uint64_t* step_ctr, int n_steps,
+                            float* loss_acc, float* loss_steps, void* barrier_ws, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Peaks measured on the box (no reference counterpart; BASELINE.md section 4 asks for measured roofs).
  *   pda_peak_mfma_bf16: one launch of iters x 16 v_mfma_f32_32x32x16_bf16 per wave on 8192 waves (two per SIMD,

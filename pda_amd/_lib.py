@@ -85,6 +85,7 @@ SIGNATURES = {
     "pda_sample_triplets_dev": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_counter_add": (_i, [_vp, _u64, _vp]),
     "pda_bpr_step_sample_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp]),
+    "pda_bpr_train_steps_f32": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "pda_sample_triplets": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
 }
 

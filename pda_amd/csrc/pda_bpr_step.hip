@@ -9,6 +9,7 @@
 // This path is HBM/latency bound (about 6*d*4 B per triplet, ~10*d flop): no MFMA.  Layout: d/4 lanes
 // per triplet, each lane owns one float4 of the three gathered rows (a 4*d-byte row is one fully
 // coalesced segment), dots by xor-shuffle inside the lane group, per-block loss reduction -> 3 atomics.
+#include <cstdlib>
 #include "pda_common.h"
 #include "pda_sample.h"
 
@@ -54,7 +55,29 @@ __device__ __forceinline__ void atomic_add4(float* p, f32x4 v) {
 // L2 (measured 25 us per 2048-triplet step).  The positives' contributions therefore go through LDS first: runs of
 // equal `pos` inside the block are summed by their first triplet and leave as ONE atomic per element.  Any batch order
 // is correct; a batch sorted by `pos` (pda_sort_triplets_by_pos, done by the device sampler) makes the runs long.
-template <int D, bool BF>
+// COH (pda_bpr_train_steps_f32): the batch and the table rows were written by OTHER workgroups of this launch -- by the sampler
+// and by the previous step's atomics, both at device scope -- and are read with device-scope loads (they miss the caches that
+// are not coherent across the XCDs), so that a grid barrier needs no cache invalidation.
+template <bool COH, typename T>
+__device__ __forceinline__ T in_load(const T* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
+}
+template <bool COH, bool BF>
+__device__ __forceinline__ f32x4 row_load4(const void* base, size_t idx) {
+    if constexpr (COH && !BF) {
+        const uint64_t* q = reinterpret_cast<const uint64_t*>(reinterpret_cast<const float*>(base) + idx);
+        const uint64_t lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f32x4 v = {__uint_as_float((uint32_t)lo), __uint_as_float((uint32_t)(lo >> 32)), __uint_as_float((uint32_t)hi),
+                   __uint_as_float((uint32_t)(hi >> 32))};
+        return v;
+    } else {
+        return pda_load4<BF>(base, idx);
+    }
+}
+
+template <int D, bool BF, bool COH = false>
 __device__ __forceinline__ void bpr_step_body(const StepArgs& a, const int bid) {
     constexpr int L = D / 4;        // lanes per triplet
     constexpr int TPB = 512 / L;    // triplets per block
@@ -72,14 +95,14 @@ __device__ __forceinline__ void bpr_step_body(const StepArgs& a, const int bid) 
     int p = -1;
     float* ptarget = nullptr;
     if (active) {
-        const int u = a.users[t], n = a.neg[t] - a.item_offset;
-        p = a.pos[t] - a.item_offset;
+        const int u = in_load<COH>(&a.users[t]), n = in_load<COH>(&a.neg[t]) - a.item_offset;
+        p = in_load<COH>(&a.pos[t]) - a.item_offset;
         float* up = a.U + (size_t)u * D + 4 * e;
         float* pp = a.I + (size_t)p * D + 4 * e;
         float* np_ = a.I + (size_t)n * D + 4 * e;
-        const f32x4 ue = pda_load4<BF>(a.Ufwd, (size_t)u * D + 4 * e);
-        const f32x4 pe = pda_load4<BF>(a.Ifwd, (size_t)p * D + 4 * e);
-        const f32x4 ne = pda_load4<BF>(a.Ifwd, (size_t)n * D + 4 * e);
+        const f32x4 ue = row_load4<COH, BF>(a.Ufwd, (size_t)u * D + 4 * e);
+        const f32x4 pe = row_load4<COH, BF>(a.Ifwd, (size_t)p * D + 4 * e);
+        const f32x4 ne = row_load4<COH, BF>(a.Ifwd, (size_t)n * D + 4 * e);
         float ps = dot4(ue, pe), ns = dot4(ue, ne);
         sq = dot4(ue, ue) + dot4(pe, pe) + dot4(ne, ne);
 #pragma unroll
@@ -89,7 +112,7 @@ __device__ __forceinline__ void bpr_step_body(const StepArgs& a, const int bid) 
         }
         float ap = 1.f, an = 1.f, psw = ps, nsw = ns;
         if (with_pop) {
-            const float qp = a.pos_pop[t], qn = a.neg_pop[t];
+            const float qp = in_load<COH>(&a.pos_pop[t]), qn = in_load<COH>(&a.neg_pop[t]);
             const float ep = ps > 0.f ? 1.f : expf(ps);   // d(elu+1)/dx  [TF-ext EluGrad]
             const float en = ns > 0.f ? 1.f : expf(ns);
             psw = (ps > 0.f ? ps + 1.f : ep) * qp;        // (elu(ps)+1)*pos_pop   MF/model_api.py:107,109
@@ -201,6 +224,76 @@ __global__ void __launch_bounds__(512) bpr_step_sample_kernel(StepArgs a, Sample
     // sampler workgroups first (they are dispatched first and have the longer dependent-load chains), kSampPerBlock triplets each
     if ((int)blockIdx.x >= n_sample_blocks) bpr_step_body<D, BF>(a, (int)blockIdx.x - n_sample_blocks);
     else if (threadIdx.x < kSampPerBlock) sample_one(sa, (int)blockIdx.x * kSampPerBlock + (int)threadIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// n_steps training steps in ONE launch: a resident grid loops over the steps on the device.  Iteration i: the step workgroups
+// run the fused SGD step on the batch in buffer set i & 1 while the sampler workgroups draw the batch of the next step into
+// set (i + 1) & 1; a grid barrier (one device-scope counter) separates the iterations -- every update of step i is visible to
+// the gathers of step i + 1, like two launches on one stream, without the launch (MF/train_new_api.py:1078-1096: the
+// session.run loop, with the generator thread sampling ahead).
+// ---------------------------------------------------------------------------------------------------------------------
+struct TrainLoopArgs {
+    StepArgs a[2];
+    SampleArgs sa[2];
+    uint64_t* step_ctr;        // device: the sampler step of the first batch drawn here; receives + n_steps at the end
+    unsigned* bar;             // [0] arrivals (zeroed by the host call), [1] error flag (a barrier gave up)
+    float* loss_steps;         // [n_steps][3] or NULL (then a[.].loss_acc accumulates over the steps)
+    int n_steps, n_sample_blocks;      // n_sample_blocks: sampler workgroups of the grid (the rest step)
+    int step_tiles, sample_tiles;       // work items of one iteration: each kind of workgroup strides over its own
+};
+
+constexpr unsigned kGridSpinMax = 1u << 22;
+
+// Everything that crosses workgroups inside the loop -- the sampled batch, the table rows, the loss words -- is written and
+// read at device scope (COH above), so the barrier is: my wave's stores and atomics are acknowledged (vmcnt(0)), count,
+// wait for the count.  (With plain accesses it needs a write-back and an invalidation of the XCD's L2 per step: 30 us.)
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target) {
+    __shared__ int s_ok;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                               // vmcnt(0) expcnt(0) lgkmcnt(0)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spin = 0;
+        int ok = 1;
+        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            if (++spin > kGridSpinMax) {
+                ok = 0;                                          // not resident together
+                break;
+            }
+        }
+        if (!ok) __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+template <int D>
+__global__ void __launch_bounds__(512) bpr_train_loop_kernel(TrainLoopArgs t) {
+    const bool sampler = (int)blockIdx.x < t.n_sample_blocks;
+    const uint64_t step0 = *t.step_ctr;
+    for (int i = 0; i < t.n_steps; ++i) {
+        if (!sampler) {
+            StepArgs a = t.a[i & 1];
+            if (t.loss_steps) a.loss_acc = t.loss_steps + 3 * (size_t)i;
+            const int n_step_wgs = (int)gridDim.x - t.n_sample_blocks;
+            for (int tile = (int)blockIdx.x - t.n_sample_blocks; tile < t.step_tiles; tile += n_step_wgs) {
+                bpr_step_body<D, false, true>(a, tile);
+                __syncthreads();                                   // (the body's LDS arrays are reused by the next tile)
+            }
+        } else if (threadIdx.x < kSampPerBlock) {
+            SampleArgs sa = t.sa[(i + 1) & 1];
+            sa.step = step0 + (uint64_t)i;
+            sa.step_dev = nullptr;
+            sa.step_next = nullptr;
+            for (int tile = (int)blockIdx.x; tile < t.sample_tiles; tile += t.n_sample_blocks)
+                sample_one<true>(sa, tile * kSampPerBlock + (int)threadIdx.x);
+        }
+        if (!grid_barrier(t.bar, (unsigned)(i + 1) * gridDim.x)) return;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *t.step_ctr = step0 + (uint64_t)t.n_steps;
 }
 
 // Sort one batch by positive item inside a single workgroup (B <= 4096): bitonic sort of (pos, slot) in LDS, then all
@@ -628,6 +721,57 @@ extern "C" int pda_bpr_step_sample_f32(float* U, float* I, const int32_t* users,
         case 256: return launch_step<256>(a, s, &sa);
         default: return PDA_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int pda_bpr_train_steps_f32(float* U, float* I, int d, float regs, float reg_div, float lr, int update_mode,
+                                       const pda_sample_job* set0, const pda_sample_job* set1, uint64_t* step_ctr, int n_steps,
+                                       float* loss_acc, float* loss_steps, void* barrier_ws, void* stream) {
+    if (!U || !I || !set0 || !set1 || !step_ctr || !barrier_ws || n_steps <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
+    if (!loss_acc && !loss_steps) return PDA_ERR_ARG;
+    const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
+    update_mode &= ~PDA_UPD_ANY_ORDER;
+    if (update_mode != PDA_UPD_SGD_FUSED) return PDA_ERR_ARG;
+    TrainLoopArgs t{};
+    const pda_sample_job* sets[2] = {set0, set1};
+    const int B = set0->B;
+    for (int q = 0; q < 2; ++q) {
+        const pda_sample_job* j = sets[q];
+        if (!j->users || !j->train_indptr || !j->train_indices || !j->pos || !j->neg || j->B != B || B <= 0 || j->neg_hi <= j->neg_lo)
+            return PDA_ERR_ARG;
+        if (j->gen_users && j->n_pool <= 0) return PDA_ERR_ARG;
+        if (j->pop_matrix && (!j->pos_pop || !j->neg_pop || j->n_slots <= 0)) return PDA_ERR_ARG;
+        if ((j->pos_pop == nullptr) != (j->neg_pop == nullptr)) return PDA_ERR_ARG;
+        t.a[q] = StepArgs{U, I, j->users, j->pos, j->neg, j->pos_pop, j->neg_pop, nullptr, nullptr, nullptr, nullptr, nullptr, loss_acc,
+                          B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I, any_order};
+        t.sa[q] = SampleArgs{j->users, j->user_pool, j->train_indptr, j->train_indices, j->train_slots, j->pop_matrix, j->pos, j->neg,
+                             j->pos_pop, j->neg_pop, j->seed, 0, B, j->n_pool, j->gen_users, j->neg_lo, j->neg_hi, j->n_slots, nullptr, nullptr};
+    }
+    if (set0->users == set1->users || set0->pos == set1->pos || set0->neg == set1->neg) return PDA_ERR_ARG;
+    t.step_ctr = step_ctr;
+    t.bar = reinterpret_cast<unsigned*>(barrier_ws);
+    t.loss_steps = loss_steps;
+    t.n_steps = n_steps;
+    t.sample_tiles = (B + kSampPerBlock - 1) / kSampPerBlock;
+    t.n_sample_blocks = t.sample_tiles < 64 ? t.sample_tiles : 64;
+    if (getenv("PDA_LOOP_NOSAMPLE")) t.sample_tiles = 0;      // timing experiment: the step and the barrier alone
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(barrier_ws, 0, 8, s) != hipSuccess) return PDA_ERR_LAUNCH;
+#define PDA_LOOP(DD)                                                                                                     \
+    case DD: {                                                                                                           \
+        constexpr int TPB = 512 / (DD / 4);                                                                              \
+        t.step_tiles = (B + TPB - 1) / TPB;                                                                              \
+        /* every workgroup must be resident: at most 384 + 64 of them (two per CU fit), striding over the batch */      \
+        const int grid = (t.step_tiles < 384 ? t.step_tiles : 384) + t.n_sample_blocks;                                  \
+        hipLaunchKernelGGL(bpr_train_loop_kernel<DD>, dim3((unsigned)grid), dim3(512), 0, s, t);                         \
+        break;                                                                                                           \
+    }
+    switch (d) {
+        PDA_LOOP(32) PDA_LOOP(64) PDA_LOOP(128) PDA_LOOP(256)
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+#undef PDA_LOOP
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
 }
 
 extern "C" int pda_bpr_step_shard_f32(const float* U, float* I_shard, int item_offset, const int32_t* users, const int32_t* pos,

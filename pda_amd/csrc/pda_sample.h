@@ -52,7 +52,16 @@ struct SampleArgs {
     uint64_t* step_next;        // optional: receives *step_dev + 1 (a DIFFERENT location: no launch in between needed)
 };
 
+// COH: the batch is handed to other workgroups of the SAME launch (pda_bpr_train_steps_f32): its five words per triplet leave
+// as device-scope stores (no cache write-back needed before the grid barrier)
+template <bool COH, typename T>
+__device__ __forceinline__ void out_store(T* p, T v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
 // one thread = one triplet r of the batch
+template <bool COH = false>
 __device__ __forceinline__ void sample_one(SampleArgs a, int r) {
     if (r >= a.B) return;
     if (a.step_dev) {
@@ -67,7 +76,7 @@ __device__ __forceinline__ void sample_one(SampleArgs a, int r) {
         const uint32_t x = a.B <= a.n_pool ? feistel_perm((uint32_t)r, (uint32_t)a.n_pool, key)
                                            : bounded(draw(a.seed, a.step, r, 7), a.n_pool);
         u = a.user_pool ? a.user_pool[x] : (int)x;
-        a.users[r] = u;
+        out_store<COH>(&a.users[r], u);
     } else {
         u = a.users[r];
     }
@@ -93,11 +102,11 @@ __device__ __forceinline__ void sample_one(SampleArgs a, int r) {
         }
         if (!(lo < e && a.indices[lo] == n)) break;
     }
-    a.pos[r] = p;
-    a.neg[r] = n;
+    out_store<COH>(&a.pos[r], p);
+    out_store<COH>(&a.neg[r], n);
     if (a.pop && a.pos_pop) {  // :402-403
-        a.pos_pop[r] = a.pop[(size_t)p * a.n_slots + slot];
-        a.neg_pop[r] = a.pop[(size_t)n * a.n_slots + slot];
+        out_store<COH>(&a.pos_pop[r], a.pop[(size_t)p * a.n_slots + slot]);
+        out_store<COH>(&a.neg_pop[r], a.pop[(size_t)n * a.n_slots + slot]);
     }
 }
 

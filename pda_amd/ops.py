@@ -719,6 +719,36 @@ def bpr_step_and_sample(U, I, users, pos, neg, pos_pop, neg_pop, *, regs: float,
     return loss_acc
 
 
+def bpr_train_steps(U, I, bufs, n_steps: int, *, regs: float, reg_div: float, lr: float, train_indptr, train_indices, seed: int,
+                    step_ctr: torch.Tensor, user_pool=None, n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None,
+                    loss_acc: Optional[torch.Tensor] = None, loss_steps: Optional[torch.Tensor] = None, grouped: bool = False,
+                    barrier_ws: Optional[torch.Tensor] = None):
+    """pda_bpr_train_steps_f32: n_steps fused SGD steps in one launch.  bufs = two sets (users, pos, neg, pos_pop|None,
+    neg_pop|None) of batch buffers; set 0 holds the first batch, set n_steps & 1 the next one afterwards.  step_ctr int64[1]
+    (device): the sampler step of the first batch drawn inside, advanced by n_steps.  Returns (loss tensor, barrier_ws) --
+    barrier_ws[1] != 0 (checked by the caller when it next synchronises) means the loop was abandoned."""
+    lib = _lib.load()
+    n_slots = pop_matrix.shape[1] if pop_matrix is not None else 0
+    jobs = []
+    for (nu, npos, nneg, npp, npn) in bufs:
+        jobs.append(_lib.SampleJob(ptr(nu), 1, ptr(user_pool), int(n_pool), nu.numel(), ptr(train_indptr), ptr(train_indices), ptr(train_slots),
+                                   int(neg_range[0]), int(neg_range[1]), ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1), None, None,
+                                   ptr(npos), ptr(nneg), ptr(npp), ptr(npn)))
+    if loss_acc is None and loss_steps is None:
+        loss_acc = torch.zeros(3, dtype=torch.float32, device=U.device)
+    if barrier_ws is None:
+        barrier_ws = torch.zeros(2, dtype=torch.int32, device=U.device)
+    if step_ctr.dtype != torch.int64 or step_ctr.numel() != 1:
+        raise ValueError("step_ctr must be int64[1] on the device")
+    m = int(UPD_SGD_FUSED) | (0 if grouped else UPD_ANY_ORDER)
+    check(lib.pda_bpr_train_steps_f32(ptr(U), ptr(I), U.shape[1], float(regs), float(reg_div), float(lr), m, C.byref(jobs[0]), C.byref(jobs[1]),
+                                      ptr(step_ctr), int(n_steps), ptr(loss_acc), ptr(loss_steps), ptr(barrier_ws), stream_ptr()),
+          "pda_bpr_train_steps_f32")
+    mark_modified(U)
+    mark_modified(I)
+    return (loss_steps if loss_steps is not None else loss_acc), barrier_ws
+
+
 def group_triplets_by_pos(users, pos, neg, pos_pop=None, neg_pop=None):
     """pda_group_triplets_by_pos (in place): equal positives become contiguous.  Batches above 4096 triplets are left alone."""
     lib = _lib.load()

@@ -620,6 +620,63 @@ def test_step_with_the_next_batch_sampled_in_the_same_launch(dev, d):
                                 seed=seed, step_dev=torch.tensor([0, 0], dtype=torch.int64, device=dev), parity=0, **kw)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_training_steps_in_one_launch(dev, d):
+    """pda_bpr_train_steps_f32 (a resident grid looping over the steps, the sampler one batch ahead, a grid barrier between
+    the steps) == the same number of (pda_bpr_step_f32, pda_sample_triplets_dev) pairs on one stream: tables to 2e-6 (fp32
+    atomics) after 1, 2 and 9 steps and after two chained calls, bit-identical batch buffers and step counter, per-step
+    losses."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("tiny", dev)
+    rng = np.random.default_rng(50 + d)
+    B, regs, lr, seed = 512, 1e-2, 0.05, 123
+    U0 = torch.from_numpy((rng.standard_normal((W.n_users, d)) * 0.2).astype(np.float32)).to(dev)
+    I0 = torch.from_numpy((rng.standard_normal((W.n_items, d)) * 0.2).astype(np.float32)).to(dev)
+    kw = dict(n_pool=W.n_users, train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+
+    def mk():
+        return (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
+
+    def reference(n):
+        U, I, bufs = U0.clone(), I0.clone(), [mk(), mk()]
+        ctr = torch.tensor([7], dtype=torch.int64, device=dev)
+        ops.sample_triplets_into(bufs[0], W.hist_indptr, W.hist_indices, seed=seed, step_dev=ctr, **kw)      # batch of step 7; ctr -> 8
+        losses = torch.zeros((n, 3), device=dev)
+        for i in range(n):
+            ops.bpr_step(U, I, *bufs[i & 1], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=losses[i])
+            ops.sample_triplets_into(bufs[(i + 1) & 1], W.hist_indptr, W.hist_indices, seed=seed, step_dev=ctr, **kw)
+        torch.cuda.synchronize()
+        return U, I, bufs, ctr, losses
+
+    def looped(chunks):
+        U, I, bufs = U0.clone(), I0.clone(), [mk(), mk()]
+        ctr = torch.tensor([7], dtype=torch.int64, device=dev)
+        ops.sample_triplets_into(bufs[0], W.hist_indptr, W.hist_indices, seed=seed, step_dev=ctr, **kw)
+        n = sum(chunks)
+        losses = torch.zeros((n, 3), device=dev)
+        done = 0
+        for c in chunks:
+            order = bufs if done % 2 == 0 else bufs[::-1]          # the set that holds the next batch goes first
+            _, ws = ops.bpr_train_steps(U, I, order, c, regs=regs, reg_div=B, lr=lr, train_indptr=W.hist_indptr, train_indices=W.hist_indices,
+                                        seed=seed, step_ctr=ctr, loss_steps=losses[done:done + c], **kw)
+            done += c
+            assert int(ws[1]) == 0
+        torch.cuda.synchronize()
+        return U, I, bufs, ctr, losses
+
+    for chunks in ((1,), (2,), (9,), (3, 4)):
+        n = sum(chunks)
+        ref, got = reference(n), looped(chunks)
+        np.testing.assert_allclose(got[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=0, atol=2e-6)
+        np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=0, atol=2e-6)
+        for a, b in zip(got[2][0] + got[2][1], ref[2][0] + ref[2][1]):
+            assert torch.equal(a, b), chunks
+        assert int(got[3]) == int(ref[3]) == 8 + n
+        np.testing.assert_allclose(got[4].cpu().numpy(), ref[4].cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert not torch.equal(ref[0], U0)
+
+
 def test_two_table_adam_sweep_equals_two_sweeps(dev):
     """pda_adam_dense_sweep2_f32 is the arithmetic of two pda_adam_dense_sweep_f32 calls, bit for bit (sizes that do not split
     evenly over the workgroups, sparse gradients, the accumulators zeroed)."""

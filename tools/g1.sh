@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_bench_contract.py -x -q -m gpu --timeout 600 2>&1 | tail -3
-timeout 900 python bench.py --no-per-config --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(json.dumps(d['train']['adam_on_headline_tables'], indent=1)); print(d['value'])"
+timeout 900 python -m pytest tests/test_gpu_bpr_step.py tests/test_gpu_bench_contract.py -x -q -m gpu --timeout 600 2>&1 | tail -3
