@@ -570,6 +570,12 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // d <= 128: the kernel needs <= 128 VGPRs -- four waves per SIMD: 8 MFMA waves + 4 loaders + 4 rescoring waves (two loaders
 // could not keep up: the MFMA waves waited 39 % of their time for tiles); d = 256 (168 VGPRs): 8 + 2 + 2.
 
+#ifndef PDA_V4_RSLEEP
+#define PDA_V4_RSLEEP 8     // idle rescoring waves: s_sleep between polls of their rings (x 64 cycles)
+#endif
+#ifndef PDA_V4_LSLEEP
+#define PDA_V4_LSLEEP 1     // loaders: s_sleep between polls for a free slot
+#endif
 #ifndef PDA_V4_UA
 #define PDA_V4_UA 1       // d <= 128: A operands (32 user rows each) per MFMA wave and B read.  2 = 512-user workgroups with
                           // half the LDS reads per MFMA and the lists in HBM: measured, no faster on the large dense sweep (the
@@ -735,7 +741,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 if (dn) break;
                 if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
                 PROF_T0(ti);
-                __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_s_sleep(PDA_V4_RSLEEP);
                 PROF_T1(ti, 7);
                 continue;
             }
@@ -864,7 +870,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 while (min_released() < want) {
                     if (lds_ld(s_stop)) { stop = true; break; }
                     if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 4u; stop = true; break; }
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(PDA_V4_LSLEEP);
                 }
                 if (stop) break;
             }

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_bpr_step.py tests/test_gpu_bench_contract.py -x -q -m gpu --timeout 600 2>&1 | tail -3
+timeout 1500 bash tools/profile_round.sh r2b_c3 > gpurun_out/r2b_c3.log 2>&1
+timeout 1500 bash tools/profile_round.sh r2b_c5 --workload c5shard > gpurun_out/r2b_c5.log 2>&1
+tail -n 3 gpurun_out/r2b_c3.log gpurun_out/r2b_c5.log
