@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--table-dtype", default="auto", choices=["auto", "f32", "bf16"],
                    help="embedding table type (auto: bf16 for c5shard -- BASELINE config 5 --, f32 otherwise)")
     p.add_argument("--user-groups", type=int, default=0,
-                   help="N > 1: user groups of the 2-D layout (0 = pda_amd.dist.default_user_groups: 2 from four GPUs on); "
+                   help="N > 1: user groups of the 2-D layout (0 = pda_amd.dist.default_user_groups: world / 2 from four GPUs on, i.e. item shards of 2); "
                         "inside a group the catalogue is item-sharded, the groups split the users of a block")
     p.add_argument("--no-per-config", action="store_true", help="skip the per_config block (C1, C2: evaluation and training beside the headline)")
     p.add_argument("--eval-block", type=int, default=262144, help="users per step (the default of the product's --eval_block)")

@@ -32,9 +32,10 @@ def grid_layout(rank: int, world: int, user_groups: int):
     """Two-dimensional layout of the node: `user_groups` groups of world / user_groups ranks.  Inside a group the catalogue
     is item-sharded (every rank owns a slice, partial lists, one collective among the group's ranks); the groups take
     different users of a block and never talk to each other.  Why: the per-block fixed cost of a rank (the exact warm-up on
-    its slice's first 256 items, list hand-over, launches: ~1.3 ms per 262 144 users, independent of the slice size) does not
-    shrink with the item shard -- 8 item shards of config 3 give 14.2 / 3.15 = 4.5x --, but it does shrink with the users:
-    2 groups x 4 shards: 0.65 + 12.9 / 8 ms -> 6.3x.  Returns (group index, rank inside the group, ranks of the group)."""
+    its slice's first 256 items, list hand-over, launches: ~0.9 ms per 262 144 users, independent of the slice size) does not
+    shrink with the item shard -- 8 item shards of config 3 give 13.6 / 2.71 = 5.0x --, but it does shrink with the users:
+    2 groups x 4 shards 5.9x, 4 groups x 2 shards 6.8x (default_user_groups).  Returns (group index, rank inside the group,
+    ranks of the group)."""
     if user_groups < 1 or world % user_groups != 0:
         raise ValueError("world size must be a multiple of the number of user groups")
     per = world // user_groups
@@ -43,13 +44,16 @@ def grid_layout(rank: int, world: int, user_groups: int):
 
 
 def default_user_groups(world: int) -> int:
-    """2 user groups from four GPUs on (item shards of 4 at eight GPUs: the north_star's item-parallel evaluation inside
-    each group); PDA_USER_GROUPS overrides."""
+    """world / 2 user groups from four GPUs on: item shards of 2 (the north_star's item-parallel evaluation inside each
+    group) x as many user groups as are left.  Measured per rank for one 262 144-user step of config 3 on one MI355X
+    (dense sweep; the exchange overlaps): 8 item shards 2.71 ms, 2 groups x 4 shards 2.30, 4 x 2 1.99, against 13.6 ms on one
+    GPU -- every rank pays the exact warm-up and the list hand-over for ITS users whatever its share of the items, so users
+    are the cheaper dimension to split.  PDA_USER_GROUPS overrides (1 = item shards only)."""
     import os
     forced = os.environ.get("PDA_USER_GROUPS")
     if forced:
         return int(forced)
-    return 2 if (world >= 4 and world % 2 == 0) else 1
+    return world // 2 if (world >= 4 and world % 2 == 0) else 1
 
 
 def make_item_group(rank: int, world: int, user_groups: int):
