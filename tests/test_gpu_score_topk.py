@@ -274,6 +274,30 @@ def test_c2_shape_sample_against_oracle(dev):
     check_against_oracle(idx0, val0, U, I, users, K, 0, None, rows, exact=True)
 
 
+def test_c1_shape_sample_against_oracle(dev):
+    """BASELINE config 1, the reference's own CPU-runnable case: Douban-shaped 47 890 users x 26 047 items (a catalogue that
+    is not a multiple of 32 or 64: ragged last tile), d = 64, mean history 140.  A 4096-user sample, whole catalogue, both
+    heads, through whichever sweep mode the fixture selects; the bench workload of the same shape through the generation-4
+    kernels in all three sweep modes with identical keys."""
+    from pda_amd import ops, synthetic
+    rng = np.random.default_rng(2019)
+    nU, nI, d, K = 47890, 26047, 64, 50
+    U, I, pop, _ = make_case(rng, nU, nI, d, max_hist=0)
+    users = rng.permutation(nU)[:4096].astype(np.int32)
+    lens = np.clip(rng.lognormal(4.6, 0.8, len(users)).astype(np.int64), 1, 3000)
+    rows = [np.sort(rng.integers(0, nI, n)).astype(np.int32) for n in lens]
+    idx, val, _ = run_gpu(dev, U, I, users, K, 1, pop, rows, by_user=False)
+    check_against_oracle(idx, val, U, I, users, K, 1, pop, rows, exact=False)
+    idx0, val0, _ = run_gpu(dev, U, I, users, K, 0, None, rows, by_user=False)
+    check_against_oracle(idx0, val0, U, I, users, K, 0, None, rows, exact=True)
+    W = synthetic.make_workload("c1", dev)
+    assert (W.n_users, W.n_items, W.d) == (nU, nI, d)
+    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+    ut = torch.arange(W.n_users, dtype=torch.int32, device=dev)
+    outs = [ops.topk_merge(ops.score_topk_keys(W.U, W.I, ut, K, 1, W.pop_last, hist, prune=pr), want="keys") for pr in (False, "order", True)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_c3_shape_properties(dev):
     """BASELINE config 3 shape (1M x 200k, d=128) is too big for the oracle: check size-independent
     properties on one 8192-user block -- sortedness, no masked item, threshold consistency against

@@ -47,3 +47,23 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
                                                                  "items_per_rank": 1504}
     c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w4_r%d.pt" % r)) for r in range(4)])
     assert torch.equal(a, c)
+
+
+def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
+    """What the driver's scaling run launches at N = 8, on one GPU over gloo: the default layout (4 user groups x 2 item
+    shards), seeded early-terminating sweeps inside each item group, the all-to-all of the partial lists -- and the
+    union of the ranks' lists equals the single-rank lists."""
+    env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PDA_BENCH_DUMP=str(tmp_path))
+    one = _run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-train", "--no-cpu-baseline",
+                "--eval-block", "2048"], env)
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", "29523", "bench.py", "--gpus", "8", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+                  "--eval-block", "2048"], env)
+    assert eight["n_gpus"] == 8 and eight["value"] > 0 and eight["scaling"] == "strong"
+    lay = eight["config"]["layout"]
+    assert lay["user_groups"] == 4 and lay["item_shards"] == 2 and lay["users_per_rank_and_step"] == 512
+    assert eight["ordered_sweep"]["value"] > 0                      # the seeded early-terminating pass ran on every rank
+    a = torch.load(os.path.join(tmp_path, "topk_w1_r0.pt"))
+    c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w8_r%d.pt" % r)) for r in range(8)])
+    assert a.shape == c.shape and torch.equal(a, c) and one["n_gpus"] == 1
