@@ -594,9 +594,13 @@ struct Geo4 {
     // the exact lists in HBM (workspace) free the LDS for four tile slots (d = 256: 8.1 instead of 9.0 ms on a config-5 shard);
     // 512 users x 57 x 8 B would not fit the LDS anyway
     static constexpr bool GL = PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0;
+#ifdef PDA_V4_NBX   /* timing experiment only (results are wrong): NBX half-tiles per block at d <= 128 */
+    static constexpr int NB = D <= 128 ? PDA_V4_NBX : 1;
+#else
     static constexpr int NB = (D <= 128 && UA == 1) ? 2 : 1;          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
-    static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : 2;
-    static constexpr int RESCORERS = (D <= 128 && UA == 1) ? 4 : 2;
+#endif
+    static constexpr int LOADERS = (D <= 128 && UA == 1 && !GL) ? 4 : 2;
+    static constexpr int RESCORERS = (D <= 128 && UA == 1 && !GL) ? 4 : 2;
     static constexpr int MPR = kMainWaves / RESCORERS;   // MFMA waves per rescoring wave
     static constexpr int WAVES = kMainWaves + LOADERS + RESCORERS;
     static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
@@ -645,7 +649,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - g.warm_tiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
-    const int n_blk = n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
+    const int n_blk = NB > 2 ? (2 * n_it) / NB : n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
     if (tid < 128) sync[tid] = 0u;
 #ifdef PDA_V4_PROF
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
