@@ -63,15 +63,16 @@ def parse():
     return p.parse_args()
 
 
-def profile_traffic(kernel_substr):
+def profile_traffic(kernel_substr, workload=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary of this round (rocprofv3 --pmc FETCH_SIZE
     / WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in guides/MI355X_MICROARCH.md).  None when no
     summary for this kernel is present -- PMC cannot be collected from inside the timed process."""
     import glob
     import re
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.txt")), reverse=True):
+    pat = "*_%s_pmc.txt" % workload if workload else "*_pmc.txt"        # (round 2 on: one summary per workload)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), reverse=True):
         txt = open(path).read()
-        if kernel_substr not in txt:
+        if kernel_substr not in txt and kernel_substr.split("_kernel")[0] not in txt:
             continue
         f = re.search(r"FETCH_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
         w = re.search(r"WRITE_SIZE\s+n=\s*\d+\s+mean=([0-9.e+]+)", txt)
@@ -216,7 +217,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
         roof = {"kernel": "%s<%d,%s,%s>%s" % (kname, W.d, hd, td_name, " visiting order, early_stop=0" if use_order else " natural order"),
                 "bound": "mfma", "achieved": alg_tf,
                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_BF16_MFMA_TFLOPS,
-                "traffic": profile_traffic(kname), "kernel_ms": k_ms, "flops_per_launch": flops,
+                "traffic": profile_traffic(kname, workload if (world_all == 1 and Bu == 262144) else "none"), "kernel_ms": k_ms, "flops_per_launch": flops,
                 # the folded threshold test is one more MFMA k-step per tile (d/16 + 1 instead of d/16): executed > algorithmic
                 "executed": {"bf16_mfma_TFLOPs": alg_tf * (W.d / 16 + 1) / (W.d / 16),
                              "frac_of_bf16_peak": alg_tf * (W.d / 16 + 1) / (W.d / 16) / PEAK_BF16_MFMA_TFLOPS,
