@@ -753,7 +753,6 @@ extern "C" int pda_bpr_train_steps_f32(float* U, float* I, int d, float regs, fl
     t.n_steps = n_steps;
     t.sample_tiles = (B + kSampPerBlock - 1) / kSampPerBlock;
     t.n_sample_blocks = t.sample_tiles < 64 ? t.sample_tiles : 64;
-    if (getenv("PDA_LOOP_NOSAMPLE")) t.sample_tiles = 0;      // timing experiment: the step and the barrier alone
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (hipMemsetAsync(barrier_ws, 0, 8, s) != hipSuccess) return PDA_ERR_LAUNCH;
 #define PDA_LOOP(DD)                                                                                                     \
