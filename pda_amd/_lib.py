@@ -65,6 +65,7 @@ SIGNATURES = {
     "pda_peak_mfma_bf16": (_i, [_vp, _i, _vp]),
     "pda_peak_copy": (_i, [_vp, _vp, _sz, _vp]),
     "pda_topk_kth_value": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "pda_topk_seed_refine": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_score_topk4_phase_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_score_topk4_phase_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

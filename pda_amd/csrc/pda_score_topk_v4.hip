@@ -1345,6 +1345,38 @@ __global__ void __launch_bounds__(256) kth_value_kernel(const uint64_t* __restri
     out[u] = best;
 }
 
+// One round of the cross-shard bisection that tightens the seed (pda_topk_seed_refine): [mode >= 1] the all-reduced count of
+// the previous threshold decides which half survives -- K entries at or above it in the shards' warm-up lists together
+// make it a lower bound of the final K-th value --, [mode <= 1] the next threshold is set and this shard's entries at or
+// above it are counted.
+__global__ void __launch_bounds__(256) seed_refine_kernel(const uint64_t* __restrict__ keys, int S, int n_users, int K, float* __restrict__ lo,
+                                                          float* __restrict__ hi, float* __restrict__ mid, int32_t* __restrict__ counts, int mode) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    float l = lo[u], h = hi[u];
+    if (mode >= 1) {
+        if (counts[u] >= K) l = mid[u];
+        else h = mid[u];
+        lo[u] = l;
+        hi[u] = h;
+    }
+    if (mode <= 1) {
+        const bool open = l > -INFINITY && h < INFINITY && h > l;
+        const float m = open ? l + 0.5f * (h - l) : l;
+        int c = 0;
+        for (int sp = 0; sp < S; ++sp) {
+            const uint64_t* row = keys + ((size_t)sp * n_users + u) * K;
+            for (int q = 0; q < K; ++q) {
+                const uint64_t k = row[q];
+                if (k == 0ull || pda_key_val(k) < m) break;          // (sorted, best first)
+                ++c;
+            }
+        }
+        mid[u] = m;
+        counts[u] = c;
+    }
+}
+
 }  // namespace
 
 #ifdef PDA_V4_PROF
@@ -1393,6 +1425,15 @@ extern "C" int pda_topk_kth_value(const uint64_t* keys, int n_splits, int n_user
     if (!keys || !out || n_splits < 1 || n_users_blk < 1 || K < 1 || pos < 0 || pos >= K) return PDA_ERR_ARG;
     hipLaunchKernelGGL(kth_value_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys,
                        n_splits, n_users_blk, K, pos, out);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_topk_seed_refine(const uint64_t* keys, int n_splits, int n_users_blk, int K, float* lo, float* hi, float* mid,
+                                    int32_t* counts, int mode, void* stream) {
+    if (!keys || !lo || !hi || !mid || !counts || n_splits < 1 || n_users_blk < 1 || K < 1 || mode < 0 || mode > 2) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(seed_refine_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys,
+                       n_splits, n_users_blk, K, lo, hi, mid, counts, mode);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

@@ -143,11 +143,15 @@ class ItemShardedTopK:
         self._pop_src = (weakref.ref(pop_full), pop_full._version)
 
     # -- one block, blocking ---------------------------------------------------------------------
-    def _seed_reduce(self, tau_k, tau_m):
-        """The shards' bounds of a user's final K-th value, in place: the MAXIMUM of their K-th values, the MINIMUM of their
-        ceil(K / R)-th values (ops.score_topk_keys; 2 x 4 bytes per user)."""
-        dist.all_reduce(tau_k, op=dist.ReduceOp.MAX, group=self.group)
-        dist.all_reduce(tau_m, op=dist.ReduceOp.MIN, group=self.group)
+    def _seed_reduce(self, mx, mn):
+        """The shards' bounds of a user's final K-th value, in place: the MAXIMUM of their K-th (and best) warm-up values, the
+        MINIMUM of their ceil(K / R)-th values (ops.score_topk_keys; 3 x 4 bytes per user)."""
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
+        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+
+    def _seed_sum(self, counts):
+        """One round of the seed's bisection: the shards' counts of warm-up entries above the common threshold, summed."""
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
 
     def local_keys(self, users, K, head, hist):
         seeded = self.world > 1 and self.seeded
@@ -157,14 +161,16 @@ class ItemShardedTopK:
             if seeded:
                 from . import ops
                 if ops.seed_exchange_applies(self.I_shard.shape[1], K, head, self.prune):
-                    tau = torch.full((2, users.numel()), float("-inf"), dtype=torch.float32, device=users.device)
-                    self._seed_reduce(tau[0], tau[1])
+                    tau = torch.full((3, users.numel()), float("-inf"), dtype=torch.float32, device=users.device)
+                    self._seed_reduce(tau[0:2], tau[2])
+                    for _ in range(ops.seed_rounds(self.world)):
+                        self._seed_sum(torch.zeros(users.numel(), dtype=torch.int32, device=users.device))
             return torch.zeros((users.numel(), K) if self.world > 1 else (1, users.numel(), K), dtype=torch.int64, device=users.device)
         extra = {} if self.prune is None else {"prune": self.prune}
         if seeded:
             # early-terminating sweeps: without the exchange every shard prunes against its own shard's K-th value only and
             # eight shards score 6.5 x the tiles of one GPU between them; with it 1.8 x (1.4 x on four, 1.07 x on two)
-            extra["seed_reduce"], extra["seed_shards"] = self._seed_reduce, self.world
+            extra["seed_reduce"], extra["seed_shards"], extra["seed_sum"] = self._seed_reduce, self.world, self._seed_sum
         keys = self.score_fn(self.U, self.I_shard, users, K, head, self.pop_shard if head else None, hist,
                              self.item_offset, 0, **extra)
         if self.world == 1:

@@ -211,6 +211,16 @@ def seed_exchange_applies(d: int, K: int, head: int, prune=None, impl: Optional[
     return (impl or score_impl(d, K, 0)) == "v2" and prune is True and d in (64, 128, 256) and K <= TOPK_K_V4
 
 
+def seed_rounds(seed_shards: int) -> int:
+    """Bisection rounds that tighten the seed of an item-sharded early-terminating sweep (pda_topk_seed_refine; one all-reduce
+    of 4 bytes per user each): none up to 3 shards (two shards score 1.07 x the tiles of one GPU with the plain seed), three
+    from 4 shards on (config 3: four shards 1.39 x -> 0.98 x, eight shards 1.78 x -> 1.03 x).  PDA_SEED_ROUNDS overrides; the same on every rank."""
+    forced = os.environ.get("PDA_SEED_ROUNDS")
+    if forced is not None and forced != "":
+        return max(0, int(forced))
+    return 3 if seed_shards >= 4 else 0
+
+
 def check_order(prep_ord: torch.Tensor, n: int, d: int):
     """Synchronising: raises if the order given to item_prep_ordered was not a permutation of 0..n-1."""
     check(_lib.load().pda_item_prep_ordered_check(ptr(prep_ord), n, d, stream_ptr()), "pda_item_prep_ordered_check")
@@ -287,12 +297,13 @@ def prune_default(head: int):
 
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
                     item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None,
-                    prune=None, stats: Optional[dict] = None, seed_reduce=None, seed_shards: int = 1) -> torch.Tensor:
-    """seed_reduce (item-sharded evaluation over `seed_shards` shards, early-terminating sweep): a callable (tau_k, tau_m)
-    that receives this shard's float32 [Bu] vectors of warm-up list values at rank K and at rank ceil(K / seed_shards) and
-    turns them IN PLACE into the maximum resp. the minimum over all shards (two dist.all_reduce).  The sweep prunes against
-    the larger of the two (pda_score_topk4_phase_*); the shard's lists may end shorter than K -- merge them with the other
-    shards' lists."""
+                    prune=None, stats: Optional[dict] = None, seed_reduce=None, seed_shards: int = 1, seed_sum=None) -> torch.Tensor:
+    """seed_reduce (item-sharded evaluation over `seed_shards` shards, early-terminating sweep): a callable (mx, mn) that
+    receives this shard's float32 [2, Bu] (warm-up list values at rank K and at rank ceil(K / seed_shards)) and [Bu] (at rank
+    ceil(K / seed_shards) again) and turns them IN PLACE into the maximum resp. the minimum over all shards (two dist.all_reduce).  The
+    sweep prunes against the larger of the K-th-value bounds (pda_score_topk4_phase_*); the shard's lists may end shorter
+    than K -- merge them with the other shards' lists.  seed_sum (optional; int32 [Bu] -> sum over the shards, in place):
+    seed_rounds(seed_shards) rounds of pda_topk_seed_refine tighten the bound first."""
     """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 -> packed keys
     int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All three return the same keys."""
     lib = _lib.load()
@@ -343,12 +354,24 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
             # R shards warm up R x 64 warm_tiles items between them: two tiles each on 2 shards, one from 4 shards on
             wt = int(os.environ.get("PDA_WARM_TILES", "0")) or max(1, 4 // max(1, seed_shards))
             check(fnp(*common, 1, wt, None, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (warm-up)")
-            tau = torch.empty((2, nu), dtype=torch.float32, device=U.device)
+            tau = torch.empty((3, nu), dtype=torch.float32, device=U.device)
             m = -(-K // max(1, seed_shards))
-            check(lib.pda_topk_kth_value(ptr(out), n_splits, nu, K, K - 1, ptr(tau[0]), stream_ptr()), "pda_topk_kth_value")
-            check(lib.pda_topk_kth_value(ptr(out), n_splits, nu, K, m - 1, ptr(tau[1]), stream_ptr()), "pda_topk_kth_value")
-            seed_reduce(tau[0], tau[1])
-            seed = torch.maximum(tau[0], tau[1])
+            # rows: the K-th value (-> MAX: a lower bound of the final K-th value), the ceil(K/R)-th value twice (-> MAX: an UPPER
+            # bound of the K-th value of the merged warm-up lists -- some shard holds ceil(K/R) of its top K --, -> MIN: a lower one)
+            for row, pos in ((0, K - 1), (1, m - 1), (2, m - 1)):
+                check(lib.pda_topk_kth_value(ptr(out), n_splits, nu, K, pos, ptr(tau[row]), stream_ptr()), "pda_topk_kth_value")
+            seed_reduce(tau[0:2], tau[2])
+            seed = torch.maximum(tau[0], tau[2])
+            rounds = seed_rounds(seed_shards) if seed_sum is not None else 0
+            if rounds > 0:
+                mid = torch.empty(nu, dtype=torch.float32, device=U.device)
+                cnt = torch.empty(nu, dtype=torch.int32, device=U.device)
+                for r in range(rounds + 1):
+                    mode = 0 if r == 0 else (2 if r == rounds else 1)
+                    check(lib.pda_topk_seed_refine(ptr(out), n_splits, nu, K, ptr(seed), ptr(tau[1]), ptr(mid), ptr(cnt), mode, stream_ptr()),
+                          "pda_topk_seed_refine")
+                    if mode < 2:
+                        seed_sum(cnt)
             check(fnp(*common, 2, wt, ptr(seed), ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (sweep)")
         else:
             fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32

@@ -5,6 +5,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -245,10 +246,12 @@ def test_item_parallel_training_two_ranks_gloo():
     assert all(all(r[1]) for r in res), res
 
 
-def score_double_seeded(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_reduce=None, seed_shards=1, prune=None):
+def score_double_seeded(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_reduce=None, seed_shards=1, prune=None,
+                        seed_sum=None):
     """The seeded contract of ops.score_topk_keys on the CPU: warm-up lists of the shard's first 16 items -> the values at
-    rank K and at rank ceil(K / R) -> seed_reduce (MAX resp. MIN over the shards, in place) -> the shard's list WITHOUT the
-    entries below the larger of the two bounds (empty slots = key 0)."""
+    rank K, rank 1 and rank ceil(K / R) -> seed_reduce (MAX resp. MIN over the shards, in place) -> ops.seed_rounds(R) rounds of
+    the bisection on summed counts (seed_sum) -> the shard's list WITHOUT the entries below the bound (empty slots = key 0)."""
+    from pda_amd import ops
     full = score_double(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits)
     if seed_reduce is None:
         return full
@@ -256,13 +259,21 @@ def score_double_seeded(U, I_shard, users, K, head, pop_shard, hist, item_offset
     wv, wi = _unpack(warm.numpy()[0])
     wv = np.where(wi >= 0, wv, -np.inf).astype(np.float32)
     m = -(-K // seed_shards)
-    tau = torch.from_numpy(np.stack([wv[:, K - 1], wv[:, m - 1]]))
-    seed_reduce(tau[0], tau[1])
-    seed = torch.maximum(tau[0], tau[1]).numpy()
+    tau = torch.from_numpy(np.stack([wv[:, K - 1], wv[:, m - 1], wv[:, m - 1]]))
+    seed_reduce(tau[0:2], tau[2])
+    lo, hi = torch.maximum(tau[0], tau[2]).numpy().copy(), tau[1].numpy().copy()
+    rounds = ops.seed_rounds(seed_shards) if seed_sum is not None else 0
+    for _ in range(rounds):
+        is_open = np.isfinite(lo) & np.isfinite(hi) & (hi > lo)
+        mid = np.where(is_open, lo + np.float32(0.5) * (hi - lo), lo).astype(np.float32)
+        cnt = torch.from_numpy((wv >= mid[:, None]).sum(1).astype(np.int32))
+        seed_sum(cnt)
+        ge = cnt.numpy() >= K
+        lo, hi = np.where(ge, mid, lo), np.where(ge, hi, mid)
     v, i = _unpack(full.numpy()[0])
     keys = full.numpy()[0].copy()
-    keys[(v < seed[:, None]) | (i < 0)] = 0
-    return torch.from_numpy(keys)[None], float((keys == 0).mean())
+    keys[(v < lo[:, None]) | (i < 0)] = 0
+    return torch.from_numpy(keys)[None], float((keys == 0).mean()), rounds
 
 
 def _worker_seeded(rank, world, port, q):
@@ -276,11 +287,12 @@ def _worker_seeded(rank, world, port, q):
     I = rng.standard_normal((nI, d), dtype=np.float32) * 0.3
     pop = (rng.uniform(0, 1, nI) ** 3).astype(np.float32)
     pop[:32] += 1.0                            # shard 0 holds the popular items: its K-th value prunes shard 1's list
-    dropped = []
+    dropped, rounds_seen = [], []
 
     def fn(*a, **k):
-        keys, frac = score_double_seeded(*a, **k)
+        keys, frac, rounds = score_double_seeded(*a, **k)
         dropped.append(frac)
+        rounds_seen.append(rounds)
         return keys
     ev = ItemShardedTopK.from_full_tables(torch.from_numpy(U), torch.from_numpy(I), torch.from_numpy(pop), rank, world,
                                           score_fn=fn, merge_fn=merge_double)
@@ -290,13 +302,16 @@ def _worker_seeded(rank, world, port, q):
     idx, val = ev.topk(users, K, 1, None)
     ridx, rval = c_oracle.score_topk(U, I, users.numpy(), K, 1, pop, order=1)
     ok = bool(np.array_equal(idx.numpy(), ridx) and np.array_equal(val.numpy(), rval))
-    q.put((rank, ok, ev.I_shard.shape[0], max(dropped) if dropped else -1.0))
+    q.put((rank, ok, ev.I_shard.shape[0], max(dropped) if dropped else -1.0, max(rounds_seen) if rounds_seen else -1))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_seeded_item_shards_with_an_empty_shard_gloo():
-    world, port = 3, _free_port()
+@pytest.mark.parametrize("world", [3, 4])
+def test_seeded_item_shards_with_an_empty_shard_gloo(world):
+    """world 3: the plain seed (two all-reduces); world 4: also the three bisection rounds on summed counts -- with TWO ranks
+    that own nothing and still have to join every collective."""
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     ps = [ctx.Process(target=_worker_seeded, args=(r, world, port, q)) for r in range(world)]
@@ -307,5 +322,6 @@ def test_seeded_item_shards_with_an_empty_shard_gloo():
         p.join(60)
         assert p.exitcode == 0
     assert all(r[1] for r in res), res
-    assert [r[2] for r in res] == [32, 28, 0]
+    assert [r[2] for r in res] == [32, 28, 0, 0][:world]
     assert res[1][3] > 0 and res[2][3] == -1.0         # the seed did drop entries of shard 1; rank 2 never scored
+    assert res[0][4] == (3 if world == 4 else 0)

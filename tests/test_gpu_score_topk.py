@@ -656,12 +656,51 @@ def test_full_size_c5_shard_bf16(dev, impl):
         assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b)
 
 
+class FakeCollectives:
+    """all_reduce among R threads of this process, one per emulated item shard (what pda_amd.dist does over RCCL)."""
+
+    def __init__(self, R):
+        import threading
+        self.R, self.bar, self.buf = R, threading.Barrier(R), [None] * R
+
+    def all_reduce(self, r, t, op):
+        self.buf[r] = t.clone()
+        self.bar.wait()
+        st = torch.stack(self.buf)
+        res = st.max(0).values if op == "max" else (st.min(0).values if op == "min" else st.sum(0))
+        self.bar.wait()
+        t.copy_(res.to(t.dtype))
+
+
+def run_emulated_shards(R, fn):
+    """fn(r, coll) in R threads; returns their results in shard order (exceptions re-raised)."""
+    import threading
+    coll, out, err = FakeCollectives(R), [None] * R, []
+
+    def work(r):
+        try:
+            out[r] = fn(r, coll)
+        except BaseException as e:            # noqa: BLE001 -- reported by the caller
+            err.append(e)
+            coll.bar.abort()
+    th = [threading.Thread(target=work, args=(r,)) for r in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    if err:
+        raise err[0]
+    return out
+
+
 @pytest.mark.parametrize("R,head", [(2, 1), (8, 1), (4, 0)])
 def test_seeded_item_shards_equal_one_shard(dev, impl, R, head):
-    """Item-sharded evaluation with exact early termination (pda_score_topk4_phase_*): R emulated shards of config 2, every
-    shard's sweep seeded with the two cross-shard bounds of the users' K-th values (maximum of the shards' K-th warm-up
-    values, minimum of their ceil(K / R)-th).  The shards' lists -- some shorter than K -- merge to exactly the one-shard
-    lists, and the shards score fewer tiles between them than with their own thresholds only."""
+    """Item-sharded evaluation with exact early termination (pda_score_topk4_phase_*, pda_topk_kth_value,
+    pda_topk_seed_refine): R emulated shards of config 2 (one thread each, all-reduces among the threads), every shard's
+    sweep seeded with the cross-shard bounds of the users' K-th values -- the maximum of the shards' K-th warm-up values, the
+    minimum of their ceil(K / R)-th, tightened from four shards on by three rounds of a bisection on summed counts.  The
+    shards' lists -- some shorter than K -- merge to exactly the one-shard lists, and the shards score fewer tiles between
+    them than with their own thresholds only."""
     if impl != "v2":
         pytest.skip("one kernel generation has the phase entry points")
     from pda_amd import ops, synthetic
@@ -672,27 +711,28 @@ def test_seeded_item_shards_equal_one_shard(dev, impl, R, head):
     pop = W.pop_last
     ref = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, head, pop if head else None, hist, prune=False), want="keys")
     shards = [(lo, W.I[lo:hi].contiguous(), pop[lo:hi].contiguous() if head else None) for lo, hi in (shard_range(W.n_items, r, R) for r in range(R))]
-    tk, tm = [], []
-    for lo, I_s, pop_s in shards:           # the all-reduces, emulated: the warm-up values of every shard first
-        ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1,
-                            seed_reduce=lambda a, b: (tk.append(a.clone()), tm.append(b.clone())), seed_shards=R)
-    seed_k, seed_m = torch.stack(tk).max(0).values, torch.stack(tm).min(0).values
+    os.environ["PDA_SCORE_KERNEL"] = "v4"
     tiles, short = {}, 0
-    for seeded in (False, True):
-        parts, tot = [], 0.0
-        for lo, I_s, pop_s in shards:
-            st = {}
-            kw = {"seed_reduce": (lambda a, b: (a.copy_(seed_k), b.copy_(seed_m))), "seed_shards": R} if seeded else {}
-            os.environ["PDA_SCORE_KERNEL"] = "v4"
-            try:
+    try:
+        for seeded in (False, True):
+            def one(r, coll):
+                lo, I_s, pop_s = shards[r]
+                st = {}
+                kw = {}
+                if seeded:
+                    kw = {"seed_reduce": lambda mx, mn: (coll.all_reduce(r, mx, "max"), coll.all_reduce(r, mn, "min")),
+                          "seed_sum": lambda c: coll.all_reduce(r, c, "sum"), "seed_shards": R}
                 k = ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1, stats=st, **kw)
-            finally:
-                os.environ.pop("PDA_SCORE_KERNEL", None)
-            tot += float(st["tiles_scored"][0])
-            parts.append(ops.topk_merge(k, want="keys"))
-            short += int((parts[-1][:, -1] == 0).sum()) if seeded else 0
-        assert torch.equal(ops.topk_merge(torch.stack(parts), want="keys"), ref), (R, head, seeded)
-        tiles[seeded] = tot
+                return ops.topk_merge(k, want="keys"), float(st["tiles_scored"][0])
+            # (the unseeded pass runs shard by shard -- no collectives -- and warms ops' per-tensor caches, which are not
+            # meant for concurrent insertion; the seeded pass then runs one thread per shard)
+            res = run_emulated_shards(R, one) if seeded else [one(r, None) for r in range(R)]
+            parts = [p for p, _ in res]
+            short += sum(int((p[:, -1] == 0).sum()) for p in parts) if seeded else 0
+            assert torch.equal(ops.topk_merge(torch.stack(parts), want="keys"), ref), (R, head, seeded)
+            tiles[seeded] = sum(t for _, t in res)
+    finally:
+        os.environ.pop("PDA_SCORE_KERNEL", None)
     # (raw head on i.i.d. norms: the suffix bounds are too loose to stop anything early, with or without a seed)
     assert tiles[True] < tiles[False] if head else tiles[True] <= tiles[False], tiles
     assert short > 0 or not head            # (popularity head) the seed did keep entries out of some shard's list
