@@ -411,6 +411,28 @@ def bench_train(args, dev, workload=None, quick=False):
     out["sgd_fused_step_and_next_batch_sampler_one_launch_graph"] = timed_graph(fused_sampled_body, max(256, args.train_steps // 2))
     out["sgd_fused_step_and_next_batch_sampler_one_launch_graph"]["batches_drawn"] = int(step_dev2.max().item())
 
+    # the sampler MANY batches ahead (the reference's generator thread fills a queue): one launch draws and groups 32 batches,
+    # 32 step launches consume them -- a fresh batch every step, grouped by positive item, at the price of two launches per 32
+    U, I = W.U.clone(), W.I.clone()
+    AH = 32
+    step_dev3 = torch.zeros(2, dtype=torch.int64, device=dev)
+    many = (torch.empty((AH, B), dtype=torch.int32, device=dev), torch.empty((AH, B), dtype=torch.int32, device=dev),
+            torch.empty((AH, B), dtype=torch.int32, device=dev), torch.empty((AH, B), dtype=torch.float32, device=dev),
+            torch.empty((AH, B), dtype=torch.float32, device=dev))
+    calls = [0]
+
+    def ahead_body(i):
+        if i % AH == 0:
+            ops.sample_batches_into(many, W.hist_indptr, W.hist_indices, seed=7, step_dev=step_dev3, parity=calls[0] & 1, group_by_pos=True, **skw)
+            calls[0] += 1
+        j = i % AH
+        ops.bpr_step(U, I, many[0][j], many[1][j], many[2][j], many[3][j], many[4][j], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED,
+                     loss_acc=loss, grouped=True)
+    out["sgd_fused_sampler_32_batches_ahead_graph"] = timed_graph(ahead_body, max(256, args.train_steps // 2))
+    out["sgd_fused_sampler_32_batches_ahead_graph"]["batches_drawn"] = int(step_dev3.max().item())
+    out["sgd_fused_sampler_32_batches_ahead_graph"]["note"] = ("pda_sample_batches_dev: one launch draws (and groups by positive item) the next 32 "
+                                                              "batches, bit for bit the per-step sampler's; 32 step launches consume them")
+
     return out, W, batches
 
 

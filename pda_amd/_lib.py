@@ -84,6 +84,8 @@ SIGNATURES = {
     "pda_adam_lazy_sync_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _f, _f, _vp]),
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pda_sample_triplets_dev": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pda_sample_batches_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pda_group_triplets_by_pos_batches": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "pda_counter_add": (_i, [_vp, _u64, _vp]),
     "pda_bpr_step_sample_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp]),
     "pda_bpr_train_steps_f32": (_i, [_vp, _vp, _i, _f, _f, _f, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

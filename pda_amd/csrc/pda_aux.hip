@@ -67,6 +67,23 @@ namespace {
 // one wave per workgroup: every thread is a chain of dependent loads, spreading the waves over CUs beats packing them (13 -> 9 us)
 __global__ void __launch_bounds__(64) sample_kernel(SampleArgs a) { sample_one(a, (int)(blockIdx.x * blockDim.x + threadIdx.x)); }
 
+// n batches in one launch (blockIdx.y = batch j, drawn with step + j into row j of [n][B] buffers): the sampler never reads
+// the tables, so a training loop can have its next 64 batches drawn by ONE launch instead of one per step
+__global__ void __launch_bounds__(64) sample_batches_kernel(SampleArgs a, int n_batches) {
+    const int j = (int)blockIdx.y, r = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const uint64_t cur = a.step_dev ? *a.step_dev : 0ull;
+    if (a.step_next && j == 0 && r == 0) *a.step_next = cur + (uint64_t)n_batches;
+    a.step += cur + (uint64_t)j;
+    a.step_dev = nullptr;
+    a.step_next = nullptr;
+    const size_t off = (size_t)j * a.B;
+    a.users += off;
+    a.pos += off;
+    a.neg += off;
+    if (a.pos_pop) { a.pos_pop += off; a.neg_pop += off; }
+    sample_one(a, r);
+}
+
 }  // namespace
 
 extern "C" int pda_abi_version(void) { return PDA_ABI_VERSION; }
@@ -126,6 +143,29 @@ extern "C" int pda_sample_triplets_dev(int32_t* users, int gen_users, const int3
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((B + 63) / 64)), dim3(64), 0,
                        reinterpret_cast<hipStream_t>(stream), a);
     PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_group_triplets_by_pos_batches(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
+                                                 int n_batches, void* stream);
+
+extern "C" int pda_sample_batches_dev(int32_t* users, int gen_users, const int32_t* user_pool, int n_pool, int B, int n_batches,
+                                      const int64_t* train_indptr, const int32_t* train_indices, const int32_t* train_slots, int neg_lo,
+                                      int neg_hi, const float* pop_matrix, int n_slots, uint64_t seed, const uint64_t* step_dev,
+                                      uint64_t* step_next, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int group_by_pos,
+                                      void* stream) {
+    if (!users || !train_indptr || !train_indices || !pos || !neg || !step_dev || B <= 0 || n_batches <= 0 || n_batches > 65535 ||
+        neg_hi <= neg_lo)
+        return PDA_ERR_ARG;
+    if (step_next == step_dev) return PDA_ERR_ARG;
+    if (gen_users && n_pool <= 0) return PDA_ERR_ARG;
+    if (pop_matrix && (!pos_pop || !neg_pop || n_slots <= 0)) return PDA_ERR_ARG;
+    SampleArgs a{users, user_pool, train_indptr, train_indices, train_slots, pop_matrix, pos, neg, pos_pop, neg_pop,
+                 seed, 0, B, n_pool, gen_users, neg_lo, neg_hi, n_slots, step_dev, step_next};
+    hipLaunchKernelGGL(sample_batches_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)n_batches), dim3(64), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, n_batches);
+    PDA_CHECK_LAUNCH();
+    if (group_by_pos) return pda_group_triplets_by_pos_batches(users, pos, neg, pos_pop, neg_pop, B, n_batches, stream);
     return PDA_OK;
 }
 

@@ -368,6 +368,13 @@ __global__ void __launch_bounds__(1024) group_by_pos_kernel(int32_t* users, int3
     __shared__ int perm[4096];         // final: perm[dst] = src
     __shared__ int wsum[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // one workgroup per batch: row blockIdx.x of [n][B] buffers (a single batch: row 0)
+        const size_t off = (size_t)blockIdx.x * B;
+        users += off;
+        pos += off;
+        neg += off;
+        if (pos_pop) { pos_pop += off; neg_pop += off; }
+    }
     for (int i = tid; i <= NBIN; i += 1024) cnt[i] = 0;
     __syncthreads();
     int bkt[4], arr[4];
@@ -868,6 +875,17 @@ extern "C" int pda_group_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* 
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     if (B > 4096) return PDA_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(group_by_pos_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), users, pos, neg,
+                       pos_pop, neg_pop, B);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_group_triplets_by_pos_batches(int32_t* users, int32_t* pos, int32_t* neg, float* pos_pop, float* neg_pop, int B,
+                                                 int n_batches, void* stream) {
+    if (!users || !pos || !neg || B <= 0 || n_batches <= 0) return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    if (B > 4096) return PDA_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(group_by_pos_kernel, dim3((unsigned)n_batches), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), users, pos, neg,
                        pos_pop, neg_pop, B);
     PDA_CHECK_LAUNCH();
     return PDA_OK;

@@ -717,6 +717,24 @@ def sample_triplets_into(out, train_indptr, train_indices, *, seed: int, step_de
     return out
 
 
+def sample_batches_into(out, train_indptr, train_indices, *, seed: int, step_dev: torch.Tensor, parity: int, user_pool=None, n_pool: int = 0,
+                        train_slots=None, neg_range=(0, 0), pop_matrix=None, group_by_pos: bool = False):
+    """pda_sample_batches_dev: `out` = (users, pos, neg, pos_pop|None, neg_pop|None) as [n, B] tensors; row j receives the batch
+    of step step_dev[parity] + j (bit for bit what sample_triplets_into draws for that step); step_dev[1 - parity] receives
+    step + n.  Graph-capturable (alternate `parity` from call to call, an even number of calls per captured graph)."""
+    lib = _lib.load()
+    users, pos, neg, pp, pn = out
+    if users.dim() != 2 or step_dev.numel() != 2:
+        raise ValueError("sample_batches_into wants [n, B] buffers and the two-slot step counter")
+    n, B = users.shape
+    n_slots = pop_matrix.shape[1] if pop_matrix is not None else 0
+    check(lib.pda_sample_batches_dev(ptr(users), 1, ptr(user_pool), int(n_pool), B, n, ptr(train_indptr), ptr(train_indices), ptr(train_slots),
+                                     int(neg_range[0]), int(neg_range[1]), ptr(pop_matrix), n_slots, seed & (2 ** 64 - 1),
+                                     ptr(step_dev[parity:parity + 1]), ptr(step_dev[1 - parity:2 - parity]), ptr(pos), ptr(neg), ptr(pp), ptr(pn),
+                                     1 if group_by_pos else 0, stream_ptr()), "pda_sample_batches_dev")
+    return out
+
+
 def bpr_step_and_sample(U, I, users, pos, neg, pos_pop, neg_pop, *, regs: float, reg_div: float, lr: float, next_out,
                         train_indptr, train_indices, seed: int, step_dev: torch.Tensor, parity: int, user_pool=None,
                         n_pool: int = 0, train_slots=None, neg_range=(0, 0), pop_matrix=None, mode: int = UPD_SGD_FUSED,

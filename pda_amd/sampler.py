@@ -64,7 +64,11 @@ def to_device_batch(batch, device):
 
 
 class DeviceSampler:
-    def __init__(self, data, device, with_pop: bool, seed: int = 2020, neg_range=None):
+    """ahead: batches drawn per sampler launch (pda_sample_batches_dev; the reference's generator thread keeps a queue of
+    batches as well, :178-220).  The batches are bit for bit those of ahead = 1 (one pda_sample_triplets launch per step); a
+    batch handed out is a row view of the queue and stays valid until `ahead` further batches have been taken."""
+
+    def __init__(self, data, device, with_pop: bool, seed: int = 2020, neg_range=None, ahead: int = 32):
         self.data, self.device, self.with_pop, self.seed = data, torch.device(device), with_pop, seed
         self.indptr, self.indices, self.slots = data.train_csr(self.device)
         pool = np.fromiter(data.train_user_list.keys(), dtype=np.int32)   # all_users = users with train rows
@@ -74,14 +78,39 @@ class DeviceSampler:
             self.pop = torch.as_tensor(np.ascontiguousarray(data.expo_popularity, dtype=np.float32), device=self.device)
         self.neg_range = neg_range or (0, data.n_items)
         self.step = 0
+        self.ahead = max(1, int(ahead))
+        self._queue, self._left, self._calls = None, 0, 0
+
+    def _refill(self):
+        B, n = self.data.batch_size, self.ahead
+        if self._queue is None or self._queue[0].shape != (n, B):
+            mk = lambda dt: torch.empty((n, B), dtype=dt, device=self.device)
+            # two queues in turn: a batch handed out stays valid while the next `ahead` are drawn and consumed
+            self._queues = [(mk(torch.int32), mk(torch.int32), mk(torch.int32), mk(torch.float32) if self.with_pop else None,
+                             mk(torch.float32) if self.with_pop else None) for _ in range(2)]
+            self._ctr = torch.tensor([self.step, 0], dtype=torch.int64, device=self.device)      # (batch() has counted this one)
+            self._calls = 0
+        self._queue = self._queues[self._calls & 1]
+        ops.sample_batches_into(self._queue, self.indptr, self.indices, seed=self.seed, step_dev=self._ctr, parity=self._calls & 1,
+                                user_pool=self.pool, n_pool=self.pool.numel(), train_slots=self.slots if self.with_pop else None,
+                                neg_range=self.neg_range, pop_matrix=self.pop)
+        self._calls += 1
+        self._left = n
 
     def batch(self):
         self.step += 1
-        u, p, n, pp, pn = ops.sample_triplets(self.indptr, self.indices, self.data.batch_size, seed=self.seed,
-                                              step=self.step, user_pool=self.pool, n_pool=self.pool.numel(),
-                                              train_slots=self.slots if self.with_pop else None,
-                                              neg_range=self.neg_range, pop_matrix=self.pop)
-        return (u, p, n, pp, pn) if self.with_pop else (u, p, n)
+        if self.ahead == 1:
+            u, p, n, pp, pn = ops.sample_triplets(self.indptr, self.indices, self.data.batch_size, seed=self.seed,
+                                                  step=self.step, user_pool=self.pool, n_pool=self.pool.numel(),
+                                                  train_slots=self.slots if self.with_pop else None,
+                                                  neg_range=self.neg_range, pop_matrix=self.pop)
+            return (u, p, n, pp, pn) if self.with_pop else (u, p, n)
+        if self._left == 0:
+            self._refill()
+        j = self.ahead - self._left
+        self._left -= 1
+        q = self._queue
+        return (q[0][j], q[1][j], q[2][j], q[3][j], q[4][j]) if self.with_pop else (q[0][j], q[1][j], q[2][j])
 
     def __call__(self):
         """Zero-argument generator: one epoch of device-tensor batches."""

@@ -620,6 +620,40 @@ def test_step_with_the_next_batch_sampled_in_the_same_launch(dev, d):
                                 seed=seed, step_dev=torch.tensor([0, 0], dtype=torch.int64, device=dev), parity=0, **kw)
 
 
+def test_sampler_many_batches_ahead(dev):
+    """pda_sample_batches_dev: 9 batches in one launch == 9 pda_sample_triplets_dev calls (steps c .. c + 8), bit for bit, and
+    the step counter moves by 9; with group_by_pos every batch is a permutation of whole triplets of the ungrouped batch with
+    the equal positives contiguous."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("tiny", dev)
+    B, n, seed = 512, 9, 77
+    kw = dict(n_pool=W.n_users, train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+    mk = lambda *shape: (torch.empty(shape, dtype=torch.int32, device=dev), torch.empty(shape, dtype=torch.int32, device=dev),
+                         torch.empty(shape, dtype=torch.int32, device=dev), torch.empty(shape, device=dev), torch.empty(shape, device=dev))
+    ctr = torch.tensor([5], dtype=torch.int64, device=dev)
+    singles = []
+    for j in range(n):
+        b = mk(B)
+        ops.sample_triplets_into(b, W.hist_indptr, W.hist_indices, seed=seed, step_dev=ctr, **kw)
+        singles.append(b)
+    for grouped in (False, True):
+        many = mk(n, B)
+        sd = torch.tensor([5, 0], dtype=torch.int64, device=dev)
+        ops.sample_batches_into(many, W.hist_indptr, W.hist_indices, seed=seed, step_dev=sd, parity=0, group_by_pos=grouped, **kw)
+        assert sd.tolist() == [5, 5 + n] and int(ctr) == 5 + n
+        for j in range(n):
+            got = [t[j] for t in many]
+            if not grouped:
+                for a, b in zip(got, singles[j]):
+                    assert torch.equal(a, b), j
+            else:
+                key = lambda t5: sorted(zip(*[x.cpu().tolist() for x in t5]))
+                assert key(got) == key(singles[j])
+                p = got[1].cpu().numpy()
+                starts = np.flatnonzero(np.r_[True, p[1:] != p[:-1]])
+                assert len(starts) == len(np.unique(p))              # every positive forms ONE run
+
+
 @pytest.mark.parametrize("d", [64, 128])
 def test_training_steps_in_one_launch(dev, d):
     """pda_bpr_train_steps_f32 (a resident grid looping over the steps, the sampler one batch ahead, a grid barrier between

@@ -114,6 +114,30 @@ def test_training_reduces_the_loss_and_beats_random_ranking(dev, toy, tmp_path):
     assert torch.equal(rec.weights["user_embedding"], sd["user_embedding"])
 
 
+@pytest.mark.parametrize("with_pop", [True, False])
+def test_device_sampler_queue_is_the_per_step_sampler(dev, toy, tmp_path, with_pop):
+    """DeviceSampler(ahead=32) -- one sampler launch per 32 batches -- hands out, batch for batch, what ahead=1 (one launch per
+    step) draws, across refills and across an epoch boundary; a batch stays valid while the next 32 are taken."""
+    from pda_amd import train_new_api as t
+    from pda_amd.sampler import DeviceSampler
+    t.configure(_argv(toy, str(tmp_path) + "/", "s_condition" if with_pop else "normal"))
+    a, d = t.args, t.data
+    if with_pop:
+        d.add_expo_popularity(np.power(t.get_popularity_from_load(t.load_popularity(a)), a.pop_exp))
+    one, many = DeviceSampler(d, dev, with_pop, ahead=1), DeviceSampler(d, dev, with_pop, ahead=32)
+    kept = []
+    for i in range(75):
+        x, y = one.batch(), many.batch()
+        assert len(x) == len(y) == (5 if with_pop else 3)
+        for p, q in zip(x, y):
+            assert torch.equal(p, q), i
+        kept.append(([p.clone() for p in y], y))
+    for clone, view in kept[-32:]:
+        for p, q in zip(clone, view):
+            assert torch.equal(p, q)
+    assert sum(1 for _ in many()) == d.n_train // d.batch_size + 1
+
+
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_adam_without_the_sweep_trains_the_same_model(dev, toy, tmp_path, dtype):
     """--adam_sweep replay vs sweep through the drop-in trainer: same seed, same device-sampled batches, two epochs; the tables
