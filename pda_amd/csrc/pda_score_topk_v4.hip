@@ -79,6 +79,8 @@ struct Args4 {
     const int* pos_of;           // [n_items_local] local id -> visiting position, or NULL: identity
     unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
     uint64_t* lists_ws;          // list slots of the workgroups whose lists live in HBM (Geo4::GL): [workgroup][UT][kCap4]
+    const uint32_t* bloom;       // [n_users_blk][32]: 1024-bit Bloom filter (two hashes) of every block row's train items, or NULL
+    const int* prep_hdr;         // header of the item prep: word 2 = built with a visiting order
     const float* seed;           // [n_users_blk] or NULL: an external LOWER bound of every user's final K-th value (other item shards)
     int n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, n_tiles;
     int warm_tiles;              // 1 .. kWarmTiles: 64-item tiles per split scored exactly by warm4_kernel
@@ -95,7 +97,7 @@ Prep4Layout prep4_layout(int n, int d) {
     Prep4Layout L{};
     L.n_tiles = (n + 63) / 64;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    L.hdr = 0;                                  // +0 int: "order is not a permutation"; +4 int: prep was built with a popularity
+    L.hdr = 0;                                  // +0 int: "order is not a permutation"; +4 int: prep was built with a popularity; +8 int: with an order
     L.pos_of = 256;
     L.sufA = L.pos_of + al((size_t)n * 4);
     L.sufB = L.sufA + al((size_t)L.n_tiles * 4);
@@ -215,6 +217,40 @@ __global__ void __launch_bounds__(1024) suffix_max4_kernel(float* __restrict__ t
     }
 }
 
+// Train items at the candidate stage: a candidate that passes the exact threshold must not be a train item of its user -- a
+// binary search in the user's id-sorted history, i.e. six to seven DEPENDENT loads from a 200 MB array: 5 of the 6.5 us of a
+// rescoring pass of 16 candidates (cycle counters, natural-order sweep).  A 1024-bit Bloom filter per block row (two hashes;
+// 50 train items: 0.9 % false positives) is read with the candidate's rows instead; only a hit pays for the search.
+__device__ __forceinline__ unsigned bloom_h1(int item) { return ((unsigned)item * 0x9E3779B1u) >> 22; }
+__device__ __forceinline__ unsigned bloom_h2(int item) { return ((unsigned)item * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 22; }
+// 32 rows per workgroup, eight lanes per row: each lane hashes every eighth train item into the row's 32 words in LDS.
+// skip_if_ordered: sweeps of the popularity head in visiting order meet next to no candidates -- the filters would cost more
+// than they save (prep header word 2 = "an order was given"; the sweep reads the same word).
+__global__ void __launch_bounds__(256) hist_bloom4_kernel(const int32_t* __restrict__ users, const int64_t* __restrict__ indptr,
+                                                          const int32_t* __restrict__ indices, int hist_row_mode, int n_users_blk,
+                                                          uint32_t* __restrict__ bloom, const int* __restrict__ prep_hdr, int skip_if_ordered) {
+    if (skip_if_ordered && prep_hdr[2] != 0) return;
+    __shared__ uint32_t w[32 * 32];
+    const int tid = threadIdx.x, r = tid >> 3, sub = tid & 7;
+    for (int q = tid; q < 32 * 32; q += 256) w[q] = 0u;
+    __syncthreads();
+    const int u = (int)blockIdx.x * 32 + r;
+    if (u < n_users_blk) {
+        const int64_t hr = hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)users[u] : (int64_t)u;
+        const int64_t b = indptr[hr], e = indptr[hr + 1];
+        for (int64_t i = b + sub; i < e; i += 8) {
+            const int item = indices[i];
+            const unsigned h1 = bloom_h1(item), h2 = bloom_h2(item);
+            atomicOr(&w[r * 32 + (h1 >> 5)], 1u << (h1 & 31u));
+            atomicOr(&w[r * 32 + (h2 >> 5)], 1u << (h2 & 31u));
+        }
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * 32 * 32;
+    for (int q = tid; q < 32 * 32; q += 256)
+        if ((int)blockIdx.x * 32 + (q >> 5) < n_users_blk) bloom[base + q] = w[q];
+}
+
 int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
     if (d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
     const Prep4Layout L = prep4_layout(n, d);
@@ -223,6 +259,7 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     int* pos_of = reinterpret_cast<int*>(pb + L.pos_of);
     if (hipMemsetAsync(hdr, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
     if (order && hipMemsetAsync(pos_of, 0xFF, (size_t)n * 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (order && hipMemsetAsync(hdr + 2, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;          // header word 2 := 1: a visiting order was given
     const int n_pad = L.n_tiles * 64;
 #define PDA_P4(DD)                                                                                                              \
     case DD: {                                                                                                                  \
@@ -687,6 +724,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             return v;
         };
         const bool hist_on = g.hist_indptr != nullptr;
+        const bool bloom_on = g.bloom != nullptr && !(HEAD == PDA_HEAD_POP && g.prep_hdr[2] != 0);
 #pragma unroll
         for (int s2 = 0; s2 < NRL; ++s2) {
             const int rl = 64 * s2 + lane;
@@ -770,6 +808,18 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             }
             float pv = 1.0f;
             if constexpr (HEAD == PDA_HEAD_POP) pv = g.pop[loc];
+            // the two filter words of (row, item), in flight with the rows
+            unsigned bh1 = 0u, bh2 = 0u;
+            uint32_t bw1 = 0xFFFFFFFFu, bw2 = 0xFFFFFFFFu;
+            if (bloom_on && valid && q == LPC - 1) {
+                const int rbb = utile * UT + row0 + row;
+                if (rbb < g.n_users_blk) {
+                    bh1 = bloom_h1(g.item_offset + loc);
+                    bh2 = bloom_h2(g.item_offset + loc);
+                    bw1 = g.bloom[(size_t)rbb * 32 + (bh1 >> 5)];
+                    bw2 = g.bloom[(size_t)rbb * 32 + (bh2 >> 5)];
+                }
+            }
 #pragma unroll
             for (int y = 0; y < kMPR; ++y) head[y] += sel == y ? (unsigned)n : 0u;
             PDA_CBAR();
@@ -811,11 +861,11 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             const float sd = row_f(seedv, row);
             bool p = valid && q == LPC - 1 && (tt >= fmaxf(taul[lrow], sd));
             if (hist_on) {
-                // train items are masked HERE: one binary search in the row's id-sorted history for a candidate that has
-                // passed the filter and the exact threshold
+                // train items are masked HERE: a binary search in the row's id-sorted history for a candidate that has passed
+                // the pre-filter and the exact threshold -- and whose two Bloom bits are set (hist_bloom4_kernel)
                 long long lo = row_l(hbv, row), hi = row_l(hev, row);
                 const long long he = hi;
-                if (p) {
+                if (p && (((bw1 >> (bh1 & 31u)) & (bw2 >> (bh2 & 31u)) & 1u) != 0u)) {
                     while (lo < hi) {
                         const long long mid = (lo + hi) >> 1;
                         if (g.hist_indices[mid] < item) lo = mid + 1; else hi = mid;
@@ -1289,7 +1339,8 @@ extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_l
         const size_t ut = (size_t)user_tile4(d);
         b += ((size_t)n_users_blk + ut - 1) / ut * (size_t)n_splits * ut * kCap4 * 8 + 256;
     }
-    return b;
+    b = (b + 255) & ~(size_t)255;
+    return b + (size_t)n_users_blk * 128;          // the Bloom filters of the block rows' train items
 }
 
 int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
@@ -1317,7 +1368,16 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) + lists_offset4(n_users_blk)), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles};
+            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) + lists_offset4(n_users_blk)), nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles};
+    if (hist_indptr && (phase & 2)) {
+        // the workspace ends with the Bloom filters (pda_score_topk4_workspace_bytes with THIS n_splits)
+        const size_t total = pda_score_topk4_workspace_bytes(n_users_blk, n_items_local, d, n_splits);
+        uint32_t* bloom = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + total - (size_t)n_users_blk * 128);
+        hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,
+                           hist_row_mode, n_users_blk, bloom, reinterpret_cast<const int*>(pb + L.hdr), head == PDA_HEAD_POP ? 1 : 0);
+        PDA_CHECK_LAUNCH();
+        g.bloom = bloom;
+    }
     if (head == PDA_HEAD_RAW) {
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;
