@@ -693,8 +693,8 @@ def run_emulated_shards(R, fn):
     return out
 
 
-@pytest.mark.parametrize("R,head", [(2, 1), (8, 1), (4, 0)])
-def test_seeded_item_shards_equal_one_shard(dev, impl, R, head):
+@pytest.mark.parametrize("R,head,bf16", [(2, 1, False), (8, 1, False), (4, 0, False), (4, 1, True)])
+def test_seeded_item_shards_equal_one_shard(dev, impl, R, head, bf16):
     """Item-sharded evaluation with exact early termination (pda_score_topk4_phase_*, pda_topk_kth_value,
     pda_topk_seed_refine): R emulated shards of config 2 (one thread each, all-reduces among the threads), every shard's
     sweep seeded with the cross-shard bounds of the users' K-th values -- the maximum of the shards' K-th warm-up values, the
@@ -705,7 +705,7 @@ def test_seeded_item_shards_equal_one_shard(dev, impl, R, head):
         pytest.skip("one kernel generation has the phase entry points")
     from pda_amd import ops, synthetic
     from pda_amd.dist import shard_range
-    W = synthetic.make_workload("c2", dev, n_users=16384)
+    W = synthetic.make_workload("c2", dev, n_users=16384, table_dtype=torch.bfloat16 if bf16 else torch.float32)      # (bf16: the _bf16 phase entry points)
     hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
     users = torch.arange(16384, dtype=torch.int32, device=dev)
     pop = W.pop_last
