@@ -84,6 +84,7 @@ struct Args4 {
     const float* seed;           // [n_users_blk] or NULL: an external LOWER bound of every user's final K-th value (other item shards)
     int n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, n_tiles;
     int warm_tiles;              // 1 .. kWarmTiles: 64-item tiles per split scored exactly by warm4_kernel
+    int warm_sorted;             // the warm-up hands its lists over sorted (phase 1 alone: pda_topk_kth_value reads ranks) or as they are
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -306,7 +307,7 @@ __device__ __forceinline__ int split_tiles(int n_tiles, int split, int n_splits)
 // when a threshold may have changed.
 template <int CAP, bool GLB = false>
 __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t key, uint64_t* lists, int* cntl, float* taul, int row0,
-                                            int n_rows, int K, int lane) {
+                                            int n_rows, int K, int lane, unsigned* uns = nullptr) {
     bool changed = false;
     for (;;) {
         bool ov = false;
@@ -322,7 +323,8 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
             while (full) {
                 const int rr = base + __builtin_ctzll(full);
                 full &= full - 1ull;
-                compact_list<CAP, GLB>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+                compact_list<CAP, GLB>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane,
+                                       uns ? &uns[(row0 + rr) >> 5] : nullptr, 1u << ((row0 + rr) & 31));
             }
         }
         changed = true;
@@ -516,7 +518,8 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
         };
         int c_t = count_ge(1u);
         uint32_t t = 1u;
-        const bool need = c_t > CAP;
+        const int cap_t = g.warm_sorted ? CAP : K;          // unsorted hand-over: exactly K survivors (out_keys has K slots per row)
+        const bool need = c_t > cap_t;
         if (__any(need)) {
             // bisection between the row's smallest and largest score in the ordered-uint domain (~ the log domain for
             // positive scores: a handful of steps for smooth or heavy-tailed scores, <= 32 always); invariant:
@@ -536,7 +539,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
             uint32_t hi = mx + 1u;                                   // (mx < 0xFFFFFFFF: NaNs are not candidates)
             if (need) t = mn;
             for (int it = 0; it < 40; ++it) {
-                const bool open = need && c_t > CAP && hi - t > 1u;
+                const bool open = need && c_t > cap_t && hi - t > 1u;
                 if (!__any(open)) break;
                 const uint32_t mid = open ? t + ((hi - t) >> 1) : t;
                 const int cnt = count_ge(mid);
@@ -550,7 +553,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
                 }
             }
         }
-        if (__any(c_t > CAP)) {
+        if (__any(c_t > cap_t)) {
 #pragma unroll
             for (int k = 0; k < NHT; ++k) {
                 const bool p = ordv[k][r] >= t;
@@ -575,8 +578,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * nwarm));
     for (int rr = 0; rr < 32; ++rr) {
         uint64_t* buf = my_lists + rr * CAP;
-        if constexpr ((PDA_W4_ABL & 4) == 0)
-        compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
+        // sorted hand-over, or a row that went through the general append path (ties at its K-th value) and may hold more than K
+        if (((PDA_W4_ABL & 4) == 0) && (g.warm_sorted || __builtin_amdgcn_readfirstlane(cntl[wave * 32 + rr]) > K))
+            compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
         const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
         if (rb < g.n_users_blk && lane < K) {
@@ -679,6 +683,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     unsigned* s_done = sync + 28;             // [8]  MFMA wave w has pushed its last candidate
     unsigned* s_tver = sync + 36;             // [8]  bumped by the rescoring wave whenever a threshold of wave w's rows rose
     unsigned* s_vote = sync + 44;             // [8][8]  early termination votes about tile it & 7
+    unsigned* s_uns = sync + 112;             // [16]  one bit per user row: its list came in unsorted and has not been compacted yet
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -744,12 +749,16 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane];
             const int c = __popcll(__ballot(key != 0ull));
             if (lane < K) my_lists[(size_t)rr * kCap4 + lane] = key;
-            const uint64_t kth = pda_readlane_u64(key, K - 1);
+            // the list may come in unsorted (the warm-up of a fused call does not sort): its K-th value is the smallest key
+            uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
             if (lane == 0) {
                 cntl[row0 + rr] = c;
-                taul[row0 + rr] = rb < g.n_users_blk ? (c >= K ? pda_key_val(kth) : -INFINITY) : INFINITY;
+                taul[row0 + rr] = rb < g.n_users_blk ? (c >= K ? pda_unordf(mn) : -INFINITY) : INFINITY;
             }
         }
+        if (lane < (RR + 31) / 32) s_uns[(row0 >> 5) + lane] = 0xFFFFFFFFu;            // (rows are owned in multiples of 32)
         if constexpr (GL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         unsigned head[kMPR], n_cand = 0;
@@ -759,6 +768,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         constexpr int CPP = 64 / LPC;               // candidates per pass
         const int q = lane % LPC, ci = lane / LPC;
         int sel = 0;                                // the ring looked at last
+        int next_sort = 0;                          // rows [0, next_sort) have been sorted in idle time
         unsigned idle = 0;
         PROF_T0(tr0);
         for (;;) {
@@ -781,6 +791,14 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             }
             if (pick < 0) {
                 if (dn) break;
+                if (next_sort < RR) {
+                    // nothing to rescore: put one more of the lists that came in unsorted in order (it has to be sorted for the
+                    // output anyway; done here it costs nothing, done behind the sweep it is a serial tail of the launch)
+                    const int rr = next_sort++;
+                    compact_list<kCap4, GL>(my_lists + (size_t)rr * kCap4, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5],
+                                            1u << ((row0 + rr) & 31));
+                    continue;
+                }
                 if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
                 PROF_T0(ti);
                 __builtin_amdgcn_s_sleep(PDA_V4_RSLEEP);
@@ -874,7 +892,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 }
             }
             const uint64_t key = pda_pack_key(tt, (uint32_t)item);
-            const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane);
+            const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns);
             if (changed && lane == 0) __hip_atomic_fetch_add(&s_tver[kMPR * r + sel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         PROF_T1(tr0, 6);
@@ -884,7 +902,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         // finalise: the lists are exact; sort and emit
         for (int rr = 0; rr < RR; ++rr) {
             uint64_t* buf = my_lists + (size_t)rr * kCap4;
-            compact_list<kCap4, GL>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane);
+            compact_list<kCap4, GL>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5], 1u << ((row0 + rr) & 31));
             const int c = cntl[row0 + rr];
             const int rb = utile * UT + row0 + rr;
             if (rb < g.n_users_blk && lane < K) {
@@ -1368,7 +1386,13 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) + lists_offset4(n_users_blk)), nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles};
+            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) + lists_offset4(n_users_blk)), nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
+            // sorted hand-over when nobody sorts behind the warm-up: phase 1 alone, or a catalogue that ends inside the warm-up
+#ifdef PDA_V4_WARM_SORTED
+            1};
+#else
+            (phase == 1 || (L.n_tiles + n_splits - 1) / n_splits <= warm_tiles) ? 1 : 0};
+#endif
     if (hist_indptr && (phase & 2)) {
         // the workspace ends with the Bloom filters (pda_score_topk4_workspace_bytes with THIS n_splits)
         const size_t total = pda_score_topk4_workspace_bytes(n_users_blk, n_items_local, d, n_splits);

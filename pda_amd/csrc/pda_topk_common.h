@@ -124,10 +124,20 @@ __device__ __forceinline__ void list_sync() {
 }
 
 template <int CAP = kCap, bool GLB = false>
-__device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane) {
+// flag_word / flag_bit (optional): a set bit says "this list came in UNSORTED" (generation 4 hands its warm-up lists over
+// unsorted): the incremental path is off until the list has been through one full compaction, which clears the bit.
+__device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane, unsigned* flag_word = nullptr,
+                                             unsigned flag_bit = 0u) {
     list_sync<GLB>();
     const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), CAP);   // failed appends may have pushed it past kCap
-    const bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
+    bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
+    if (flag_word != nullptr) {
+        const unsigned fw = __builtin_amdgcn_readfirstlane(*flag_word);
+        if (fw & flag_bit) {
+            sorted_prefix = false;
+            if (lane == 0) *flag_word = fw & ~flag_bit;
+        }
+    }
     uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);  // fillers: unique, below any real key
     int rank;
     // First compaction of a row (all <= 59 keys against each other): the keys to rank against come from LDS as broadcast
