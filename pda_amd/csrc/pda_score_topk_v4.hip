@@ -692,7 +692,28 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - g.warm_tiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
     const int n_blk = NB > 2 ? (2 * n_it) / NB : n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
-    if (tid < 128) sync[tid] = 0u;
+    if (tid < 128) sync[tid] = tid >= 112 ? 0xFFFFFFFFu : 0u;       // (words 112 .. 127: every list comes in unsorted, see s_uns)
+    // The lists of the warm-up -> LDS (or the workspace), their counts and K-th values: ALL waves share the rows (the MFMA
+    // waves wait for the thresholds behind the barrier: 64 rows per rescoring wave, one after the other, were 50 us of every
+    // workgroup's life -- 13 % of an early-terminating sweep).  A list may come in unsorted: its K-th value is the smallest key.
+    {
+        constexpr int NW = G::WAVES;
+        for (int rr = wave; rr < UT; rr += NW) {
+            const int rb = utile * UT + rr;
+            uint64_t key = 0ull;
+            if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane];
+            const int c = __popcll(__ballot(key != 0ull));
+            if (lane < K) lists[(size_t)rr * kCap4 + lane] = key;
+            uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            if (lane == 0) {
+                cntl[rr] = c;
+                taul[rr] = rb < g.n_users_blk ? (c >= K ? pda_unordf(mn) : -INFINITY) : INFINITY;
+            }
+        }
+        if constexpr (GL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
 #ifdef PDA_V4_PROF
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -743,22 +764,6 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 hev[s2] = g.hist_indptr[hr + 1];
             }
         }
-        for (int rr = 0; rr < RR; ++rr) {
-            const int rb = utile * UT + row0 + rr;
-            uint64_t key = 0ull;
-            if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane];
-            const int c = __popcll(__ballot(key != 0ull));
-            if (lane < K) my_lists[(size_t)rr * kCap4 + lane] = key;
-            // the list may come in unsorted (the warm-up of a fused call does not sort): its K-th value is the smallest key
-            uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-            if (lane == 0) {
-                cntl[row0 + rr] = c;
-                taul[row0 + rr] = rb < g.n_users_blk ? (c >= K ? pda_unordf(mn) : -INFINITY) : INFINITY;
-            }
-        }
-        if (lane < (RR + 31) / 32) s_uns[(row0 >> 5) + lane] = 0xFFFFFFFFu;            // (rows are owned in multiples of 32)
         if constexpr (GL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
         unsigned head[kMPR], n_cand = 0;
