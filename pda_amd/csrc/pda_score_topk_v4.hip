@@ -904,21 +904,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         PROF_INC(9, n_cand);
         PROF_FLUSH(6, 9);
         if (lane == 0) atomicAdd(g.stats + 1, n_cand);
-        // finalise: the lists are exact; sort and emit
-        for (int rr = 0; rr < RR; ++rr) {
-            uint64_t* buf = my_lists + (size_t)rr * kCap4;
-            compact_list<kCap4, GL>(buf, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5], 1u << ((row0 + rr) & 31));
-            const int c = cntl[row0 + rr];
-            const int rb = utile * UT + row0 + rr;
-            if (rb < g.n_users_blk && lane < K) {
-                const uint64_t k = lane < c ? buf[lane] : 0ull;
-                g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
-            }
-        }
-        return;
-    }
-
-    if (wave >= kMainWaves) {
+    } else if (wave >= kMainWaves) {
         // ================================== loader ==================================
         // Issued through inline asm: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
         // s_waitcnt vmcnt(0) in front of the next ds_read of ANY address (the hand-over polls): the loads would be
@@ -989,9 +975,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             if (!stop) lds_st(&s_landed[l], (unsigned)n_blk);
         }
         PROF_FLUSH(10, 12);
-        return;
-    }
-
+    } else {
     // ================================== MFMA wave ==================================
     const int w = wave;
     const int j = lane & 31, h = lane >> 5;
@@ -1314,6 +1298,22 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     lds_st(&s_done[w], 1u);
     if (stopped) lds_st(s_stop, 1u);
     if (lane == 0 && w == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * n_done * (UT / kUserTile)));
+    }
+    // ================================== all waves: sort and emit ==================================
+    // Behind this barrier every candidate has been rescored and nobody appends any more (the rescoring waves arrive last).  The
+    // lists are exact; what is left is their order -- rows the rescoring waves did not get to in their idle time -- and the
+    // copy out: shared by all waves (64 rows per rescoring wave, one after the other, were the tail of every workgroup).
+    __syncthreads();
+    for (int rr = wave; rr < UT; rr += G::WAVES) {
+        uint64_t* buf = lists + (size_t)rr * kCap4;
+        compact_list<kCap4, GL>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
+        const int c = cntl[rr];
+        const int rb = utile * UT + rr;
+        if (rb < g.n_users_blk && lane < K) {
+            const uint64_t k = lane < c ? buf[lane] : 0ull;
+            g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+        }
+    }
 }
 
 template <int D, int HEAD, bool BF>
