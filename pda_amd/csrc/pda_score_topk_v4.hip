@@ -1380,7 +1380,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (K > kCap4 - 3) return PDA_ERR_UNSUPPORTED;
     if ((uint64_t)n_items_local > (1ull << 26)) return PDA_ERR_UNSUPPORTED;          // ring words: 6-bit row, 26-bit local item id
     if (warm_tiles < 0 || warm_tiles > kWarmTiles) return PDA_ERR_ARG;
-    if (warm_tiles == 0) warm_tiles = kWarmTiles;
+#ifndef PDA_V4_WARM_DEFAULT
+#define PDA_V4_WARM_DEFAULT kWarmTiles
+#endif
+    if (warm_tiles == 0) warm_tiles = d <= 128 ? PDA_V4_WARM_DEFAULT : kWarmTiles;
     if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
     const Prep4Layout L = prep4_layout(n_items_local, d);
     const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
