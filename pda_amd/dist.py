@@ -255,7 +255,9 @@ class ItemShardedBPR:
         all_gather_into_tensor   the only collective: B_local * (d + 4) * 4 bytes per rank (RCCL over xGMI)
         pda_apply_user_grads_f32 every rank applies all R * B_local user gradients -> the replicas of U stay identical
 
-    which equals one fused SGD step of the single-GPU kernel on the concatenated batch (tests/test_gpu_bpr_step.py).
+    which equals one fused SGD step of the single-GPU kernel on the concatenated batch (tests/test_gpu_bpr_step.py) -- like that
+    step, the item rows take their updates inside the launch that still gathers them (hogwild within a batch: include/pda_hip.h,
+    PDA_UPD_SGD_FUSED); optimizer="adam" accumulates first and is exact.
     The exchange is latency-bound (tens of microseconds against a ~9 us step at B=2048): item-parallel training buys
     capacity, not speed -- every BASELINE config fits one MI355X (288 GB), hence bench.py trains on one GPU.
 

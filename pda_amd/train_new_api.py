@@ -201,8 +201,17 @@ class evaluation:
         self.eval_who = eval_who
 
     def set_testing_popularity(self, popularity):
+        """MF/train_new_api.py:710.  The reference indexes testing_popularity[range(ITEM_NUM)] (:788): a vector longer than the
+        catalogue is cut to n_items here, a shorter one is an error (there: IndexError at the first evaluation)."""
         self.testing_popularity = popularity
-        self._pop_dev = None if popularity is None else torch.as_tensor(np.asarray(popularity, dtype=np.float32), device=self.device)
+        if popularity is None:
+            self._pop_dev = None
+            return
+        pop = np.asarray(popularity, dtype=np.float32).reshape(-1)
+        n = self.data.n_items
+        if pop.shape[0] < n:
+            raise IndexError("testing popularity has %d entries for %d items" % (pop.shape[0], n))
+        self._pop_dev = torch.as_tensor(np.ascontiguousarray(pop[:n]), device=self.device)
 
     def set_evaluate_obj_pre(self, eval_who="test"):
         """Evaluation users (file order), their targets as CSR, and the train-history mask (:713-739).
