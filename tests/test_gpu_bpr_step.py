@@ -711,6 +711,44 @@ def test_training_steps_in_one_launch(dev, d):
     assert not torch.equal(ref[0], U0)
 
 
+def test_training_steps_in_one_launch_large_batch(dev):
+    """B = 16 384 at d = 64: 512 step tiles and 256 sampler tiles on a grid of 384 + 64 workgroups -- every workgroup strides
+    over several tiles per step.  Per-step losses (a missing tile would lower them by 1/512), the sampled batches and the
+    counter equal the launch-per-step sequence; tables to fp32-atomics accuracy."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload("c2", dev)
+    B, regs, lr, seed, n = 16384, 1e-2, 0.05, 321, 3
+    kw = dict(n_pool=W.n_users, train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train)
+
+    def mk():
+        return (torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, dtype=torch.int32, device=dev),
+                torch.empty(B, dtype=torch.int32, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev))
+    out = []
+    for looped in (False, True):
+        U, I, bufs = W.U.clone(), W.I.clone(), [mk(), mk()]
+        ctr = torch.tensor([11], dtype=torch.int64, device=dev)
+        ops.sample_triplets_into(bufs[0], W.hist_indptr, W.hist_indices, seed=seed, step_dev=ctr, **kw)
+        losses = torch.zeros((n, 3), device=dev)
+        if looped:
+            _, ws = ops.bpr_train_steps(U, I, bufs, n, regs=regs, reg_div=B, lr=lr, train_indptr=W.hist_indptr, train_indices=W.hist_indices,
+                                        seed=seed, step_ctr=ctr, loss_steps=losses, **kw)
+            assert int(ws[1]) == 0
+        else:
+            for i in range(n):
+                ops.bpr_step(U, I, *bufs[i & 1], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=losses[i])
+                ops.sample_triplets_into(bufs[(i + 1) & 1], W.hist_indptr, W.hist_indices, seed=seed, step_dev=ctr, **kw)
+        torch.cuda.synchronize()
+        out.append((U, I, bufs, int(ctr), losses))
+    ref, got = out
+    assert got[3] == ref[3] == 12 + n
+    for a, b in zip(got[2][0] + got[2][1], ref[2][0] + ref[2][1]):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(got[4].cpu().numpy(), ref[4].cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(got[0].cpu().numpy(), ref[0].cpu().numpy(), rtol=0, atol=5e-6)
+    np.testing.assert_allclose(got[1].cpu().numpy(), ref[1].cpu().numpy(), rtol=0, atol=5e-5)       # hot item rows: hogwild within a step
+    assert float((got[1] - W.I).abs().max()) > 1e-8              # (updates are lr x gradient / B: tiny at this batch size)
+
+
 def test_two_table_adam_sweep_equals_two_sweeps(dev):
     """pda_adam_dense_sweep2_f32 is the arithmetic of two pda_adam_dense_sweep_f32 calls, bit for bit (sizes that do not split
     evenly over the workgroups, sparse gradients, the accumulators zeroed)."""
