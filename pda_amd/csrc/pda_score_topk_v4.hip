@@ -79,6 +79,7 @@ struct Args4 {
     const int* pos_of;           // [n_items_local] local id -> visiting position, or NULL: identity
     unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
     uint64_t* lists_ws;          // list slots of the workgroups whose lists live in HBM (Geo4::GL): [workgroup][UT][kCap4]
+    const uint32_t* hmask_ws;    // [workgroups of warm4_kernel][128][2 kWarmTiles]: train-item bits of the warm positions, or NULL
     const uint32_t* bloom;       // [n_users_blk][32]: 1024-bit Bloom filter (two hashes) of every block row's train items, or NULL
     const int* prep_hdr;         // header of the item prep: word 2 = built with a visiting order
     const float* seed;           // [n_users_blk] or NULL: an external LOWER bound of every user's final K-th value (other item shards)
@@ -333,45 +334,9 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
     return changed;
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// warm-up: the first kWarmTiles tiles of every split, exact (fp32 matrix cores, k order of v1), lists -> out_keys
-// ---------------------------------------------------------------------------------------------------------------------
-template <int D, int HEAD, bool BF>
-__global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Args4 g) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int RB = row_bytes(D);
-    constexpr int NC = D / 8;                 // k-chunks of 8
-    constexpr int CPR4 = D / 4;               // 16-byte chunks per fp32 row
-    constexpr int NLD4 = (32 * CPR4) / kThreads;
-    constexpr int CAP = kCap4;
-    float* Bt = reinterpret_cast<float*>(smem);                                              // [32][D] fp32, swizzled
-    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 32 * D * 4);                        // [128][CAP]
-    int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * CAP);                     // [128]
-    float* taul = reinterpret_cast<float*>(cntl + kUserTile);                                // [128]
-    unsigned* hmask = reinterpret_cast<unsigned*>(taul + kUserTile);                         // [128][2 kWarmTiles]
-    float* popw = reinterpret_cast<float*>(hmask + kUserTile * 2 * kWarmTiles);              // [32]
-    int* idw = reinterpret_cast<int*>(popw + 32);                                            // [32]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
-    const int K = g.K;
-    const int nt = split_tiles(g.n_tiles, split, g.n_splits);
-    const int nwarm = min(g.warm_tiles, nt);
-
-    const int row_blk = utile * kUserTile + wave * 32 + j;
-    const bool row_ok = row_blk < g.n_users_blk;
-    const int uid = row_ok ? g.users[row_blk] : 0;
-
-    if (lane < 32) {
-        cntl[wave * 32 + lane] = 0;
-        taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
-    }
-    for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = 0u;
-    __syncthreads();
-    // train items among the warm positions: a wave walks the histories of its 32 rows, 64 entries of a row per step and four
-    // rows in flight (two dependent loads per entry: the id, its visiting position)
-    if (g.hist_indptr != nullptr && !(PDA_W4_ABL & 1)) {
+// Train items among the warm positions of a 128-user tile -> bit masks [128][2 kWarmTiles] in LDS: a wave walks the histories of
+// its 32 rows, 64 entries of a row per step and four rows in flight (two dependent loads per entry: the id, its visiting position).
+__device__ __forceinline__ void warm_hist_walk(const Args4& g, unsigned* hmask, int utile, int split, int nwarm, int wave, int lane) {
         long long hb_l = 0, he_l = 0;
         {
             const int rb = utile * kUserTile + wave * 32 + (lane & 31);
@@ -418,6 +383,65 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
                 }
             }
         }
+}
+
+// The same as a kernel of its own (grid and workgroup = warm4_kernel's): at eight waves per SIMD the two dependent, mostly missing
+// loads per train item are hidden; inside warm4_kernel (256 VGPRs, two waves per SIMD) they were a quarter of its time.
+__global__ void __launch_bounds__(kThreads) warm_mask4_kernel(Args4 g, uint32_t* __restrict__ out) {
+    __shared__ unsigned hmask[kUserTile * 2 * kWarmTiles];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    const int nwarm = min(g.warm_tiles, split_tiles(g.n_tiles, split, g.n_splits));
+    for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = 0u;
+    __syncthreads();
+    warm_hist_walk(g, hmask, utile, split, nwarm, wave, lane);
+    __syncthreads();
+    uint32_t* dst = out + (size_t)blockIdx.x * kUserTile * 2 * kWarmTiles;
+    for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) dst[q] = hmask[q];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// warm-up: the first kWarmTiles tiles of every split, exact (fp32 matrix cores, k order of v1), lists -> out_keys
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, int HEAD, bool BF>
+__global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Args4 g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int RB = row_bytes(D);
+    constexpr int NC = D / 8;                 // k-chunks of 8
+    constexpr int CPR4 = D / 4;               // 16-byte chunks per fp32 row
+    constexpr int NLD4 = (32 * CPR4) / kThreads;
+    constexpr int CAP = kCap4;
+    float* Bt = reinterpret_cast<float*>(smem);                                              // [32][D] fp32, swizzled
+    uint64_t* lists = reinterpret_cast<uint64_t*>(smem + 32 * D * 4);                        // [128][CAP]
+    int* cntl = reinterpret_cast<int*>(lists + (size_t)kUserTile * CAP);                     // [128]
+    float* taul = reinterpret_cast<float*>(cntl + kUserTile);                                // [128]
+    unsigned* hmask = reinterpret_cast<unsigned*>(taul + kUserTile);                         // [128][2 kWarmTiles]
+    float* popw = reinterpret_cast<float*>(hmask + kUserTile * 2 * kWarmTiles);              // [32]
+    int* idw = reinterpret_cast<int*>(popw + 32);                                            // [32]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    const int K = g.K;
+    const int nt = split_tiles(g.n_tiles, split, g.n_splits);
+    const int nwarm = min(g.warm_tiles, nt);
+
+    const int row_blk = utile * kUserTile + wave * 32 + j;
+    const bool row_ok = row_blk < g.n_users_blk;
+    const int uid = row_ok ? g.users[row_blk] : 0;
+
+    if (lane < 32) {
+        cntl[wave * 32 + lane] = 0;
+        taul[wave * 32 + lane] = row_ok ? -INFINITY : INFINITY;
+    }
+    for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = 0u;
+    __syncthreads();
+    // train items among the warm positions: precomputed by warm_mask4_kernel (hmask_ws), or walked here
+    if (g.hmask_ws != nullptr) {
+        const uint32_t* src = g.hmask_ws + (size_t)blockIdx.x * kUserTile * 2 * kWarmTiles;
+        for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = src[q];
+    } else if (g.hist_indptr != nullptr && !(PDA_W4_ABL & 1)) {
+        warm_hist_walk(g, hmask, utile, split, nwarm, wave, lane);
     }
     f32x4 areg[NC];
 #pragma unroll
@@ -1353,17 +1377,29 @@ int user_tile4(int d) { return d == 64 ? Geo4<64>::UT : d == 128 ? Geo4<128>::UT
 static bool lists_in_hbm4(int d) { return d == 64 ? Geo4<64>::GL : d == 128 ? Geo4<128>::GL : Geo4<256>::GL; }
 // the workspace of the pda_score_topk4_* calls: the counters of pda_score_topk_workspace_bytes, then (workgroups of 512 users:
 // d <= 128) the list slots of every workgroup
-static size_t lists_offset4(int n_users_blk) { return (pda_score_topk_workspace_bytes(n_users_blk) + 255) & ~(size_t)255; }
-extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
-    if (n_users_blk <= 0 || n_items_local <= 0 || (d != 64 && d != 128 && d != 256)) return 0;
-    if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
-    size_t b = lists_offset4(n_users_blk);
+// the workspace of the pda_score_topk4_* calls: [counters of pda_score_topk_workspace_bytes | list slots of every workgroup when the
+// lists live in HBM | Bloom filters, 128 B per user | warm-position train-item masks, 32 B per user and split]
+struct Ws4 {
+    size_t lists, bloom, hmask, total;
+};
+static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    Ws4 w{};
+    w.lists = al(pda_score_topk_workspace_bytes(n_users_blk));
+    size_t b = w.lists;
     if (lists_in_hbm4(d)) {
         const size_t ut = (size_t)user_tile4(d);
         b += ((size_t)n_users_blk + ut - 1) / ut * (size_t)n_splits * ut * kCap4 * 8 + 256;
     }
-    b = (b + 255) & ~(size_t)255;
-    return b + (size_t)n_users_blk * 128;          // the Bloom filters of the block rows' train items
+    w.bloom = al(b);
+    w.hmask = al(w.bloom + (size_t)n_users_blk * 128);
+    w.total = w.hmask + ((size_t)n_users_blk + kUserTile - 1) / kUserTile * (size_t)n_splits * kUserTile * 2 * kWarmTiles * 4;
+    return w;
+}
+extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
+    if (n_users_blk <= 0 || n_items_local <= 0 || (d != 64 && d != 128 && d != 256)) return 0;
+    if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
+    return ws4_layout(n_users_blk, d, n_splits).total;
 }
 
 int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
@@ -1388,13 +1424,15 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     const Prep4Layout L = prep4_layout(n_items_local, d);
     const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
     if ((phase & 1) && hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
+    const Ws4 W = ws4_layout(n_users_blk, d, n_splits);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
     const float* sA = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufA : L.sufB));
     const float* sB = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufB : L.sufR));
     // raw head: bound = ||u|| max ||i||: sufA := 0 is not stored -- the raw-head vote uses (sufB' = sufR, sufA' = 0) through
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(reinterpret_cast<unsigned char*>(workspace) + lists_offset4(n_users_blk)), nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
+            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(wsb + W.lists), nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
             // sorted hand-over when nobody sorts behind the warm-up: phase 1 alone, or a catalogue that ends inside the warm-up
 #ifdef PDA_V4_WARM_SORTED
             1};
@@ -1402,13 +1440,20 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
             (phase == 1 || (L.n_tiles + n_splits - 1) / n_splits <= warm_tiles) ? 1 : 0};
 #endif
     if (hist_indptr && (phase & 2)) {
-        // the workspace ends with the Bloom filters (pda_score_topk4_workspace_bytes with THIS n_splits)
-        const size_t total = pda_score_topk4_workspace_bytes(n_users_blk, n_items_local, d, n_splits);
-        uint32_t* bloom = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + total - (size_t)n_users_blk * 128);
+        uint32_t* bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
         hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,
                            hist_row_mode, n_users_blk, bloom, reinterpret_cast<const int*>(pb + L.hdr), head == PDA_HEAD_POP ? 1 : 0);
         PDA_CHECK_LAUNCH();
         g.bloom = bloom;
+    }
+    if (hist_indptr && (phase & 1) && n_users_blk >= 98304) {
+        // the train-item bits of the warm positions, by a kernel of its own (see warm_mask4_kernel) -- where it pays for its launch:
+        // 1.35 -> 1.29 ms per early-terminating sweep of 262 144 users, but 0.267 -> 0.277 ms at 50 000
+        uint32_t* hm = reinterpret_cast<uint32_t*>(wsb + W.hmask);
+        const int utiles = (n_users_blk + kUserTile - 1) / kUserTile;
+        hipLaunchKernelGGL(warm_mask4_kernel, dim3((unsigned)(utiles * n_splits)), dim3(kThreads), 0, s, g, hm);
+        PDA_CHECK_LAUNCH();
+        g.hmask_ws = hm;
     }
     if (head == PDA_HEAD_RAW) {
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep

@@ -602,6 +602,24 @@ def test_full_size_c3_sweep_modes_agree(dev, impl):
     assert torch.equal(exact, out["natural"][:2048])
     idx, val = ops.unpack_keys(out["stop"][:64])
     assert (np.diff(val, axis=1) <= 0).all() and (idx >= 0).all() and (idx < W.n_items).all()
+    # a block of the size the product evaluates (131 072 users: the warm-up's train-item masks come from their own kernel from
+    # 98 304 users on), both kernel generations, early-terminating and dense in visiting order
+    big = torch.arange(200_000, 200_000 + 131072, dtype=torch.int32, device=dev)
+    got = {}
+    old = os.environ.get("PDA_SCORE_KERNEL")
+    try:
+        for kern in ("v3", "v4"):
+            os.environ["PDA_SCORE_KERNEL"] = kern
+            for prune in (True, "order"):
+                got[(kern, prune)] = ops.topk_merge(ops.score_topk_keys(W.U, W.I, big, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
+    finally:
+        if old is None:
+            os.environ.pop("PDA_SCORE_KERNEL", None)
+        else:
+            os.environ["PDA_SCORE_KERNEL"] = old
+    ref = got[("v3", True)]
+    for k, v in got.items():
+        assert torch.equal(ref, v), k
 
 
 def test_full_size_c5_shard_bf16(dev, impl):
