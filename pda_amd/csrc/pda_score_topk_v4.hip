@@ -1148,6 +1148,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     constexpr int S = NB * NM, PF = S < PDA_V4_PF ? S : PDA_V4_PF;
     constexpr bool PFX = NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
     u32x4 bq[PF];
+    int dead_from = 0x7FFFFFFF;                // first tile from which no row of this wave can be reached (early termination)
     for (int b = 0; b < n_blk && !stopped; ++b) {
         const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
         // ---- early termination.  In front of the last block of tile i every wave votes "nothing at or behind tile i + kVL
@@ -1163,6 +1164,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 #pragma unroll
             for (int u = 0; u < UA; ++u) dead = dead && (__builtin_fmaf(nu_row[u], sb_nx, sa_nx) * 1.000002f < thr_own[u]);
             const bool alldead = __all(dead);
+            if (alldead && dead_from > it + kVL) dead_from = it + kVL;          // (suffix bounds: dead for every later tile as well)
             if (lane == 0) lds_st(&s_vote[(it & 7) * kMainWaves + w], alldead ? 1u : 0u);
             // the bounds of the next vote: loaded a tile ahead
             const int inx = it + kVoteEvery + kVL;
@@ -1170,6 +1172,24 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             sa_nx = g.sufA[tn];               // (no use before the next vote: the loads stay in flight over the block)
             sb_nx = g.sufB[tn];
             nx_ok = inx < n_it;
+        }
+        // A wave none of whose rows anything can reach any more stops scoring: it keeps in step with the others (landing, votes,
+        // release) and leaves the matrix pipe of its SIMD to the wave that still has live rows -- the workgroup as a whole
+        // goes on until every wave is dead, i.e. for its slowest user.
+        if (g.sufA != nullptr && it >= dead_from) {
+            ensure_landed(b);
+            if (tile_first && it >= kVL && ((it - kVL) & (kVoteEvery - 1)) == kVoteEvery - 1) {
+                const unsigned* v = &s_vote[((it - kVL) & 7) * kMainWaves];
+                unsigned all = 1u;
+#pragma unroll
+                for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
+                stopped = all != 0u;
+            }
+            PDA_CBAR();
+            lds_st(&s_released[w], (unsigned)(b + 1));
+            PDA_CBAR();
+            if (!(NB == 1 && (b & 1) == 0)) ++n_done;
+            continue;
         }
         // With three slots the first B fragments of block b + 1 are read while the MFMAs of block b are still being issued: the
         // wave comes back from the accumulator test of block b with its operands in registers.
