@@ -683,7 +683,9 @@ struct Geo4 {
     static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
 };
 
-template <int D, int HEAD, bool BF>
+// ES: exact early termination on (sufA / sufB non-NULL).  Two instantiations: the votes and the dead-wave path are a handful of
+// instructions, but their presence in the loop cost the DENSE sweep 6 % at d = 256 (register allocation of the prefetched loop).
+template <int D, int HEAD, bool BF, bool ES>
 __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     using G = Geo4<D>;
     constexpr int kLoaders = G::LOADERS, kMPR = G::MPR;
@@ -1139,7 +1141,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     constexpr int kVoteEvery = PDA_V4_VOTE_EVERY;      // a vote in front of every kVoteEvery-th tile (1, 2 or 4)
     constexpr int kVL = (NSLOT + 2) / 2;               // a vote is about the tile kVL behind the one it is stored in front of
     float sa_nx = 0.0f, sb_nx = 0.0f;          // suffix bounds at tile it + kVL of the coming vote
-    bool nx_ok = g.sufA != nullptr && kVoteEvery - 1 + kVL < n_it;
+    bool nx_ok = ES && kVoteEvery - 1 + kVL < n_it;
     if (nx_ok) {
         const int tn = split + (g.warm_tiles + kVoteEvery - 1 + kVL) * g.n_splits;
         sa_nx = g.sufA[tn];
@@ -1159,7 +1161,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         // of tile i are written again for tile i + 8: by then every wave has released block 2 i + 17 - NSLOT, far behind.
         const int it = (b * NB) >> 1;
         const bool tile_first = NB == 2 || (b & 1) == 0, tile_last = NB == 2 || (b & 1) == 1;
-        if (g.sufA != nullptr && tile_last && (it & (kVoteEvery - 1)) == kVoteEvery - 1) {
+        if (ES && tile_last && (it & (kVoteEvery - 1)) == kVoteEvery - 1) {
             bool dead = nx_ok;
 #pragma unroll
             for (int u = 0; u < UA; ++u) dead = dead && (__builtin_fmaf(nu_row[u], sb_nx, sa_nx) * 1.000002f < thr_own[u]);
@@ -1176,7 +1178,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         // A wave none of whose rows anything can reach any more stops scoring: it keeps in step with the others (landing, votes,
         // release) and leaves the matrix pipe of its SIMD to the wave that still has live rows -- the workgroup as a whole
         // goes on until every wave is dead, i.e. for its slowest user.
-        if (g.sufA != nullptr && it >= dead_from) {
+        if (ES && it >= dead_from) {
             ensure_landed(b);
             if (tile_first && it >= kVL && ((it - kVL) & (kVoteEvery - 1)) == kVoteEvery - 1) {
                 const unsigned* v = &s_vote[((it - kVL) & 7) * kMainWaves];
@@ -1270,7 +1272,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         }
         // (the votes about this tile, read while the MFMAs run and BEFORE the release -- a wave that sees it may store its vote
         // four tiles on into the same words; the block is finished either way)
-        if (g.sufA != nullptr && tile_first && it >= kVL && ((it - kVL) & (kVoteEvery - 1)) == kVoteEvery - 1) {
+        if (ES && tile_first && it >= kVL && ((it - kVL) & (kVoteEvery - 1)) == kVoteEvery - 1) {
             const unsigned* v = &s_vote[((it - kVL) & 7) * kMainWaves];
             unsigned all = 1u;
 #pragma unroll
@@ -1381,13 +1383,18 @@ int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = 
     if (phase & 2) {
         static int attr_set = 0;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)G::lds_total) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)G::lds_total) != hipSuccess)
                 return PDA_ERR_LAUNCH;
             attr_set = 1;
         }
         const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+        if (g.sufA != nullptr)
+            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+        else
+            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
         PDA_CHECK_LAUNCH();
     }
     return PDA_OK;

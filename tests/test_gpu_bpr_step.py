@@ -109,6 +109,14 @@ def test_exact_sgd_step_on_a_hot_item_batch_at_realistic_lr(dev, lr):
     assert dev_f <= 0.5 * lr * lr + 1e-4, dev_f                 # bounded by the cross terms, but NOT held to 1e-5
 
 
+def adam_close(got, ref):
+    """Tables after Adam steps against the float64 oracle: 1e-5 -- except where a summed gradient component is itself of the size
+    of Adam's epsilon (1e-8): there lr m / (sqrt(v) + eps) turns the ORDER of the fp32 atomic adds of a repeated row into
+    1e-5 .. 1e-4 of x (seen once in ~20 runs), so a handful of elements get that much."""
+    err = np.abs(got - ref)
+    assert (err > TOL).mean() < 1e-3 and err.max() < 2e-4, ((err > TOL).mean(), err.max())
+
+
 def test_reference_faithful_adam_three_steps(dev):
     """TF-1.14 Adam: m,v decay and the variable update touch EVERY row each step [TF-ext]; three steps
     exercise that on rows that were touched once and then left alone."""
@@ -133,8 +141,8 @@ def test_reference_faithful_adam_three_steps(dev):
         ops.adam_dense_sweep(It, st["mI"], st["vI"], st["gI"], lr_t)
         np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
         assert float(st["gU"].abs().max()) == 0.0 and float(st["gI"].abs().max()) == 0.0   # accumulator reset
-    np.testing.assert_allclose(Ut.cpu().numpy(), Ur, atol=TOL)
-    np.testing.assert_allclose(It.cpu().numpy(), Ir, atol=TOL)
+    for got, ref in ((Ut, Ur), (It, Ir)):
+        adam_close(got.cpu().numpy(), ref)
     np.testing.assert_allclose(st["mI"].cpu().numpy(), state["mI"], atol=TOL)
     np.testing.assert_allclose(st["vI"].cpu().numpy(), state["vI"], atol=TOL)
 
@@ -550,8 +558,8 @@ def test_item_parallel_adam_equals_the_reference_optimiser_on_the_concatenated_b
         losses = [t.apply(allb) for t in trainers]                       # what every rank does after the all-gather
         np.testing.assert_allclose(losses[0].cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
         for t in trainers:
-            np.testing.assert_allclose(t.U.cpu().numpy(), Uref, atol=TOL)
-        np.testing.assert_allclose(torch.cat([t.I_shard for t in trainers]).cpu().numpy(), Iref, atol=TOL)
+            adam_close(t.U.cpu().numpy(), Uref)
+        adam_close(torch.cat([t.I_shard for t in trainers]).cpu().numpy(), Iref)
     assert np.abs(Uref - U).max() > 1e-3
 
 
