@@ -79,6 +79,8 @@ struct Args4 {
     const int* pos_of;           // [n_items_local] local id -> visiting position, or NULL: identity
     unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
     uint64_t* lists_ws;          // list slots of the workgroups whose lists live in HBM (Geo4::GL): [workgroup][UT][kCap4]
+    int32_t* regroup_ws;         // [1024 + 2 n_users_blk] or NULL: bins | bin of every user | row_perm (launch4 fills them)
+    const int32_t* row_perm;     // [n_users_blk] or NULL: sweep row -> block row (users regrouped by predicted stopping tile)
     const uint32_t* hmask_ws;    // [workgroups of warm4_kernel][128][2 kWarmTiles]: train-item bits of the warm positions, or NULL
     const uint32_t* bloom;       // [n_users_blk][32]: 1024-bit Bloom filter (two hashes) of every block row's train items, or NULL
     const int* prep_hdr;         // header of the item prep: word 2 = built with a visiting order
@@ -718,6 +720,8 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - g.warm_tiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
     const int n_blk = NB > 2 ? (2 * n_it) / NB : n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
+    // block row of sweep row rb (rb < n_users_blk): the users of an early-terminating sweep are regrouped (stop_predict4_kernel)
+    auto orig_row = [&](int rb) __attribute__((always_inline)) -> int { if constexpr (!ES) return rb; else return (g.row_perm != nullptr && rb < g.n_users_blk) ? g.row_perm[rb] : rb; };
     if (tid < 128) sync[tid] = tid >= 112 ? 0xFFFFFFFFu : 0u;       // (words 112 .. 127: every list comes in unsorted, see s_uns)
     // The lists of the warm-up -> LDS (or the workspace), their counts and K-th values: ALL waves share the rows (the MFMA
     // waves wait for the thresholds behind the barrier: 64 rows per rescoring wave, one after the other, were 50 us of every
@@ -727,7 +731,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         for (int rr = wave; rr < UT; rr += NW) {
             const int rb = utile * UT + rr;
             uint64_t key = 0ull;
-            if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane];
+            if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + orig_row(rb)) * K + lane];
             const int c = __popcll(__ballot(key != 0ull));
             if (lane < K) lists[(size_t)rr * kCap4 + lane] = key;
             uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
@@ -780,8 +784,9 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 #pragma unroll
         for (int s2 = 0; s2 < NRL; ++s2) {
             const int rl = 64 * s2 + lane;
-            const int rb_l = utile * UT + row0 + rl;
-            const bool ok = rl < RR && rb_l < g.n_users_blk;
+            const int rb_s = utile * UT + row0 + rl;
+            const bool ok = rl < RR && rb_s < g.n_users_blk;
+            const int rb_l = ok ? orig_row(rb_s) : 0;
             uidv[s2] = ok ? g.users[rb_l] : 0;
             if (g.seed != nullptr && ok) seedv[s2] = g.seed[rb_l];
             if (hist_on && ok) {
@@ -861,8 +866,9 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
             unsigned bh1 = 0u, bh2 = 0u;
             uint32_t bw1 = 0xFFFFFFFFu, bw2 = 0xFFFFFFFFu;
             if (bloom_on && valid && q == LPC - 1) {
-                const int rbb = utile * UT + row0 + row;
-                if (rbb < g.n_users_blk) {
+                const int rbs = utile * UT + row0 + row;
+                if (rbs < g.n_users_blk) {
+                    const int rbb = orig_row(rbs);
                     bh1 = bloom_h1(g.item_offset + loc);
                     bh2 = bloom_h2(g.item_offset + loc);
                     bw1 = g.bloom[(size_t)rbb * 32 + (bh1 >> 5)];
@@ -1014,7 +1020,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     for (int u = 0; u < UA; ++u) {
         const int rb = utile * UT + row0 + 32 * u + j;
         const bool ok = rb < g.n_users_blk;
-        const int uid = ok ? g.users[rb] : 0;
+        const int uid = ok ? g.users[orig_row(rb)] : 0;
         float ss = 0.f;
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
@@ -1045,7 +1051,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
 #pragma unroll
     for (int u = 0; u < UA; ++u) {
         const int rb = utile * UT + row0 + 32 * u + j;
-        seed_own[u] = (g.seed != nullptr && rb < g.n_users_blk) ? g.seed[rb] : -INFINITY;
+        seed_own[u] = (g.seed != nullptr && rb < g.n_users_blk) ? g.seed[orig_row(rb)] : -INFINITY;
     }
     auto refresh_thr = [&]() __attribute__((always_inline)) {
 #pragma unroll
@@ -1357,9 +1363,98 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         const int rb = utile * UT + rr;
         if (rb < g.n_users_blk && lane < K) {
             const uint64_t k = lane < c ? buf[lane] : 0ull;
-            g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+            g.out_keys[((size_t)split * g.n_users_blk + orig_row(rb)) * K + lane] = k;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Regrouping the users of an early-terminating sweep.  A workgroup sweeps until its LAST user is done; with the users as they
+// come, the slowest of 256 decides (116 tiles on average at config 3 where a user needs ~50).  After the warm-up a user's
+// stopping tile is predictable -- the first tile whose suffix bound falls below the K-th value of its warm-up list --, so the
+// sweep takes the users sorted by that prediction (longest first): workgroups of alike users.  A counting sort on 1024 bins;
+// the sweep reads and writes every per-user array through row_perm, the caller sees nothing of it.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int D, bool BF>
+__global__ void __launch_bounds__(256) stop_predict4_kernel(Args4 g, int* __restrict__ bin_of) {
+    const int tid = threadIdx.x, sub = tid & 7;
+    const int u = (int)blockIdx.x * 32 + (tid >> 3);
+    if (u >= g.n_users_blk) return;
+    const int uid = g.users[u];
+    float ss = 0.f;
+    for (int c = sub * 4; c < D; c += 32) {
+        const f32x4 x = pda_load4<BF>(g.U, (size_t)uid * D + c);
+        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    uint32_t mn = 0xFFFFFFFFu;
+    int cnt = 0;
+    for (int k = sub; k < g.K; k += 8) {
+        const uint64_t key = g.out_keys[(size_t)u * g.K + k];
+        if (key != 0ull) { mn = min(mn, (uint32_t)(key >> 32)); ++cnt; }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        ss += __shfl_xor(ss, o, 64);
+        mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+        cnt += __shfl_xor(cnt, o, 64);
+    }
+    if (sub != 0) return;
+    float tau = cnt >= g.K ? pda_unordf(mn) : -INFINITY;
+    if (g.seed != nullptr) tau = fmaxf(tau, g.seed[u]);
+    const float nu = sqrtf(ss) * 1.0009765625f * 1.0001f;
+    int lo = min(g.warm_tiles, g.n_tiles), hi = g.n_tiles;          // first tile t in [lo, hi) with bound(t) < tau; hi: never
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (__builtin_fmaf(nu, g.sufB[mid], g.sufA[mid]) * 1.000002f < tau) hi = mid; else lo = mid + 1;
+    }
+    const int bin = 1023 - min(1023, (int)((long long)lo * 1024 / (g.n_tiles + 1)));      // longest first
+    bin_of[u] = bin;
+}
+// the users pile up in a few dozen bins: counted in LDS per 4096 users, one global add per workgroup and bin in use
+__global__ void __launch_bounds__(1024) stop_hist4_kernel(const int* __restrict__ bin_of, int n, int* __restrict__ bins) {
+    __shared__ int sh[1024];
+    const int t = threadIdx.x;
+    sh[t] = 0;
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        const int u = (int)blockIdx.x * 4096 + i * 1024 + t;
+        if (u < n) atomicAdd(&sh[bin_of[u]], 1);
+    }
+    __syncthreads();
+    if (sh[t]) atomicAdd(&bins[t], sh[t]);
+}
+__global__ void __launch_bounds__(1024) stop_scan4_kernel(int* __restrict__ bins) {      // counts -> exclusive starts, in place
+    __shared__ int sh[1024];
+    const int t = threadIdx.x;
+    const int v = bins[t];
+    sh[t] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int a = t >= o ? sh[t - o] : 0;
+        __syncthreads();
+        sh[t] += a;
+        __syncthreads();
+    }
+    bins[t] = sh[t] - v;
+}
+__global__ void __launch_bounds__(1024) stop_scatter4_kernel(const int* __restrict__ bin_of, int* __restrict__ bins, int n, int32_t* __restrict__ perm) {
+    __shared__ int sh[1024];
+    const int t = threadIdx.x;
+    sh[t] = 0;
+    __syncthreads();
+    int b[4], r[4];
+    for (int i = 0; i < 4; ++i) {
+        const int u = (int)blockIdx.x * 4096 + i * 1024 + t;
+        b[i] = u < n ? bin_of[u] : -1;
+        r[i] = b[i] >= 0 ? atomicAdd(&sh[b[i]], 1) : 0;          // rank within the workgroup's share of the bin
+    }
+    __syncthreads();
+    const int c = sh[t];
+    __syncthreads();
+    sh[t] = c ? atomicAdd(&bins[t], c) : 0;                      // where that share starts
+    __syncthreads();
+    for (int i = 0; i < 4; ++i)
+        if (b[i] >= 0) perm[sh[b[i]] + r[i]] = (int)blockIdx.x * 4096 + i * 1024 + t;
 }
 
 template <int D, int HEAD, bool BF>
@@ -1391,7 +1486,21 @@ int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = 
             attr_set = 1;
         }
         const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
-        if (g.sufA != nullptr)
+        if (g.sufA != nullptr && g.regroup_ws != nullptr) {
+            Args4 gp = g;
+            int* bins = g.regroup_ws;
+            int* bin_of = bins + 1024;
+            int32_t* perm = bin_of + g.n_users_blk;
+            if (hipMemsetAsync(bins, 0, 1024 * sizeof(int), stream) != hipSuccess) return PDA_ERR_LAUNCH;
+            hipLaunchKernelGGL((stop_predict4_kernel<D, BF>), dim3((unsigned)((g.n_users_blk + 31) / 32)), dim3(256), 0, stream, g, bin_of);
+            const unsigned hb = (unsigned)((g.n_users_blk + 4095) / 4096);
+            hipLaunchKernelGGL(stop_hist4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, g.n_users_blk, bins);
+            hipLaunchKernelGGL(stop_scan4_kernel, dim3(1), dim3(1024), 0, stream, bins);
+            hipLaunchKernelGGL(stop_scatter4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, bins, g.n_users_blk, perm);
+            PDA_CHECK_LAUNCH();
+            gp.row_perm = perm;
+            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
+        } else if (g.sufA != nullptr)
             hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
         else
             hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
@@ -1405,9 +1514,9 @@ static bool lists_in_hbm4(int d) { return d == 64 ? Geo4<64>::GL : d == 128 ? Ge
 // the workspace of the pda_score_topk4_* calls: the counters of pda_score_topk_workspace_bytes, then (workgroups of 512 users:
 // d <= 128) the list slots of every workgroup
 // the workspace of the pda_score_topk4_* calls: [counters of pda_score_topk_workspace_bytes | list slots of every workgroup when the
-// lists live in HBM | Bloom filters, 128 B per user | warm-position train-item masks, 32 B per user and split]
+// lists live in HBM | Bloom filters, 128 B per user | warm-position train-item masks, 32 B per user and split | regrouping: 1024 bins, bin and sweep row of every user]
 struct Ws4 {
-    size_t lists, bloom, hmask, total;
+    size_t lists, bloom, hmask, regroup, total;
 };
 static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1420,7 +1529,8 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     }
     w.bloom = al(b);
     w.hmask = al(w.bloom + (size_t)n_users_blk * 128);
-    w.total = w.hmask + ((size_t)n_users_blk + kUserTile - 1) / kUserTile * (size_t)n_splits * kUserTile * 2 * kWarmTiles * 4;
+    w.regroup = al(w.hmask + ((size_t)n_users_blk + kUserTile - 1) / kUserTile * (size_t)n_splits * kUserTile * 2 * kWarmTiles * 4);
+    w.total = w.regroup + (1024 + 2 * (size_t)n_users_blk) * 4;
     return w;
 }
 extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
@@ -1459,7 +1569,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(wsb + W.lists), nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
+            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(wsb + W.lists), nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
             // sorted hand-over when nobody sorts behind the warm-up: phase 1 alone, or a catalogue that ends inside the warm-up
 #ifdef PDA_V4_WARM_SORTED
             1};
@@ -1482,6 +1592,11 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
         PDA_CHECK_LAUNCH();
         g.hmask_ws = hm;
     }
+#ifndef PDA_V4_REGROUP_MIN
+#define PDA_V4_REGROUP_MIN 98304
+#endif
+    // users regrouped by predicted stopping tile (stop_predict4_kernel): where the workgroups come in more than one round
+    if (early_stop && (phase & 2) && n_splits == 1 && n_users_blk >= PDA_V4_REGROUP_MIN) g.regroup_ws = reinterpret_cast<int32_t*>(wsb + W.regroup);
     if (head == PDA_HEAD_RAW) {
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;

@@ -754,3 +754,45 @@ def test_seeded_item_shards_equal_one_shard(dev, impl, R, head, bf16):
     # (raw head on i.i.d. norms: the suffix bounds are too loose to stop anything early, with or without a seed)
     assert tiles[True] < tiles[False] if head else tiles[True] <= tiles[False], tiles
     assert short > 0 or not head            # (popularity head) the seed did keep entries out of some shard's list
+
+
+@pytest.mark.parametrize("head", [0, 1])
+def test_regrouped_early_terminating_sweep(dev, impl, head):
+    """From 98 304 users a block on, the early-terminating sweep takes its users regrouped by predicted stopping tile
+    (stop_predict4_kernel and the counting sort behind it): every per-user array is then read and written through the
+    permutation.  131 072 block rows of config 2 -- user ids shuffled, some repeated, the history given per BLOCK ROW -- return
+    the keys of the dense natural-order sweep, from one shard and from two seeded shards (phase entry points, seeds read
+    through the permutation too)."""
+    if impl != "v2":
+        pytest.skip("one kernel generation regroups")
+    from pda_amd import ops, synthetic
+    from pda_amd.dist import shard_range
+    W = synthetic.make_workload("c2", dev, n_users=65536)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    users = torch.randint(0, 65536, (131072,), generator=g, dtype=torch.int32).to(dev)
+    ul = users.long()
+    lens = W.hist_indptr[ul + 1] - W.hist_indptr[ul]
+    indptr = torch.zeros(users.numel() + 1, dtype=torch.int64, device=dev)
+    indptr[1:] = torch.cumsum(lens, 0)
+    within = torch.arange(int(indptr[-1]), device=dev) - torch.repeat_interleave(indptr[:-1], lens)
+    indices = W.hist_indices[torch.repeat_interleave(W.hist_indptr[ul], lens) + within].contiguous()
+    hist = ops.HistoryCSR(indptr, indices, by_user=False)
+    pop = W.pop_last if head else None
+    ref = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, head, pop, hist, prune=False), want="keys")
+    os.environ["PDA_SCORE_KERNEL"] = "v4"
+    try:
+        one = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, head, pop, hist, prune=True, n_splits=1), want="keys")
+        assert torch.equal(one, ref)
+        R = 2
+        shards = [(lo, W.I[lo:hi].contiguous(), pop[lo:hi].contiguous() if head else None) for lo, hi in (shard_range(W.n_items, r, R) for r in range(R))]
+
+        def shard(r, coll):
+            lo, I_s, pop_s = shards[r]
+            kw = {} if coll is None else {"seed_reduce": lambda mx, mn: (coll.all_reduce(r, mx, "max"), coll.all_reduce(r, mn, "min")),
+                                          "seed_sum": lambda c: coll.all_reduce(r, c, "sum"), "seed_shards": R}
+            return ops.topk_merge(ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1, **kw), want="keys")
+        [shard(r, None) for r in range(R)]            # (warms ops' per-tensor caches: see test_seeded_item_shards_equal_one_shard)
+        parts = run_emulated_shards(R, shard)
+        assert torch.equal(ops.topk_merge(torch.stack(parts), want="keys"), ref)
+    finally:
+        os.environ.pop("PDA_SCORE_KERNEL", None)
