@@ -521,64 +521,12 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     // Per row (two at a time: one per half-wave) a threshold t with K <= #(scores >= t) <= CAP by bitwise descent over the
     // ordered-uint scores (counts = ballots over the register file), then the survivors go to their list slots directly.
     // More than CAP survivors at the exact K-th value (ties): the general append path with its compactions.
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        if constexpr ((PDA_W4_ABL & 2) != 0) {
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-            for (int k = 0; k < NHT; ++k) asm volatile("" ::"v"(ordv[k][r]));
-#endif
-            continue;
-        }
+    // Two registers (= four rows) per descent: the steps of one descent are a dependent chain (compare, ballot, popcount, select),
+    // two independent chains share the wave's issue slots.
+    const int cap_t = g.warm_sorted ? CAP : K;          // unsorted hand-over: exactly K survivors (out_keys has K slots per row)
+    auto emit_row = [&](const int r, const uint32_t t, const int c_t) __attribute__((always_inline)) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int lrow = wave * 32 + row;
-        auto count_ge = [&](uint32_t cand) __attribute__((always_inline)) -> int {
-            int lo = 0, hi = 0;
-#pragma unroll
-            for (int k = 0; k < NHT; ++k) {
-                const uint64_t bm = __ballot(ordv[k][r] >= cand);
-                lo += __popc((uint32_t)bm);
-                hi += __popc((uint32_t)(bm >> 32));
-            }
-            return h ? hi : lo;
-        };
-        int c_t = count_ge(1u);
-        uint32_t t = 1u;
-        const int cap_t = g.warm_sorted ? CAP : K;          // unsorted hand-over: exactly K survivors (out_keys has K slots per row)
-        const bool need = c_t > cap_t;
-        if (__any(need)) {
-            // bisection between the row's smallest and largest score in the ordered-uint domain (~ the log domain for
-            // positive scores: a handful of steps for smooth or heavy-tailed scores, <= 32 always); invariant:
-            // #(>= t) = c_t >= K, #(>= hi) < K
-            uint32_t mx = 0u, mn = 0xFFFFFFFFu;
-#pragma unroll
-            for (int k = 0; k < NHT; ++k) {
-                const uint32_t v = ordv[k][r];
-                mx = max(mx, v);
-                mn = min(mn, v != 0u ? v : 0xFFFFFFFFu);
-            }
-#pragma unroll
-            for (int o = 16; o >= 1; o >>= 1) {                      // (xor < 32: stays inside the half-wave)
-                mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-                mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
-            }
-            uint32_t hi = mx + 1u;                                   // (mx < 0xFFFFFFFF: NaNs are not candidates)
-            if (need) t = mn;
-            for (int it = 0; it < 40; ++it) {
-                const bool open = need && c_t > cap_t && hi - t > 1u;
-                if (!__any(open)) break;
-                const uint32_t mid = open ? t + ((hi - t) >> 1) : t;
-                const int cnt = count_ge(mid);
-                if (open) {
-                    if (cnt >= K) {
-                        t = mid;
-                        c_t = cnt;
-                    } else {
-                        hi = mid;
-                    }
-                }
-            }
-        }
         if (__any(c_t > cap_t)) {
 #pragma unroll
             for (int k = 0; k < NHT; ++k) {
@@ -599,6 +547,85 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
             }
             if (j == 0) cntl[lrow] = run;
         }
+    };
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        if constexpr ((PDA_W4_ABL & 2) != 0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+            for (int k = 0; k < NHT; ++k) asm volatile("" ::"v"(ordv[k][r]), "v"(ordv[k][r + 1]));
+#endif
+            continue;
+        }
+        auto count_ge2 = [&](uint32_t ca, uint32_t cb, int& na, int& nb) __attribute__((always_inline)) {
+            int loa = 0, hia = 0, lob = 0, hib = 0;
+#pragma unroll
+            for (int k = 0; k < NHT; ++k) {
+                const uint64_t bma = __ballot(ordv[k][r] >= ca);
+                const uint64_t bmb = __ballot(ordv[k][r + 1] >= cb);
+                loa += __popc((uint32_t)bma);
+                hia += __popc((uint32_t)(bma >> 32));
+                lob += __popc((uint32_t)bmb);
+                hib += __popc((uint32_t)(bmb >> 32));
+            }
+            na = h ? hia : loa;
+            nb = h ? hib : lob;
+        };
+        int ca_t, cb_t;
+        count_ge2(1u, 1u, ca_t, cb_t);
+        uint32_t ta = 1u, tb = 1u;
+        const bool needa = ca_t > cap_t, needb = cb_t > cap_t;
+        if (__any(needa || needb)) {
+            // bisection between the row's smallest and largest score in the ordered-uint domain (~ the log domain for
+            // positive scores: a handful of steps for smooth or heavy-tailed scores, <= 32 always); invariant:
+            // #(>= t) = c_t >= K, #(>= hi) < K
+            uint32_t mxa = 0u, mna = 0xFFFFFFFFu, mxb = 0u, mnb = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < NHT; ++k) {
+                const uint32_t va = ordv[k][r], vb = ordv[k][r + 1];
+                mxa = max(mxa, va);
+                mna = min(mna, va != 0u ? va : 0xFFFFFFFFu);
+                mxb = max(mxb, vb);
+                mnb = min(mnb, vb != 0u ? vb : 0xFFFFFFFFu);
+            }
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) {                      // (xor < 32: stays inside the half-wave)
+                mxa = max(mxa, (uint32_t)__shfl_xor((int)mxa, o, 64));
+                mna = min(mna, (uint32_t)__shfl_xor((int)mna, o, 64));
+                mxb = max(mxb, (uint32_t)__shfl_xor((int)mxb, o, 64));
+                mnb = min(mnb, (uint32_t)__shfl_xor((int)mnb, o, 64));
+            }
+            uint32_t hia = mxa + 1u, hib = mxb + 1u;                 // (mx < 0xFFFFFFFF: NaNs are not candidates)
+            if (needa) ta = mna;
+            if (needb) tb = mnb;
+            for (int it = 0; it < 40; ++it) {
+                const bool opena = needa && ca_t > cap_t && hia - ta > 1u;
+                const bool openb = needb && cb_t > cap_t && hib - tb > 1u;
+                if (!__any(opena || openb)) break;
+                const uint32_t mida = opena ? ta + ((hia - ta) >> 1) : ta;
+                const uint32_t midb = openb ? tb + ((hib - tb) >> 1) : tb;
+                int cnta, cntb;
+                count_ge2(mida, midb, cnta, cntb);
+                if (opena) {
+                    if (cnta >= K) {
+                        ta = mida;
+                        ca_t = cnta;
+                    } else {
+                        hia = mida;
+                    }
+                }
+                if (openb) {
+                    if (cntb >= K) {
+                        tb = midb;
+                        cb_t = cntb;
+                    } else {
+                        hib = midb;
+                    }
+                }
+            }
+        }
+        emit_row(r, ta, ca_t);
+        emit_row(r + 1, tb, cb_t);
     }
     pda_wave_sync();
     if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * nwarm));
