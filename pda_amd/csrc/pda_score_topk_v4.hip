@@ -749,16 +749,37 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     const int n_blk = NB > 2 ? (2 * n_it) / NB : n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
     // block row of sweep row rb (rb < n_users_blk): the users of an early-terminating sweep are regrouped (stop_predict4_kernel)
     auto orig_row = [&](int rb) __attribute__((always_inline)) -> int { if constexpr (!ES) return rb; else return (g.row_perm != nullptr && rb < g.n_users_blk) ? g.row_perm[rb] : rb; };
+#ifdef PDA_V4_STAMP      /* debug build: phase clocks (100 MHz) of a few workgroups, printed */
+    const unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0;
+#define PDA_STAMP(x) x = __builtin_amdgcn_s_memrealtime()
+#else
+#define PDA_STAMP(x)
+#endif
     if (tid < 128) sync[tid] = tid >= 112 ? 0xFFFFFFFFu : 0u;       // (words 112 .. 127: every list comes in unsorted, see s_uns)
     // The lists of the warm-up -> LDS (or the workspace), their counts and K-th values: ALL waves share the rows (the MFMA
     // waves wait for the thresholds behind the barrier: 64 rows per rescoring wave, one after the other, were 50 us of every
     // workgroup's life -- 13 % of an early-terminating sweep).  A list may come in unsorted: its K-th value is the smallest key.
     {
-        constexpr int NW = G::WAVES;
-        for (int rr = wave; rr < UT; rr += NW) {
+        // (eight rows of a wave in flight: one row after the other was 16 x the latency of a load -- two with the permutation)
+        constexpr int NW = G::WAVES, PB = 8;
+        for (int r0 = wave; r0 < UT; r0 += PB * NW) {
+          int rov[PB];
+          uint64_t keyv[PB];
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+              const int rb = utile * UT + r0 + q * NW;
+              rov[q] = (r0 + q * NW < UT && rb < g.n_users_blk) ? orig_row(rb) : -1;
+          }
+#pragma unroll
+          for (int q = 0; q < PB; ++q)
+              keyv[q] = (rov[q] >= 0 && lane < K) ? g.out_keys[((size_t)split * g.n_users_blk + rov[q]) * K + lane] : 0ull;
+#pragma unroll
+          for (int q = 0; q < PB; ++q) {
+            const int rr = r0 + q * NW;
+            if (rr >= UT) break;
             const int rb = utile * UT + rr;
-            uint64_t key = 0ull;
-            if (rb < g.n_users_blk && lane < K) key = g.out_keys[((size_t)split * g.n_users_blk + orig_row(rb)) * K + lane];
+            const uint64_t key = keyv[q];
             const int c = __popcll(__ballot(key != 0ull));
             if (lane < K) lists[(size_t)rr * kCap4 + lane] = key;
             uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
@@ -768,12 +789,14 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 cntl[rr] = c;
                 taul[rr] = rb < g.n_users_blk ? (c >= K ? pda_unordf(mn) : -INFINITY) : INFINITY;
             }
+          }
         }
         if constexpr (GL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
 #ifdef PDA_V4_PROF
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+    PDA_STAMP(st1);
 
     if (wave >= kMainWaves + kLoaders) {
         // ============================== rescoring wave ==============================
@@ -1066,7 +1089,9 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         ss += __shfl_xor(ss, 32, 64);
         nu_row[u] = sqrtf(ss) * 1.0009765625f * 1.0001f;           // padded ||u||
     }
+    PDA_STAMP(st2);
     __syncthreads();                       // lists, thresholds and hand-over words are initialised
+    PDA_STAMP(st3);
 
     // threshold of the lane's own row (finite: +-1e30 stand for +-inf), lowered by 2^-16 relative (the rounding of the
     // extra k-step, pda_score_topk_v3.hip), as the A operand of the extra k-step:
@@ -1378,21 +1403,43 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
     if (stopped) lds_st(s_stop, 1u);
     if (lane == 0 && w == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * n_done * (UT / kUserTile)));
     }
+    PDA_STAMP(st4);
     // ================================== all waves: sort and emit ==================================
     // Behind this barrier every candidate has been rescored and nobody appends any more (the rescoring waves arrive last).  The
     // lists are exact; what is left is their order -- rows the rescoring waves did not get to in their idle time -- and the
     // copy out: shared by all waves (64 rows per rescoring wave, one after the other, were the tail of every workgroup).
     __syncthreads();
-    for (int rr = wave; rr < UT; rr += G::WAVES) {
-        uint64_t* buf = lists + (size_t)rr * kCap4;
-        compact_list<kCap4, GL>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
-        const int c = cntl[rr];
-        const int rb = utile * UT + rr;
-        if (rb < g.n_users_blk && lane < K) {
-            const uint64_t k = lane < c ? buf[lane] : 0ull;
-            g.out_keys[((size_t)split * g.n_users_blk + orig_row(rb)) * K + lane] = k;
+    PDA_STAMP(st5);
+    // (The sort is bound by the compares -- ~57 x 3 issue slots per row, four waves per SIMD at it: 20 - 35 us of a workgroup's
+    // ~130 in an early-terminating sweep; ranking four rows at a time, on the 32-bit score halves, measured no faster.)
+    constexpr int EB = 8;                  // (the rows' places in out_keys: eight loads of the permutation in flight)
+    for (int r0 = wave; r0 < UT; r0 += EB * G::WAVES) {
+        int rov[EB];
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int rb = utile * UT + r0 + q * G::WAVES;
+            rov[q] = (r0 + q * G::WAVES < UT && rb < g.n_users_blk) ? orig_row(rb) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int rr = r0 + q * G::WAVES;
+            if (rr >= UT) break;
+            uint64_t* buf = lists + (size_t)rr * kCap4;
+            compact_list<kCap4, GL>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
+            const int c = cntl[rr];
+            if (rov[q] >= 0 && lane < K) {
+                const uint64_t k = lane < c ? buf[lane] : 0ull;
+                g.out_keys[((size_t)split * g.n_users_blk + rov[q]) * K + lane] = k;
+            }
         }
     }
+#ifdef PDA_V4_STAMP
+    if (ES && lane == 0 && (wave == 0 || wave == G::WAVES - 1) && (blockIdx.x % 100) == 7) {
+        const unsigned long long st6 = __builtin_amdgcn_s_memrealtime();
+        printf("wg %4d wave %2d start %llu: prologue %llu  A rows %llu  barrier %llu  sweep %llu  wait-all %llu  epilogue %llu (x10 ns) tiles %d\n", (int)blockIdx.x, wave,
+               st0, st1 - st0, st2 - st1, st3 - st2, st4 - st3, st5 - st4, st6 - st5, n_it);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
