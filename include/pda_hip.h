@@ -189,7 +189,7 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        passed to the call, <= 0 = automatic): the counters, and for d <= 128 -- workgroups of 512 users, whose exact lists
  *        do not fit the LDS -- 57 list slots of 8 bytes per user and item split (120 MB at 262 144 users), and 128 bytes per
  *        user for the Bloom filters of the train items (the history mask at the candidate stage)
- *        and 8 bytes per user + 4 KiB for regrouping the users of an early-terminating sweep by predicted stopping tile
+ *        and 16 bytes per user + 4 KiB for regrouping the users of an early-terminating sweep by predicted stopping tile
  *        (blocks of 98 304 users and more with one item split; internal: rows of out_keys stay the caller's block rows)
  * d in {64,128,256}; K <= 54; n_items_local <= 2^26.  out_keys doubles as the
  * hand-over buffer between the exact warm-up kernel and the sweep.  PDA_ERR_UNSUPPORTED: use the entry points above. */

@@ -80,6 +80,7 @@ struct Args4 {
     unsigned* stats;             // workspace as v3: u32 at +4 pairs rescored, u64 at +8 32-item tiles x 128-user tiles scored
     uint64_t* lists_ws;          // list slots of the workgroups whose lists live in HBM (Geo4::GL): [workgroup][UT][kCap4]
     int32_t* regroup_ws;         // [1024 + 2 n_users_blk] or NULL: bins | bin of every user | row_perm (launch4 fills them)
+    float* pred_ws;              // [n_users_blk][2] or NULL: warm4_kernel leaves (a lower bound of the K-th value, padded ||u||) for the regrouping
     const int32_t* row_perm;     // [n_users_blk] or NULL: sweep row -> block row (users regrouped by predicted stopping tile)
     const uint32_t* hmask_ws;    // [workgroups of warm4_kernel][128][2 kWarmTiles]: train-item bits of the warm positions, or NULL
     const uint32_t* bloom;       // [n_users_blk][32]: 1024-bit Bloom filter (two hashes) of every block row's train items, or NULL
@@ -420,6 +421,8 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     unsigned* hmask = reinterpret_cast<unsigned*>(taul + kUserTile);                         // [128][2 kWarmTiles]
     float* popw = reinterpret_cast<float*>(hmask + kUserTile * 2 * kWarmTiles);              // [32]
     int* idw = reinterpret_cast<int*>(popw + 32);                                            // [32]
+    float* predt = reinterpret_cast<float*>(idw + 32);                                       // [128] for pred_ws: K-th value (bound)
+    float* nul = predt + kUserTile;                                                          // [128] for pred_ws: padded norm
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
@@ -451,6 +454,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row_ok) v = pda_load4<BF>(g.U, (size_t)uid * D + 4 * h + 8 * c);
         areg[c] = v;
+    }
+    if (g.pred_ws != nullptr) {          // the row's padded norm, as the sweep's votes use it (stop_predict4_kernel)
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) ss += areg[c][0] * areg[c][0] + areg[c][1] * areg[c][1] + areg[c][2] * areg[c][2] + areg[c][3] * areg[c][3];
+        ss += __shfl_xor(ss, 32, 64);
+        if (h == 0) nul[wave * 32 + j] = sqrtf(ss) * 1.0009765625f * 1.0001f;
     }
     const float* brow = Bt + j * D;
     const int bswz = swz<D>(j);
@@ -527,6 +537,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     auto emit_row = [&](const int r, const uint32_t t, const int c_t) __attribute__((always_inline)) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int lrow = wave * 32 + row;
+        if (j == 0) predt[lrow] = c_t >= K ? pda_unordf(t) : -INFINITY;       // K scores at or above t
         if (__any(c_t > cap_t)) {
 #pragma unroll
             for (int k = 0; k < NHT; ++k) {
@@ -639,6 +650,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
         if (rb < g.n_users_blk && lane < K) {
             const uint64_t k = lane < c ? buf[lane] : 0ull;
             g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+        }
+    }
+    if (g.pred_ws != nullptr && lane < 32) {
+        const int rb = utile * kUserTile + wave * 32 + lane;
+        if (rb < g.n_users_blk) {
+            g.pred_ws[2 * (size_t)rb] = predt[wave * 32 + lane];
+            g.pred_ws[2 * (size_t)rb + 1] = nul[wave * 32 + lane];
         }
     }
 }
@@ -1454,6 +1472,19 @@ __global__ void __launch_bounds__(256) stop_predict4_kernel(Args4 g, int* __rest
     const int tid = threadIdx.x, sub = tid & 7;
     const int u = (int)blockIdx.x * 32 + (tid >> 3);
     if (u >= g.n_users_blk) return;
+    if (g.pred_ws != nullptr) {           // the warm-up of this call left both numbers: 8 bytes per user instead of the row and K keys
+        if (sub != 0) return;
+        float tau = g.pred_ws[2 * (size_t)u];
+        if (g.seed != nullptr) tau = fmaxf(tau, g.seed[u]);
+        const float nu = g.pred_ws[2 * (size_t)u + 1];
+        int lo = min(g.warm_tiles, g.n_tiles), hi = g.n_tiles;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (__builtin_fmaf(nu, g.sufB[mid], g.sufA[mid]) * 1.000002f < tau) hi = mid; else lo = mid + 1;
+        }
+        bin_of[u] = 1023 - min(1023, (int)((long long)lo * 1024 / (g.n_tiles + 1)));
+        return;
+    }
     const int uid = g.users[u];
     float ss = 0.f;
     for (int c = sub * 4; c < D; c += 32) {
@@ -1536,7 +1567,7 @@ int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = 
     using G = Geo4<D>;
     if (phase & 1) {
         constexpr int CAP = kCap4;
-        const size_t smem = 32 * D * 4 + (size_t)kUserTile * (CAP * 8 + 8) + kUserTile * 2 * kWarmTiles * 4 + 256;
+        const size_t smem = 32 * D * 4 + (size_t)kUserTile * (CAP * 8 + 8) + kUserTile * 2 * kWarmTiles * 4 + 256 + kUserTile * 8;
         static int attr_set = 0;
         if (!attr_set) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&warm4_kernel<D, HEAD, BF>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1604,7 +1635,7 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     w.bloom = al(b);
     w.hmask = al(w.bloom + (size_t)n_users_blk * 128);
     w.regroup = al(w.hmask + ((size_t)n_users_blk + kUserTile - 1) / kUserTile * (size_t)n_splits * kUserTile * 2 * kWarmTiles * 4);
-    w.total = w.regroup + (1024 + 2 * (size_t)n_users_blk) * 4;
+    w.total = w.regroup + (1024 + 4 * (size_t)n_users_blk) * 4;       // bins, bin_of, row_perm, pred_ws
     return w;
 }
 extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
@@ -1643,7 +1674,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // the same fma; a zero array is the front of sufA of a prep WITHOUT popularity (tile_bound4_kernel, has_pop = 0)
     Args4 g{U, I_shard, pop_shard, users, hist_indptr, hist_indices, out_keys, pb + L.rows,
             early_stop ? sA : nullptr, early_stop ? sB : nullptr, reinterpret_cast<const int*>(pb + L.pos_of),
-            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(wsb + W.lists), nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
+            reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(wsb + W.lists), nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
             // sorted hand-over when nobody sorts behind the warm-up: phase 1 alone, or a catalogue that ends inside the warm-up
 #ifdef PDA_V4_WARM_SORTED
             1};
@@ -1670,7 +1701,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
 #define PDA_V4_REGROUP_MIN 98304
 #endif
     // users regrouped by predicted stopping tile (stop_predict4_kernel): where the workgroups come in more than one round
-    if (early_stop && (phase & 2) && n_splits == 1 && n_users_blk >= PDA_V4_REGROUP_MIN) g.regroup_ws = reinterpret_cast<int32_t*>(wsb + W.regroup);
+    if (early_stop && (phase & 2) && n_splits == 1 && n_users_blk >= PDA_V4_REGROUP_MIN) {
+        g.regroup_ws = reinterpret_cast<int32_t*>(wsb + W.regroup);
+        if (phase & 1) g.pred_ws = reinterpret_cast<float*>(g.regroup_ws + 1024 + 2 * (size_t)n_users_blk);       // (a sweep of its own reads the lists)
+    }
     if (head == PDA_HEAD_RAW) {
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;
