@@ -546,7 +546,9 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
         blocks.append(users)
         coos.append((rows, indices[lo:hi].long()))
     rec = "condition" if args.head == "condition" else "main_branch"
-    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget)
+    # value: the reference block cut into 64-row slabs over all host threads (cb.eval_block_slabbed: the same ops row for row;
+    # torch's own intra-op threading -- `torch_intraop_threads` below -- parallelises the matmul only: 2 x one core on 128)
+    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget, block_fn=cb.eval_block_slabbed)
     cpu_model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -558,9 +560,18 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
     out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
            "protocol": "3 warm-up blocks, median of the timed 2048-user blocks (up to 10, bounded by the budget)",
            "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d (torch-CPU restatement of "
-                     "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk; NOT TensorFlow itself)" % (n, W.n_items, W.d)}
+                     "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk; NOT TensorFlow itself), every block cut into "
+                     "64-row slabs over the %d host threads" % (n, W.n_items, W.d, cores)}
     if not full:
         return out
+    rate_i, n_i = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.5)
+    out["torch_intraop_threads"] = {"value": rate_i, "unit": "users/s", "users": n_i, "threads": cores,
+                                    "what": "the same ops on whole 2048-user blocks, parallelism left to torch's intra-op pool (round 1-2's figure)"}
+    if cb.eval_block_reference_topk(U[:4], I[:64], pop[:64], torch.arange(4), torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 8, rec) is not None:
+        rate_r, n_r = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.4, block_fn=cb.eval_block_reference_topk)
+        out["reference_arg_topk"] = {"value": rate_r, "unit": "users/s", "users": n_r, "threads": cores,
+                                     "what": "matmul + head + mask as above; the selection by the reference's own arg_top_k_2d "
+                                             "(util/cython/include/arg_topk.h:29, compiled where it lies into oracle/_ref)"}
     # BASELINE.md section 3 "CPU-native-topk": the same block with the selection by a from-scratch native top-K (a heap per row,
     # rows over all OpenMP threads: the algorithm class of the reference's arg_topk.h)
     rate_n, n_n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.6, block_fn=cb.eval_block_native_topk)

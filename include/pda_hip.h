@@ -232,6 +232,20 @@ int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void*
  * Without it every rank prunes against its own shard's K-th value only and scores 8 x 32 % instead of 3.9 % of the
  * catalogue (config 3, eight shards).  n_splits must be the same (> 0) in both phases. */
 int pda_topk_kth_value(const uint64_t* keys, int n_splits, int n_users_blk, int K, int pos, float* out, void* stream);
+/* The same exchange in TWO collectives per user block (round 3; replaces kth_value x 3 + MAX + MIN + three sequential SUM rounds):
+ *   pda_topk_seed_bounds  bounds f32 [3][n_users_blk] := (value at rank K - 1, value at rank m - 1, MINUS the value at rank
+ *            m - 1) of the shard's warm-up lists, m = ceil(K / R).  ONE all-reduce MAX over the 3 n_users_blk floats (min x =
+ *            -max -x).  A rank without items contributes (-inf, -inf, +inf).
+ *   pda_topk_seed_counts  counts i32 [n_thr][n_users_blk] := this shard's warm-up entries at or above the n_thr common thresholds
+ *            lo + (hi - lo) (j + 1) / (n_thr + 1) between lo = max(bounds 0, -bounds 2) and hi = bounds 1 (the grid that
+ *            `rounds` bisection rounds walk, n_thr = 2^rounds - 1 <= 15).  ONE all-reduce SUM.
+ *   pda_topk_seed_pick    seed[u] := the largest threshold with a summed count >= K, else lo (n_thr = 0: lo).
+ * Both collectives are a few bytes per user and depend on the warm-up only: a caller with several user blocks issues them for
+ * block b + 1 on a side stream under the sweep of block b (pda_amd/dist.py). */
+int pda_topk_seed_bounds(const uint64_t* keys, int n_splits, int n_users_blk, int K, int m, float* bounds, void* stream);
+int pda_topk_seed_counts(const uint64_t* keys, int n_splits, int n_users_blk, int K, const float* bounds, int n_thr, int32_t* counts,
+                         void* stream);
+int pda_topk_seed_pick(const float* bounds, const int32_t* counts, int n_thr, int n_users_blk, int K, float* seed, void* stream);
 int pda_topk_seed_refine(const uint64_t* keys, int n_splits, int n_users_blk, int K, float* lo, float* hi, float* mid, int32_t* counts,
                          int mode, void* stream);
 int pda_score_topk4_phase_f32(const float* U, const float* I_shard, const void* prep, const float* pop_shard, const int32_t* users,
@@ -271,6 +285,36 @@ int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* po
                      const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div, float lr,
                      int update_mode, float* g_user, float* g_pos, float* g_neg, float* gU, float* gI,
                      float* loss_acc, void* stream);
+
+/* ---- The exact mini-batch SGD step without atomics (round 3; pda_bpr_plan.hip): plan + two launches -------------------------
+ * The reference applies the SUM of a batch's gradients, all computed from the tables as they stood (MF/model_api.py:83,102-121;
+ * IndexedSlices are summed per row [TF-ext]).  PDA_UPD_SGD_FUSED above is hogwild inside a batch and spends 3 d fp32 atomics per
+ * triplet; this path is exact, bit-reproducible and writes every touched row ONCE with plain stores.
+ *   pda_triplet_plan(users, pos, neg, B, n_batches, plans)   one workgroup per batch ([n_batches, B] arrays, B <= 4096): the 2B item
+ *            references pos ++ neg sorted by item (LDS counting sort) -> segments of equal item, two bits per triplet ("my positive /
+ *            negative is referenced once in the batch"), and a flag "a user occurs twice".  plans: n_batches x
+ *            pda_triplet_plan_bytes(B) bytes.  The plan depends on the ids only: a sampler computes it batches ahead of the step.
+ *   pda_bpr_step_plan_f32(..., plan, scratch, exact, loss_acc)
+ *            exact = 1: launch A (per triplet) gathers, computes loss and the triplet's two coefficients, moves the USER row with
+ *            a plain store (users are distinct inside a batch -- the sampler contract, rd.sample at MF/train_new_api.py:380-381)
+ *            and leaves the old user row + coefficients in scratch (pda_bpr_step_plan_scratch_bytes(B, d) bytes); launch B (per
+ *            distinct item row) sums coefficient x old user row over the row's references in plan order, adds the L2 term, and
+ *            stores the row.  No gather of either launch can see a row of this batch already moved.
+ *            exact = 0: ONE launch: user rows and once-referenced item rows take plain stores, shared item rows keep the atomics
+ *            of PDA_UPD_SGD_FUSED (hogwild on those rows only).  fp32 tables only.
+ *            A batch in which a user occurs twice is REJECTED by the plan: loss_acc receives NaN and no table is written
+ *            (use PDA_UPD_NONE + pda_sgd_apply_f32 for such batches).
+ *   pda_bpr_step_plan_bf16  the exact step on bf16 tables (config 5): forward pass on the bf16 rows, update on the fp32 masters,
+ *            the touched bf16 rows re-rounded (RNE) by the same two launches (no pda_refresh_rows_bf16 afterwards). */
+size_t pda_triplet_plan_bytes(int B);
+size_t pda_bpr_step_plan_scratch_bytes(int B, int d);
+int pda_triplet_plan(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int n_batches, void* plans, void* stream);
+int pda_bpr_step_plan_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg, const float* pos_pop,
+                          const float* neg_pop, int B, int d, float regs, float reg_div, float lr, const void* plan, float* scratch,
+                          int exact, float* loss_acc, void* stream);
+int pda_bpr_step_plan_bf16(uint16_t* U_bf16, uint16_t* I_bf16, float* U_master, float* I_master, const int32_t* users,
+                           const int32_t* pos, const int32_t* neg, const float* pos_pop, const float* neg_pop, int B, int d,
+                           float regs, float reg_div, float lr, const void* plan, float* scratch, float* loss_acc, void* stream);
 
 /* Apply phase of the EXACT mini-batch SGD step: after pda_bpr_step_f32(PDA_UPD_NONE, g_user, g_pos, g_neg) -- forward pass
  * and per-occurrence gradients of the WHOLE batch against the unchanged tables -- this scatters

@@ -36,11 +36,102 @@ def eval_block_native_topk(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type=
     return c_oracle.arg_topk_2d(R.numpy(), K)
 
 
+_POOLS = {}
+
+
+def eval_block_slabbed(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition", threads=None, slab=64):
+    """The same op sequence -- matmul, elu + 1, * pop, -inf at the train items, topk -- with the 2048-user reference block cut
+    into `slab`-row pieces handed to `threads` host threads, each running single-threaded torch ops on its piece (torch releases
+    the GIL inside an op).  eval_block above leaves the threading to torch's intra-op pool, which parallelises the matmul but
+    runs the scatter and most of topk on one core: 128 cores give 2 x one core there.  Same results row for row (the ops are
+    row-independent).  coo_rows must be ascending (they are: the block's rows are built user by user).
+    The caller sets torch.set_num_threads(1) around the timed region (time_eval does when block_fn is this function)."""
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or (torch.get_num_interop_threads() and __import__("os").cpu_count()) or 1
+    pool = _POOLS.get(threads)
+    if pool is None:
+        pool = _POOLS[threads] = ThreadPoolExecutor(max_workers=threads)
+    n = users.numel()
+    bounds = torch.searchsorted(coo_rows, torch.arange(0, n + slab, slab))
+    out = torch.empty((n, K), dtype=torch.int64)
+
+    def piece(s):
+        lo, hi = s * slab, min(n, (s + 1) * slab)
+        a, b = int(bounds[s]), int(bounds[s + 1])
+        out[lo:hi] = eval_block(U, I, pop, users[lo:hi], coo_rows[a:b] - lo, coo_cols[a:b], K, rec_type)
+    list(pool.map(piece, range((n + slab - 1) // slab)))
+    return out
+
+
+def eval_block_blocked(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition", threads=None, slab=64, chunk=4096):
+    """eval_block_slabbed with the catalogue cut as well: every host thread takes 64 user rows and walks the items in chunks of
+    4096 -- matmul, elu + 1, * pop, -inf at the train items, topk(K) of the 1 MB piece -- and selects the K best of its
+    n_chunks x K candidates at the end.  The [2048, n_items] block of the reference (1.6 GB at config 3) is never materialised:
+    at 200 000 items even a 64-row slab of it (51 MB) streams through DRAM six times.  Same lists up to the order of exactly
+    equal scores."""
+    from concurrent.futures import ThreadPoolExecutor
+    import os
+    threads = threads or os.cpu_count() or 1
+    pool = _POOLS.get(threads)
+    if pool is None:
+        pool = _POOLS[threads] = ThreadPoolExecutor(max_workers=threads)
+    n, n_items = users.numel(), I.shape[0]
+    bounds = torch.searchsorted(coo_rows, torch.arange(0, n + slab, slab))
+    out = torch.empty((n, K), dtype=torch.int64)
+    condition = rec_type != "main_branch"
+
+    def piece(s):
+        lo, hi = s * slab, min(n, (s + 1) * slab)
+        a, b = int(bounds[s]), int(bounds[s + 1])
+        cols, order = torch.sort(coo_cols[a:b])
+        rows = (coo_rows[a:b] - lo)[order]
+        cb = torch.searchsorted(cols, torch.arange(0, n_items + chunk, chunk))
+        Us = U.index_select(0, users[lo:hi])
+        vals, idxs = [], []
+        for c in range((n_items + chunk - 1) // chunk):
+            c0, c1 = c * chunk, min(n_items, (c + 1) * chunk)
+            R = Us @ I[c0:c1].t()
+            if condition:
+                R = (F.elu(R) + 1.0) * pop[c0:c1].unsqueeze(0)
+            x, y = int(cb[c]), int(cb[c + 1])
+            if y > x:
+                R[rows[x:y], cols[x:y] - c0] = float("-inf")
+            v, i = torch.topk(R, min(K, c1 - c0), dim=1, sorted=False)
+            vals.append(v)
+            idxs.append(i + c0)
+        v, i = torch.cat(vals, 1), torch.cat(idxs, 1)
+        out[lo:hi] = torch.gather(i, 1, torch.topk(v, K, dim=1, sorted=True).indices)
+    list(pool.map(piece, range((n + slab - 1) // slab)))
+    return out
+
+
+def eval_block_reference_topk(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition", threads=None):
+    """Scores, head and mask as eval_block; the selection by the REFERENCE'S OWN native top-K (util/cython/include/arg_topk.h:29
+    arg_top_k_2d, compiled where it lies into oracle/_ref by oracle/Makefile) with its own thread pool.  None when oracle/_ref
+    is absent."""
+    from . import c_oracle
+    if c_oracle.ref_lib() is None:
+        return None
+    R = U.index_select(0, users) @ I.t()
+    if rec_type != "main_branch":
+        R = (F.elu(R) + 1.0) * pop.unsqueeze(0)
+    R[coo_rows, coo_cols] = float("-inf")
+    return c_oracle.ref_arg_topk(R.numpy(), K, threads=threads or __import__("os").cpu_count())
+
+
 def time_eval(U, I, pop, users_blocks, coo_blocks, K=50, rec_type="condition", budget_s=20.0, warmups=3, reps=10, block_fn=None):
     """BASELINE.md section 3 protocol: `warmups` untimed reference blocks, then the MEDIAN block time of up to `reps` timed
     blocks (fewer when `budget_s` of wall time is used up first; at least one).  Returns (users/s, users timed)."""
     import statistics
     fn = block_fn or eval_block
+    if fn is eval_block_slabbed or fn is eval_block_blocked:      # the slabs are the parallelism: one torch thread inside every piece
+        prev = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            return time_eval(U, I, pop, users_blocks, coo_blocks, K, rec_type, budget_s, warmups, reps,
+                             block_fn=lambda *a: fn(*a, threads=prev))
+        finally:
+            torch.set_num_threads(prev)
     t_start = time.perf_counter()
     blocks = list(zip(users_blocks, coo_blocks))
     for users, (rows, cols) in blocks[:warmups]:

@@ -66,10 +66,18 @@ SIGNATURES = {
     "pda_peak_copy": (_i, [_vp, _vp, _sz, _vp]),
     "pda_topk_kth_value": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pda_topk_seed_refine": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "pda_topk_seed_bounds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "pda_topk_seed_counts": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "pda_topk_seed_pick": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pda_score_topk4_phase_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_score_topk4_phase_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "pda_triplet_plan_bytes": (_sz, [_i]),
+    "pda_bpr_step_plan_scratch_bytes": (_sz, [_i, _i]),
+    "pda_triplet_plan": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "pda_bpr_step_plan_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
+    "pda_bpr_step_plan_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "pda_sgd_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "pda_bpr_step_shard_f32": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _i, _vp, _vp, _vp]),
     "pda_apply_user_grads_f32": (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),

@@ -1764,7 +1764,96 @@ __global__ void __launch_bounds__(256) seed_refine_kernel(const uint64_t* __rest
     }
 }
 
+
+// ---- the seed exchange in TWO collectives (round 3; MAX, MIN and three sequential SUM rounds before) ----------------------
+// bounds [3][n_users]: row 0 = the value at rank K - 1 of the user's warm-up lists (max over the splits), row 1 = the value at
+// rank m - 1 (m = ceil(K / R)), row 2 = MINUS row 1.  ONE all-reduce MAX over the 3 n_users floats leaves: the largest K-th
+// value, the largest m-th value (an upper bound of the K-th value of the merged warm-up lists) and minus the smallest m-th value
+// (min x = -max -x: R shards with m entries above it hold K entries above it).
+__global__ void __launch_bounds__(256) seed_bounds_kernel(const uint64_t* __restrict__ keys, int S, int n_users, int K, int m,
+                                                          float* __restrict__ out) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    float a = -INFINITY, b = -INFINITY;
+    for (int sp = 0; sp < S; ++sp) {
+        const uint64_t* row = keys + ((size_t)sp * n_users + u) * K;
+        const uint64_t ka = row[K - 1], kb = row[m - 1];
+        if (ka != 0ull) a = fmaxf(a, pda_key_val(ka));
+        if (kb != 0ull) b = fmaxf(b, pda_key_val(kb));
+    }
+    out[u] = a;
+    out[(size_t)n_users + u] = b;
+    out[2 * (size_t)n_users + u] = -b;
+}
+// the common thresholds between the seed lo = max(bounds 0, -bounds 2) and the upper bound hi = bounds 1: the grid the three
+// bisection rounds used to walk one round trip at a time (n_thr = 2^rounds - 1 interior points), computed identically on
+// every rank and in both kernels below (-ffp-contract=off; the reduced bounds are the same bits everywhere)
+__device__ __forceinline__ float seed_thr(float lo, float hi, int j, int n_thr) {
+    const bool open = lo > -INFINITY && hi < INFINITY && hi > lo;
+    return open ? lo + (hi - lo) * ((float)(j + 1) / (float)(n_thr + 1)) : lo;
+}
+constexpr int kSeedThrMax = 15;
+// counts [n_thr][n_users]: this shard's warm-up entries at or above threshold j (sorted lists, best first)
+__global__ void __launch_bounds__(256) seed_counts_kernel(const uint64_t* __restrict__ keys, int S, int n_users, int K,
+                                                          const float* __restrict__ bounds, int n_thr, int32_t* __restrict__ counts) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    const float lo = fmaxf(bounds[u], -bounds[2 * (size_t)n_users + u]), hi = bounds[(size_t)n_users + u];
+    float thr[kSeedThrMax];
+    int c[kSeedThrMax];
+#pragma unroll
+    for (int j = 0; j < kSeedThrMax; ++j) { thr[j] = seed_thr(lo, hi, j < n_thr ? j : 0, n_thr); c[j] = 0; }
+    for (int sp = 0; sp < S; ++sp) {
+        const uint64_t* row = keys + ((size_t)sp * n_users + u) * K;
+        for (int q = 0; q < K; ++q) {
+            const uint64_t k = row[q];
+            if (k == 0ull) break;
+            const float v = pda_key_val(k);
+            if (v < thr[0]) break;                 // (thr[0] is the smallest threshold; the list is sorted)
+#pragma unroll
+            for (int j = 0; j < kSeedThrMax; ++j) c[j] += (v >= thr[j]) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kSeedThrMax; ++j)
+        if (j < n_thr) counts[(size_t)j * n_users + u] = c[j];
+}
+// seed = the largest threshold at or above which the shards hold K warm-up entries between them (summed counts), else lo
+__global__ void __launch_bounds__(256) seed_pick_kernel(const float* __restrict__ bounds, const int32_t* __restrict__ counts, int n_thr,
+                                                        int n_users, int K, float* __restrict__ seed) {
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= n_users) return;
+    const float lo = fmaxf(bounds[u], -bounds[2 * (size_t)n_users + u]), hi = bounds[(size_t)n_users + u];
+    float s = lo;
+    for (int j = 0; j < n_thr; ++j)
+        if (counts[(size_t)j * n_users + u] >= K) s = fmaxf(s, seed_thr(lo, hi, j, n_thr));
+    seed[u] = s;
+}
+
 }  // namespace
+
+extern "C" int pda_topk_seed_bounds(const uint64_t* keys, int n_splits, int n_users_blk, int K, int m, float* bounds, void* stream) {
+    if (!keys || !bounds || n_splits < 1 || n_users_blk < 1 || K < 1 || m < 1 || m > K) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(seed_bounds_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys,
+                       n_splits, n_users_blk, K, m, bounds);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+extern "C" int pda_topk_seed_counts(const uint64_t* keys, int n_splits, int n_users_blk, int K, const float* bounds, int n_thr, int32_t* counts,
+                                    void* stream) {
+    if (!keys || !bounds || !counts || n_splits < 1 || n_users_blk < 1 || K < 1 || n_thr < 1 || n_thr > kSeedThrMax) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(seed_counts_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys,
+                       n_splits, n_users_blk, K, bounds, n_thr, counts);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+extern "C" int pda_topk_seed_pick(const float* bounds, const int32_t* counts, int n_thr, int n_users_blk, int K, float* seed, void* stream) {
+    if (!bounds || !seed || n_users_blk < 1 || K < 1 || n_thr < 0 || n_thr > kSeedThrMax || (n_thr > 0 && !counts)) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(seed_pick_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), bounds,
+                       counts, n_thr, n_users_blk, K, seed);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
 
 #ifdef PDA_V4_PROF
 extern "C" int pda_debug_prof4(unsigned long long* out16, int reset) {

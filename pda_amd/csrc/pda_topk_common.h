@@ -119,7 +119,7 @@ __device__ __forceinline__ void list_sync() {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     } else {
-        list_sync<GLB>();
+        pda_wave_sync();
     }
 }
 

@@ -8,6 +8,9 @@ collective over xGMI and a merge with pda_topk_merge:
                    lists of ITS slice of the users -- what bench.py times for N > 1 (at R = 8 the all-gather would move
                    183 MB per rank and 65 536-user block, more time than the scoring)
 The collective + merge of block b run on a side stream while block b+1 is being scored.
+Early-terminating sweeps add the seed exchange (ops.seeded_begin / seeded_counts / seeded_finish): ONE all-reduce MAX of 12 bytes
+per user and, from four shards on, ONE all-reduce SUM of 28 bytes per user -- both depend on the block's warm-up only and are
+issued for block b + 1 on a second side stream under the sweep of block b (`topk_blocks`): at most three collectives per block.
 
 `score_fn` / `merge_fn` default to the HIP entry points; tests inject doubles to exercise the
 orchestration under gloo on CPU (there is no CPU product path).
@@ -117,6 +120,11 @@ class ItemShardedTopK:
         self.seeded = score_fn is _ops_score_fn()
         self.prune = None            # None: ops' default per head; else passed through to score_fn (the same on every rank)
         self._side = torch.cuda.Stream() if U.is_cuda and world > 1 else None
+        self._seed_stream = torch.cuda.Stream() if U.is_cuda and world > 1 else None
+        # (begin, counts, finish) of the seeded sweep as separate calls: topk_blocks pipelines them across blocks.  Default:
+        # ops.seeded_* when score_fn is ops.score_topk_keys; tests inject doubles.
+        self.seeded_api = None
+        self.n_collectives = 0       # collectives issued by this object (tests: at most three per user block)
 
     @classmethod
     def from_full_tables(cls, U, I_full, pop_full=None, rank=0, world=1, **kw) -> "ItemShardedTopK":
@@ -143,33 +151,68 @@ class ItemShardedTopK:
         self._pop_src = (weakref.ref(pop_full), pop_full._version)
 
     # -- one block, blocking ---------------------------------------------------------------------
-    def _seed_reduce(self, mx, mn):
-        """The shards' bounds of a user's final K-th value, in place: the MAXIMUM of their K-th (and best) warm-up values, the
-        MINIMUM of their ceil(K / R)-th values (ops.score_topk_keys; 3 x 4 bytes per user)."""
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self.group)
-        dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self.group)
+    def _seed_reduce(self, bounds):
+        """The shards' bounds of a user's final K-th value, in place: ONE all-reduce MAX over float32 [3, Bu] = (K-th warm-up
+        value, ceil(K / R)-th, minus the ceil(K / R)-th: min x = -max -x) -- ops.seeded_begin."""
+        self.n_collectives += 1
+        dist.all_reduce(bounds, op=dist.ReduceOp.MAX, group=self.group)
 
     def _seed_sum(self, counts):
-        """One round of the seed's bisection: the shards' counts of warm-up entries above the common threshold, summed."""
+        """The shards' counts of warm-up entries at or above the common thresholds, summed: ONE all-reduce SUM over int32
+        [n_thr, Bu] (the grid three sequential bisection rounds used to walk) -- ops.seeded_counts."""
+        self.n_collectives += 1
         dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=self.group)
 
+    def _seed_applies(self, K, head) -> bool:
+        from . import ops
+        return self.world > 1 and self.seeded and ops.seed_exchange_applies(self.I_shard.shape[1], K, head, self.prune)
+
+    def _validate_once(self, head):
+        """Conditions that differ from rank to rank (the shard's size, its popularity slice) are checked on every rank BEFORE the
+        first collective of a seeded sweep and the verdict is shared: a rank that raised alone would leave the others waiting in
+        an all-reduce forever.  Once per (popularity version, head)."""
+        key = (head, id(self.pop_shard), None if self.pop_shard is None else self.pop_shard._version)
+        if getattr(self, "_validated", None) == key:
+            return
+        err = ""
+        if self.I_shard.shape[0] > (1 << 26):
+            err = "seeded item-sharded evaluation: at most 2^26 item rows per shard"
+        elif head and self.pop_shard is None and self.I_shard.shape[0] > 0:
+            err = "the popularity head needs a popularity vector"
+        elif head and self.pop_shard is not None and self.pop_shard.numel() and bool((self.pop_shard < 0).any()):
+            err = "pop_shard must be >= 0 (it is pop**gamma of a normalised count)"
+        flag = torch.tensor([1.0 if err else 0.0], dtype=torch.float32, device=self.U.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+        if float(flag[0]) != 0.0:
+            raise ValueError(err or "another rank of the item group rejected its shard (see its message)")
+        self._validated = key
+
+    def _empty_shard_seed(self, users, K):
+        """A rank without items joins the block's seed collectives with neutral values."""
+        from . import ops
+        nu, dev = users.numel(), users.device
+        b = torch.empty((3, nu), dtype=torch.float32, device=dev)
+        b[0:2] = float("-inf")
+        b[2] = float("inf")
+        self._seed_reduce(b)
+        n_thr = ops.seed_thresholds(self.world)
+        if n_thr > 0:
+            self._seed_sum(torch.zeros((n_thr, nu), dtype=torch.int32, device=dev))
+
     def local_keys(self, users, K, head, hist):
-        seeded = self.world > 1 and self.seeded
+        seeded = self._seed_applies(K, head)
+        if seeded:
+            self._validate_once(head)
         if self.I_shard.shape[0] == 0:
             # more ranks than 32-item tiles: this rank owns nothing and contributes empty lists (key 0 = empty slot), so that
             # the collectives of the other ranks do not wait for a call that would fail on a 0-row shard
             if seeded:
-                from . import ops
-                if ops.seed_exchange_applies(self.I_shard.shape[1], K, head, self.prune):
-                    tau = torch.full((3, users.numel()), float("-inf"), dtype=torch.float32, device=users.device)
-                    self._seed_reduce(tau[0:2], tau[2])
-                    for _ in range(ops.seed_rounds(self.world)):
-                        self._seed_sum(torch.zeros(users.numel(), dtype=torch.int32, device=users.device))
+                self._empty_shard_seed(users, K)
             return torch.zeros((users.numel(), K) if self.world > 1 else (1, users.numel(), K), dtype=torch.int64, device=users.device)
         extra = {} if self.prune is None else {"prune": self.prune}
         if seeded:
             # early-terminating sweeps: without the exchange every shard prunes against its own shard's K-th value only and
-            # eight shards score 6.5 x the tiles of one GPU between them; with it 1.8 x (1.4 x on four, 1.07 x on two)
+            # eight shards score 6.5 x the tiles of one GPU between them; with it 1.03 x (0.98 x on four, 1.07 x on two)
             extra["seed_reduce"], extra["seed_shards"], extra["seed_sum"] = self._seed_reduce, self.world, self._seed_sum
         keys = self.score_fn(self.U, self.I_shard, users, K, head, self.pop_shard if head else None, hist,
                              self.item_offset, 0, **extra)
@@ -180,6 +223,7 @@ class ItemShardedTopK:
     def topk(self, users, K=50, head=0, hist=None):
         keys = self.local_keys(users, K, head, hist)
         if self.world > 1:
+            self.n_collectives += 1
             keys = _all_gather_keys(keys, self.world, self.group)     # [R, Bu, K] -- the one collective
         return self.merge_fn(keys, users, hist, want="idx_val")
 
@@ -191,6 +235,7 @@ class ItemShardedTopK:
     def _finish(self, keys, users, hist, sharded: bool):
         """The exchange + final merge of one block.  sharded: all-to-all, this rank merges its slice of the users and
         returns (idx, val) for those rows only; else all-gather and every rank merges everything."""
+        self.n_collectives += 1
         if sharded and users.numel() % self.world == 0 and (hist is None or getattr(hist, "mode", 1) == 1):
             lo, hi = self.user_slice(users.numel())
             allk = _exchange_user_slices(keys, self.world, self.group)
@@ -212,34 +257,121 @@ class ItemShardedTopK:
         return self._finish(keys, users, hist, True)
 
     # -- many blocks, collective + merge of block b overlapped with scoring of block b+1 ----------
+    def _seeded_steps(self):
+        """(begin, counts, finish) when the seeded sweep can be driven step by step, else None."""
+        if self.seeded_api is not None:
+            return self.seeded_api
+        if self.score_fn is _ops_score_fn():
+            from . import ops
+            return ops.seeded_begin, ops.seeded_counts, ops.seeded_finish
+        return None
+
     def topk_blocks(self, blocks: Iterable[torch.Tensor], K=50, head=0, hist=None, sharded: bool = False) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
-        if self.world == 1 or self._side is None:
+        if self.world == 1:
             for users in blocks:
                 yield self.topk_sharded(users, K, head, hist) if sharded else self.topk(users, K, head, hist)
             return
-        main = torch.cuda.current_stream()
+        # (a rank without items follows the same order of collectives as the others: same pipeline, neutral values)
+        steps = self._seeded_steps() if self._seed_applies(K, head) else None
+        if self._side is None and steps is None:
+            for users in blocks:
+                yield self.topk_sharded(users, K, head, hist) if sharded else self.topk(users, K, head, hist)
+            return
+        cuda = self._side is not None
+        main = torch.cuda.current_stream() if cuda else None
         pending = None                       # (result, done-event) of the previous block, produced on the side stream
 
         def hand_over(p):
             res, done = p
-            main.wait_event(done)            # orders only what the consumer enqueues next; scoring of b+1 is already queued
-            for t in res:
-                t.record_stream(main)
+            if cuda:
+                main.wait_event(done)        # orders only what the consumer enqueues next; scoring of b+1 is already queued
+                for t in res:
+                    t.record_stream(main)
             return res
 
-        for users in blocks:
-            keys = self.local_keys(users, K, head, hist)
+        def exchange(keys, users):
+            """collective + final merge of one block on the side stream"""
+            if not cuda:
+                return self._finish(keys, users, hist, sharded), None
             ev = torch.cuda.Event()
             ev.record(main)
-            if pending is not None:
-                yield hand_over(pending)
             with torch.cuda.stream(self._side):
                 self._side.wait_event(ev)
                 keys.record_stream(self._side)
                 res = self._finish(keys, users, hist, sharded)
                 done = torch.cuda.Event()
                 done.record(self._side)
-                pending = (res, done)
+            return res, done
+
+        if steps is None:
+            for users in blocks:
+                keys = self.local_keys(users, K, head, hist)
+                nxt = exchange(keys, users)
+                if pending is not None:
+                    yield hand_over(pending)
+                pending = nxt
+            if pending is not None:
+                yield hand_over(pending)
+            return
+
+        # Seeded early-terminating sweeps, software-pipelined: main stream  W(b+1)  S(b)  W(b+2)  S(b+1) ...  (W = warm-up + bounds,
+        # S = pick + sweep + local merge); seed stream  MAX(b+1), counts(b+1), SUM(b+1)  under S(b); side stream  all-to-all + merge.
+        begin, counts, finish = steps
+        self._validate_once(head)
+        popv = self.pop_shard if head else None
+
+        empty = self.I_shard.shape[0] == 0
+
+        def start(users):
+            if empty:
+                c = None
+            else:
+                c = begin(self.U, self.I_shard, users, K, head, popv, hist, self.item_offset, 0, self.world)
+            if not cuda or empty:
+                if empty:
+                    self._empty_shard_seed(users, K)
+                    return c, users, None
+                self._seed_reduce(c.bounds)
+                cnt = counts(c)
+                if cnt is not None:
+                    self._seed_sum(cnt)
+                return c, users, None
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(self._seed_stream):
+                self._seed_stream.wait_event(ev)
+                self._seed_reduce(c.bounds)
+                cnt = counts(c)
+                if cnt is not None:
+                    self._seed_sum(cnt)
+                ready = torch.cuda.Event()
+                ready.record(self._seed_stream)
+            return c, users, ready
+
+        def sweep(st):
+            c, users, ready = st
+            if ready is not None:
+                main.wait_event(ready)
+            if c is None:
+                keys = torch.zeros((users.numel(), K), dtype=torch.int64, device=users.device)
+            else:
+                keys = self.merge_fn(finish(c), users, hist, want="keys")
+            return exchange(keys, users)
+
+        waiting = None
+        for users in blocks:
+            st = start(users)
+            if waiting is not None:
+                nxt = sweep(waiting)
+                if pending is not None:
+                    yield hand_over(pending)
+                pending = nxt
+            waiting = st
+        if waiting is not None:
+            nxt = sweep(waiting)
+            if pending is not None:
+                yield hand_over(pending)
+            pending = nxt
         if pending is not None:
             yield hand_over(pending)
 

@@ -219,8 +219,14 @@ def seed_rounds(seed_shards: int) -> int:
     from 4 shards on (config 3: four shards 1.39 x -> 0.98 x, eight shards 1.78 x -> 1.03 x).  PDA_SEED_ROUNDS overrides; the same on every rank."""
     forced = os.environ.get("PDA_SEED_ROUNDS")
     if forced is not None and forced != "":
-        return max(0, int(forced))
+        return min(4, max(0, int(forced)))
     return 3 if seed_shards >= 4 else 0
+
+
+def seed_thresholds(seed_shards: int) -> int:
+    """Common thresholds of the ONE count exchange that replaces seed_rounds(seed_shards) sequential bisection rounds: the
+    2^rounds - 1 interior grid points those rounds walk (7 from four shards on; 0 = the plain seed, no count exchange)."""
+    return (1 << seed_rounds(seed_shards)) - 1
 
 
 def check_order(prep_ord: torch.Tensor, n: int, d: int):
@@ -300,17 +306,95 @@ def prune_default(head: int, d: Optional[int] = None):
     return "order" if d in (64, 128) else False
 
 
+class SeededCall:
+    """One user block of an item-sharded early-terminating sweep between its steps (seeded_begin -> the MAX all-reduce of
+    .bounds -> seeded_counts -> the SUM all-reduce of .counts -> seeded_finish): what lets pda_amd.dist run the two collectives
+    of block b + 1 on a side stream under the sweep of block b."""
+    __slots__ = ("lib", "fnp", "common", "wt", "out", "ws", "bounds", "counts", "n_thr", "K", "nu", "n_splits", "nloc", "stats", "keep")
+
+
+def seeded_begin(U, I_shard, users, K, head, pop_shard, hist, item_offset=0, n_splits=0, seed_shards=1, prune=True,
+                 stats: Optional[dict] = None) -> SeededCall:
+    """Step 1: the exact warm-up of this shard (pda_score_topk4_phase_*, phase 1) and the shard's three bounds per user
+    (pda_topk_seed_bounds) -> .bounds float32 [3, Bu], to be MAX-reduced over the shards in place."""
+    lib = _lib.load()
+    bf = I_shard.dtype == torch.bfloat16
+    U = _need(U, torch.bfloat16 if bf else torch.float32, "U")
+    I_shard = _need(I_shard, torch.bfloat16 if bf else torch.float32, "I_shard")
+    users = _need(users, torch.int32, "users")
+    pop_shard = _need(pop_shard, torch.float32, "pop_shard", optional=True)
+    nu, nloc, d = users.numel(), I_shard.shape[0], I_shard.shape[1]
+    if U.shape[1] != d:
+        raise ValueError("U and I_shard disagree on embed dim")
+    if pop_shard is not None and pop_shard.numel() != nloc:
+        raise ValueError("pop_shard must have one entry per local item row")
+    if nloc > (1 << 26):
+        raise ValueError("seeded item-sharded evaluation: at most 2^26 item rows per shard")
+    if head == HEAD_POP and pop_shard is not None:
+        _check_pop(pop_shard)
+    if hist is not None and hist.indices.numel() == 0:
+        hist = None
+    c = SeededCall()
+    order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None)
+    prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
+    if n_splits <= 0:
+        n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
+    c.lib, c.K, c.nu, c.n_splits, c.nloc, c.stats = lib, K, nu, n_splits, nloc, stats
+    c.out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
+    c.ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
+    c.fnp = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32
+    c.common = (ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+                ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head, 1, n_splits)
+    c.keep = (U, I_shard, prep, pop_shard, users, hist)          # the pointers above stay valid until seeded_finish
+    # R shards warm up R x 64 warm_tiles items between them: two tiles each on 2 shards, one from 4 shards on
+    c.wt = int(os.environ.get("PDA_WARM_TILES", "0")) or max(1, 4 // max(1, seed_shards))
+    check(c.fnp(*c.common, 1, c.wt, None, ptr(c.out), ptr(c.ws), stream_ptr()), "pda_score_topk4_phase (warm-up)")
+    c.bounds = torch.empty((3, nu), dtype=torch.float32, device=U.device)
+    m = -(-K // max(1, seed_shards))
+    check(lib.pda_topk_seed_bounds(ptr(c.out), n_splits, nu, K, m, ptr(c.bounds), stream_ptr()), "pda_topk_seed_bounds")
+    c.n_thr, c.counts = seed_thresholds(seed_shards), None
+    return c
+
+
+def seeded_counts(c: SeededCall) -> Optional[torch.Tensor]:
+    """Step 2 (after the MAX all-reduce of c.bounds): this shard's warm-up entries at or above the common thresholds ->
+    int32 [n_thr, Bu], to be SUM-reduced in place; None below four shards (plain seed: no second collective)."""
+    if c.n_thr <= 0:
+        return None
+    c.counts = torch.empty((c.n_thr, c.nu), dtype=torch.int32, device=c.bounds.device)
+    check(c.lib.pda_topk_seed_counts(ptr(c.out), c.n_splits, c.nu, c.K, ptr(c.bounds), c.n_thr, ptr(c.counts), stream_ptr()),
+          "pda_topk_seed_counts")
+    return c.counts
+
+
+def seeded_finish(c: SeededCall) -> torch.Tensor:
+    """Step 3 (after the SUM all-reduce of c.counts): the seed per user (pda_topk_seed_pick) and the sweep that prunes against
+    it (phase 2).  Returns the shard's packed keys int64 [n_splits, Bu, K]; lists may end shorter than K."""
+    seed = torch.empty(c.nu, dtype=torch.float32, device=c.bounds.device)
+    check(c.lib.pda_topk_seed_pick(ptr(c.bounds), ptr(c.counts), c.n_thr if c.counts is not None else 0, c.nu, c.K, ptr(seed), stream_ptr()),
+          "pda_topk_seed_pick")
+    check(c.fnp(*c.common, 2, c.wt, ptr(seed), ptr(c.out), ptr(c.ws), stream_ptr()), "pda_score_topk4_phase (sweep)")
+    if c.stats is not None:
+        c.stats["tiles_scored"] = c.ws[8:16].view(torch.int64)
+        c.stats["pairs_rescored"] = c.ws[4:8].view(torch.int32)
+        c.stats["tiles_dense"] = ((c.nloc + 31) // 32) * ((c.nu + 127) // 128)
+    out, c.keep = c.out, None
+    return out
+
+
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
                     item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None,
                     prune=None, stats: Optional[dict] = None, seed_reduce=None, seed_shards: int = 1, seed_sum=None) -> torch.Tensor:
-    """seed_reduce (item-sharded evaluation over `seed_shards` shards, early-terminating sweep): a callable (mx, mn) that
-    receives this shard's float32 [2, Bu] (warm-up list values at rank K and at rank ceil(K / seed_shards)) and [Bu] (at rank
-    ceil(K / seed_shards) again) and turns them IN PLACE into the maximum resp. the minimum over all shards (two dist.all_reduce).  The
-    sweep prunes against the larger of the K-th-value bounds (pda_score_topk4_phase_*); the shard's lists may end shorter
-    than K -- merge them with the other shards' lists.  seed_sum (optional; int32 [Bu] -> sum over the shards, in place):
-    seed_rounds(seed_shards) rounds of pda_topk_seed_refine tighten the bound first."""
-    """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 -> packed keys
-    int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All three return the same keys."""
+    """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 / pda_score_topk4_* -> packed keys
+    int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All of them return the same keys.
+
+    seed_reduce (item-sharded evaluation over `seed_shards` shards, early-terminating sweep): a callable that receives this
+    shard's float32 [3, Bu] bounds (pda_topk_seed_bounds: warm-up values at rank K, at rank ceil(K / seed_shards), and minus the
+    latter) and turns them IN PLACE into the maximum over all shards (ONE dist.all_reduce MAX).  seed_sum (optional; int32
+    [n_thr, Bu] -> the sum over the shards in place, ONE all_reduce SUM): the counts at seed_thresholds(seed_shards) common
+    thresholds tighten the bound first.  The sweep prunes against the resulting seed (pda_score_topk4_phase_*); the shard's lists
+    may end shorter than K -- merge them with the other shards' lists.  (seeded_begin / seeded_counts / seeded_finish are the
+    same three steps as separate calls.)"""
     lib = _lib.load()
     bf = I_shard is not None and I_shard.dtype == torch.bfloat16       # bf16 tables: pda_score_topk_bf16 (both tables bf16)
     U = _need(U, torch.bfloat16 if bf else torch.float32, "U")
@@ -332,57 +416,35 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         hist = None                       # an all-empty mask: the kernel must never dereference a 0-length buffer
     n_splits_auto = n_splits <= 0
     out_given = out
+    impl = impl or score_impl(d, K, item_offset + nloc)
+    if prune is None:
+        prune = prune_default(head, d)
+    if seed_reduce is not None and seed_exchange_applies(d, K, head, prune, impl):
+        if out_given is not None:
+            raise ValueError("the seeded sweep allocates its own output")
+        c = seeded_begin(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_shards, stats=stats)
+        seed_reduce(c.bounds)
+        cnt = seeded_counts(c) if seed_sum is not None else None
+        if cnt is not None:
+            seed_sum(cnt)
+        return seeded_finish(c)
     if n_splits <= 0:
         n_splits = lib.pda_score_topk_auto_splits(nu, nloc)
     if out is None:
         out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
     elif out.shape != (n_splits, nu, K) or out.dtype != torch.int64:
         raise ValueError("out must be int64 [n_splits, Bu, K]")
-    impl = impl or score_impl(d, K, item_offset + nloc)
-    if prune is None:
-        prune = prune_default(head, d)
-    seeded = seed_reduce is not None and seed_exchange_applies(d, K, head, prune, impl)
-    if seeded and nloc > (1 << 26):
-        raise ValueError("seeded item-sharded evaluation: at most 2^26 item rows per shard")
-    if impl == "v2" and (seeded or score_kernel(d, K, nloc, prune, head) == "v4"):
+    if impl == "v2" and score_kernel(d, K, nloc, prune, head) == "v4":
         order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
         if n_splits_auto and out_given is None:
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
-        if seeded:
-            # warm-up -> K-th values -> maximum over the shards -> seeded sweep
-            fnp = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32
-            common = (ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
-                      ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head, 1, n_splits)
-            # R shards warm up R x 64 warm_tiles items between them: two tiles each on 2 shards, one from 4 shards on
-            wt = int(os.environ.get("PDA_WARM_TILES", "0")) or max(1, 4 // max(1, seed_shards))
-            check(fnp(*common, 1, wt, None, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (warm-up)")
-            tau = torch.empty((3, nu), dtype=torch.float32, device=U.device)
-            m = -(-K // max(1, seed_shards))
-            # rows: the K-th value (-> MAX: a lower bound of the final K-th value), the ceil(K/R)-th value twice (-> MAX: an UPPER
-            # bound of the K-th value of the merged warm-up lists -- some shard holds ceil(K/R) of its top K --, -> MIN: a lower one)
-            for row, pos in ((0, K - 1), (1, m - 1), (2, m - 1)):
-                check(lib.pda_topk_kth_value(ptr(out), n_splits, nu, K, pos, ptr(tau[row]), stream_ptr()), "pda_topk_kth_value")
-            seed_reduce(tau[0:2], tau[2])
-            seed = torch.maximum(tau[0], tau[2])
-            rounds = seed_rounds(seed_shards) if seed_sum is not None else 0
-            if rounds > 0:
-                mid = torch.empty(nu, dtype=torch.float32, device=U.device)
-                cnt = torch.empty(nu, dtype=torch.int32, device=U.device)
-                for r in range(rounds + 1):
-                    mode = 0 if r == 0 else (2 if r == rounds else 1)
-                    check(lib.pda_topk_seed_refine(ptr(out), n_splits, nu, K, ptr(seed), ptr(tau[1]), ptr(mid), ptr(cnt), mode, stream_ptr()),
-                          "pda_topk_seed_refine")
-                    if mode < 2:
-                        seed_sum(cnt)
-            check(fnp(*common, 2, wt, ptr(seed), ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (sweep)")
-        else:
-            fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
-            check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
-                     ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
-                     K, head, 1 if prune is True else 0, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
+        fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
+        check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+                 ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
+                 K, head, 1 if prune is True else 0, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
         if stats is not None:
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["pairs_rescored"] = ws[4:8].view(torch.int32)
@@ -488,6 +550,65 @@ def sgd_step_exact(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: f
     check(lib.pda_sgd_apply_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(scratch[0]), ptr(scratch[1]), ptr(scratch[2]),
                                 B, d, float(lr), stream_ptr()), "pda_sgd_apply_f32")
     mark_modified(U, I)
+    return scratch
+
+
+def triplet_plan(users, pos, neg, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """pda_triplet_plan: users / pos / neg int32 [B] or [n, B] -> uint8 [n, pda_triplet_plan_bytes(B)] (one plan per batch; the
+    plan of batch j is out[j]).  B <= 4096."""
+    lib = _lib.load()
+    users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
+    B = users.shape[-1]
+    n = users.numel() // B
+    nb = lib.pda_triplet_plan_bytes(B)
+    if out is None:
+        out = torch.empty((n, nb), dtype=torch.uint8, device=users.device)
+    elif out.shape != (n, nb) or out.dtype != torch.uint8 or not out.is_contiguous():
+        raise ValueError("out must be contiguous uint8 [n_batches, pda_triplet_plan_bytes(B)]")
+    check(lib.pda_triplet_plan(ptr(users), ptr(pos), ptr(neg), B, n, ptr(out), stream_ptr()), "pda_triplet_plan")
+    return out
+
+
+def plan_header(plan: torch.Tensor):
+    """Host view of a plan's header (synchronising; tests and diagnostics): (segments, a user occurs twice, 2B, B)."""
+    return tuple(int(x) for x in plan.reshape(-1)[:16].view(torch.int32).cpu())
+
+
+def bpr_step_plan(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float, plan: torch.Tensor,
+                  scratch: Optional[torch.Tensor] = None, exact: bool = True, loss_acc: Optional[torch.Tensor] = None,
+                  U_master=None, I_master=None) -> Optional[torch.Tensor]:
+    """pda_bpr_step_plan_f32 / _bf16 (U, I bf16 with fp32 U_master / I_master): the exact mini-batch SGD step of a batch with
+    DISTINCT users, two launches, no atomics (exact=False: one launch, plain stores on user rows and once-referenced item rows,
+    atomics on shared item rows; fp32 tables only).  plan = triplet_plan(users, pos, neg)[j].  Returns the scratch buffer for reuse."""
+    lib = _lib.load()
+    bf = U.dtype == torch.bfloat16
+    users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
+    pos_pop = _need(pos_pop, torch.float32, "pos_pop", optional=True)
+    neg_pop = _need(neg_pop, torch.float32, "neg_pop", optional=True)
+    plan = _need(plan, torch.uint8, "plan")
+    B, d = users.numel(), U.shape[1]
+    if plan.numel() != lib.pda_triplet_plan_bytes(B):
+        raise ValueError("plan does not belong to a batch of %d triplets" % B)
+    if exact:
+        ns = lib.pda_bpr_step_plan_scratch_bytes(B, d) // 4
+        if scratch is None or scratch.numel() != ns:
+            scratch = torch.empty(ns, dtype=torch.float32, device=U.device)
+    loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
+    if bf:
+        U, I = _need(U, torch.bfloat16, "U"), _need(I, torch.bfloat16, "I")
+        U_master, I_master = _need(U_master, torch.float32, "U_master"), _need(I_master, torch.float32, "I_master")
+        if not exact:
+            raise ValueError("bf16 tables take the exact planned step only")
+        check(lib.pda_bpr_step_plan_bf16(ptr(U), ptr(I), ptr(U_master), ptr(I_master), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop),
+                                         B, d, float(regs), float(reg_div), float(lr), ptr(plan), ptr(scratch), ptr(loss_acc), stream_ptr()),
+              "pda_bpr_step_plan_bf16")
+        mark_modified(U, I, U_master, I_master)
+    else:
+        U, I = _need(U, torch.float32, "U"), _need(I, torch.float32, "I")
+        check(lib.pda_bpr_step_plan_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), B, d, float(regs),
+                                        float(reg_div), float(lr), ptr(plan), ptr(scratch), 1 if exact else 0, ptr(loss_acc), stream_ptr()),
+              "pda_bpr_step_plan_f32")
+        mark_modified(U, I)
     return scratch
 
 

@@ -246,71 +246,124 @@ def test_item_parallel_training_two_ranks_gloo():
     assert all(all(r[1]) for r in res), res
 
 
-def score_double_seeded(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_reduce=None, seed_shards=1, prune=None,
-                        seed_sum=None):
-    """The seeded contract of ops.score_topk_keys on the CPU: warm-up lists of the shard's first 16 items -> the values at
-    rank K, rank 1 and rank ceil(K / R) -> seed_reduce (MAX resp. MIN over the shards, in place) -> ops.seed_rounds(R) rounds of
-    the bisection on summed counts (seed_sum) -> the shard's list WITHOUT the entries below the bound (empty slots = key 0)."""
-    from pda_amd import ops
-    full = score_double(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits)
-    if seed_reduce is None:
-        return full
+def _warm_bounds(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_shards):
+    """Warm-up lists of the shard's first 16 items and the three bounds of pda_topk_seed_bounds."""
     warm = score_double(U, I_shard[:16], users, K, head, None if pop_shard is None else pop_shard[:16], hist, item_offset, n_splits)
     wv, wi = _unpack(warm.numpy()[0])
     wv = np.where(wi >= 0, wv, -np.inf).astype(np.float32)
     m = -(-K // seed_shards)
-    tau = torch.from_numpy(np.stack([wv[:, K - 1], wv[:, m - 1], wv[:, m - 1]]))
-    seed_reduce(tau[0:2], tau[2])
-    lo, hi = torch.maximum(tau[0], tau[2]).numpy().copy(), tau[1].numpy().copy()
-    rounds = ops.seed_rounds(seed_shards) if seed_sum is not None else 0
-    for _ in range(rounds):
-        is_open = np.isfinite(lo) & np.isfinite(hi) & (hi > lo)
-        mid = np.where(is_open, lo + np.float32(0.5) * (hi - lo), lo).astype(np.float32)
-        cnt = torch.from_numpy((wv >= mid[:, None]).sum(1).astype(np.int32))
+    return wv, torch.from_numpy(np.stack([wv[:, K - 1], wv[:, m - 1], -wv[:, m - 1]]))
+
+
+def _thresholds(bounds, n_thr):
+    b = bounds.numpy()
+    lo, hi = np.maximum(b[0], -b[2]), b[1]
+    is_open = np.isfinite(lo) & np.isfinite(hi) & (hi > lo)
+    with np.errstate(invalid="ignore"):
+        thr = np.stack([np.where(is_open, lo + (hi - lo) * np.float32((j + 1) / (n_thr + 1)), lo) for j in range(n_thr)]) if n_thr else np.zeros((0, len(lo)), np.float32)
+    return lo.astype(np.float32), thr.astype(np.float32)
+
+
+class SeededDouble:
+    """ops.SeededCall on the CPU"""
+
+
+def seeded_begin_double(U, I_shard, users, K, head, pop_shard, hist, item_offset=0, n_splits=0, seed_shards=1, prune=True, stats=None):
+    from pda_amd import ops
+    c = SeededDouble()
+    c.full = score_double(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits)
+    c.wv, c.bounds = _warm_bounds(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_shards)
+    c.n_thr, c.K, c.counts = ops.seed_thresholds(seed_shards), K, None
+    return c
+
+
+def seeded_counts_double(c):
+    if c.n_thr <= 0:
+        return None
+    _, thr = _thresholds(c.bounds, c.n_thr)
+    c.counts = torch.from_numpy(np.stack([(c.wv >= t[:, None]).sum(1) for t in thr]).astype(np.int32))
+    return c.counts
+
+
+def seeded_finish_double(c):
+    lo, thr = _thresholds(c.bounds, c.n_thr if c.counts is not None else 0)
+    seed = lo.copy()
+    if c.counts is not None:
+        for j in range(c.n_thr):
+            seed = np.where(c.counts.numpy()[j] >= c.K, np.maximum(seed, thr[j]), seed)
+    v, i = _unpack(c.full.numpy()[0])
+    keys = c.full.numpy()[0].copy()
+    keys[(v < seed[:, None]) | (i < 0)] = 0
+    c.dropped = float((keys == 0).mean())
+    return torch.from_numpy(keys)[None]
+
+
+def score_double_seeded(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_reduce=None, seed_shards=1, prune=None,
+                        seed_sum=None):
+    """The seeded contract of ops.score_topk_keys on the CPU: warm-up lists of the shard's first 16 items -> the three bounds
+    (values at rank K, at rank ceil(K / R), minus the latter) -> seed_reduce (ONE MAX over the shards, in place) -> the counts at
+    ops.seed_thresholds(R) common thresholds -> seed_sum (ONE SUM) -> the shard's list WITHOUT the entries below the seed (empty
+    slots = key 0)."""
+    if seed_reduce is None:
+        return score_double(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits)
+    c = seeded_begin_double(U, I_shard, users, K, head, pop_shard, hist, item_offset, n_splits, seed_shards)
+    seed_reduce(c.bounds)
+    cnt = seeded_counts_double(c) if seed_sum is not None else None
+    if cnt is not None:
         seed_sum(cnt)
-        ge = cnt.numpy() >= K
-        lo, hi = np.where(ge, mid, lo), np.where(ge, hi, mid)
-    v, i = _unpack(full.numpy()[0])
-    keys = full.numpy()[0].copy()
-    keys[(v < lo[:, None]) | (i < 0)] = 0
-    return torch.from_numpy(keys)[None], float((keys == 0).mean()), rounds
+    keys = seeded_finish_double(c)
+    return keys, c.dropped, (c.n_thr if cnt is not None else 0)
 
 
 def _worker_seeded(rank, world, port, q):
-    """Three ranks, 60 items = two 32-item tiles: rank 2 owns NOTHING and must still join the two seed all-reduces."""
+    """Three ranks, 60 items = two 32-item tiles: rank 2 owns NOTHING and must still join the seed all-reduces.  Then the same
+    users as three blocks through topk_blocks with the step-by-step doubles (the software-pipelined path of pda_amd.dist):
+    identical lists, and at most three collectives per user block."""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from pda_amd.dist import ItemShardedTopK
+    from pda_amd import ops
     rng = np.random.default_rng(11)
     nU, nI, d, K = 48, 60, 64, 10
     U = rng.standard_normal((nU, d), dtype=np.float32) * 0.3
     I = rng.standard_normal((nI, d), dtype=np.float32) * 0.3
     pop = (rng.uniform(0, 1, nI) ** 3).astype(np.float32)
     pop[:32] += 1.0                            # shard 0 holds the popular items: its K-th value prunes shard 1's list
-    dropped, rounds_seen = [], []
+    dropped, thr_seen = [], []
 
     def fn(*a, **k):
-        keys, frac, rounds = score_double_seeded(*a, **k)
+        keys, frac, n_thr = score_double_seeded(*a, **k)
         dropped.append(frac)
-        rounds_seen.append(rounds)
+        thr_seen.append(n_thr)
         return keys
     ev = ItemShardedTopK.from_full_tables(torch.from_numpy(U), torch.from_numpy(I), torch.from_numpy(pop), rank, world,
                                           score_fn=fn, merge_fn=merge_double)
     assert ev.seeded is False
     ev.seeded = True
+    ev.prune = True
     users = torch.arange(nU, dtype=torch.int32)
     idx, val = ev.topk(users, K, 1, None)
     ridx, rval = c_oracle.score_topk(U, I, users.numpy(), K, 1, pop, order=1)
     ok = bool(np.array_equal(idx.numpy(), ridx) and np.array_equal(val.numpy(), rval))
-    q.put((rank, ok, ev.I_shard.shape[0], max(dropped) if dropped else -1.0, max(rounds_seen) if rounds_seen else -1))
+    # one validation all-reduce (once), MAX, SUM (from four shards on), all-gather
+    per_block_first = ev.n_collectives
+    # the pipelined path: three blocks, step-by-step doubles
+    ev.seeded_api = (seeded_begin_double, seeded_counts_double, seeded_finish_double)
+    ev.n_collectives = 0
+    blocks = [users[0:16], users[16:32], users[32:48]]
+    got = list(ev.topk_blocks(blocks, K, 1, None))
+    ok2 = all(np.array_equal(i.numpy(), ridx[16 * b:16 * b + 16]) and np.array_equal(v.numpy(), rval[16 * b:16 * b + 16]) for b, (i, v) in enumerate(got))
+    q.put((rank, ok and ok2, ev.I_shard.shape[0], max(dropped) if dropped else -1.0, max(thr_seen) if thr_seen else -1,
+           per_block_first, ev.n_collectives / 3.0))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [3, 4])
 def test_seeded_item_shards_with_an_empty_shard_gloo(world):
-    """world 3: the plain seed (two all-reduces); world 4: also the three bisection rounds on summed counts -- with TWO ranks
-    that own nothing and still have to join every collective."""
+    """world 3: the plain seed (ONE all-reduce MAX); world 4: also the counts at seven common thresholds (ONE all-reduce SUM)
+    -- with TWO ranks that own nothing and still have to join every collective.  At most three collectives per user block
+    including the exchange of the lists."""
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -324,4 +377,6 @@ def test_seeded_item_shards_with_an_empty_shard_gloo(world):
     assert all(r[1] for r in res), res
     assert [r[2] for r in res] == [32, 28, 0, 0][:world]
     assert res[1][3] > 0 and res[2][3] == -1.0         # the seed did drop entries of shard 1; rank 2 never scored
-    assert res[0][4] == (3 if world == 4 else 0)
+    assert res[0][4] == (7 if world == 4 else 0)
+    want = 3 if world == 4 else 2                      # MAX (+ SUM) + the exchange of the lists
+    assert all(r[5] == want and r[6] == want for r in res), res

@@ -579,6 +579,33 @@ def test_negative_popularity_is_rejected(dev):
         ops.score_topk_keys(U, I, torch.arange(8, dtype=torch.int32, device=dev), 5, 1, pop)
 
 
+def oracle_sample_lists(W, users_t, head, n=256):
+    """c_oracle.score_topk (the fp32 fmaf chain of the kernels, order=1) on the first n of `users_t` against the WHOLE
+    catalogue of workload W with the users' real train rows; bf16 tables are widened (that is how their scores are defined)."""
+    sub = users_t[:n].cpu().numpy()
+    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
+    rows = [ix[ip[u]:ip[u + 1]] for u in sub]
+    bip, bix = csr(rows)
+    Uw, Iw = W.U[users_t[:n].long()].float().cpu().numpy(), W.I.float().cpu().numpy()
+    pop = W.pop_last.cpu().numpy() if head else None
+    return c_oracle.score_topk(Uw, Iw, np.arange(len(sub), dtype=np.int32), 50, head, pop, bip, bix, order=1, want_scores=True)
+
+
+def assert_lists_match_oracle(keys, ridx, rval, sc, head):
+    """Merged packed keys of the kernels against the oracle's lists: raw head bit-exact; popularity head 1e-5 on the values and
+    any list disagreement a near-tie inside that tolerance (hardware v_exp_f32 vs libm expf in the last ulp)."""
+    from pda_amd import ops
+    idx, val = ops.unpack_keys(keys[:len(ridx)])
+    if head == 0:
+        np.testing.assert_array_equal(val, rval)
+        np.testing.assert_array_equal(idx, ridx)
+        return
+    np.testing.assert_allclose(val, rval, rtol=TOL, atol=TOL)
+    for r, k in np.argwhere(idx != ridx):
+        a, b = idx[r, k], ridx[r, k]
+        assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b)
+
+
 def test_full_size_c3_sweep_modes_agree(dev, impl):
     """BASELINE config 3 at full size (1M users x 200k items, d=128, PDA head, real history CSR of 49M entries): the
     natural-order, visiting-order and early-terminating sweeps return identical merged keys for 16 384 users, and the exact
@@ -620,6 +647,21 @@ def test_full_size_c3_sweep_modes_agree(dev, impl):
     ref = got[("v3", True)]
     for k, v in got.items():
         assert torch.equal(ref, v), k
+    # ---- the operating point of bench.py's headline: a 262 144-user block (MF/train_new_api.py:780-794 at the product's
+    # --eval_block), both heads, product-default sweep mode and the dense sweep in visiting order.  (a) the first 256 lists
+    # equal the oracle's on config 3's real history; (b) the keys of the users shared with the 131 072-user block are the same.
+    huge = torch.arange(200_000, 200_000 + 262144, dtype=torch.int32, device=dev)
+    oracle = {h: oracle_sample_lists(W, huge, h) for h in (0, 1)}
+    for prune in ("order", True):
+        k262 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
+        assert torch.equal(k262[:131072], ref), prune
+        assert_lists_match_oracle(k262, *oracle[1], head=1)
+    raw = {}
+    for prune in (None, False):                   # raw head: the product default (visiting order by norm) and natural order
+        raw[prune] = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_RAW, None, hist, prune=prune), want="keys")
+        assert_lists_match_oracle(raw[prune], *oracle[0], head=0)
+    assert torch.equal(raw[None], raw[False])
+    torch.cuda.synchronize()
 
 
 def test_full_size_c5_shard_bf16(dev, impl):
@@ -672,6 +714,14 @@ def test_full_size_c5_shard_bf16(dev, impl):
     for r, k in bad:
         a, b = idx[r, k], ridx[r, k]
         assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b)
+    # ---- the block size bench.py --workload c5shard times (262 144 users; the regrouping and the masks' own kernel start at
+    # 98 304): dense in visiting order and early-terminating, generation 4 -- the users shared with the 8 192-user block above
+    # carry the same keys, and the first 256 lists equal the oracle's
+    huge = torch.arange(300_000, 300_000 + 262144, dtype=torch.int32, device=dev)
+    for prune in ("order", True):
+        k262 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
+        assert torch.equal(k262[:8192], ref), prune
+        assert_lists_match_oracle(k262, ridx, rval, sc, head=1)
 
 
 class FakeCollectives:
@@ -716,7 +766,8 @@ def test_seeded_item_shards_equal_one_shard(dev, impl, R, head, bf16):
     """Item-sharded evaluation with exact early termination (pda_score_topk4_phase_*, pda_topk_kth_value,
     pda_topk_seed_refine): R emulated shards of config 2 (one thread each, all-reduces among the threads), every shard's
     sweep seeded with the cross-shard bounds of the users' K-th values -- the maximum of the shards' K-th warm-up values, the
-    minimum of their ceil(K / R)-th, tightened from four shards on by three rounds of a bisection on summed counts.  The
+    minimum of their ceil(K / R)-th (one MAX all-reduce), tightened from four shards on by the summed counts at seven common
+    thresholds (one SUM all-reduce).  The
     shards' lists -- some shorter than K -- merge to exactly the one-shard lists, and the shards score fewer tiles between
     them than with their own thresholds only."""
     if impl != "v2":
@@ -738,7 +789,7 @@ def test_seeded_item_shards_equal_one_shard(dev, impl, R, head, bf16):
                 st = {}
                 kw = {}
                 if seeded:
-                    kw = {"seed_reduce": lambda mx, mn: (coll.all_reduce(r, mx, "max"), coll.all_reduce(r, mn, "min")),
+                    kw = {"seed_reduce": lambda b: coll.all_reduce(r, b, "max"),
                           "seed_sum": lambda c: coll.all_reduce(r, c, "sum"), "seed_shards": R}
                 k = ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1, stats=st, **kw)
                 return ops.topk_merge(k, want="keys"), float(st["tiles_scored"][0])
@@ -788,7 +839,7 @@ def test_regrouped_early_terminating_sweep(dev, impl, head):
 
         def shard(r, coll):
             lo, I_s, pop_s = shards[r]
-            kw = {} if coll is None else {"seed_reduce": lambda mx, mn: (coll.all_reduce(r, mx, "max"), coll.all_reduce(r, mn, "min")),
+            kw = {} if coll is None else {"seed_reduce": lambda b: coll.all_reduce(r, b, "max"),
                                           "seed_sum": lambda c: coll.all_reduce(r, c, "sum"), "seed_shards": R}
             return ops.topk_merge(ops.score_topk_keys(W.U, I_s, users, 50, head, pop_s, hist, item_offset=lo, prune=True, n_splits=1, **kw), want="keys")
         [shard(r, None) for r in range(R)]            # (warms ops' per-tensor caches: see test_seeded_item_shards_equal_one_shard)
