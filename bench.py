@@ -128,8 +128,10 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
     from pda_amd.dist import default_user_groups, make_item_group
     ugroups = (args.user_groups or default_user_groups(world)) if world > 1 else 1
     gidx, grank, gsize, pgroup = make_item_group(rank, world, ugroups) if world > 1 else (0, 0, 1, None)
-    ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, grank, gsize, group=pgroup, score_fn=timed)
-    ev.seeded = True                                    # (the wrapper passes seed_reduce through)
+    # N = 1: the score call is wrapped with HIP events (roofline.kernel_ms).  N > 1: the product's own path -- early-terminating
+    # sweeps run software-pipelined (pda_amd.dist.topk_blocks: the seed collectives of block b + 1 under the sweep of block b),
+    # which a per-call wrapper would serialise; kernel_ms is then the step time.
+    ev = ItemShardedTopK.from_full_tables(W.U, W.I, W.pop_last, grank, gsize, group=pgroup, score_fn=timed if world == 1 else None)
     world_all, world = world, gsize                     # below, "world" is the item-shard group; world_all the whole job
     hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
     Bu = min(args.eval_block, W.n_users)
@@ -143,24 +145,25 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
 
     last = [None]
 
-    def run(bl):
+    def run(bl, hd):
         # N > 1: the all-to-all exchange -- every rank merges and keeps the lists of its slice of the users
-        for idx, val in ev.topk_blocks(bl, args.K, head, hist, sharded=world > 1):
+        for idx, val in ev.topk_blocks(bl, args.K, hd, hist, sharded=world > 1):
             sink.append(idx[0, 0])                        # keep the result alive without a sync
             last[0] = idx
 
-    def timed_pass(prune):
+    def timed_pass(prune, hd=None):
         """W untimed + K timed steps, barrier + synchronize on both sides, MAX over ranks."""
+        hd = head if hd is None else hd
         timed.prune, timed.enabled, timed.events, timed.stats = prune, False, [], {}
         ev.prune = prune
-        run(blocks[:max(1, args.warmup)])
+        run(blocks[:max(1, args.warmup)], hd)
         torch.cuda.synchronize()
         if world_all > 1:
             dist.barrier()
         torch.cuda.synchronize()
         timed.enabled = True
         t0 = time.perf_counter()
-        run(blocks[args.warmup:])
+        run(blocks[args.warmup:], hd)
         torch.cuda.synchronize()
         if world_all > 1:
             dist.barrier()
@@ -170,7 +173,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
-        return dt, timed.mean_ms(), dict(timed.stats)
+        return dt, (timed.mean_ms() if timed.events else dt / steps * 1e3), dict(timed.stats)
 
     # headline: a DENSE sweep -- every user x item pair is scored.  With the PDA head the catalogue is visited most
     # popular first (early_stop = 0: nothing is skipped; the running thresholds just rise early, so far fewer
@@ -182,7 +185,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
         dt_n, k_ms_n, _ = timed_pass(False)
         natural = {"value": Bu * steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / steps * 1e3, "kernel_ms": k_ms_n}
     dt, k_ms, st_d = timed_pass("order" if use_order else False)
-    if use_order:
+    if use_order and "tiles_scored" in st_d:
         # (generation 4 counts whole 64-item tiles and whole 128-user tiles: >= the 32-item count)
         assert int(st_d["tiles_scored"][0]) >= st_d["tiles_dense"], "the dense sweep must score every tile"
     # beside it: the product default for the PDA head -- ordered sweep WITH exact early termination (same keys).
@@ -197,6 +200,20 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
                            "bit-identical keys (tests/test_gpu_score_topk.py); data-dependent, hence not the headline"}
     if os.environ.get("PDA_BENCH_DUMP"):                  # tests/test_gpu_two_rank.py: the lists of the last step (this rank's rows)
         torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_w%d_r%d.pt" % (world_all, rank)))
+    # the raw head ('main_branch'): the reference evaluates it in EVERY evaluation epoch before the two PDA passes
+    # (MF/train_new_api.py:1139-1141, head at :597-598) and it is the only head of --train normal.  Product-default sweep mode.
+    raw = None
+    if head == ops.HEAD_POP and v2 and not args.headline_only and not light and world_all == 1:
+        rp = ops.prune_default(ops.HEAD_RAW, W.d)
+        dt_r, k_ms_r, _ = timed_pass(rp, ops.HEAD_RAW)
+        fl_r = 2.0 * blocks[0].numel() * ev.I_shard.shape[0] * W.d
+        gen_r = ops.score_kernel(W.d, args.K, ev.I_shard.shape[0], rp, ops.HEAD_RAW)
+        raw = {"value": Bu * steps / dt_r, "unit": "users/s", "ms_per_step": dt_r / steps * 1e3, "kernel_ms": k_ms_r,
+               "roofline_frac": fl_r / (k_ms_r * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+               "kernel": "%s<%d,RAW,%s>" % ("sweep4_kernel" if gen_r == "v4" else "score_topk_v3_kernel", W.d, td_name),
+               "sweep": {"order": "dense, items visited largest norm first", False: "dense, natural item order", True: "early-terminating"}[rp],
+               "note": "rec_type 'main_branch' (top_k(R + M), MF/train_new_api.py:597-598); bit-exact fp32 scores and lists vs the oracle "
+                       "(tests/test_gpu_score_topk.py); no popularity to order by: ~K ln(I / K) true list insertions per user"}
     n_local = ev.I_shard.shape[0]
     Bu_rank = blocks[0].numel()                           # users this rank scores per step (its group's share)
     flops = 2.0 * Bu_rank * n_local * W.d
@@ -259,8 +276,71 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
                 "note": "one pass over all %d users after a weight update = item prep + %d steps of the headline sweep" % (W.n_users, n_steps_all)}
     res = {"users_per_s": Bu * steps / dt, "ms_per_step": dt / steps * 1e3, "Bu": Bu, "W": W, "steps": steps, "table_dtype": td_name,
            "layout": {"user_groups": ugroups, "item_shards": gsize, "users_per_rank_and_step": Bu_rank, "items_per_rank": n_local},
-           "roofline": roof, "hist": hist, "ordered": ordered, "natural": natural, "prep": prep}
+           "roofline": roof, "hist": hist, "ordered": ordered, "natural": natural, "prep": prep, "raw_head": raw}
     return res
+
+
+def timed_graph_steps(body, n_steps, B, G=64):
+    """`body(i)` = one training step; G of them captured into a HIP graph, replayed n_steps / G times."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for i in range(3):
+            body(i)
+    torch.cuda.current_stream().wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(G):
+            body(i)
+    reps = max(1, n_steps // G)
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        g.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"triplets_per_s": reps * G * B / dt, "us_per_step": dt / (reps * G) * 1e6, "steps": reps * G}
+
+
+def sgd_rates_on_tables(args, dev, W, Bs=(2048, 4096)):
+    """SGD step throughput on the tables of workload W (pre-staged device-sampled batches, HIP graphs of 64 steps):
+    the fused hogwild step and the planned exact step (pda_triplet_plan + pda_bpr_step_plan_*: two launches, no atomics; the plan
+    is the sampler's work, batches ahead).  bf16 tables (config 5): forward on the bf16 rows, fp32 masters take the update, the
+    touched bf16 rows are re-rounded -- by three pda_refresh_rows_bf16 launches behind the fused step, inside the two launches of
+    the planned one."""
+    from pda_amd import ops
+    bf = W.U.dtype == torch.bfloat16
+    regs, lr, NB = 1e-2, 1e-2, 64
+    esz = 2 if bf else 4
+    out = {"tables": "%s: %d + %d rows x %d, %s" % (W.name.upper(), W.n_users, W.n_items, W.d, "bf16 rows + fp32 masters" if bf else "fp32"),
+           "bytes_per_triplet": 6 * W.d * esz + 20}
+    loss = torch.zeros(3, device=dev)
+    Bs = [B for B in Bs if B <= W.n_users]            # (distinct users inside a batch: the sampler contract the planned step relies on)
+    if bf:
+        U16, I16, Um, Im = W.U.clone(), W.I.clone(), W.U.float(), W.I.float()
+    else:
+        U, I = W.U.clone(), W.I.clone()
+    for B in Bs:
+        raw = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2022, step=s_, n_pool=W.n_users, train_slots=W.hist_slots,
+                                   neg_range=(0, W.n_items), pop_matrix=W.pop_train) for s_ in range(NB)]
+        plans = [ops.triplet_plan(b[0], b[1], b[2])[0] for b in raw]
+        sc = [None]
+        if bf:
+            fused = lambda i: ops.bpr_step_bf16(U16, I16, *raw[i % NB], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, U_master=Um, I_master=Im, loss_acc=loss)
+
+            def planned(i):
+                sc[0] = ops.bpr_step_plan(U16, I16, *raw[i % NB], regs=regs, reg_div=B, lr=lr, plan=plans[i % NB], scratch=sc[0], loss_acc=loss, U_master=Um, I_master=Im)
+        else:
+            fused = lambda i: ops.bpr_step(U, I, *raw[i % NB], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss)
+
+            def planned(i):
+                sc[0] = ops.bpr_step_plan(U, I, *raw[i % NB], regs=regs, reg_div=B, lr=lr, plan=plans[i % NB], scratch=sc[0], loss_acc=loss)
+        r = {"fused_hogwild": timed_graph_steps(fused, args.train_steps, B), "exact_planned": timed_graph_steps(planned, args.train_steps, B)}
+        for v in r.values():
+            v["hbm_frac"] = v["triplets_per_s"] * out["bytes_per_triplet"] / 1e9 / PEAK_HBM_GBS
+        out["B%d" % B] = r
+    return out
 
 
 def bench_train(args, dev, workload=None, quick=False):
@@ -277,26 +357,7 @@ def bench_train(args, dev, workload=None, quick=False):
     out = {"workload": "%s: synthetic %d users x %d items, d=%d, B=%d, PD/PDA (s_condition, gamma=%.2f)" %
                        (W.name.upper(), W.n_users, W.n_items, W.d, B, W.gamma), "graph_launches": G}
 
-    def timed_graph(body, n_steps):
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for i in range(3):
-                body(i)
-        torch.cuda.current_stream().wait_stream(s)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for i in range(G):
-                body(i)
-        reps = max(1, n_steps // G)
-        g.replay()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            g.replay()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        return {"triplets_per_s": reps * G * B / dt, "us_per_step": dt / (reps * G) * 1e6, "steps": reps * G}
+    timed_graph = lambda body, n_steps: timed_graph_steps(body, n_steps, B, G)
 
     U, I = W.U.clone(), W.I.clone()
     loss = torch.zeros(3, device=dev)
@@ -311,6 +372,28 @@ def bench_train(args, dev, workload=None, quick=False):
         args.train_steps)
     out["sgd_fused"]["bytes_per_triplet"] = 6 * W.d * 4 + 20
     out["sgd_fused"]["hbm_frac"] = out["sgd_fused"]["triplets_per_s"] * (6 * W.d * 4 + 20) / 1e9 / PEAK_HBM_GBS
+
+    # the EXACT mini-batch step without atomics: plan (the sampler's work, batches ahead) + two launches; and the planned one-launch step
+    U, I = W.U.clone(), W.I.clone()
+    plans_raw = [ops.triplet_plan(b[0], b[1], b[2])[0] for b in raw_batches]
+    sc = [None]
+
+    def planned(i):
+        sc[0] = ops.bpr_step_plan(U, I, *raw_batches[i % NB], regs=regs, reg_div=B, lr=lr, plan=plans_raw[i % NB], scratch=sc[0], loss_acc=loss)
+    out["sgd_exact_planned"] = timed_graph(planned, args.train_steps)
+    out["sgd_exact_planned"]["note"] = ("pda_triplet_plan (pre-staged with the batch) + pda_bpr_step_plan_f32: launch A per triplet (user rows by plain "
+                                        "stores), launch B per distinct item row (segment sums in plan order): exact 'sum then apply', bit-reproducible, no atomics")
+    out["sgd_exact_planned"]["hbm_frac"] = out["sgd_exact_planned"]["triplets_per_s"] * (6 * W.d * 4 + 20) / 1e9 / PEAK_HBM_GBS
+    U, I = W.U.clone(), W.I.clone()
+    out["sgd_planned_one_launch"] = timed_graph(lambda i: ops.bpr_step_plan(U, I, *raw_batches[i % NB], regs=regs, reg_div=B, lr=lr, plan=plans_raw[i % NB],
+                                                                             exact=False, loss_acc=loss), args.train_steps)
+    out["sgd_planned_one_launch"]["note"] = "plain stores on user rows and once-referenced item rows, atomics on shared item rows only (hogwild there)"
+    U, I = W.U.clone(), W.I.clone()
+    sc0 = [None]
+
+    def old_exact(i):
+        sc0[0] = ops.sgd_step_exact(U, I, *raw_batches[i % NB], regs=regs, reg_div=B, lr=lr, loss_acc=loss, scratch=sc0[0])
+    out["sgd_exact_two_launch_atomics"] = timed_graph(old_exact, max(256, args.train_steps // 2))
 
     U, I = W.U.clone(), W.I.clone()
     st = [torch.zeros_like(t) for t in (U, U, U, I, I, I)]   # mU vU gU mI vI gI
@@ -433,7 +516,29 @@ def bench_train(args, dev, workload=None, quick=False):
     out["sgd_fused_sampler_32_batches_ahead_graph"]["note"] = ("pda_sample_batches_dev: one launch draws (and groups by positive item) the next 32 "
                                                               "batches, bit for bit the per-step sampler's; 32 step launches consume them")
 
+    # the same with the EXACT step: one more launch per 32 batches plans them (pda_triplet_plan), two launches per step
+    U, I = W.U.clone(), W.I.clone()
+    step_dev4 = torch.zeros(2, dtype=torch.int64, device=dev)
+    many2 = tuple(torch.empty_like(t) for t in many)
+    plans32 = torch.empty((AH, _lib_plan_bytes(B)), dtype=torch.uint8, device=dev)
+    calls2, sc2 = [0], [None]
+
+    def ahead_exact_body(i):
+        if i % AH == 0:
+            ops.sample_batches_into(many2, W.hist_indptr, W.hist_indices, seed=7, step_dev=step_dev4, parity=calls2[0] & 1, group_by_pos=False, **skw)
+            ops.triplet_plan(many2[0], many2[1], many2[2], out=plans32)
+            calls2[0] += 1
+        j = i % AH
+        sc2[0] = ops.bpr_step_plan(U, I, many2[0][j], many2[1][j], many2[2][j], many2[3][j], many2[4][j], regs=regs, reg_div=B, lr=lr, plan=plans32[j],
+                                   scratch=sc2[0], loss_acc=loss)
+    out["sgd_exact_planned_sampler_32_batches_ahead_graph"] = timed_graph(ahead_exact_body, max(256, args.train_steps // 2))
+    out["sgd_exact_planned_sampler_32_batches_ahead_graph"]["batches_drawn"] = int(step_dev4.max().item())
     return out, W, batches
+
+
+def _lib_plan_bytes(B):
+    from pda_amd import _lib
+    return _lib.load().pda_triplet_plan_bytes(B)
 
 
 def bench_adam_big_tables(args, dev, workload):
@@ -451,10 +556,10 @@ def bench_adam_big_tables(args, dev, workload):
     loss = torch.zeros(3, device=dev)
     z = torch.zeros_like
 
-    def run(lazy, steps):
+    def run(lazy, steps, fast=False):
         U, I = W.U.float().clone(), W.I.float().clone()
         st = [z(U), z(U), z(U), z(I), z(I), z(I)]
-        lz = ops.LazyAdamState(W.n_users, W.n_items, lr, dev) if lazy else None
+        lz = ops.LazyAdamState(W.n_users, W.n_items, lr, dev, fast=fast) if lazy else None
         t = 0
 
         def step():
@@ -490,6 +595,9 @@ def bench_adam_big_tables(args, dev, workload):
     out["replay"] = run(True, 1536 if workload != "tiny" else 64)
     out["replay"]["note"] = ("pda_adam_lazy_f32: bit-identical tables after the sync (tests/test_gpu_bpr_step.py); three launches per step, "
                              "traffic = the batch rows")
+    out["replay_fast"] = run(True, 1536 if workload != "tiny" else 64, fast=True)
+    out["replay_fast"]["note"] = ("PDA_ADAM_REPLAY_FAST (the product's default above 64 MB of tables): the same catch-up to 1e-6 on x instead of bit "
+                                  "for bit -- running sqrt, hardware reciprocal, closed-form powers for m and v")
     return out
 
 
@@ -546,9 +654,9 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
         blocks.append(users)
         coos.append((rows, indices[lo:hi].long()))
     rec = "condition" if args.head == "condition" else "main_branch"
-    # value: the reference block cut into 64-row slabs over all host threads (cb.eval_block_slabbed: the same ops row for row;
+    # value: the reference block cut into 64-row slabs over all host threads (cb.eval_block_blocked: the same ops on 64-row x 16 384-item pieces, the K best of the pieces' candidates at the end;
     # torch's own intra-op threading -- `torch_intraop_threads` below -- parallelises the matmul only: 2 x one core on 128)
-    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget, block_fn=cb.eval_block_slabbed)
+    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget, block_fn=cb.eval_block_blocked)
     cpu_model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -561,7 +669,7 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
            "protocol": "3 warm-up blocks, median of the timed 2048-user blocks (up to 10, bounded by the budget)",
            "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d (torch-CPU restatement of "
                      "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk; NOT TensorFlow itself), every block cut into "
-                     "64-row slabs over the %d host threads" % (n, W.n_items, W.d, cores)}
+                     "64-row x 16 384-item pieces over the %d host threads" % (n, W.n_items, W.d, cores)}
     if not full:
         return out
     rate_i, n_i = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.5)
@@ -618,6 +726,13 @@ def main():
         train_pack = bench_train(args, dev)
         if not args.headline_only and args.workload in ("c3", "tiny"):
             train_pack[0]["adam_on_headline_tables"] = bench_adam_big_tables(args, dev, args.workload)
+        if not args.headline_only and args.workload in ("c3", "c5shard", "tiny"):
+            # BASELINE configs 3 and 5: the SGD step on the headline workload's own tables (d = 128 fp32 / d = 256 bf16)
+            td = table_dtype_of(args, args.workload)[1]
+            key = "sgd_bf16" if td == torch.bfloat16 else "sgd_on_headline_tables"
+            from pda_amd import synthetic as _syn
+            train_pack[0][key] = sgd_rates_on_tables(args, dev, _syn.make_workload(args.workload, dev, table_dtype=td))
+            torch.cuda.empty_cache()
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, ev, train_pack)
@@ -645,7 +760,7 @@ def main():
                                       "first 256 items, list hand-over, launch) is a visible share of the step" % (e["W"].n_items, -(-e["W"].n_items // 64))}}
             if not args.no_train:
                 t = bench_train(args, dev, workload=wl, quick=True)[0]
-                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_fused_loop_one_launch", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful") if k in t}
+                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_exact_planned", "sgd_planned_one_launch", "sgd_fused_loop_one_launch", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful") if k in t}
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(args, e, None, budget=6.0, full=False)
             per_config[wl] = entry
@@ -674,7 +789,7 @@ def main():
                                      ("bf16 tables; scores = the fp32 fmaf chain on the widened values (exact products), bit-identical to the exact "
                                       "kernel on the widened tables; the bf16 MFMA pass is a pre-filter with a rigorous error bound")},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "dense_natural_order": ev["natural"],
-            "ordered_sweep": ev["ordered"], "prep": ev["prep"], "per_config": per_config,
+            "ordered_sweep": ev["ordered"], "raw_head": ev["raw_head"], "prep": ev["prep"], "per_config": per_config,
             "train": train_pack[0] if train_pack else ({"item_parallel_sgd": sharded_train} if sharded_train else None),
         }
         print(json.dumps(line))

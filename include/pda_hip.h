@@ -403,6 +403,14 @@ int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, float* gU, int3
                       const float* lr_tab, float beta1, float beta2, float eps, void* stream);
 int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
                            float beta1, float beta2, float eps, void* stream);
+/* The same catch-up to the north_star's tolerance instead of bit for bit (round 3): phase | PDA_ADAM_REPLAY_FAST resp.
+ * pda_adam_lazy_sync_fast_f32.  sqrt(v_k) as a running product, the division a hardware reciprocal, the loop over a row's idle
+ * steps ends when its geometrically falling terms can no longer move x, and m, v take their closed-form powers: x within 1e-6
+ * of the exact replay / the dense sweep, m and v within 1e-4 relative, over idle gaps of thousands of steps
+ * (tests/test_gpu_bpr_step.py); ~6 instead of ~35 VALU per element and replayed step, and a few dozen instead of ~180 steps. */
+#define PDA_ADAM_REPLAY_FAST 0x10
+int pda_adam_lazy_sync_fast_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
+                                float beta1, float beta2, float eps, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Ranking metrics (A8; replaces get_performance + the Pool(5) reduction, MF/used_metric.py:4-80,

@@ -63,9 +63,9 @@ def eval_block_slabbed(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="con
     return out
 
 
-def eval_block_blocked(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition", threads=None, slab=64, chunk=4096):
+def eval_block_blocked(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition", threads=None, slab=64, chunk=16384):
     """eval_block_slabbed with the catalogue cut as well: every host thread takes 64 user rows and walks the items in chunks of
-    4096 -- matmul, elu + 1, * pop, -inf at the train items, topk(K) of the 1 MB piece -- and selects the K best of its
+    16 384 -- matmul, elu + 1, * pop, -inf at the train items, topk(K) of the 4 MB piece (measured best of 16..64 rows x 4096..65536 items on 128 threads) -- and selects the K best of its
     n_chunks x K candidates at the end.  The [2048, n_items] block of the reference (1.6 GB at config 3) is never materialised:
     at 200 000 items even a 64-row slab of it (51 MB) streams through DRAM six times.  Same lists up to the order of exactly
     equal scores."""

@@ -18,6 +18,7 @@ HEAD_RAW, HEAD_POP = 0, 1
 HIST_BY_BLOCK_ROW, HIST_BY_USER_ID = 0, 1
 UPD_NONE, UPD_SGD_FUSED, UPD_DENSE_GRAD = 0, 1, 2
 UPD_ANY_ORDER = 0x100
+ADAM_REPLAY_FAST = 0x10
 MAX_K = 64
 TOPK_CAP = 60
 
@@ -90,6 +91,7 @@ SIGNATURES = {
     "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "pda_adam_lazy_f32": (_i, [_i] + [_vp] * 13 + [_i, _i, _i, _vp, _f, _f, _f, _vp]),
     "pda_adam_lazy_sync_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _f, _f, _vp]),
+    "pda_adam_lazy_sync_fast_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _f, _f, _vp]),
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "pda_sample_triplets_dev": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_sample_batches_dev": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _u64, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -9,6 +9,7 @@
 // This path is HBM/latency bound (about 6*d*4 B per triplet, ~10*d flop): no MFMA.  Layout: d/4 lanes
 // per triplet, each lane owns one float4 of the three gathered rows (a 4*d-byte row is one fully
 // coalesced segment), dots by xor-shuffle inside the lane group, per-block loss reduction -> 3 atomics.
+#include <cmath>
 #include <cstdlib>
 #include "pda_common.h"
 #include "pda_sample.h"
@@ -556,10 +557,12 @@ struct LazyAdamArgs {
     float b1, b2, eps;
 };
 
-// Steps from .. upto of an idle row, in registers.  The update lr_k m / (sqrt(v) + eps) shrinks by at least 0.905 per step (m by
-// 0.9, the denominator by no more than sqrt(0.999), lr_k grows by less than 0.5 % per step), so once a step leaves all four
-// x unchanged -- the update is below half an ulp -- every later step does too: from there on only m and v decay (two
-// multiplications per element and step instead of a square root and a division).  Same results, bit for bit.
+// Steps from .. upto of an idle row, in registers.  The update lr_k m / (sqrt(v) + eps) shrinks by at least 0.912 per step: m by
+// 0.9, the denominator by no more than sqrt(0.999) = 0.9995, and lr_k = lr sqrt(1 - b2^k) / (1 - b1^k) -- NOT monotone: it falls
+// until k ~ 10 and then rises, fastest around k = 20 .. 50, by at most 1.2 % per step (sqrt((k + 1) / k) while b2^k ~ 1 - 0.001 k)
+// -- 0.9 x 1.012 / 0.9995 = 0.911.  So once a step leaves all four x unchanged -- the update is below half an ulp -- every later
+// step does too: from there on only m and v decay (two multiplications per element and step instead of a square root and a
+// division).  Same results, bit for bit (tests: idle gaps inside steps 1 .. 100, where lr_k is not monotone, included).
 template <int D>
 __device__ __forceinline__ void adam_replay(f32x4& xx, f32x4& mm, f32x4& vv, int from, int upto, const float* __restrict__ lr_tab, float b1,
                                             float b2, float eps) {
@@ -586,8 +589,42 @@ __device__ __forceinline__ void adam_replay(f32x4& xx, f32x4& mm, f32x4& vv, int
     }
 }
 
+// The same catch-up to the north_star's tolerance instead of bit for bit (round 3).  What the exact replay pays per element and
+// idle step is a correctly rounded square root and a division (~35 VALU); but sqrt(v_k) = sqrt(v_0) sqrt(b2)^k is a running
+// product, the division a v_rcp_f32 (1 ulp), and the terms lr_k m_k / (sqrt(v_k) + eps) fall by >= 0.91 per step, so the loop
+// ends when a term can no longer move x (the remaining geometric tail is below 1e-11 or 2^-28 |x|) -- a few dozen steps of 6
+// VALU -- and m, v take their closed-form powers b^n (one v_exp_f32 each) whatever the length of the gap.  Against the exact
+// replay / the dense sweep: x to 1e-6 absolute, m and v to 1e-4 relative (the sweep's own 3 000 roundings are ~1e-5 from the
+// real-number value); tests/test_gpu_bpr_step.py.
+struct FastConsts { float sqrt_b2, log2_b1, log2_b2; };
 template <int D>
-__global__ void __launch_bounds__(256) adam_lazy_kernel(LazyAdamArgs a) {
+__device__ __forceinline__ void adam_replay_fast(f32x4& xx, f32x4& mm, f32x4& vv, int from, int upto, const float* __restrict__ lr_tab, float b1,
+                                                 float eps, const FastConsts fc) {
+    const int n = upto - from + 1;
+    if (n <= 0) return;
+    f32x4 s, m = mm;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] = sqrtf(vv[q]);
+    for (int k = from; k <= upto; ++k) {
+        const float lr_k = lr_tab[k];
+        bool live = false;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            m[q] *= b1;
+            s[q] *= fc.sqrt_b2;
+            const float t = lr_k * m[q] * __builtin_amdgcn_rcpf(s[q] + eps);
+            xx[q] -= t;
+            live |= fabsf(t) > fmaxf(fabsf(xx[q]) * 3.7e-9f, 1.0e-12f);
+        }
+        if (!live) break;
+    }
+    const float p1 = exp2f((float)n * fc.log2_b1), p2 = exp2f((float)n * fc.log2_b2);
+    mm = mm * p1;
+    vv = vv * p2;
+}
+
+template <int D, bool FAST = false>
+__global__ void __launch_bounds__(256) adam_lazy_kernel(LazyAdamArgs a, FastConsts fc = FastConsts{}) {
     constexpr int L = D / 4, RPB = 256 / L;
     const int ridx = blockIdx.x * RPB + threadIdx.x / L, e = threadIdx.x % L;
     if (ridx >= 3 * a.B) return;
@@ -606,7 +643,8 @@ __global__ void __launch_bounds__(256) adam_lazy_kernel(LazyAdamArgs a) {
     if (old >= target) return;                                       // current already, or another group of this launch owns the row
     const size_t off = (size_t)row * D + 4 * e;
     f32x4 mm = *reinterpret_cast<f32x4*>(m + off), vv = *reinterpret_cast<f32x4*>(v + off), xx = *reinterpret_cast<f32x4*>(var + off);
-    adam_replay<D>(xx, mm, vv, old + 1, a.t - 1, a.lr_tab, a.b1, a.b2, a.eps);
+    if constexpr (FAST) adam_replay_fast<D>(xx, mm, vv, old + 1, a.t - 1, a.lr_tab, a.b1, a.eps, fc);
+    else adam_replay<D>(xx, mm, vv, old + 1, a.t - 1, a.lr_tab, a.b1, a.b2, a.eps);
     if (a.phase == 1) {
         const f32x4 gg = *reinterpret_cast<f32x4*>(g + off);
         const float lr_t = a.lr_tab[a.t];
@@ -624,9 +662,10 @@ __global__ void __launch_bounds__(256) adam_lazy_kernel(LazyAdamArgs a) {
 }
 
 // every row of a table up to step t (before an evaluation, a checkpoint, a switch of optimiser)
-template <int D>
+template <int D, bool FAST = false>
 __global__ void __launch_bounds__(256) adam_lazy_sync_kernel(float* var, float* m, float* v, int32_t* last, size_t n_rows, int t,
-                                                             const float* __restrict__ lr_tab, float b1, float b2, float eps) {
+                                                             const float* __restrict__ lr_tab, float b1, float b2, float eps,
+                                                             FastConsts fc = FastConsts{}) {
     constexpr int L = D / 4, RPB = 256 / L;
     const int e = threadIdx.x % L;
     for (size_t row = (size_t)blockIdx.x * RPB + threadIdx.x / L; row < n_rows; row += (size_t)gridDim.x * RPB) {
@@ -634,7 +673,8 @@ __global__ void __launch_bounds__(256) adam_lazy_sync_kernel(float* var, float* 
         if (old >= t) continue;
         const size_t off = row * D + 4 * e;
         f32x4 mm = *reinterpret_cast<f32x4*>(m + off), vv = *reinterpret_cast<f32x4*>(v + off), xx = *reinterpret_cast<f32x4*>(var + off);
-        adam_replay<D>(xx, mm, vv, old + 1, t, lr_tab, b1, b2, eps);
+        if constexpr (FAST) adam_replay_fast<D>(xx, mm, vv, old + 1, t, lr_tab, b1, eps, fc);
+        else adam_replay<D>(xx, mm, vv, old + 1, t, lr_tab, b1, b2, eps);
         *reinterpret_cast<f32x4*>(m + off) = mm;
         *reinterpret_cast<f32x4*>(v + off) = vv;
         *reinterpret_cast<f32x4*>(var + off) = xx;
@@ -942,13 +982,18 @@ extern "C" int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, floa
                                  float* gI, int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d, int t,
                                  const float* lr_tab, float beta1, float beta2, float eps, void* stream) {
     if (!U || !mU || !vU || !gU || !lastU || !I || !mI || !vI || !gI || !lastI || !users || !pos || !neg || !lr_tab) return PDA_ERR_ARG;
+    const bool fast = (phase & PDA_ADAM_REPLAY_FAST) != 0;
+    phase &= ~PDA_ADAM_REPLAY_FAST;
     if (B <= 0 || t < 1 || (phase != 0 && phase != 1)) return PDA_ERR_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const LazyAdamArgs a{U, mU, vU, gU, lastU, I, mI, vI, gI, lastI, users, pos, neg, lr_tab, B, t, phase, beta1, beta2, eps};
+    const FastConsts fc{(float)sqrt((double)beta2), (float)log2((double)beta1), (float)log2((double)beta2)};
 #define PDA_LAZY(DD)                                                                                                   \
     case DD: {                                                                                                         \
         constexpr int RPB = 256 / (DD / 4);                                                                            \
-        hipLaunchKernelGGL(adam_lazy_kernel<DD>, dim3((unsigned)((3 * (size_t)B + RPB - 1) / RPB)), dim3(256), 0, s, a); \
+        const dim3 grid((unsigned)((3 * (size_t)B + RPB - 1) / RPB));                                                  \
+        if (fast) hipLaunchKernelGGL((adam_lazy_kernel<DD, true>), grid, dim3(256), 0, s, a, fc);                      \
+        else hipLaunchKernelGGL((adam_lazy_kernel<DD, false>), grid, dim3(256), 0, s, a, fc);                          \
         break;                                                                                                         \
     }
     switch (d) {
@@ -960,16 +1005,18 @@ extern "C" int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, floa
     return PDA_OK;
 }
 
-extern "C" int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
-                                      float beta1, float beta2, float eps, void* stream) {
+static int run_lazy_sync(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
+                         float beta1, float beta2, float eps, bool fast, void* stream) {
     if (!var || !m || !v || !last || !lr_tab || n_rows == 0 || t < 0) return PDA_ERR_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FastConsts fc{(float)sqrt((double)beta2), (float)log2((double)beta1), (float)log2((double)beta2)};
 #define PDA_LSYNC(DD)                                                                                                  \
     case DD: {                                                                                                         \
         constexpr int RPB = 256 / (DD / 4);                                                                            \
         const size_t nb = (n_rows + RPB - 1) / RPB;                                                                    \
-        hipLaunchKernelGGL(adam_lazy_sync_kernel<DD>, dim3((unsigned)(nb < 16384 ? nb : 16384)), dim3(256), 0, s, var, m, v, last, n_rows, \
-                           t, lr_tab, beta1, beta2, eps);                                                              \
+        const dim3 grid((unsigned)(nb < 16384 ? nb : 16384));                                                          \
+        if (fast) hipLaunchKernelGGL((adam_lazy_sync_kernel<DD, true>), grid, dim3(256), 0, s, var, m, v, last, n_rows, t, lr_tab, beta1, beta2, eps, fc); \
+        else hipLaunchKernelGGL((adam_lazy_sync_kernel<DD, false>), grid, dim3(256), 0, s, var, m, v, last, n_rows, t, lr_tab, beta1, beta2, eps, fc);    \
         break;                                                                                                         \
     }
     switch (d) {
@@ -979,6 +1026,14 @@ extern "C" int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* l
 #undef PDA_LSYNC
     PDA_CHECK_LAUNCH();
     return PDA_OK;
+}
+extern "C" int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
+                                      float beta1, float beta2, float eps, void* stream) {
+    return run_lazy_sync(var, m, v, last, n_rows, d, t, lr_tab, beta1, beta2, eps, false, stream);
+}
+extern "C" int pda_adam_lazy_sync_fast_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
+                                           float beta1, float beta2, float eps, void* stream) {
+    return run_lazy_sync(var, m, v, last, n_rows, d, t, lr_tab, beta1, beta2, eps, true, stream);
 }
 
 extern "C" int pda_bpr_step_bf16(const uint16_t* U_bf16, const uint16_t* I_bf16, float* U_master, float* I_master,

@@ -265,6 +265,7 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     if (hipMemsetAsync(hdr, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
     if (order && hipMemsetAsync(pos_of, 0xFF, (size_t)n * 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
     if (order && hipMemsetAsync(hdr + 2, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;          // header word 2 := 1: a visiting order was given
+    if (pop && hipMemsetAsync(hdr + 1, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;            // header word 1 := 1: the test operands carry 1/pop pieces
     const int n_pad = L.n_tiles * 64;
 #define PDA_P4(DD)                                                                                                              \
     case DD: {                                                                                                                  \
@@ -682,6 +683,10 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // d <= 128: the kernel needs <= 128 VGPRs -- four waves per SIMD: 8 MFMA waves + 4 loaders + 4 rescoring waves (two loaders
 // could not keep up: the MFMA waves waited 39 % of their time for tiles); d = 256 (168 VGPRs): 8 + 2 + 2.
 
+#include "pda_v4_block_asm.h"
+#ifndef PDA_V4_ASM
+#define PDA_V4_ASM 1      // d <= 128: the reads and MFMAs of a block as ONE inline-asm statement with a counted software pipeline
+#endif
 #ifndef PDA_V4_RSLEEP
 #define PDA_V4_RSLEEP 8     // idle rescoring waves: s_sleep between polls of their rings (x 64 cycles)
 #endif
@@ -1198,6 +1203,9 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         }
     };
     const unsigned char* lane_base = tiles + j * RB + 16 * h;       // B fragment (cb, m) of slot s: + s BB + cb HB + 32 m
+    [[maybe_unused]] const unsigned lane_base_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles + (unsigned)(j * RB + 16 * h);
+    // (raw head: a prep built WITH a popularity carries 1/pop pieces in its test operands -- header word 1)
+    [[maybe_unused]] const bool raw_on_pop_prep = HEAD == PDA_HEAD_RAW && g.prep_hdr[1] != 0;
 
 #ifndef PDA_V4_PF
 #define PDA_V4_PF 4       // B fragments in flight per MFMA wave (the compiler keeps fewer when registers are short)
@@ -1289,7 +1297,26 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         f32x16 acc[UA][NB];
         float popv[NB];
         int locv[NB];
-        {
+        // d <= 128: the block as one inline-asm statement (pda_v4_block_asm.h): BlockAsm<D>::kFragmentsInFlight B reads ahead of
+        // their MFMAs, counted waits.  Left to hipcc, every read sat one or two instructions in front of its MFMA whatever depth
+        // the source asked for -- an LDS round trip per pair of MFMAs, ~1 740 cycles per block and wave for 576 cycles of MFMAs,
+        // the pipe 66 % busy with two such waves per SIMD (what PMC measured in round 2).  The raw head on a prep that carries
+        // popularity pieces (never built by pda_amd.ops) rewrites the test operands and keeps the compiler's schedule.
+        constexpr bool kAsmBlock = PDA_V4_ASM != 0 && D <= 128 && UA == 1 && NB == 2 && !PFX;
+        bool asm_done = false;
+        if constexpr (kAsmBlock) {
+            if (HEAD == PDA_HEAD_POP || !raw_on_pop_prep) {
+                u32x4 piq;
+                const unsigned a0 = lane_base_lds + (unsigned)((b % NSLOT) * BB);
+                BlockAsm<D>::run(acc[0][0], acc[0][1], piq, ah[0], aex[0], a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
+                popv[0] = __uint_as_float(piq[0]);
+                locv[0] = (int)piq[1];
+                popv[1] = __uint_as_float(piq[2]);
+                locv[1] = (int)piq[3];
+                asm_done = true;
+            }
+        }
+        if (!asm_done) {
             auto b_load = [&](const unsigned char* base, int s_) __attribute__((always_inline)) -> u32x4 {
                 const int m = s_ / NB, cb = s_ % NB;
                 return *reinterpret_cast<const u32x4*>(base + cb * HB + 32 * m);

@@ -80,10 +80,13 @@ class _MFBase:
         # tables outgrow ADAM_SWEEP_MAX_BYTES; args.adam_exact_lazy = True | False forces one
         forced = getattr(args, "adam_exact_lazy", None)
         mode = getattr(args, "adam_sweep", "auto")
-        if mode not in ("auto", "sweep", "replay"):
-            raise NotImplementedError("adam_sweep must be auto | sweep | replay")
+        if mode not in ("auto", "sweep", "replay", "replay_fast"):
+            raise NotImplementedError("adam_sweep must be auto | sweep | replay | replay_fast")
         if forced is None and mode != "auto":
-            forced = mode == "replay"
+            forced = mode != "sweep"
+        # replay: bit-identical to the sweeps; replay_fast (and auto, above 64 MB of tables): the same catch-up to 1e-6
+        # (PDA_ADAM_REPLAY_FAST: running sqrt, hardware reciprocal, closed-form powers for m and v) -- ~4 x less arithmetic
+        self.adam_replay_fast = mode in ("auto", "replay_fast")
         table_bytes = (self.n_users + self.n_items) * self.emb_dim * 4
         self.adam_exact_lazy = (table_bytes > self.ADAM_SWEEP_MAX_BYTES) if forced is None else bool(forced)
         self._lazy = None
@@ -126,7 +129,7 @@ class _MFBase:
 
     def _lazy_state(self):
         if self._lazy is None:
-            self._lazy = ops.LazyAdamState(self.n_users, self.n_items, self.lr, self.device)
+            self._lazy = ops.LazyAdamState(self.n_users, self.n_items, self.lr, self.device, fast=self.adam_replay_fast)
             self._lazy.synced = self._t - 1 if self._t > 0 else 0      # (rows are current for everything before this step)
             if self._t > 1:
                 self._lazy.lastU.fill_(self._t - 1)
@@ -177,8 +180,11 @@ class _MFBase:
         return self._loss
 
     # ---- one training step (A1-A5) --------------------------------------------------------------------
-    def train_step(self, users, pos, neg, pos_pop=None, neg_pop=None) -> torch.Tensor:
+    def train_step(self, users, pos, neg, pos_pop=None, neg_pop=None, plan=None) -> torch.Tensor:
         """Forward + loss + gradient + update on one batch of device tensors (int32 / float32).
+        plan (--optimizer sgd): the batch's pda_triplet_plan from a sampler that guarantees distinct users -- the exact step then
+        runs without atomics (ops.bpr_step_plan: two launches, bit-reproducible); without a plan the exact step is
+        pda_bpr_step_f32(PDA_UPD_NONE) + pda_sgd_apply_f32, which accepts any batch.
         Returns the float32[3] device tensor (loss, mf_loss, reg_loss) of THIS step (no host sync): a view into a ring of
         16 buffers -- valid until 16 further steps have been enqueued."""
         U, I = self.weights["user_embedding"], self.weights["item_embedding"]
@@ -189,6 +195,15 @@ class _MFBase:
         self._loss_i = (self._loss_i + 1) & 15
         self._loss = self._loss_ring[self._loss_i]
         self._loss.zero_()
+        if self.optimizer == "sgd" and plan is not None:
+            if self.tables16 is not None:
+                self._plan_scratch = ops.bpr_step_plan(self.tables16["user_embedding"], self.tables16["item_embedding"], users, pos, neg, pos_pop,
+                                                       neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr, plan=plan,
+                                                       scratch=getattr(self, "_plan_scratch", None), loss_acc=self._loss, U_master=U, I_master=I)
+            else:
+                self._plan_scratch = ops.bpr_step_plan(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,
+                                                       lr=self.lr, plan=plan, scratch=getattr(self, "_plan_scratch", None), loss_acc=self._loss)
+            return self._loss
         if self.tables16 is not None:
             return self._train_step_bf16(users, pos, neg, pos_pop, neg_pop)
         if self.optimizer == "sgd_fused":

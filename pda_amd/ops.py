@@ -553,6 +553,10 @@ def sgd_step_exact(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: f
     return scratch
 
 
+def triplet_plan_bytes(B: int) -> int:
+    return _lib.load().pda_triplet_plan_bytes(B)
+
+
 def triplet_plan(users, pos, neg, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pda_triplet_plan: users / pos / neg int32 [B] or [n, B] -> uint8 [n, pda_triplet_plan_bytes(B)] (one plan per batch; the
     plan of batch j is out[j]).  B <= 4096."""
@@ -730,7 +734,8 @@ class LazyAdamState:
     """The bookkeeping of the exact lazy dense-decay Adam (pda_adam_lazy_f32): per-row `last` steps and the device table of
     bias-corrected rates lr_tab[k] = float32(adam_lr_t(lr, k)) -- the value the dense sweep receives as its lr_t argument."""
 
-    def __init__(self, n_users: int, n_items: int, lr: float, device, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+    def __init__(self, n_users: int, n_items: int, lr: float, device, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, fast: bool = False):
+        self.fast = bool(fast)              # PDA_ADAM_REPLAY_FAST: catch-up to 1e-6 instead of bit for bit (see include/pda_hip.h)
         self.lastU = torch.zeros(n_users, dtype=torch.int32, device=device)
         self.lastI = torch.zeros(n_items, dtype=torch.int32, device=device)
         self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
@@ -756,7 +761,7 @@ def adam_lazy(phase: int, st: LazyAdamState, U, mU, vU, gU, I, mI, vI, gI, users
     for x in (users, pos, neg):
         _need(x, torch.int32, "batch rows")
     tab = st.rates(t)
-    check(lib.pda_adam_lazy_f32(phase, ptr(U), ptr(mU), ptr(vU), ptr(gU), ptr(st.lastU), ptr(I), ptr(mI), ptr(vI), ptr(gI), ptr(st.lastI),
+    check(lib.pda_adam_lazy_f32(phase | (_lib.ADAM_REPLAY_FAST if st.fast else 0), ptr(U), ptr(mU), ptr(vU), ptr(gU), ptr(st.lastU), ptr(I), ptr(mI), ptr(vI), ptr(gI), ptr(st.lastI),
                                 ptr(users), ptr(pos), ptr(neg), users.numel(), U.shape[1], t, ptr(tab), st.beta1, st.beta2, st.eps,
                                 stream_ptr()), "pda_adam_lazy_f32")
     mark_modified(U)
@@ -769,8 +774,9 @@ def adam_lazy_sync(st: LazyAdamState, U, mU, vU, I, mI, vI, t: int):
         return
     lib = _lib.load()
     tab = st.rates(t)
+    fn = lib.pda_adam_lazy_sync_fast_f32 if st.fast else lib.pda_adam_lazy_sync_f32
     for var, m, v, last in ((U, mU, vU, st.lastU), (I, mI, vI, st.lastI)):
-        check(lib.pda_adam_lazy_sync_f32(ptr(var), ptr(m), ptr(v), ptr(last), var.shape[0], var.shape[1], t, ptr(tab), st.beta1, st.beta2,
+        check(fn(ptr(var), ptr(m), ptr(v), ptr(last), var.shape[0], var.shape[1], t, ptr(tab), st.beta1, st.beta2,
                                          st.eps, stream_ptr()), "pda_adam_lazy_sync_f32")
         mark_modified(var)
     st.synced = t

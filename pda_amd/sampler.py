@@ -80,6 +80,11 @@ class DeviceSampler:
         self.step = 0
         self.ahead = max(1, int(ahead))
         self._queue, self._left, self._calls = None, 0, 0
+        # users are distinct inside a batch (pda_sample_triplets: a keyed permutation of the pool) as long as the batch is not
+        # larger than the pool -- the contract the planned exact SGD step relies on (ops.bpr_step_plan)
+        self.distinct_users = data.batch_size <= self.pool.numel()
+        self.with_plan = False        # set by the trainer (--optimizer sgd): every batch comes with its pda_triplet_plan
+        self.plan = None              # the plan of the batch handed out last
 
     def _refill(self):
         B, n = self.data.batch_size, self.ahead
@@ -90,10 +95,17 @@ class DeviceSampler:
                              mk(torch.float32) if self.with_pop else None) for _ in range(2)]
             self._ctr = torch.tensor([self.step, 0], dtype=torch.int64, device=self.device)      # (batch() has counted this one)
             self._calls = 0
+            self._plans = None
         self._queue = self._queues[self._calls & 1]
         ops.sample_batches_into(self._queue, self.indptr, self.indices, seed=self.seed, step_dev=self._ctr, parity=self._calls & 1,
                                 user_pool=self.pool, n_pool=self.pool.numel(), train_slots=self.slots if self.with_pop else None,
                                 neg_range=self.neg_range, pop_matrix=self.pop)
+        if self.with_plan and B <= 4096:
+            # the plans of the whole queue in ONE launch (one workgroup per batch), like the batches themselves
+            if self._plans is None:
+                nb = ops.triplet_plan_bytes(B)
+                self._plans = [torch.empty((n, nb), dtype=torch.uint8, device=self.device) for _ in range(2)]
+            ops.triplet_plan(self._queue[0], self._queue[1], self._queue[2], out=self._plans[self._calls & 1])
         self._calls += 1
         self._left = n
 
@@ -104,12 +116,14 @@ class DeviceSampler:
                                                   step=self.step, user_pool=self.pool, n_pool=self.pool.numel(),
                                                   train_slots=self.slots if self.with_pop else None,
                                                   neg_range=self.neg_range, pop_matrix=self.pop)
+            self.plan = ops.triplet_plan(u, p, n)[0] if (self.with_plan and self.data.batch_size <= 4096) else None
             return (u, p, n, pp, pn) if self.with_pop else (u, p, n)
         if self._left == 0:
             self._refill()
         j = self.ahead - self._left
         self._left -= 1
         q = self._queue
+        self.plan = self._plans[(self._calls - 1) & 1][j] if (self.with_plan and self._plans is not None) else None
         return (q[0][j], q[1][j], q[2][j], q[3][j], q[4][j]) if self.with_pop else (q[0][j], q[1][j], q[2][j])
 
     def __call__(self):

@@ -57,7 +57,8 @@ class Session:
         rec = owners.pop()
         if not any(f.name == "opt" for f in fetches):
             raise NotImplementedError("fetching %s without the optimiser op" % [f.name for f in fetches])
-        return rec.train_step(*self.model.next_batch())
+        b = self.model.next_batch()
+        return rec.train_step(*b, plan=self.model.batch_plan)
 
     def run_async(self, fetches):
         return self._step(fetches)
@@ -78,6 +79,9 @@ class DatasetApi_Model:
         self.device = torch.device(device if device is not None else "cuda")
         self.generator_sampler = generator_sampler
         self._iter = None
+        self.batch_plan = None        # pda_triplet_plan of the batch next_batch() returned last (--optimizer sgd, device sampler)
+        if getattr(args, "optimizer", "adam") == "sgd" and getattr(generator_sampler, "distinct_users", False) and hasattr(generator_sampler, "with_plan"):
+            generator_sampler.with_plan = True       # the exact SGD step without atomics wants the batch's plan (ops.bpr_step_plan)
         self.sess = None
         self.testing_model_type, self.testing_popularity = "o", None
         if args.train in ("s_condition", "condition"):
@@ -112,6 +116,7 @@ class DatasetApi_Model:
             raise OutOfRangeError() from None
         if not torch.is_tensor(b[0]):
             b = to_device_batch(b, self.device)
+        self.batch_plan = getattr(self.generator_sampler, "plan", None)
         return b
 
     # ---- scoring side ---------------------------------------------------------------------------------

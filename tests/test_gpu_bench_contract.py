@@ -40,6 +40,15 @@ def test_bench_emits_one_contract_line(dev):
     assert r["hbm"]["peak_measured_GBs"] > 500
     assert c["native_topk"]["value"] > 0 and c["native_topk"]["threads"] == c["cores"] and "median" in c["protocol"]
     assert d["dtype"] == "f32"
+    # round 3: the raw head the reference evaluates every epoch (MF/train_new_api.py:1139-1141), the exact planned SGD step,
+    # SGD on the headline workload's own tables, the CPU port cut over the host threads
+    rh = d["raw_head"]
+    assert rh["value"] > 0 and 0 < rh["roofline_frac"] < 1 and "RAW" in rh["kernel"]
+    assert t["sgd_exact_planned"]["triplets_per_s"] > 0 and t["sgd_planned_one_launch"]["triplets_per_s"] > 0
+    assert t["sgd_exact_planned_sampler_32_batches_ahead_graph"]["batches_drawn"] > 0
+    big = t["sgd_on_headline_tables"]
+    assert big["B2048"]["exact_planned"]["triplets_per_s"] > 0 and big["B2048"]["fused_hogwild"]["hbm_frac"] > 0
+    assert c["torch_intraop_threads"]["value"] > 0
 
 
 def test_bench_bf16_tables_line(dev):
@@ -50,3 +59,16 @@ def test_bench_bf16_tables_line(dev):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["dtype"] == "bf16" and d["value"] > 0 and d["ordered_sweep"]["value"] > 0
+
+
+def test_bench_bf16_train_keys(dev):
+    """BASELINE config 5 asks for bf16 train throughput: the bf16 line carries train.sgd_bf16 (fused + refreshes, planned exact)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--table-dtype", "bf16", "--steps", "2",
+                          "--warmup", "1", "--eval-block", "1024", "--no-cpu-baseline", "--train-steps", "128"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    sb = d["train"]["sgd_bf16"]
+    assert sb["bytes_per_triplet"] == 6 * 64 * 2 + 20
+    for B in ("B2048",):
+        assert sb[B]["exact_planned"]["triplets_per_s"] > 0 and sb[B]["fused_hogwild"]["triplets_per_s"] > 0

@@ -239,6 +239,119 @@ def test_exact_lazy_adam_long_idle_gap(dev):
     assert not torch.equal(vl, torch.from_numpy(var).to(dev))
 
 
+@pytest.mark.parametrize("fast", [False, True])
+def test_lazy_adam_idle_gaps_inside_the_first_hundred_steps(dev, fast):
+    """The bias-corrected rate lr_k = lr sqrt(1 - b2^k) / (1 - b1^k) is NOT monotone over the first steps (it falls until k ~ 10,
+    then rises by up to 1.2 % per step): rows that go idle at step a and come back at step b, for many (a, b) inside 1 .. 100,
+    replayed == swept (exact replay: bit for bit; fast replay: x to 1e-6, m and v to 1e-4 relative)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(47)
+    n, d, lr, T = 128, 64, 1e-2, 100
+    var = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    v0 = (rng.uniform(0, 1, (n, d)) ** 4 * 1e-5).astype(np.float32)
+    # moments as Adam produces them: |m| <= ~3 sqrt(v) (m is a (1 - b1)-average of gradients whose squares make up v); the exact
+    # replay is also run on wild pairs (m >> sqrt(v): x moves by hundreds) in test_exact_lazy_adam_long_idle_gap
+    m0 = ((np.sqrt(v0) * rng.uniform(-2, 2, (n, d))) if fast else rng.standard_normal((n, d)) * 1e-3).astype(np.float32)
+    starts = rng.integers(0, 60, n)                 # row r is current for step starts[r] and idle until ends[r]
+    ends = np.minimum(T, starts + rng.integers(1, 60, n))
+    vd, md, vvd = to(dev, var, m0, v0)
+    g = torch.zeros_like(vd)
+    # dense: sweep step k touches only the rows with starts < k <= ends (emulated by restoring the others)
+    for k in range(1, T + 1):
+        act = torch.from_numpy(((starts < k) & (k <= ends))).to(dev)
+        keep = (vd.clone(), md.clone(), vvd.clone())
+        ops.adam_dense_sweep(vd, md, vvd, g, ops.adam_lr_t(lr, k))
+        for t_, k_ in zip((vd, md, vvd), keep):
+            t_[~act] = k_[~act]
+    vl, ml, vvl = to(dev, var, m0, v0)
+    lz = ops.LazyAdamState(n, n, lr, dev, fast=fast)
+    lz.lastU.copy_(torch.from_numpy(starts.astype(np.int32)))
+    lz.lastI.fill_(T)
+    dummy = [x.clone() for x in (vl, ml, vvl)]
+    # bring every row to ITS end step: rows grouped by end step, synced with t = end (others are pushed back afterwards)
+    for e in np.unique(ends):
+        rows = torch.from_numpy(np.nonzero(ends == e)[0]).to(dev)
+        sub = [t_[rows].contiguous() for t_ in (vl, ml, vvl)]
+        st = ops.LazyAdamState(len(rows), len(rows), lr, dev, fast=fast)
+        st.lastU.copy_(lz.lastU[rows])
+        st.lastI.fill_(int(e))
+        d2 = [x.clone() for x in sub]
+        ops.adam_lazy_sync(st, sub[0], sub[1], sub[2], *d2, int(e))
+        for t_, s_ in zip((vl, ml, vvl), sub):
+            t_[rows] = s_
+    if fast:
+        np.testing.assert_allclose(vl.cpu().numpy(), vd.cpu().numpy(), atol=1e-6, rtol=1e-6)
+        np.testing.assert_allclose(ml.cpu().numpy(), md.cpu().numpy(), rtol=1e-4, atol=1e-12)
+        np.testing.assert_allclose(vvl.cpu().numpy(), vvd.cpu().numpy(), rtol=1e-4, atol=1e-14)
+    else:
+        assert torch.equal(vl, vd) and torch.equal(ml, md) and torch.equal(vvl, vvd)
+
+
+def test_fast_lazy_adam_long_idle_gap_and_training(dev):
+    """PDA_ADAM_REPLAY_FAST: (a) 3 000 idle steps in one go against 3 000 dense sweeps: x within 1e-6, m and v within 1e-4
+    relative -- zero / tiny rows, zero moments and moments at the size of Adam's epsilon included; (b) twelve training steps with
+    repeats against the dense-sweep path: every tensor within the same bounds."""
+    from pda_amd import ops
+    rng = np.random.default_rng(53)
+    n, d, T, lr = 96, 64, 3000, 1e-2
+    var = (rng.standard_normal((n, d)) * 0.1).astype(np.float32)
+    v = (rng.uniform(0, 1, (n, d)) ** 4 * 1e-5).astype(np.float32)
+    m = (np.sqrt(v) * rng.uniform(-2, 2, (n, d))).astype(np.float32)        # |m| <= ~3 sqrt(v), as Adam's moments are
+    var[0] = 0.0
+    var[1] *= 1e-20
+    m[2] = 0.0
+    v[3] = 0.0
+    m[3] = 0.0
+    m[4] = (rng.standard_normal(d) * 1e-9).astype(np.float32)               # gradients of the size of epsilon: sqrt(v) ~ eps
+    v[4] = (m[4] * 3) ** 2
+    m[5] = (rng.standard_normal(d) * 1e-3).astype(np.float32)               # a wild pair: m >> sqrt(v), x moves by tens
+    v[5] = 1e-12
+    vd, md, vvd = to(dev, var, m, v)
+    vl, ml, vvl = to(dev, var, m, v)
+    g = torch.zeros_like(vd)
+    for t in range(1, T + 1):
+        ops.adam_dense_sweep(vd, md, vvd, g, ops.adam_lr_t(lr, t))
+    lz = ops.LazyAdamState(n, n, lr, dev, fast=True)
+    dummy = [x.clone() for x in (vl, ml, vvl)]
+    ops.adam_lazy_sync(lz, vl, ml, vvl, *dummy, T)
+    np.testing.assert_allclose(vl.cpu().numpy(), vd.cpu().numpy(), atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(ml.cpu().numpy(), md.cpu().numpy(), rtol=1e-4, atol=1e-30)
+    np.testing.assert_allclose(vvl.cpu().numpy(), vvd.cpu().numpy(), rtol=1e-4, atol=1e-30)
+    assert not torch.equal(vl, torch.from_numpy(var).to(dev))
+    # (b) training
+    nU, nI, B, regs, N = 900, 400, 96, 1e-2, 12
+    U = (rng.standard_normal((nU, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.1).astype(np.float32)
+    Ud, Id = to(dev, U, I)
+    Ul, Il = to(dev, U, I)
+    z = torch.zeros_like
+    sd = {k: z(t) for k, t in (("mU", Ud), ("vU", Ud), ("gU", Ud), ("mI", Id), ("vI", Id), ("gI", Id))}
+    sl = {k: z(t) for k, t in (("mU", Ul), ("vU", Ul), ("gU", Ul), ("mI", Il), ("vI", Il), ("gI", Il))}
+    lz = ops.LazyAdamState(nU, nI, lr, dev, fast=True)
+    for t in range(1, N + 1):
+        users = rng.permutation(nU)[:B].astype(np.int32)
+        pos = rng.integers(0, 40 if t % 3 else nI, B).astype(np.int32)
+        neg = rng.integers(0, nI, B).astype(np.int32)
+        pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+        pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+        args = to(dev, users, pos, neg, pp, pn)
+        ld, ll = torch.zeros(3, device=dev), torch.zeros(3, device=dev)
+        ops.bpr_step(Ud, Id, *args, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sd["gU"], gI=sd["gI"], loss_acc=ld)
+        ops.adam_dense_sweep2(Ud, sd["mU"], sd["vU"], sd["gU"], Id, sd["mI"], sd["vI"], sd["gI"], ops.adam_lr_t(lr, t))
+        ops.adam_lazy(0, lz, Ul, sl["mU"], sl["vU"], sl["gU"], Il, sl["mI"], sl["vI"], sl["gI"], *args[:3], t)
+        ops.bpr_step(Ul, Il, *args, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sl["gU"], gI=sl["gI"], loss_acc=ll)
+        ops.adam_lazy(1, lz, Ul, sl["mU"], sl["vU"], sl["gU"], Il, sl["mI"], sl["vI"], sl["gI"], *args[:3], t)
+        np.testing.assert_allclose(ll.cpu().numpy(), ld.cpu().numpy(), atol=TOL, rtol=TOL)
+    ops.adam_lazy_sync(lz, Ul, sl["mU"], sl["vU"], Il, sl["mI"], sl["vI"], N)
+    for a, b in ((Ul, Ud), (Il, Id)):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=2e-6, rtol=0)
+    # (m = b1 m + (1 - b1) g can cancel to a few 1e-9 where both terms are 1e-5: absolute floors at 1e-6 of the typical size)
+    for k in ("mU", "mI"):
+        np.testing.assert_allclose(sl[k].cpu().numpy(), sd[k].cpu().numpy(), rtol=2e-4, atol=1e-10)
+    for k in ("vU", "vI"):
+        np.testing.assert_allclose(sl[k].cpu().numpy(), sd[k].cpu().numpy(), rtol=2e-4, atol=1e-16)
+
+
 def test_lazy_adam_rows_matches_dense_on_touched_rows(dev):
     from pda_amd import ops
     rng = np.random.default_rng(29)

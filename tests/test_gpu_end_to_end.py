@@ -189,3 +189,32 @@ def test_eval_user_without_train_rows_raises_keyerror_under_data2(dev, toy, tmp_
     ev = t.evaluation(t.data, [20], dev)
     with pytest.raises(KeyError):
         ev.set_evaluate_obj_pre("valid")
+
+
+def test_exact_sgd_through_the_trainer_takes_the_planned_step(dev, toy, tmp_path):
+    """--optimizer sgd with the device sampler: every batch arrives with its pda_triplet_plan and the step runs without atomics
+    (ops.bpr_step_plan); the tables after 20 steps equal those of the plan-less exact path on the same batches (2e-6)."""
+    from pda_amd import train_new_api as t, ops
+    from pda_amd.sampler import DeviceSampler
+    res = []
+    for planned in (True, False):
+        t.configure(_argv(toy, str(tmp_path) + "/", "s_condition", ("--optimizer", "sgd", "--lr", "0.05")))
+        a, d = t.args, t.data
+        pop_all = t.load_popularity(a)
+        d.add_expo_popularity(np.power(t.get_popularity_from_load(pop_all), a.pop_exp))
+        smp = DeviceSampler(d, dev, True)
+        model = t.DatasetApi_Model(a, {"n_users": d.n_users, "n_items": d.n_items}, 256, smp, dev)
+        assert smp.with_plan is True
+        if not planned:
+            smp.with_plan = False
+        sess = t.Session(model)
+        rec = model.Recommender
+        fetches = [rec.opt_pop_global, rec.loss_pop_global, rec.mf_loss_pop_global, rec.reg_loss_pop_global]
+        model.switch_to_training_or_reinitsampler(sess)
+        for _ in range(20):
+            sess.run_async(fetches)
+            assert (model.batch_plan is not None) == planned
+        torch.cuda.synchronize()
+        res.append((rec.weights["user_embedding"].clone(), rec.weights["item_embedding"].clone()))
+    np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), atol=2e-6)
+    np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), atol=2e-6)

@@ -36,6 +36,11 @@ def timed_graph(body, n_steps=2048):
     return (time.perf_counter() - t0) / (reps * G) * 1e6
 
 
+ctr = torch.zeros(1, dtype=torch.int64, device=dev)
+from pda_amd import _lib
+floor = timed_graph(lambda i: _lib.check(_lib.load().pda_counter_add(_lib.ptr(ctr), 1, _lib.stream_ptr()), "pda_counter_add"))
+print("launch floor: a one-thread kernel (pda_counter_add) as a node of the same 64-node graphs: %.2f us per node" % floor)
+
 for B in Bs:
     raw = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2020, step=s, n_pool=W.n_users, train_slots=W.hist_slots,
                                neg_range=(0, W.n_items), pop_matrix=W.pop_train) for s in range(NB)]

@@ -1,0 +1,148 @@
+// micro-benchmark 5 (round 3): which MACHINE MAPPING of the sweep's block loop can keep the matrix pipe busy, with every LDS read
+// and MFMA of a block in one inline-asm statement (counted software pipeline, 6 fragments in flight -- the compiler's own schedule
+// put every read one or two instructions in front of its MFMA).  d = 128, 64-item blocks, row stride 304 B, LDS-DMA loader waves
+// streaming tiles into two LDS slots beside the MFMA waves (no hand-over: the data is garbage, the traffic is real).
+//   A  the kernel as it is: 2 MFMA waves per SIMD x 32 user rows (UA = 1): 18 MFMAs per block and wave, then a VALU read of the
+//      block's own accumulators (the filter); 4 loader waves; 16 waves per workgroup
+//   B  1 MFMA wave per SIMD x 64 user rows (UA = 2): 36 MFMAs per block on four chains, ONE B read per two MFMAs, the filter runs
+//      on the PREVIOUS block's accumulators (double-buffered) so that it never waits for the pipe; 2 or 4 loader waves
+// build: python tools/ubench/gen_blk.py 6 > tools/ubench/blk.h && hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_struct tools/ubench/mfma_struct.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#include "blk.h"
+constexpr int RB = 304, HB = 32 * RB, BB = 2 * HB;      // 19 456 B per 64-item block
+
+__device__ __forceinline__ unsigned or16(const f32x16& v) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) m |= __float_as_uint(v[r]);
+    return m;
+}
+
+// UA: A operands per MFMA wave; MW: MFMA waves per workgroup; LW: loader waves; IW: idle waves (sleeping, like rescoring waves
+// without candidates); DB: the filter reads the previous block's accumulators (UA = 2) instead of the block's own
+template <int UA, int MW, int LW, int IW, bool DB>
+__global__ void __launch_bounds__(64 * (MW + LW + IW)) k(const unsigned char* __restrict__ rows, size_t n_bytes, unsigned* out, int n_blk, unsigned seed) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 2 * BB / 4; i += blockDim.x) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + (seed * i & 0x00ff00ffu);
+    __syncthreads();
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    if (wave < MW) {
+        const int j = lane & 31, h = lane >> 5;
+        u32x4 a[UA][8], aex[UA];
+        for (int u = 0; u < UA; ++u) {
+            for (int m = 0; m < 8; ++m) a[u][m] = u32x4{0x3c003c00u + seed + m, 0xbc003c00u + tid, 0x3c00bc00u + u, 0x3c003c00u};
+            aex[u] = u32x4{0x3c003c00u, 0xbc00bc00u, seed, 0u};
+        }
+        f32x16 acc[2][UA][2];
+        unsigned sink = 0;
+        u32x4 pi;
+        const unsigned base = lds0 + (unsigned)(j * RB + 16 * h);
+        for (int u = 0; u < UA; ++u)
+            for (int cb = 0; cb < 2; ++cb) acc[1][u][cb] = (f32x16)(0.f);
+        for (int b = 0; b < n_blk; b += 2) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const unsigned addr = base + (unsigned)(p * BB);
+                Blk<UA>::run(acc[DB ? p : 0], pi, a, aex, addr, addr - 16u * h + 288u);
+                // the filter: OR of a lane's accumulator registers, sign bit = "a candidate"
+                if (DB) {
+#pragma unroll
+                    for (int u = 0; u < UA; ++u)
+                        for (int cb = 0; cb < 2; ++cb) sink |= or16(acc[p ^ 1][u][cb]);
+                } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");      // XDL write -> VALU read of the accumulators
+#endif
+#pragma unroll
+                    for (int u = 0; u < UA; ++u)
+                        for (int cb = 0; cb < 2; ++cb) sink |= or16(acc[0][u][cb]);
+                }
+                sink |= pi[0];
+                if (__builtin_expect(__any((int)sink < 0 && (sink & 0x7fffffffu) == 0x12345u), 0)) out[1] = sink;     // (never true; keeps the test alive)
+            }
+        }
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+#endif
+        for (int p = 0; p < (DB ? 2 : 1); ++p)
+            for (int u = 0; u < UA; ++u)
+                for (int cb = 0; cb < 2; ++cb) sink |= or16(acc[p][u][cb]);
+        if (sink == 0x7654321u) out[2] = sink;
+    } else if (wave < MW + LW) {
+        // loaders: 19 pieces of 1 KiB per block over LW waves, two blocks in flight, no hand-over
+        const int l = wave - MW;
+        constexpr int NP = 19, MYP = (NP + LW - 1) / LW;
+        const size_t tile0 = ((size_t)blockIdx.x * 977) % (n_bytes / BB - (size_t)n_blk - 2);
+        for (int b = 0; b < n_blk; ++b) {
+            const unsigned char* src = rows + (tile0 + (size_t)b) * BB + lane * 16;
+            const unsigned dst = lds0 + (unsigned)((b & 1) * BB);
+#pragma unroll
+            for (int c = 0; c < MYP; ++c) {
+                const int piece = l + LW * c;
+                if (piece < NP) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                    unsigned keep;
+                    const unsigned char* gsrc = src + (size_t)piece * 1024;
+                    const unsigned ldst = __builtin_amdgcn_readfirstlane(dst + (unsigned)piece * 1024u);
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+#endif
+                }
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYP) : "memory");
+            // pace the loaders to the MFMA waves (they would otherwise run ahead): ~1 150 cycles of MFMAs per block and SIMD
+            __builtin_amdgcn_s_sleep(LW >= 4 ? 6 : 1);
+#endif
+        }
+    } else {
+        for (int b = 0; b < n_blk; ++b) __builtin_amdgcn_s_sleep(16);
+    }
+    if (tid == 0 && blockIdx.x == 0) out[0] = n_blk;
+}
+
+template <int UA, int MW, int LW, int IW, bool DB>
+void run(const unsigned char* rows, size_t n_bytes, unsigned* d, const char* what) {
+    const int n_blk = 3000, grid = 1024;
+    const size_t lds = 156 * 1024;                      // one workgroup per CU, like the sweep (tiles + lists)
+    auto fn = k<UA, MW, LW, IW, DB>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * (MW + LW + IW)), lds, 0, rows, n_bytes, d, n_blk, 12345u);
+    hipDeviceSynchronize();
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(64 * (MW + LW + IW)), lds, 0, rows, n_bytes, d, n_blk, 12345u);
+        hipEventRecord(e1, 0);
+        hipDeviceSynchronize();
+        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    if (hipGetLastError() != hipSuccess) { printf("%s: launch failed\n", what); return; }
+    const double mf = (double)grid * n_blk * MW * UA * 18;                   // MFMAs
+    printf("%-72s %7.3f ms  %7.1f TFLOP/s executed  %7.1f algorithmic (x 8/9)\n", what, best, mf * 32768.0 / (best * 1e-3) / 1e12,
+           mf * 32768.0 / (best * 1e-3) / 1e12 * 8 / 9);
+}
+
+int main() {
+    const size_t n_bytes = (size_t)64 << 20;
+    unsigned char* rows;
+    unsigned* d;
+    hipMalloc(&rows, n_bytes);
+    hipMemset(rows, 0x3c, n_bytes);
+    hipMalloc(&d, 64);
+    run<1, 8, 4, 4, false>(rows, n_bytes, d, "A  2 MFMA waves/SIMD x 32 rows, own-block filter, 4 loaders, 4 idle");
+    run<1, 8, 4, 0, false>(rows, n_bytes, d, "A' the same without the idle waves");
+    run<2, 4, 2, 2, true>(rows, n_bytes, d, "B  1 MFMA wave/SIMD x 64 rows, filter on the previous block, 2 loaders, 2 idle");
+    run<2, 4, 4, 0, true>(rows, n_bytes, d, "B' the same with 4 loaders, no idle waves");
+    run<2, 4, 2, 2, false>(rows, n_bytes, d, "B0 1 MFMA wave/SIMD x 64 rows, own-block filter (stalls), 2 loaders, 2 idle");
+    run<1, 4, 2, 2, false>(rows, n_bytes, d, "C  1 MFMA wave/SIMD x 32 rows, own-block filter");
+    return 0;
+}
