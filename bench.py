@@ -113,7 +113,7 @@ def table_dtype_of(args, workload):
     return td, (torch.bfloat16 if td == "bf16" else torch.float32)
 
 
-def bench_eval(args, rank, world, dev, workload=None, light=False):
+def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=None):
     """light: the per_config form -- headline sweep and early-terminating sweep only, a third of the steps."""
     import torch.distributed as dist
     from pda_amd import ops, synthetic
@@ -126,7 +126,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
     timed = TimedScore()
     # N > 1: `ugroups` user groups x (world / ugroups) item shards (pda_amd.dist.grid_layout)
     from pda_amd.dist import default_user_groups, make_item_group
-    ugroups = (args.user_groups or default_user_groups(world)) if world > 1 else 1
+    ugroups = (user_groups or args.user_groups or default_user_groups(world)) if world > 1 else 1
     gidx, grank, gsize, pgroup = make_item_group(rank, world, ugroups) if world > 1 else (0, 0, 1, None)
     # N = 1: the score call is wrapped with HIP events (roofline.kernel_ms).  N > 1: the product's own path -- early-terminating
     # sweeps run software-pipelined (pda_amd.dist.topk_blocks: the seed collectives of block b + 1 under the sweep of block b),
@@ -198,7 +198,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False):
                    "note": "pda_score_topk_ordered_f32: catalogue visited most-popular-first, a user block stops once "
                            "pop + ||u||*pop*||i|| of everything unvisited is below every user's running K-th value; "
                            "bit-identical keys (tests/test_gpu_score_topk.py); data-dependent, hence not the headline"}
-    if os.environ.get("PDA_BENCH_DUMP"):                  # tests/test_gpu_two_rank.py: the lists of the last step (this rank's rows)
+    if os.environ.get("PDA_BENCH_DUMP") and user_groups is None:      # tests/test_gpu_two_rank.py: the lists of the last step (this rank's rows)
         torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_w%d_r%d.pt" % (world_all, rank)))
     # the raw head ('main_branch'): the reference evaluates it in EVERY evaluation epoch before the two PDA passes
     # (MF/train_new_api.py:1139-1141, head at :597-598) and it is the only head of --train normal.  Product-default sweep mode.
@@ -720,6 +720,17 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
     ev = bench_eval(args, rank, world, dev)
+    # BASELINE config 4 literally -- the catalogue item-sharded over ALL ranks, one list exchange among them -- beside the default
+    # layout (user groups x item shards), whenever the two differ
+    ev_items = None
+    if world >= 4 and ev["layout"]["user_groups"] != 1 and not args.headline_only:
+        e2 = bench_eval(args, rank, world, dev, light=True, user_groups=1)
+        ev_items = {"value": e2["users_per_s"], "unit": "users/s", "ms_per_step": e2["ms_per_step"], "layout": e2["layout"],
+                    "early_terminating_sweep": e2["ordered"],
+                    "note": "--user-groups 1: every rank scores ALL users of a step against its 1/N of the catalogue (the north_star's layout); "
+                            "every rank pays the exact warm-up and the list hand-over for all users, which is why the default splits users first"}
+        del e2
+        torch.cuda.empty_cache()
     sharded_train = bench_train_sharded(args, rank, world, dev) if (world > 1 and args.train_sharded) else None
     train_pack = None
     if world == 1 and not args.no_train:
@@ -789,7 +800,7 @@ def main():
                                      ("bf16 tables; scores = the fp32 fmaf chain on the widened values (exact products), bit-identical to the exact "
                                       "kernel on the widened tables; the bf16 MFMA pass is a pre-filter with a rigorous error bound")},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "dense_natural_order": ev["natural"],
-            "ordered_sweep": ev["ordered"], "raw_head": ev["raw_head"], "prep": ev["prep"], "per_config": per_config,
+            "ordered_sweep": ev["ordered"], "raw_head": ev["raw_head"], "item_sharded_only": ev_items, "prep": ev["prep"], "per_config": per_config,
             "train": train_pack[0] if train_pack else ({"item_parallel_sgd": sharded_train} if sharded_train else None),
         }
         print(json.dumps(line))

@@ -64,6 +64,9 @@ SIGNATURES = {
     "pda_score_topk4_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "pda_peak_mfma_flops_per_launch": (C.c_double, [_i]),
     "pda_peak_mfma_bf16": (_i, [_vp, _i, _vp]),
+    "pda_peak_mfma_bf16_const": (_i, [_vp, _i, _vp]),
+    "pda_peak_mfma_lds_flops_per_launch": (C.c_double, [_i]),
+    "pda_peak_mfma_lds_bf16": (_i, [_vp, _sz, _vp, _i, _vp]),
     "pda_peak_copy": (_i, [_vp, _vp, _sz, _vp]),
     "pda_topk_kth_value": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pda_topk_seed_refine": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -705,19 +705,25 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_NSLOT
 #define PDA_V4_NSLOT 4    // tile slots in LDS when the lists live in HBM (<= 5: the vote words of the early termination)
 #endif
-template <int D>
+// GLX (d <= 128; round 3): the exact lists in the workspace instead of the LDS, which pays for FOUR tile slots and loaders that run
+// ahead.  With two slots the loaders can start on block b + 2 only when the SLOWEST MFMA wave has released block b, and need
+// ~900 cycles from there (5 pieces of ~136 issue cycles per loader, then the latency) against ~1 150 cycles of a block's MFMAs:
+// any skew between the eight MFMA waves turns into waiting -- 22 % of their time in the dense sweep (cycle counters of the
+// profiling build).  Candidate-heavy sweeps (natural order, raw head: hundreds of list insertions per user) keep their lists in
+// the LDS: every insertion would be a round trip to L2.  The caller says which (pda_score_topk4_*: early_stop bit 1).
+template <int D, bool GLX = false>
 struct Geo4 {
     static constexpr int UA = D <= 128 ? PDA_V4_UA : 1;  // A operands per B read: 32 UA user rows per MFMA wave
     // the exact lists in HBM (workspace) free the LDS for four tile slots (d = 256: 8.1 instead of 9.0 ms on a config-5 shard);
     // 512 users x 57 x 8 B would not fit the LDS anyway
-    static constexpr bool GL = PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0;
+    static constexpr bool GL = (PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0) || GLX;
 #ifdef PDA_V4_NBX   /* timing experiment only (results are wrong): NBX half-tiles per block at d <= 128 */
     static constexpr int NB = D <= 128 ? PDA_V4_NBX : 1;
 #else
     static constexpr int NB = (D <= 128 && UA == 1) ? 2 : 1;          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
 #endif
-    static constexpr int LOADERS = (D <= 128 && UA == 1 && !GL) ? 4 : 2;
-    static constexpr int RESCORERS = (D <= 128 && UA == 1 && !GL) ? 4 : 2;
+    static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : 2;
+    static constexpr int RESCORERS = (D <= 128 && UA == 1) ? 4 : 2;
     static constexpr int MPR = kMainWaves / RESCORERS;   // MFMA waves per rescoring wave
     static constexpr int WAVES = kMainWaves + LOADERS + RESCORERS;
     static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
@@ -737,9 +743,9 @@ struct Geo4 {
 
 // ES: exact early termination on (sufA / sufB non-NULL).  Two instantiations: the votes and the dead-wave path are a handful of
 // instructions, but their presence in the loop cost the DENSE sweep 6 % at d = 256 (register allocation of the prefetched loop).
-template <int D, int HEAD, bool BF, bool ES>
-__global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
-    using G = Geo4<D>;
+template <int D, int HEAD, bool BF, bool ES, bool GLX = false>
+__global__ void __launch_bounds__((64 * Geo4<D, GLX>::WAVES)) sweep4_kernel(Args4 g) {
+    using G = Geo4<D, GLX>;
     constexpr int kLoaders = G::LOADERS, kMPR = G::MPR;
     constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP, UA = G::UA, NSLOT = G::NSLOT;
     constexpr bool GL = G::GL;
@@ -1232,7 +1238,8 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         sb_nx = g.sufB[tn];
     }
     constexpr int S = NB * NM, PF = S < PDA_V4_PF ? S : PDA_V4_PF;
-    constexpr bool PFX = NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
+    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && D <= 128 && UA == 1 && NB == 2;     // the block as one asm statement (below)
+    constexpr bool PFX = !kAsmGeo && NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
     u32x4 bq[PF];
     int dead_from = 0x7FFFFFFF;                // first tile from which no row of this wave can be reached (early termination)
     for (int b = 0; b < n_blk && !stopped; ++b) {
@@ -1279,12 +1286,13 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         }
         // With three slots the first B fragments of block b + 1 are read while the MFMAs of block b are still being issued: the
         // wave comes back from the accumulator test of block b with its operands in registers.
-        const bool has_next = PFX && b + 1 < n_blk;
-        if (b == 0 || !PFX) ensure_landed(b);
+        const bool has_next = (PFX || kAsmGeo) && b + 1 < n_blk;
+        if (b == 0 || !PFX) ensure_landed(b);       // (asm path: a poll only when the answer read under the previous block said "not yet")
         // "has block b + 1 landed?" is asked here and looked at half a block later, in front of the first read of block b + 1:
         // a synchronous poll costs an LDS round trip per block (440 cycles of a block's 1 600 on a busy LDS)
         unsigned lnd[kLoaders];
-        if (has_next && landed_c < (unsigned)(b + 2)) {
+        const bool asked = has_next && landed_c < (unsigned)(b + 2);
+        if (asked) {
 #pragma unroll
             for (int z = 0; z < kLoaders; ++z) lnd[z] = lds_ld(&s_landed[z]);
         } else {
@@ -1302,7 +1310,7 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
         // the source asked for -- an LDS round trip per pair of MFMAs, ~1 740 cycles per block and wave for 576 cycles of MFMAs,
         // the pipe 66 % busy with two such waves per SIMD (what PMC measured in round 2).  The raw head on a prep that carries
         // popularity pieces (never built by pda_amd.ops) rewrites the test operands and keeps the compiler's schedule.
-        constexpr bool kAsmBlock = PDA_V4_ASM != 0 && D <= 128 && UA == 1 && NB == 2 && !PFX;
+        constexpr bool kAsmBlock = kAsmGeo;
         bool asm_done = false;
         if constexpr (kAsmBlock) {
             if (HEAD == PDA_HEAD_POP || !raw_on_pop_prep) {
@@ -1314,6 +1322,12 @@ __global__ void __launch_bounds__(64 * Geo4<D>::WAVES) sweep4_kernel(Args4 g) {
                 popv[1] = __uint_as_float(piq[2]);
                 locv[1] = (int)piq[3];
                 asm_done = true;
+                if (asked) {                      // the hand-over words were read in front of the block: an LDS round trip hidden
+                    unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+                    for (int z = 0; z < kLoaders; ++z) mn = min(mn, lnd[z]);
+                    landed_c = mn;
+                }
             }
         }
         if (!asm_done) {
@@ -1589,9 +1603,43 @@ __global__ void __launch_bounds__(1024) stop_scatter4_kernel(const int* __restri
         if (b[i] >= 0) perm[sh[b[i]] + r[i]] = (int)blockIdx.x * 4096 + i * 1024 + t;
 }
 
+template <int D, int HEAD, bool BF, bool GLX>
+int launch_sweep4(const Args4& g, hipStream_t stream) {
+    using G = Geo4<D, GLX>;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false, GLX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)G::lds_total) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true, GLX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)G::lds_total) != hipSuccess)
+            return PDA_ERR_LAUNCH;
+        attr_set = 1;
+    }
+    const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
+    if (g.sufA != nullptr && g.regroup_ws != nullptr) {
+        Args4 gp = g;
+        int* bins = g.regroup_ws;
+        int* bin_of = bins + 1024;
+        int32_t* perm = bin_of + g.n_users_blk;
+        if (hipMemsetAsync(bins, 0, 1024 * sizeof(int), stream) != hipSuccess) return PDA_ERR_LAUNCH;
+        hipLaunchKernelGGL((stop_predict4_kernel<D, BF>), dim3((unsigned)((g.n_users_blk + 31) / 32)), dim3(256), 0, stream, g, bin_of);
+        const unsigned hb = (unsigned)((g.n_users_blk + 4095) / 4096);
+        hipLaunchKernelGGL(stop_hist4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, g.n_users_blk, bins);
+        hipLaunchKernelGGL(stop_scan4_kernel, dim3(1), dim3(1024), 0, stream, bins);
+        hipLaunchKernelGGL(stop_scatter4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, bins, g.n_users_blk, perm);
+        PDA_CHECK_LAUNCH();
+        gp.row_perm = perm;
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GLX>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
+    } else if (g.sufA != nullptr)
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GLX>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+    else
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false, GLX>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
 template <int D, int HEAD, bool BF>
-int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = warm-up only, 2 = sweep only, 3 = both
-    using G = Geo4<D>;
+int launch4(const Args4& g, int phase, hipStream_t stream, bool lists_in_hbm) {      // phase: 1 = warm-up only, 2 = sweep only, 3 = both
     if (phase & 1) {
         constexpr int CAP = kCap4;
         const size_t smem = 32 * D * 4 + (size_t)kUserTile * (CAP * 8 + 8) + kUserTile * 2 * kWarmTiles * 4 + 256 + kUserTile * 8;
@@ -1608,41 +1656,16 @@ int launch4(const Args4& g, int phase, hipStream_t stream) {      // phase: 1 = 
     }
     if ((g.n_tiles + g.n_splits - 1) / g.n_splits <= g.warm_tiles) return PDA_OK;      // every split ends inside its warm-up
     if (phase & 2) {
-        static int attr_set = 0;
-        if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)G::lds_total) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)G::lds_total) != hipSuccess)
-                return PDA_ERR_LAUNCH;
-            attr_set = 1;
+        if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
+            if (lists_in_hbm) return launch_sweep4<D, HEAD, BF, true>(g, stream);
         }
-        const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
-        if (g.sufA != nullptr && g.regroup_ws != nullptr) {
-            Args4 gp = g;
-            int* bins = g.regroup_ws;
-            int* bin_of = bins + 1024;
-            int32_t* perm = bin_of + g.n_users_blk;
-            if (hipMemsetAsync(bins, 0, 1024 * sizeof(int), stream) != hipSuccess) return PDA_ERR_LAUNCH;
-            hipLaunchKernelGGL((stop_predict4_kernel<D, BF>), dim3((unsigned)((g.n_users_blk + 31) / 32)), dim3(256), 0, stream, g, bin_of);
-            const unsigned hb = (unsigned)((g.n_users_blk + 4095) / 4096);
-            hipLaunchKernelGGL(stop_hist4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, g.n_users_blk, bins);
-            hipLaunchKernelGGL(stop_scan4_kernel, dim3(1), dim3(1024), 0, stream, bins);
-            hipLaunchKernelGGL(stop_scatter4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, bins, g.n_users_blk, perm);
-            PDA_CHECK_LAUNCH();
-            gp.row_perm = perm;
-            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
-        } else if (g.sufA != nullptr)
-            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
-        else
-            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
-        PDA_CHECK_LAUNCH();
+        return launch_sweep4<D, HEAD, BF, false>(g, stream);
     }
     return PDA_OK;
 }
 
 int user_tile4(int d) { return d == 64 ? Geo4<64>::UT : d == 128 ? Geo4<128>::UT : Geo4<256>::UT; }
-static bool lists_in_hbm4(int d) { return d == 64 ? Geo4<64>::GL : d == 128 ? Geo4<128>::GL : Geo4<256>::GL; }
+static bool lists_in_hbm4(int) { return true; }       // (every d may run with its lists in the workspace since round 3: Geo4<D, true>)
 // the workspace of the pda_score_topk4_* calls: the counters of pda_score_topk_workspace_bytes, then (workgroups of 512 users:
 // d <= 128) the list slots of every workgroup
 // the workspace of the pda_score_topk4_* calls: [counters of pda_score_topk_workspace_bytes | list slots of every workgroup when the
@@ -1678,6 +1701,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
+    if (early_stop < 0 || (early_stop & ~0x73) != 0) return PDA_ERR_ARG;
+    const bool lists_in_hbm = (early_stop & PDA_SWEEP_FEW_CANDIDATES) != 0;       // geometry hint (Geo4<D, true>): results do not depend on it
+    if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
+    early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
     if (head == PDA_HEAD_POP && !pop_shard) return PDA_ERR_ARG;
     if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
@@ -1736,7 +1763,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;
     }
-#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, phase, s) : launch4<DD, PDA_HEAD_RAW, BFV>(g, phase, s))
+#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, phase, s, lists_in_hbm) : launch4<DD, PDA_HEAD_RAW, BFV>(g, phase, s, lists_in_hbm))
     switch (d) {
         case 64: return bf16 ? PDA_V4_(64, true) : PDA_V4_(64, false);
         case 128: return bf16 ? PDA_V4_(128, true) : PDA_V4_(128, false);

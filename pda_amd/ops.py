@@ -205,6 +205,19 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
     return "v4"
 
 
+def few_candidates_hint(head: int, prune) -> int:
+    """PDA_SWEEP_FEW_CANDIDATES for pda_score_topk4_*: the popularity head swept in visiting order meets next to no candidates
+    behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
+    four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
+    forced = os.environ.get("PDA_SCORE_LISTS", "")
+    if forced in ("lds", "hbm"):
+        return 2 if forced == "hbm" else 0
+    # Measured (round 3, config 3, 262 144 users, same box): dense sweep 12.58 vs 12.71 ms with the lists in the workspace (four
+    # tile slots), early-terminating sweep 1.18 vs 1.04 ms, C1 / C2 0.28 vs 0.25 ms: the hand-over of the warm-up lists and the
+    # final sort go through L2 instead of the LDS.  Not worth it: off unless forced.
+    return 0
+
+
 def seed_exchange_applies(d: int, K: int, head: int, prune=None, impl: Optional[str] = None) -> bool:
     """Does score_topk_keys(seed_reduce=...) call seed_reduce for these arguments?  A function of arguments that are the same
     on every rank, so that ranks which cannot score (an empty item shard) still know whether to join the two all-reduces."""
@@ -344,7 +357,8 @@ def seeded_begin(U, I_shard, users, K, head, pop_shard, hist, item_offset=0, n_s
     c.ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
     c.fnp = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32
     c.common = (ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
-                ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head, 1, n_splits)
+                ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head,
+                1 | few_candidates_hint(head, True), n_splits)
     c.keep = (U, I_shard, prep, pop_shard, users, hist)          # the pointers above stay valid until seeded_finish
     # R shards warm up R x 64 warm_tiles items between them: two tiles each on 2 shards, one from 4 shards on
     c.wt = int(os.environ.get("PDA_WARM_TILES", "0")) or max(1, 4 // max(1, seed_shards))
@@ -384,7 +398,8 @@ def seeded_finish(c: SeededCall) -> torch.Tensor:
 
 def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist: Optional[HistoryCSR] = None,
                     item_offset=0, n_splits=0, out: Optional[torch.Tensor] = None, impl: Optional[str] = None,
-                    prune=None, stats: Optional[dict] = None, seed_reduce=None, seed_shards: int = 1, seed_sum=None) -> torch.Tensor:
+                    prune=None, stats: Optional[dict] = None, seed_reduce=None, seed_shards: int = 1, seed_sum=None,
+                    warm_tiles: int = 0) -> torch.Tensor:
     """pda_score_topk_f32 / pda_score_topk_prepped_f32 / pda_score_topk_ordered_f32 / pda_score_topk4_* -> packed keys
     int64[n_splits, Bu, K] (uint64 bit patterns), best first.  All of them return the same keys.
 
@@ -394,7 +409,9 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     [n_thr, Bu] -> the sum over the shards in place, ONE all_reduce SUM): the counts at seed_thresholds(seed_shards) common
     thresholds tighten the bound first.  The sweep prunes against the resulting seed (pda_score_topk4_phase_*); the shard's lists
     may end shorter than K -- merge them with the other shards' lists.  (seeded_begin / seeded_counts / seeded_finish are the
-    same three steps as separate calls.)"""
+    same three steps as separate calls.)
+    warm_tiles (generation 4 only; 0 = the library's default of 4): 64-item tiles per split scored by the exact warm-up kernel --
+    an item shard of an R-rank job wants 4 / R (pda_amd.dist): the R warm-ups cover R x 64 x warm_tiles items between them."""
     lib = _lib.load()
     bf = I_shard is not None and I_shard.dtype == torch.bfloat16       # bf16 tables: pda_score_topk_bf16 (both tables bf16)
     U = _need(U, torch.bfloat16 if bf else torch.float32, "U")
@@ -441,10 +458,11 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
+        es = (1 if prune is True else 0) | few_candidates_hint(head, prune) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
         fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
         check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
-                 K, head, 1 if prune is True else 0, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
+                 K, head, es, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
         if stats is not None:
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["pairs_rescored"] = ws[4:8].view(torch.int32)
@@ -957,9 +975,36 @@ def measured_peaks(device=None, mfma_iters: int = 4000, copy_mb: int = 1024) -> 
         e[2].record()
         torch.cuda.synchronize()
         best_mfma, best_copy = min(best_mfma, e[0].elapsed_time(e[1])), min(best_copy, e[1].elapsed_time(e[2]))
+    # the same register-operand loop with every operand 1.0, and the sweep's own kind of loop (B from the LDS, tiles by LDS-DMA)
+    # on random and on constant bf16 rows: the second data points behind `peak_measured`
+    best_const = best_lds = best_lds_const = float("inf")
+    n_blk = 3000
+    nb = (n_blk + 1024) * 19456
+    rows = torch.randint(-(1 << 15), (1 << 15) - 1, (nb // 2,), dtype=torch.int16, device=dev)
+    rows = ((rows & 0x7F) | ((0x3B + (torch.arange(nb // 2, device=dev, dtype=torch.int16) & 3)) << 7) | (rows & -0x8000)).contiguous()   # |x| ~ 0.1 .. 1
+    rows_c = torch.full_like(rows, 0x3C00)
+    scratch = torch.zeros(4, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        e[0].record()
+        check(lib.pda_peak_mfma_bf16_const(ptr(sink), mfma_iters, stream_ptr()), "pda_peak_mfma_bf16_const")
+        e[1].record()
+        check(lib.pda_peak_mfma_lds_bf16(ptr(rows), nb, ptr(scratch), n_blk, stream_ptr()), "pda_peak_mfma_lds_bf16")
+        e[2].record()
+        check(lib.pda_peak_mfma_lds_bf16(ptr(rows_c), nb, ptr(scratch), n_blk, stream_ptr()), "pda_peak_mfma_lds_bf16")
+        e[3].record()
+        torch.cuda.synchronize()
+        best_const = min(best_const, e[0].elapsed_time(e[1]))
+        best_lds, best_lds_const = min(best_lds, e[1].elapsed_time(e[2])), min(best_lds_const, e[2].elapsed_time(e[3]))
+    lds_fl = lib.pda_peak_mfma_lds_flops_per_launch(n_blk)
     return {"bf16_mfma_TFLOPs": lib.pda_peak_mfma_flops_per_launch(mfma_iters) / (best_mfma * 1e-3) / 1e12,
+            "bf16_mfma_constant_operands_TFLOPs": lib.pda_peak_mfma_flops_per_launch(mfma_iters) / (best_const * 1e-3) / 1e12,
+            "bf16_mfma_lds_fed_TFLOPs": lds_fl / (best_lds * 1e-3) / 1e12,
+            "bf16_mfma_lds_fed_constant_rows_TFLOPs": lds_fl / (best_lds_const * 1e-3) / 1e12,
             "hbm_copy_GBs": 2.0 * 4.0 * n / (best_copy * 1e-3) / 1e9,
-            "note": "bf16 MFMA: 2 waves per SIMD x 4 accumulator chains, random register operands (power-limited clock); "
+            "note": "bf16 MFMA: 2 waves per SIMD x 4 accumulator chains, register operands, random mantissas (power-limited clock) / every operand "
+                    "1.0; lds_fed: the sweep's own block statement -- B from the LDS, one ds_read_b128 per MFMA, four LDS-DMA loader waves streaming "
+                    "tiles, no hand-over (executed flops: 18 MFMAs per block, of which 16 algorithmic) on random / constant bf16 rows; "
                     "HBM: float4 copy of %d MiB, read + write bytes" % copy_mb}
 
 

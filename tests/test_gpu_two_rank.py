@@ -64,6 +64,9 @@ def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
     lay = eight["config"]["layout"]
     assert lay["user_groups"] == 4 and lay["item_shards"] == 2 and lay["users_per_rank_and_step"] == 512
     assert eight["ordered_sweep"]["value"] > 0                      # the seeded early-terminating pass ran on every rank
+    # BASELINE config 4 literally (item shards only) is timed beside the default layout
+    iso = eight["item_sharded_only"]
+    assert iso["value"] > 0 and iso["layout"]["user_groups"] == 1 and iso["layout"]["item_shards"] == 8 and iso["early_terminating_sweep"]["value"] > 0
     a = torch.load(os.path.join(tmp_path, "topk_w1_r0.pt"))
     c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w8_r%d.pt" % r)) for r in range(8)])
     assert a.shape == c.shape and torch.equal(a, c) and one["n_gpus"] == 1

@@ -35,8 +35,14 @@ __global__ void __launch_bounds__(64 * (MW + LW + IW)) k(const unsigned char* __
         const int j = lane & 31, h = lane >> 5;
         u32x4 a[UA][8], aex[UA];
         for (int u = 0; u < UA; ++u) {
-            for (int m = 0; m < 8; ++m) a[u][m] = u32x4{0x3c003c00u + seed + m, 0xbc003c00u + tid, 0x3c00bc00u + u, 0x3c003c00u};
-            aex[u] = u32x4{0x3c003c00u, 0xbc00bc00u, seed, 0u};
+            for (int m = 0; m < 8; ++m) {
+                unsigned x = (seed + 977u * tid + 131u * m + 7u * u) * 2654435761u;
+                for (int q = 0; q < 4; ++q) {
+                    x = x * 1664525u + 1013904223u;
+                    a[u][m][q] = (x & 0x807f807fu) | 0x3c003c80u;          // two bf16 of magnitude ~1 with random signs and mantissas
+                }
+            }
+            aex[u] = u32x4{0x3c003c00u + tid, 0xbc00bc00u, seed, 0u};
         }
         f32x16 acc[2][UA][2];
         unsigned sink = 0;
@@ -136,7 +142,17 @@ int main() {
     unsigned char* rows;
     unsigned* d;
     hipMalloc(&rows, n_bytes);
-    hipMemset(rows, 0x3c, n_bytes);
+    {   // random bf16 values of realistic magnitude (the chip is power-limited: constant operands clock higher and prove nothing)
+        unsigned short* h = (unsigned short*)malloc(n_bytes);
+        unsigned long long x = 88172645463325252ull;
+        for (size_t i = 0; i < n_bytes / 2; ++i) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            h[i] = (unsigned short)(((x >> 20) & 0x807f) | (((unsigned)(0x3b + ((x >> 40) & 3))) << 7));     // sign, 7 mantissa bits, exponent 0x3b .. 0x3e
+        }
+        if (getenv("UB_CONST")) for (size_t i = 0; i < n_bytes / 2; ++i) h[i] = 0x3c00;
+        hipMemcpy(rows, h, n_bytes, hipMemcpyHostToDevice);
+        free(h);
+    }
     hipMalloc(&d, 64);
     run<1, 8, 4, 4, false>(rows, n_bytes, d, "A  2 MFMA waves/SIMD x 32 rows, own-block filter, 4 loaders, 4 idle");
     run<1, 8, 4, 0, false>(rows, n_bytes, d, "A' the same without the idle waves");
