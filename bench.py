@@ -654,9 +654,9 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
         blocks.append(users)
         coos.append((rows, indices[lo:hi].long()))
     rec = "condition" if args.head == "condition" else "main_branch"
-    # value: the reference block cut into 64-row slabs over all host threads (cb.eval_block_blocked: the same ops on 64-row x 16 384-item pieces, the K best of the pieces' candidates at the end;
-    # torch's own intra-op threading -- `torch_intraop_threads` below -- parallelises the matmul only: 2 x one core on 128)
-    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget, block_fn=cb.eval_block_blocked)
+    # value: the native C / OpenMP port (oracle/pda_cpu_port.c: fused, AVX2 + FMA, cache-blocked, heap top-K, all host threads) --
+    # the path written for host cores.  Beside it the torch restatement of the TF op sequence in three threadings.
+    rate, n = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.5, block_fn=cb.eval_block_native)
     cpu_model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -667,12 +667,16 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
         pass
     out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
            "protocol": "3 warm-up blocks, median of the timed 2048-user blocks (up to 10, bounded by the budget)",
-           "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d (torch-CPU restatement of "
-                     "the TF op sequence: matmul, elu+1, *pop, scatter -inf, topk; NOT TensorFlow itself), every block cut into "
-                     "64-row x 16 384-item pieces over the %d host threads" % (n, W.n_items, W.d, cores)}
+           "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d; C / OpenMP port of the path "
+                     "(oracle/pda_cpu_port.c: fused score + head + mask + heap top-K, AVX2 + FMA, 8 users x 4 items cache blocks) on "
+                     "%d host threads; NOT TensorFlow itself (TF 1.14 cannot be installed here)" % (n, W.n_items, W.d, cores)}
     if not full:
         return out
-    rate_i, n_i = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.5)
+    rate_b, n_b = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.4, block_fn=cb.eval_block_blocked)
+    out["torch_op_sequence_blocked"] = {"value": rate_b, "unit": "users/s", "users": n_b, "threads": cores,
+                                        "what": "torch-CPU restatement of the TF op sequence (matmul, elu+1, *pop, scatter -inf, topk) on 64-row x "
+                                                "16 384-item pieces over the host threads, the K best of the pieces' candidates at the end"}
+    rate_i, n_i = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=budget * 0.4)
     out["torch_intraop_threads"] = {"value": rate_i, "unit": "users/s", "users": n_i, "threads": cores,
                                     "what": "the same ops on whole 2048-user blocks, parallelism left to torch's intra-op pool (round 1-2's figure)"}
     if cb.eval_block_reference_topk(U[:4], I[:64], pop[:64], torch.arange(4), torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long), 8, rec) is not None:
@@ -690,6 +694,18 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
     rate1, n1 = cb.time_eval(U, I, pop, blocks, coos, args.K, rec, budget_s=min(6.0, budget / 3), warmups=1, reps=3)
     torch.set_num_threads(cores)
     out["single_thread"] = {"value": rate1, "unit": "users/s", "users": n1}
+    # the native port on ONE thread (a 256-user block): what the host threads buy it
+    try:
+        import ctypes as _C
+        gomp = _C.CDLL("libgomp.so.1")
+        gomp.omp_set_num_threads(1)
+        sub = [(blocks[0][:256], (coos[0][0][coos[0][0] < 256], coos[0][1][coos[0][0] < 256]))]
+        rate_n1, n_n1 = cb.time_eval(U, I, pop, [b for b, _ in sub] * 3, [c for _, c in sub] * 3, args.K, rec, budget_s=6.0, warmups=1, reps=2,
+                                     block_fn=cb.eval_block_native)
+        gomp.omp_set_num_threads(cores)
+        out["native_single_thread"] = {"value": rate_n1, "unit": "users/s", "users": n_n1, "threads_speedup": rate / rate_n1}
+    except OSError:
+        pass
     if train_pack is not None:
         _, W2, batches = train_pack
         cpu_batches = [tuple(t.cpu().long() if t.dtype == torch.int32 else t.cpu() for t in b) for b in batches[:16]]

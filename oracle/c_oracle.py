@@ -72,6 +72,28 @@ def score_topk(U, I, users, K=50, mode=0, pop=None, hist_indptr=None, hist_indic
     return (idx, val, sc) if want_scores else (idx, val)
 
 
+def cpu_port_score_topk(U, I, users, K=50, mode=0, pop=None, hist_indptr=None, hist_indices=None):
+    """cpu_port_score_topk (oracle/pda_cpu_port.c): the native fused CPU baseline, all OpenMP threads.  U, I float32 C-contiguous
+    (numpy or the .numpy() view of a torch CPU tensor: no copy); hist CSR by BLOCK row.  -> (idx int32 [B, K], val float32 [B, K])."""
+    U = np.ascontiguousarray(U, dtype=np.float32)
+    I = np.ascontiguousarray(I, dtype=np.float32)
+    users = np.ascontiguousarray(users, dtype=np.int32)
+    if pop is not None:
+        pop = np.ascontiguousarray(pop, dtype=np.float32)
+    if hist_indptr is not None:
+        hist_indptr = np.ascontiguousarray(hist_indptr, dtype=np.int64)
+        hist_indices = np.ascontiguousarray(hist_indices, dtype=np.int32)
+    B = users.shape[0]
+    idx = np.empty((B, K), dtype=np.int32)
+    val = np.empty((B, K), dtype=np.float32)
+    rc = lib().cpu_port_score_topk(_ptr(U, C.c_float), _ptr(I, C.c_float), _ptr(pop, C.c_float), _ptr(users, C.c_int32), C.c_int(B),
+                                   C.c_int(I.shape[0]), C.c_int(U.shape[1]), _ptr(hist_indptr, C.c_int64), _ptr(hist_indices, C.c_int32),
+                                   C.c_int(K), C.c_int(mode), _ptr(idx, C.c_int32), _ptr(val, C.c_float))
+    if rc != 0:
+        raise ValueError("cpu_port_score_topk: bad arguments")
+    return idx, val
+
+
 def arg_topk_2d(ratings, K=50):
     """oracle_arg_topk_2d: the native CPU top-K baseline (all OpenMP threads).  ratings float32 [rows, n] -> int32 [rows, K]."""
     ratings = np.ascontiguousarray(ratings, dtype=np.float32)

@@ -105,6 +105,19 @@ def eval_block_blocked(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="con
     return out
 
 
+def eval_block_native(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition"):
+    """The block through oracle/pda_cpu_port.c: the path as one would write it in C for host cores -- fused (no rating matrix),
+    AVX2 + FMA dot products on 8 users x 4 items cache blocks, the head bounded before the exponential, a K-entry heap per user,
+    users over all OpenMP threads.  The fair native CPU figure beside the torch restatement of the TF op sequence."""
+    import numpy as np
+    from . import c_oracle
+    n = users.numel()
+    indptr = torch.searchsorted(coo_rows.contiguous(), torch.arange(0, n + 1)).numpy().astype(np.int64)
+    idx, _ = c_oracle.cpu_port_score_topk(U.numpy(), I.numpy(), users.numpy().astype(np.int32), K, 0 if rec_type == "main_branch" else 1,
+                                          None if rec_type == "main_branch" else pop.numpy(), indptr, coo_cols.numpy().astype(np.int32))
+    return idx
+
+
 def eval_block_reference_topk(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition", threads=None):
     """Scores, head and mask as eval_block; the selection by the REFERENCE'S OWN native top-K (util/cython/include/arg_topk.h:29
     arg_top_k_2d, compiled where it lies into oracle/_ref by oracle/Makefile) with its own thread pool.  None when oracle/_ref

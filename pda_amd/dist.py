@@ -210,9 +210,9 @@ class ItemShardedTopK:
                 self._empty_shard_seed(users, K)
             return torch.zeros((users.numel(), K) if self.world > 1 else (1, users.numel(), K), dtype=torch.int64, device=users.device)
         extra = {} if self.prune is None else {"prune": self.prune}
-        if self.world > 1 and self.score_fn is _ops_score_fn():
-            # R item shards warm up R x 64 warm_tiles items between them: 4 / R tiles per shard keep the per-rank fixed cost down
-            extra["warm_tiles"] = max(1, 4 // self.world)
+        # (fewer warm-up tiles per shard pay only together with the seed exchange -- ops.seeded_begin picks 4 / R there: an UNSEEDED
+        # shard with one warm tile starts its sweep with thresholds from 64 items and drowns in candidates: 3.47 instead of 2.33 ms
+        # per 262 144 users on a 25 000-item shard, profiles/round3_shard_scaling.txt)
         if seeded:
             # early-terminating sweeps: without the exchange every shard prunes against its own shard's K-th value only and
             # eight shards score 6.5 x the tiles of one GPU between them; with it 1.03 x (0.98 x on four, 1.07 x on two)

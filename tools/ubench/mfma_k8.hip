@@ -9,7 +9,7 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-template <int MODE>   // 0: 8 x k16;  1: 8 x k8;  2: 8 x k16 + 1 x k16 (today's block shape);  3: 8 x k16 + 1 x k8
+template <int MODE>   // 0: 8 x k16;  1: 8 x k8;  2: 8 x k16 + 1 x k16 (today's block shape);  3: 8 x k16 + 1 x k8;  4: 8 x fp8 k16;  5: 8 x k16 + 1 x fp8 k16
 __global__ void __launch_bounds__(512) k(unsigned* out, int iters, unsigned seed) {
     const unsigned t = threadIdx.x * 2654435761u + seed;
     u32x4 a16 = {(t & 0x807f807fu) | 0x3c003c80u, ((t * 3) & 0x807f807fu) | 0x3c003c80u, ((t * 5) & 0x807f807fu) | 0x3c003c80u, ((t * 7) & 0x807f807fu) | 0x3c003c80u};
@@ -22,10 +22,12 @@ __global__ void __launch_bounds__(512) k(unsigned* out, int iters, unsigned seed
         for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                if (MODE == 1) acc[c] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a8), __builtin_bit_cast(s16x4, b8), acc[c], 0, 0, 0);
+                if (MODE == 4) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(long, a8), __builtin_bit_cast(long, b8), acc[c], 0, 0, 0);
+                else if (MODE == 1) acc[c] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, a8), __builtin_bit_cast(s16x4, b8), acc[c], 0, 0, 0);
                 else acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a16), __builtin_bit_cast(bf16x8, b16), acc[c], 0, 0, 0);
             }
             if (MODE == 2) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, b16), __builtin_bit_cast(bf16x8, a16), acc[c], 0, 0, 0);
+            if (MODE == 5) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(__builtin_bit_cast(long, b8), __builtin_bit_cast(long, a8), acc[c], 0, 0, 0);
             if (MODE == 3) acc[c] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(s16x4, b8), __builtin_bit_cast(s16x4, a8), acc[c], 0, 0, 0);
         }
     }
@@ -62,5 +64,8 @@ int main() {
     run<1>(d, "32 x v_mfma_f32_32x32x8_bf16_1k", 0, 32);
     run<2>(d, "32 x k16 + 4 x k16 (block shape today)", 36, 0);
     run<3>(d, "32 x k16 + 4 x k8  (half-size test step)", 32, 4);
+    run<4>(d, "32 x v_mfma_f32_32x32x16_fp8_fp8", 32, 0);
+    run<5>(d, "32 x k16 + 4 x fp8 k16", 36, 0);
+    run<0>(d, "32 x v_mfma_f32_32x32x16_bf16 (again)", 32, 0);
     return 0;
 }
