@@ -595,6 +595,30 @@ def bench_adam_big_tables(args, dev, workload):
     out["replay"] = run(True, 1536 if workload != "tiny" else 64)
     out["replay"]["note"] = ("pda_adam_lazy_f32: bit-identical tables after the sync (tests/test_gpu_bpr_step.py); three launches per step, "
                              "traffic = the batch rows")
+    # the same three launches per step captured in HIP graphs of 64 steps: the step counter lives in device memory
+    # (pda_adam_lazy_dev_f32), so a replayed graph advances the optimiser and the host is out of the loop
+    def run_graph(fast, steps):
+        U, I = W.U.float().clone(), W.I.float().clone()
+        st = [z(U), z(U), z(U), z(I), z(I), z(I)]
+        lz = ops.LazyAdamState(W.n_users, W.n_items, lr, dev, fast=fast)
+        t_dev = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+        n_tab = steps + 4 * 64 + 8
+        lz.rates(n_tab)
+
+        calls = [0]                                  # (the counter slots alternate with every step enqueued, warm-up steps included)
+
+        def body(i):
+            b = batches[i % NBt]
+            par = calls[0] & 1
+            calls[0] += 1
+            ops.adam_lazy_dev(0, lz, U, st[0], st[1], st[2], I, st[3], st[4], st[5], b[0], b[1], b[2], t_dev, par, n_tab)
+            ops.bpr_step(U, I, *b, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=st[2], gI=st[5], loss_acc=loss)
+            ops.adam_lazy_dev(1, lz, U, st[0], st[1], st[2], I, st[3], st[4], st[5], b[0], b[1], b[2], t_dev, par, n_tab)
+        r = timed_graph_steps(body, steps, B)
+        r["steps_taken_on_device"] = int(t_dev.max().item()) - 1
+        return r
+    out["replay_fast_graph"] = run_graph(True, 1536 if workload != "tiny" else 128)
+    out["replay_fast_graph"]["note"] = "the three launches of a step in HIP graphs of 64 steps, the step counter in device memory (pda_adam_lazy_dev_f32)"
     out["replay_fast"] = run(True, 1536 if workload != "tiny" else 64, fast=True)
     out["replay_fast"]["note"] = ("PDA_ADAM_REPLAY_FAST (the product's default above 64 MB of tables): the same catch-up to 1e-6 on x instead of bit "
                                   "for bit -- running sqrt, hardware reciprocal, closed-form powers for m and v")

@@ -418,6 +418,14 @@ int pda_adam_lazy_sync_f32(float* var, float* m, float* v, int32_t* last, size_t
  * steps ends when its geometrically falling terms can no longer move x, and m, v take their closed-form powers: x within 1e-6
  * of the exact replay / the dense sweep, m and v within 1e-4 relative, over idle gaps of thousands of steps
  * (tests/test_gpu_bpr_step.py); ~6 instead of ~35 VALU per element and replayed step, and a few dozen instead of ~180 steps. */
+/* pda_adam_lazy_dev_f32: pda_adam_lazy_f32 with the step in DEVICE memory (t = t_dev[0]; phase 1 stores t + 1 into t_next, the
+ * other of two int32 counter slots which the caller alternates from step to step; lr_tab holds n_tab entries, a step beyond it
+ * leaves the tables alone): the three launches of a training step -- phase 0, pda_bpr_step_f32(PDA_UPD_DENSE_GRAD), phase 1 --
+ * can be captured into a HIP graph whose replays advance the optimiser. */
+int pda_adam_lazy_dev_f32(int phase, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI,
+                          float* gI, int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d,
+                          const int32_t* t_dev, int32_t* t_next, const float* lr_tab, int n_tab, float beta1, float beta2, float eps,
+                          void* stream);
 #define PDA_ADAM_REPLAY_FAST 0x10
 int pda_adam_lazy_sync_fast_f32(float* var, float* m, float* v, int32_t* last, size_t n_rows, int d, int t, const float* lr_tab,
                                 float beta1, float beta2, float eps, void* stream);
@@ -497,8 +505,10 @@ int pda_group_triplets_by_pos_batches(int32_t* users, int32_t* pos, int32_t* neg
  * batch buffers with the sampler's configuration (step_dev / step_next unused); set0 must hold the first batch on entry, and
  * after the call set (n_steps & 1) holds the batch of the next step.  step_ctr u64 (device): the sampler step of the first
  * batch drawn here, advanced by n_steps.  loss_steps f32 [n_steps][3] (NULL: everything is summed into loss_acc [3]).
- * barrier_ws: 8 device bytes; barrier_ws[1] (u32) != 0 afterwards: the grid was not resident as a whole (another kernel held
- * CUs) and the loop was abandoned.  update_mode: PDA_UPD_SGD_FUSED (| PDA_UPD_ANY_ORDER).  Equals n_steps x
+ * barrier_ws: 8 device bytes, zeroed by the caller before the FIRST call; word 0 is the arrival counter (reset by every call),
+ * word 1 is STICKY: != 0 means some launch since the caller last cleared it found the grid not resident as a whole (another
+ * kernel held CUs) and abandoned its loop -- that launch trained nothing and did not advance step_ctr.  Read it whenever the
+ * stream is next synchronised.  update_mode: PDA_UPD_SGD_FUSED (| PDA_UPD_ANY_ORDER).  Equals n_steps x
  * (pda_bpr_step_f32, pda_sample_triplets_dev) on one stream (fp32 atomics: 1e-6).  The grid is at most 384 + 64
  * workgroups, striding over larger batches. */
 int pda_bpr_train_steps_f32(float* U, float* I, int d, float regs, float reg_div, float lr, int update_mode,

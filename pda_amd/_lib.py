@@ -93,6 +93,7 @@ SIGNATURES = {
     "pda_adam_dense_sweep2_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_rows_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp]),
     "pda_adam_lazy_f32": (_i, [_i] + [_vp] * 13 + [_i, _i, _i, _vp, _f, _f, _f, _vp]),
+    "pda_adam_lazy_dev_f32": (_i, [_i] + [_vp] * 13 + [_i, _i, _vp, _vp, _vp, _i, _f, _f, _f, _vp]),
     "pda_adam_lazy_sync_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _f, _f, _vp]),
     "pda_adam_lazy_sync_fast_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _i, _i, _vp, _f, _f, _f, _vp]),
     "pda_metrics": (_i, [_vp, _i, _i, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -555,6 +555,9 @@ struct LazyAdamArgs {
     const float* lr_tab;
     int B, t, phase;
     float b1, b2, eps;
+    const int32_t* t_dev;      // NULL, or the step in device memory (pda_adam_lazy_dev_f32: HIP-graph replays advance it)
+    int32_t* t_next;           // phase 1 stores t + 1 here (the OTHER of two counter slots: no block reads it in this launch)
+    int n_tab;                 // entries of lr_tab (t_dev mode: a step beyond the table leaves the tables alone)
 };
 
 // Steps from .. upto of an idle row, in registers.  The update lr_k m / (sqrt(v) + eps) shrinks by at least 0.912 per step: m by
@@ -630,6 +633,11 @@ __global__ void __launch_bounds__(256) adam_lazy_kernel(LazyAdamArgs a, FastCons
     if (ridx >= 3 * a.B) return;
     const int which = ridx / a.B, i = ridx - which * a.B;
     const bool user = which == 0;
+    if (a.t_dev != nullptr) {
+        a.t = *a.t_dev;
+        if (a.phase == 1 && ridx == 0 && e == 0) *a.t_next = a.t + 1;
+        if (a.t < 1 || a.t >= a.n_tab) return;
+    }
     const int row = user ? a.users[i] : (which == 1 ? a.pos[i] : a.neg[i]);
     float* var = user ? a.U : a.I;
     float* m = user ? a.mU : a.mI;
@@ -801,7 +809,9 @@ extern "C" int pda_bpr_train_steps_f32(float* U, float* I, int d, float regs, fl
     t.sample_tiles = (B + kSampPerBlock - 1) / kSampPerBlock;
     t.n_sample_blocks = t.sample_tiles < 64 ? t.sample_tiles : 64;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(barrier_ws, 0, 8, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    // only the arrival counter: bar[1] ("a barrier gave up: the loop was abandoned") is STICKY -- the caller zeroes it once and reads it
+    // whenever it next synchronises, however many launches later (zeroing it here hid a failed launch behind the next one)
+    if (hipMemsetAsync(barrier_ws, 0, 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
 #define PDA_LOOP(DD)                                                                                                     \
     case DD: {                                                                                                           \
         constexpr int TPB = 512 / (DD / 4);                                                                              \
@@ -978,6 +988,24 @@ extern "C" int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const
     return PDA_OK;
 }
 
+static int run_adam_lazy(int phase, bool fast, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI, float* gI,
+                         int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d, int t, const int32_t* t_dev,
+                         int32_t* t_next, const float* lr_tab, int n_tab, float beta1, float beta2, float eps, hipStream_t s);
+
+// The same with the step in DEVICE memory: t = t_dev[0] is read by the kernel, phase 1 stores t + 1 into t_next (the other of two
+// counter slots; the caller alternates them from step to step), so a captured HIP graph of steps advances on every replay.
+extern "C" int pda_adam_lazy_dev_f32(int phase, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI,
+                                     float* gI, int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d,
+                                     const int32_t* t_dev, int32_t* t_next, const float* lr_tab, int n_tab, float beta1, float beta2, float eps,
+                                     void* stream) {
+    if (!U || !mU || !vU || !gU || !lastU || !I || !mI || !vI || !gI || !lastI || !users || !pos || !neg || !lr_tab || !t_dev || !t_next) return PDA_ERR_ARG;
+    const bool fast = (phase & PDA_ADAM_REPLAY_FAST) != 0;
+    phase &= ~PDA_ADAM_REPLAY_FAST;
+    if (B <= 0 || n_tab < 2 || t_dev == t_next || (phase != 0 && phase != 1)) return PDA_ERR_ARG;
+    return run_adam_lazy(phase, fast, U, mU, vU, gU, lastU, I, mI, vI, gI, lastI, users, pos, neg, B, d, 1, t_dev, t_next, lr_tab, n_tab, beta1, beta2, eps,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
 extern "C" int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI,
                                  float* gI, int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d, int t,
                                  const float* lr_tab, float beta1, float beta2, float eps, void* stream) {
@@ -986,7 +1014,13 @@ extern "C" int pda_adam_lazy_f32(int phase, float* U, float* mU, float* vU, floa
     phase &= ~PDA_ADAM_REPLAY_FAST;
     if (B <= 0 || t < 1 || (phase != 0 && phase != 1)) return PDA_ERR_ARG;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const LazyAdamArgs a{U, mU, vU, gU, lastU, I, mI, vI, gI, lastI, users, pos, neg, lr_tab, B, t, phase, beta1, beta2, eps};
+    return run_adam_lazy(phase, fast, U, mU, vU, gU, lastU, I, mI, vI, gI, lastI, users, pos, neg, B, d, t, nullptr, nullptr, lr_tab, 0, beta1, beta2, eps, s);
+}
+
+static int run_adam_lazy(int phase, bool fast, float* U, float* mU, float* vU, float* gU, int32_t* lastU, float* I, float* mI, float* vI, float* gI,
+                         int32_t* lastI, const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int d, int t, const int32_t* t_dev,
+                         int32_t* t_next, const float* lr_tab, int n_tab, float beta1, float beta2, float eps, hipStream_t s) {
+    const LazyAdamArgs a{U, mU, vU, gU, lastU, I, mI, vI, gI, lastI, users, pos, neg, lr_tab, B, t, phase, beta1, beta2, eps, t_dev, t_next, n_tab};
     const FastConsts fc{(float)sqrt((double)beta2), (float)log2((double)beta1), (float)log2((double)beta2)};
 #define PDA_LAZY(DD)                                                                                                   \
     case DD: {                                                                                                         \

@@ -786,6 +786,27 @@ def adam_lazy(phase: int, st: LazyAdamState, U, mU, vU, gU, I, mI, vI, gI, users
     mark_modified(I)
 
 
+def adam_lazy_dev(phase: int, st: LazyAdamState, U, mU, vU, gU, I, mI, vI, gI, users, pos, neg, t_dev: torch.Tensor, parity: int, n_tab: int):
+    """pda_adam_lazy_dev_f32: adam_lazy with the step in device memory -- t_dev int32 [2]: slot `parity` is read, phase 1 stores
+    t + 1 into slot 1 - parity (the caller alternates the parity from step to step: an even number of steps per captured graph).
+    n_tab: steps the rate table must cover (built once, before the capture)."""
+    lib = _lib.load()
+    for x in (U, mU, vU, gU, I, mI, vI, gI):
+        _need(x, torch.float32, "adam state")
+    for x in (users, pos, neg):
+        _need(x, torch.int32, "batch rows")
+    t_dev = _need(t_dev, torch.int32, "t_dev")
+    if t_dev.numel() != 2:
+        raise ValueError("t_dev must be int32 [2]")
+    tab = st.rates(n_tab)
+    check(lib.pda_adam_lazy_dev_f32(phase | (_lib.ADAM_REPLAY_FAST if st.fast else 0), ptr(U), ptr(mU), ptr(vU), ptr(gU), ptr(st.lastU), ptr(I), ptr(mI),
+                                    ptr(vI), ptr(gI), ptr(st.lastI), ptr(users), ptr(pos), ptr(neg), users.numel(), U.shape[1],
+                                    ptr(t_dev[parity:parity + 1]), ptr(t_dev[1 - parity:2 - parity]), ptr(tab), tab.numel(), st.beta1, st.beta2, st.eps,
+                                    stream_ptr()), "pda_adam_lazy_dev_f32")
+    mark_modified(U)
+    mark_modified(I)
+
+
 def adam_lazy_sync(st: LazyAdamState, U, mU, vU, I, mI, vI, t: int):
     """pda_adam_lazy_sync_f32 on both tables: every row current for step t (a no-op when nothing is behind)."""
     if st.synced >= t:

@@ -33,6 +33,7 @@ def test_bench_emits_one_contract_line(dev):
     assert t["sgd_fused"]["triplets_per_s"] > 0 and t["adam_dense_reference_faithful"]["triplets_per_s"] > 0
     a = t["adam_on_headline_tables"]         # the reference's optimiser on the headline tables: with and without the sweep
     assert a["dense_sweep"]["triplets_per_s"] > 0 and a["replay"]["triplets_per_s"] > 0 and a["replay"]["final_sync_ms"] > 0
+    assert a["replay_fast"]["triplets_per_s"] > 0 and a["replay_fast_graph"]["steps_taken_on_device"] >= 128
     # round 2: what one pass costs after a weight update, roofs measured on the box, the native CPU top-K, the protocol
     p = d["prep"]
     assert p["prep_ms"] > 0 and p["users_per_s_incl_prep"] > 0 and p["steps_per_pass"] >= 1

@@ -352,6 +352,75 @@ def test_fast_lazy_adam_long_idle_gap_and_training(dev):
         np.testing.assert_allclose(sl[k].cpu().numpy(), sd[k].cpu().numpy(), rtol=2e-4, atol=1e-16)
 
 
+def test_lazy_adam_with_the_step_counter_on_the_device(dev):
+    """pda_adam_lazy_dev_f32: sixteen steps with t read from device memory (two alternating counter slots), eager and replayed from a
+    HIP graph, equal the same steps with t passed from the host (bit for bit: the same kernels, the same arithmetic)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(61)
+    nU, nI, d, B, regs, lr, N = 900, 400, 64, 96, 1e-2, 1e-2, 16
+    U = (rng.standard_normal((nU, d)) * 0.1).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.1).astype(np.float32)
+    batches = []
+    for t in range(N):
+        pi = rng.permutation(nI).astype(np.int32)
+        batches.append(to(dev, rng.permutation(nU)[:B].astype(np.int32), pi[:B], pi[B:2 * B], (rng.uniform(0, 1, B) ** 0.22).astype(np.float32),
+                          (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)))
+    z = torch.zeros_like
+
+    def fresh():
+        Ut, It = to(dev, U, I)
+        return Ut, It, [z(Ut), z(Ut), z(Ut), z(It), z(It), z(It)], ops.LazyAdamState(nU, nI, lr, dev), torch.zeros(3, device=dev)
+    Ua, Ia, sa, la, lossa = fresh()
+    for t in range(1, N + 1):
+        b = batches[t - 1]
+        ops.adam_lazy(0, la, Ua, sa[0], sa[1], sa[2], Ia, sa[3], sa[4], sa[5], *b[:3], t)
+        ops.bpr_step(Ua, Ia, *b, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sa[2], gI=sa[5], loss_acc=lossa)
+        ops.adam_lazy(1, la, Ua, sa[0], sa[1], sa[2], Ia, sa[3], sa[4], sa[5], *b[:3], t)
+    for graph in (False, True):
+        Ub, Ib, sb, lb, lossb = fresh()
+        t_dev = torch.tensor([1, 0], dtype=torch.int32, device=dev)
+        lb.rates(N + 8)
+
+        def step(i):
+            b = batches[i]
+            ops.adam_lazy_dev(0, lb, Ub, sb[0], sb[1], sb[2], Ib, sb[3], sb[4], sb[5], *b[:3], t_dev, i & 1, N + 8)
+            ops.bpr_step(Ub, Ib, *b, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sb[2], gI=sb[5], loss_acc=lossb)
+            ops.adam_lazy_dev(1, lb, Ub, sb[0], sb[1], sb[2], Ib, sb[3], sb[4], sb[5], *b[:3], t_dev, i & 1, N + 8)
+        if not graph:
+            for i in range(N):
+                step(i)
+        else:
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s):
+                with torch.cuda.graph(g):
+                    for i in range(N // 2):
+                        step(i)                              # eight steps per replay: the second replay must go on at step 9
+            torch.cuda.current_stream().wait_stream(s)
+            # (the capture itself launched nothing; the second half replays the same graph on the batches of the first: feed both halves the same batches)
+            g.replay()
+            torch.cuda.synchronize()
+            assert int(t_dev[0]) == N // 2 + 1
+            continue_ok = True
+            # compare after the first replay against the host-counter run truncated to eight steps
+            Uc, Ic, sc_, lc, lossc = fresh()
+            for t in range(1, N // 2 + 1):
+                b = batches[t - 1]
+                ops.adam_lazy(0, lc, Uc, sc_[0], sc_[1], sc_[2], Ic, sc_[3], sc_[4], sc_[5], *b[:3], t)
+                ops.bpr_step(Uc, Ic, *b, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sc_[2], gI=sc_[5], loss_acc=lossc)
+                ops.adam_lazy(1, lc, Uc, sc_[0], sc_[1], sc_[2], Ic, sc_[3], sc_[4], sc_[5], *b[:3], t)
+            assert torch.equal(Ub, Uc) and torch.equal(Ib, Ic) and torch.equal(lb.lastU, lc.lastU) and continue_ok
+            g.replay()                                        # steps 9 .. 16 of the optimiser on the batches 1 .. 8 again
+            torch.cuda.synchronize()
+            assert int(t_dev[0]) == N + 1 and int(lb.lastU.max()) == N
+            continue
+        assert int(t_dev[0]) == N + 1
+        assert torch.equal(Ub, Ua) and torch.equal(Ib, Ia)
+        for x, y in zip(sb, sa):
+            assert torch.equal(x, y)
+
+
 def test_lazy_adam_rows_matches_dense_on_touched_rows(dev):
     from pda_amd import ops
     rng = np.random.default_rng(29)
