@@ -692,7 +692,7 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
     out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
            "protocol": "3 warm-up blocks, median of the timed 2048-user blocks (up to 10, bounded by the budget)",
            "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d; C / OpenMP port of the path "
-                     "(oracle/pda_cpu_port.c: fused score + head + mask + heap top-K, AVX2 + FMA, 8 users x 4 items cache blocks) on "
+                     "(oracle/pda_cpu_port.c: fused score + head + mask + heap top-K, AVX2 + FMA, 32 users x 4 items cache blocks) on "
                      "%d host threads; NOT TensorFlow itself (TF 1.14 cannot be installed here)" % (n, W.n_items, W.d, cores)}
     if not full:
         return out

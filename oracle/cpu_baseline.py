@@ -107,7 +107,7 @@ def eval_block_blocked(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="con
 
 def eval_block_native(U, I, pop, users, coo_rows, coo_cols, K=50, rec_type="condition"):
     """The block through oracle/pda_cpu_port.c: the path as one would write it in C for host cores -- fused (no rating matrix),
-    AVX2 + FMA dot products on 8 users x 4 items cache blocks, the head bounded before the exponential, a K-entry heap per user,
+    AVX2 + FMA dot products on 32 users x 4 items cache blocks, the head bounded before the exponential, a K-entry heap per user,
     users over all OpenMP threads.  The fair native CPU figure beside the torch restatement of the TF op sequence."""
     import numpy as np
     from . import c_oracle
