@@ -357,7 +357,7 @@ __global__ void __launch_bounds__(512) plan_triplets_kernel(PlanStepArgs a) {
         red[1][wave] = sq;
     }
     __syncthreads();
-    if (tid == 0 && a.loss_acc) {
+    if (tid == 0 && (a.loss_acc || a.exact)) {
         float sm = 0.f, ss = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) {
@@ -367,58 +367,111 @@ __global__ void __launch_bounds__(512) plan_triplets_kernel(PlanStepArgs a) {
         float mf = -sm * a.inv_B;                   // -mean(maxi)          :114 / :704
         float rg = a.reg_c * 0.5f * ss;             // regs * l2 / batch    :117-120
         if (rejected) mf = rg = __int_as_float(0x7FC00000);
-        unsafeAtomicAdd(a.loss_acc + 0, mf + rg);
-        unsafeAtomicAdd(a.loss_acc + 1, mf);
-        unsafeAtomicAdd(a.loss_acc + 2, rg);
+        if (a.exact) {
+            // two plain stores per workgroup; launch B adds them up (64 workgroups x 3 float atomics on the same three words were
+            // a visible share of this latency-bound launch)
+            float* part = a.scratch + (size_t)a.B * (D + 2) + 2 * (size_t)blockIdx.x;
+            part[0] = mf;
+            part[1] = rg;
+        } else {
+            unsafeAtomicAdd(a.loss_acc + 0, mf + rg);
+            unsafeAtomicAdd(a.loss_acc + 1, mf);
+            unsafeAtomicAdd(a.loss_acc + 2, rg);
+        }
     }
 }
 
-// launch B: one segment (one distinct item row) per D/4 lanes
+// launch B: one segment (one distinct item row) per D/4 lanes.  The launch is a chain of dependent loads -- segment -> entries ->
+// coefficients and old user rows -> the row's store --, so every level is issued for ALL of a lane group's entries at once
+// (branch-free, clamped indices): three round trips for a segment of up to 8 entries, one more per 4 further entries and group.
 template <int D, bool BF>
-__global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a) {
-    constexpr int L = D / 4, G = 256 / L, SHORT = 8;
+__global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_parts) {
+    constexpr int L = D / 4, G = 256 / L, SHORT = 8, LONGU = 4;
     __shared__ __attribute__((aligned(16))) float s_part[G * D];
     __shared__ int s_long[G];
     __shared__ int s_nlong;
-    if (a.hdr[1] != 0) return;                        // rejected batch (uniform over the grid)
-    const int n_seg = a.hdr[0];
-    if ((int)blockIdx.x * G >= n_seg) return;
     const int tid = threadIdx.x, g = tid / L, e = tid % L;
     const int s = (int)blockIdx.x * G + g;
     const int B = a.B;
-    const float* coef = a.scratch + (size_t)B * D;
+    const float* __restrict__ coef = a.scratch + (size_t)B * D;
+    const float* __restrict__ rows_old = a.scratch;
+    const int* __restrict__ entries = a.entries;
+    // level 1: header, segment bounds (in-bounds for every s < 2B whatever they hold)
+    const int rejected = a.hdr[1], n_seg = a.hdr[0];
+    const int x_raw = a.seg_item[s], b0_raw = a.seg_start[s], b1_raw = a.seg_start[s + 1];
+    if (blockIdx.x == 0 && a.loss_acc != nullptr && tid < 64) {
+        // the loss of the batch: launch A left one (mf, reg) pair per workgroup
+        float mf = 0.f, rg = 0.f;
+        const float* part = a.scratch + (size_t)B * (D + 2);
+        for (int q = tid; q < n_parts; q += 64) {
+            mf += part[2 * q];
+            rg += part[2 * q + 1];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mf += __shfl_xor(mf, o, 64);
+            rg += __shfl_xor(rg, o, 64);
+        }
+        if (tid == 0) {           // (one writer per launch, launches of a stream in order: plain adds would do; atomics keep other streams safe)
+            unsafeAtomicAdd(a.loss_acc + 0, mf + rg);
+            unsafeAtomicAdd(a.loss_acc + 1, mf);
+            unsafeAtomicAdd(a.loss_acc + 2, rg);
+        }
+    }
+    if (rejected != 0) return;                        // rejected batch (uniform over the grid)
+    if ((int)blockIdx.x * G >= n_seg) return;
     if (tid == 0) s_nlong = 0;
     __syncthreads();
-    auto contribution = [&](int i) __attribute__((always_inline)) -> f32x4 {
-        const int en = a.entries[i];
-        const int t = en < B ? en : en - B;
-        const float2 co = *reinterpret_cast<const float2*>(coef + 2 * (size_t)t);
-        const float w = en < B ? co.x : -co.y;
-        const f32x4 ur = *reinterpret_cast<const f32x4*>(a.scratch + (size_t)t * D + 4 * e);
-        return ur * w;
-    };
     const bool have = s < n_seg;
-    int x = 0, b0 = 0, b1 = 0;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    if (have) {
-        x = a.seg_item[s];
-        b0 = a.seg_start[s];
-        b1 = a.seg_start[s + 1];
-        const int m = min(b1, b0 + SHORT);
-#pragma unroll 4
-        for (int i = b0; i < m; ++i) sum += contribution(i);
-        if (b1 - b0 > SHORT && e == 0) s_long[atomicAdd(&s_nlong, 1)] = g;
+    const int x = have ? x_raw : 0, b0 = have ? b0_raw : 0, b1 = have ? b1_raw : 0;
+    // level 2: the first SHORT entries and the row itself
+    int en[SHORT];
+#pragma unroll
+    for (int i = 0; i < SHORT; ++i) en[i] = entries[min(b0 + i, 2 * B - 1)];
+    const f32x4 row = pda_load4<BF>(a.Ifwd, (size_t)x * D + 4 * e);
+    f32x4 old = row;
+    if constexpr (BF) old = *reinterpret_cast<const f32x4*>(a.I + (size_t)x * D + 4 * e);
+    // level 3: their coefficients and old user rows
+    float w[SHORT];
+    f32x4 ur[SHORT];
+#pragma unroll
+    for (int i = 0; i < SHORT; ++i) {
+        const bool on = b0 + i < b1;
+        const int t = en[i] < B ? en[i] : en[i] - B;
+        const float2 co = *reinterpret_cast<const float2*>(coef + 2 * (size_t)t);
+        w[i] = on ? (en[i] < B ? co.x : -co.y) : 0.f;
+        ur[i] = *reinterpret_cast<const f32x4*>(rows_old + (size_t)t * D + 4 * e);
     }
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SHORT; ++i) sum += ur[i] * w[i];          // plan order: bit-reproducible
+    if (have && b1 - b0 > SHORT && e == 0) s_long[atomicAdd(&s_nlong, 1)] = g;
     __syncthreads();
     const int nl = s_nlong;
     for (int k = 0; k < nl; ++k) {
-        // a long segment: every lane group takes every G-th of its remaining entries; the owner adds the G partial sums in
-        // group order (which long segment comes first does not matter: each one's sum is formed the same way)
+        // a long segment: every lane group takes every G-th of its remaining entries, LONGU of them per round trip; the owner
+        // adds the G partial sums in group order (which long segment comes first does not matter: each sum is formed the same way)
         const int og = s_long[k];
         const int so = (int)blockIdx.x * G + og;
         const int ob0 = a.seg_start[so] + SHORT, ob1 = a.seg_start[so + 1];
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
-        for (int i = ob0 + g; i < ob1; i += G) part += contribution(i);
+        for (int i0 = ob0 + g; i0 < ob1; i0 += G * LONGU) {
+            int en2[LONGU];
+#pragma unroll
+            for (int q = 0; q < LONGU; ++q) en2[q] = entries[min(i0 + q * G, 2 * B - 1)];
+            float w2[LONGU];
+            f32x4 u2[LONGU];
+#pragma unroll
+            for (int q = 0; q < LONGU; ++q) {
+                const bool on = i0 + q * G < ob1;
+                const int t = en2[q] < B ? en2[q] : en2[q] - B;
+                const float2 co = *reinterpret_cast<const float2*>(coef + 2 * (size_t)t);
+                w2[q] = on ? (en2[q] < B ? co.x : -co.y) : 0.f;
+                u2[q] = *reinterpret_cast<const f32x4*>(rows_old + (size_t)t * D + 4 * e);
+            }
+#pragma unroll
+            for (int q = 0; q < LONGU; ++q) part += u2[q] * w2[q];
+        }
         *reinterpret_cast<f32x4*>(s_part + g * D + 4 * e) = part;
         __syncthreads();
         if (g == og) {
@@ -427,9 +480,6 @@ __global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a) {
         __syncthreads();
     }
     if (have) {
-        const f32x4 row = pda_load4<BF>(a.Ifwd, (size_t)x * D + 4 * e);
-        f32x4 old = row;
-        if constexpr (BF) old = *reinterpret_cast<const f32x4*>(a.I + (size_t)x * D + 4 * e);
         const float cc = a.reg_c * (float)(b1 - b0);
         const f32x4 nw = old - (sum + row * cc) * a.lr;
         *reinterpret_cast<f32x4*>(a.I + (size_t)x * D + 4 * e) = nw;
@@ -440,10 +490,13 @@ __global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a) {
 template <int D, bool BF>
 int launch_plan_step(const PlanStepArgs& a, hipStream_t s) {
     constexpr int TPB = 512 / (D / 4), G = 256 / (D / 4);
-    hipLaunchKernelGGL((plan_triplets_kernel<D, BF>), dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
+#ifndef PDA_PLAN_ONLY
+#define PDA_PLAN_ONLY 0       // timing experiments: 1 = launch A only, 2 = launch B only (results are wrong)
+#endif
+    if (PDA_PLAN_ONLY != 2) hipLaunchKernelGGL((plan_triplets_kernel<D, BF>), dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
     PDA_CHECK_LAUNCH();
-    if (a.exact) {
-        hipLaunchKernelGGL((plan_items_kernel<D, BF>), dim3((unsigned)((2 * a.B + G - 1) / G)), dim3(256), 0, s, a);
+    if (a.exact && PDA_PLAN_ONLY != 1) {
+        hipLaunchKernelGGL((plan_items_kernel<D, BF>), dim3((unsigned)((2 * a.B + G - 1) / G)), dim3(256), 0, s, a, (a.B + TPB - 1) / TPB);
         PDA_CHECK_LAUNCH();
     }
     return PDA_OK;
@@ -471,7 +524,10 @@ int run_plan_step(float* U, float* I, const void* Ufwd, const void* Ifwd, uint16
 }  // namespace
 
 extern "C" size_t pda_triplet_plan_bytes(int B) { return B > 0 ? plan_bytes(B) : 0; }
-extern "C" size_t pda_bpr_step_plan_scratch_bytes(int B, int d) { return (B > 0 && d > 0) ? (size_t)B * (size_t)(d + 2) * 4 : 0; }
+// old user rows [B][d], coefficients [B][2], one (mf, reg) pair per workgroup of launch A (at most B / 8 + 1 of them: d = 256)
+extern "C" size_t pda_bpr_step_plan_scratch_bytes(int B, int d) {
+    return (B > 0 && d > 0) ? ((size_t)B * (size_t)(d + 2) + 2 * ((size_t)B / 8 + 8)) * 4 : 0;
+}
 
 extern "C" int pda_triplet_plan(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int n_batches, void* plans, void* stream) {
     if (!users || !pos || !neg || !plans || B <= 0 || n_batches <= 0) return PDA_ERR_ARG;
