@@ -711,16 +711,24 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // any skew between the eight MFMA waves turns into waiting -- 22 % of their time in the dense sweep (cycle counters of the
 // profiling build).  Candidate-heavy sweeps (natural order, raw head: hundreds of list insertions per user) keep their lists in
 // the LDS: every insertion would be a round trip to L2.  The caller says which (pda_score_topk4_*: early_stop bit 1).
-template <int D, bool GLX = false>
+// GM = 2 (d <= 128; round 3), the WIDE geometry: 64 user rows per MFMA wave (two A operands per B read), 512 users per workgroup,
+// lists in the workspace, four tile slots, 8 MFMA + 2 loader + 2 rescoring waves at <= 168 VGPRs.  Half the LDS reads AND half the
+// tile traffic per MFMA: on a power-limited chip that is clock (tools/ubench/mfma_struct D: 1 494 - 1 520 TFLOP/s executed against
+// 1 335 for the 256-user mapping, random data).  Only for large user blocks with few candidates (the caller's hint): 512-user
+// workgroups leave half the chip idle below 131 072 users, and every list insertion is a round trip to L2.
+template <int D, int GM = 0>
 struct Geo4 {
-    static constexpr int UA = D <= 128 ? PDA_V4_UA : 1;  // A operands per B read: 32 UA user rows per MFMA wave
+    static constexpr bool WIDE = D <= 128 && GM == 2;
+    static constexpr int UA = D <= 128 ? (WIDE ? 2 : PDA_V4_UA) : 1;  // A operands per B read: 32 UA user rows per MFMA wave
     // the exact lists in HBM (workspace) free the LDS for four tile slots (d = 256: 8.1 instead of 9.0 ms on a config-5 shard);
     // 512 users x 57 x 8 B would not fit the LDS anyway
-    static constexpr bool GL = (PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0) || GLX;
+    static constexpr bool GL = (PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0) || GM >= 1;
 #ifdef PDA_V4_NBX   /* timing experiment only (results are wrong): NBX half-tiles per block at d <= 128 */
     static constexpr int NB = D <= 128 ? PDA_V4_NBX : 1;
 #else
     static constexpr int NB = (D <= 128 && UA == 1) ? 2 : 1;          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
+    // (wide: 64 rows x 64 items per block would hold 64 + 64 registers of A operands and accumulators -- the block statement and what
+    // lives across it do not fit 168 VGPRs: hipcc spilled the accumulators behind every block; 64 rows x 32 items do)
 #endif
     static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : 2;
     static constexpr int RESCORERS = (D <= 128 && UA == 1) ? 4 : 2;
@@ -743,9 +751,9 @@ struct Geo4 {
 
 // ES: exact early termination on (sufA / sufB non-NULL).  Two instantiations: the votes and the dead-wave path are a handful of
 // instructions, but their presence in the loop cost the DENSE sweep 6 % at d = 256 (register allocation of the prefetched loop).
-template <int D, int HEAD, bool BF, bool ES, bool GLX = false>
-__global__ void __launch_bounds__((64 * Geo4<D, GLX>::WAVES)) sweep4_kernel(Args4 g) {
-    using G = Geo4<D, GLX>;
+template <int D, int HEAD, bool BF, bool ES, int GM = 0>
+__global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4 g) {
+    using G = Geo4<D, GM>;
     constexpr int kLoaders = G::LOADERS, kMPR = G::MPR;
     constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP, UA = G::UA, NSLOT = G::NSLOT;
     constexpr bool GL = G::GL;
@@ -1238,7 +1246,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GLX>::WAVES)) sweep4_kernel(Args
         sb_nx = g.sufB[tn];
     }
     constexpr int S = NB * NM, PF = S < PDA_V4_PF ? S : PDA_V4_PF;
-    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && D <= 128 && UA == 1 && NB == 2;     // the block as one asm statement (below)
+    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && D <= 128 && ((UA == 1 && NB == 2) || (UA == 2 && NB == 1 && G::WIDE));     // the block as one asm statement (below)
     constexpr bool PFX = !kAsmGeo && NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
     u32x4 bq[PF];
     int dead_from = 0x7FFFFFFF;                // first tile from which no row of this wave can be reached (early termination)
@@ -1314,13 +1322,20 @@ __global__ void __launch_bounds__((64 * Geo4<D, GLX>::WAVES)) sweep4_kernel(Args
         bool asm_done = false;
         if constexpr (kAsmBlock) {
             if (HEAD == PDA_HEAD_POP || !raw_on_pop_prep) {
-                u32x4 piq;
                 const unsigned a0 = lane_base_lds + (unsigned)((b % NSLOT) * BB);
-                BlockAsm<D>::run(acc[0][0], acc[0][1], piq, ah[0], aex[0], a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
-                popv[0] = __uint_as_float(piq[0]);
-                locv[0] = (int)piq[1];
-                popv[1] = __uint_as_float(piq[2]);
-                locv[1] = (int)piq[3];
+                if constexpr (UA == 1) {
+                    u32x4 piq;
+                    BlockAsm<D>::run(acc[0][0], acc[0][1], piq, ah[0], aex[0], a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
+                    popv[0] = __uint_as_float(piq[0]);
+                    locv[0] = (int)piq[1];
+                    popv[NB - 1] = __uint_as_float(piq[2]);
+                    locv[NB - 1] = (int)piq[3];
+                } else {
+                    u32x2 pid;
+                    BlockAsm2<D>::run(acc[0][0], acc[UA - 1][0], pid, ah, aex, a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
+                    popv[0] = __uint_as_float(pid[0]);
+                    locv[0] = (int)pid[1];
+                }
                 asm_done = true;
                 if (asked) {                      // the hand-over words were read in front of the block: an LDS round trip hidden
                     unsigned mn = 0xFFFFFFFFu;
@@ -1603,14 +1618,14 @@ __global__ void __launch_bounds__(1024) stop_scatter4_kernel(const int* __restri
         if (b[i] >= 0) perm[sh[b[i]] + r[i]] = (int)blockIdx.x * 4096 + i * 1024 + t;
 }
 
-template <int D, int HEAD, bool BF, bool GLX>
+template <int D, int HEAD, bool BF, int GM>
 int launch_sweep4(const Args4& g, hipStream_t stream) {
-    using G = Geo4<D, GLX>;
+    using G = Geo4<D, GM>;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false, GLX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false, GM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G::lds_total) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true, GLX>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true, GM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G::lds_total) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
@@ -1629,17 +1644,17 @@ int launch_sweep4(const Args4& g, hipStream_t stream) {
         hipLaunchKernelGGL(stop_scatter4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, bins, g.n_users_blk, perm);
         PDA_CHECK_LAUNCH();
         gp.row_perm = perm;
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GLX>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
     } else if (g.sufA != nullptr)
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GLX>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
     else
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false, GLX>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
 
 template <int D, int HEAD, bool BF>
-int launch4(const Args4& g, int phase, hipStream_t stream, bool lists_in_hbm) {      // phase: 1 = warm-up only, 2 = sweep only, 3 = both
+int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      // phase: 1 = warm-up only, 2 = sweep only, 3 = both
     if (phase & 1) {
         constexpr int CAP = kCap4;
         const size_t smem = 32 * D * 4 + (size_t)kUserTile * (CAP * 8 + 8) + kUserTile * 2 * kWarmTiles * 4 + 256 + kUserTile * 8;
@@ -1656,10 +1671,12 @@ int launch4(const Args4& g, int phase, hipStream_t stream, bool lists_in_hbm) { 
     }
     if ((g.n_tiles + g.n_splits - 1) / g.n_splits <= g.warm_tiles) return PDA_OK;      // every split ends inside its warm-up
     if (phase & 2) {
-        if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
-            if (lists_in_hbm) return launch_sweep4<D, HEAD, BF, true>(g, stream);
+        // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
+        if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
+            if (geometry == 2) return launch_sweep4<D, HEAD, BF, 2>(g, stream);
+            if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
         }
-        return launch_sweep4<D, HEAD, BF, false>(g, stream);
+        return launch_sweep4<D, HEAD, BF, 0>(g, stream);
     }
     return PDA_OK;
 }
@@ -1679,7 +1696,7 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     w.lists = al(pda_score_topk_workspace_bytes(n_users_blk));
     size_t b = w.lists;
     if (lists_in_hbm4(d)) {
-        const size_t ut = (size_t)user_tile4(d);
+        const size_t ut = 512;          // (the widest user tile of any geometry)
         b += ((size_t)n_users_blk + ut - 1) / ut * (size_t)n_splits * ut * kCap4 * 8 + 256;
     }
     w.bloom = al(b);
@@ -1701,8 +1718,9 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
-    if (early_stop < 0 || (early_stop & ~0x73) != 0) return PDA_ERR_ARG;
-    const bool lists_in_hbm = (early_stop & PDA_SWEEP_FEW_CANDIDATES) != 0;       // geometry hint (Geo4<D, true>): results do not depend on it
+    if (early_stop < 0 || (early_stop & ~0x77) != 0) return PDA_ERR_ARG;
+    // geometry hints (Geo4<D, 1 | 2>): results do not depend on them.  The wide geometry needs one item split and whole waves of work
+    int geometry = (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
@@ -1763,7 +1781,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
         g.sufA = early_stop ? reinterpret_cast<const float*>(pb + L.sufA) : nullptr;     // all zero for a raw prep
         g.sufB = early_stop ? reinterpret_cast<const float*>(pb + L.sufR) : nullptr;
     }
-#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, phase, s, lists_in_hbm) : launch4<DD, PDA_HEAD_RAW, BFV>(g, phase, s, lists_in_hbm))
+#define PDA_V4_(DD, BFV) (head == PDA_HEAD_POP ? launch4<DD, PDA_HEAD_POP, BFV>(g, phase, s, geometry) : launch4<DD, PDA_HEAD_RAW, BFV>(g, phase, s, geometry))
     switch (d) {
         case 64: return bf16 ? PDA_V4_(64, true) : PDA_V4_(64, false);
         case 128: return bf16 ? PDA_V4_(128, true) : PDA_V4_(128, false);

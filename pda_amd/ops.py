@@ -205,13 +205,18 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
     return "v4"
 
 
-def few_candidates_hint(head: int, prune) -> int:
+WIDE_MIN_USERS = 131072      # below that, 512-user workgroups leave CUs idle
+
+
+def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:
     """PDA_SWEEP_FEW_CANDIDATES for pda_score_topk4_*: the popularity head swept in visiting order meets next to no candidates
     behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
     four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
     forced = os.environ.get("PDA_SCORE_LISTS", "")
-    if forced in ("lds", "hbm"):
-        return 2 if forced == "hbm" else 0
+    if forced in ("lds", "hbm", "wide"):
+        return {"lds": 0, "hbm": 2, "wide": 4}[forced]
+    if head == HEAD_POP and prune == "order" and n_users >= WIDE_MIN_USERS and d in (64, 128):
+        return 4            # PDA_SWEEP_WIDE: the dense sweep of a large user block (512-user workgroups, half the LDS and tile traffic per MFMA)
     # Measured (round 3, config 3, 262 144 users, same box): dense sweep 12.58 vs 12.71 ms with the lists in the workspace (four
     # tile slots), early-terminating sweep 1.18 vs 1.04 ms, C1 / C2 0.28 vs 0.25 ms: the hand-over of the warm-up lists and the
     # final sort go through L2 instead of the LDS.  Not worth it: off unless forced.
@@ -358,7 +363,7 @@ def seeded_begin(U, I_shard, users, K, head, pop_shard, hist, item_offset=0, n_s
     c.fnp = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32
     c.common = (ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                 ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head,
-                1 | few_candidates_hint(head, True), n_splits)
+                1 | few_candidates_hint(head, True, nu, d), n_splits)
     c.keep = (U, I_shard, prep, pop_shard, users, hist)          # the pointers above stay valid until seeded_finish
     # R shards warm up R x 64 warm_tiles items between them: two tiles each on 2 shards, one from 4 shards on
     c.wt = int(os.environ.get("PDA_WARM_TILES", "0")) or max(1, 4 // max(1, seed_shards))
@@ -458,7 +463,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
-        es = (1 if prune is True else 0) | few_candidates_hint(head, prune) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
+        es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
         fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
         check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop", "k4hbm"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop", "k4hbm", "k4wide"])
 def impl(request, monkeypatch):
     """Every test runs against all scoring paths: v1 = exact fp32 MFMA; v2 / v2ord / v2order_only = the pre-filtered path
     (bf16 MFMA filter + exact rescoring) in natural order / visiting order with early termination / visiting order without
@@ -28,9 +28,10 @@ def impl(request, monkeypatch):
     # k4*: the generation-4 kernel (pda_score_topk_v4.hip) in its three sweep modes; the older generations are pinned to v3
     # (v2 where the library picks it) so that they stay covered now that v4 is the default
     monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order", "k3": "1", "k4ord": "order",
-                                           "k4stop": "1", "k4hbm": "1"}.get(request.param, "0"))
-    # k4hbm: generation 4 with its exact lists in the workspace and four tile slots at d <= 128 (PDA_SWEEP_FEW_CANDIDATES)
-    monkeypatch.setenv("PDA_SCORE_LISTS", "hbm" if request.param == "k4hbm" else "lds")
+                                           "k4stop": "1", "k4hbm": "1", "k4wide": "order"}.get(request.param, "0"))
+    # k4hbm: generation 4 with its exact lists in the workspace and four tile slots at d <= 128 (PDA_SWEEP_FEW_CANDIDATES);
+    # k4wide: the wide geometry (PDA_SWEEP_WIDE: 512 users per workgroup, 64 user rows per MFMA wave), dense in visiting order
+    monkeypatch.setenv("PDA_SCORE_LISTS", {"k4hbm": "hbm", "k4wide": "wide"}.get(request.param, "lds"))
     if request.param == "k3":
         monkeypatch.setenv("PDA_SCORE_KERNEL", "v3")
     elif request.param.startswith("k4"):
@@ -658,12 +659,14 @@ def test_full_size_c3_sweep_modes_agree(dev, impl):
         k262 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
         assert torch.equal(k262[:131072], ref), prune
         assert_lists_match_oracle(k262, *oracle[1], head=1)
-    os.environ["PDA_SCORE_LISTS"] = "hbm"            # the same block with the lists in the workspace (four tile slots)
-    try:
-        k262h = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune="order"), want="keys")
-    finally:
-        os.environ["PDA_SCORE_LISTS"] = "lds"
-    assert torch.equal(k262h, k262)
+    for geo, prunes in (("hbm", ("order",)), ("wide", ("order", True))):     # the other geometries on the same block: identical keys
+        os.environ["PDA_SCORE_LISTS"] = geo
+        try:
+            for prune in prunes:
+                kg = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
+                assert torch.equal(kg, k262), (geo, prune)
+        finally:
+            os.environ["PDA_SCORE_LISTS"] = "lds"
     raw = {}
     for prune in (None, False):                   # raw head: the product default (visiting order by norm) and natural order
         raw[prune] = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_RAW, None, hist, prune=prune), want="keys")

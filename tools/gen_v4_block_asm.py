@@ -11,9 +11,10 @@ pipeline, once the two accumulator chains one after the other with the reads one
 """
 
 F_DEFAULT = 6
+F_WIDE = 6
 
 
-def block(D, F):
+def block(D, F, UA=1):
     NM = D // 16
     RB = 2 * D + 48
     HB = 32 * RB
@@ -37,9 +38,11 @@ def block(D, F):
         issued = min(s + F, n_loads)
         lines.append("s_waitcnt lgkmcnt(%d)" % (issued - (s + 1)))
         m, cb = (s // 2, s % 2) if s < S else (NM, s - S)
-        a = "%%[a%d]" % m if s < S else "%[aex]"
-        c = "0" if m == 0 else "%%[acc%d]" % cb
-        lines.append("v_mfma_f32_32x32x16_bf16 %%[acc%d], %s, %%[t%d], %s" % (cb, a, s % F, c))
+        for u in range(UA):
+            sfx = "" if UA == 1 else "_%d" % u
+            a = ("%%[a%d%s]" % (m, sfx)) if s < S else ("%%[aex%s]" % sfx)
+            acc = "%%[acc%d%s]" % (cb, sfx)
+            lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %%[t%d], %s" % (acc, a, s % F, "0" if m == 0 else acc))
         if s + F < n_loads:
             issue(s + F)
     lines.append("s_waitcnt lgkmcnt(0)")
@@ -74,6 +77,64 @@ def emit(D, F):
     return "\n".join(out)
 
 
+def block_wide(D, F):
+    """one 32-item half-tile, TWO A operands (64 user rows) per B read: 2 NM + 2 MFMAs on two chains, NM + 2 LDS reads"""
+    NM = D // 16
+    loads = [("frag", 32 * m) for m in range(NM)] + [("frag", 2 * D)] + [("pi", 0)]
+    n_steps = NM + 1
+    n_loads = len(loads)
+    lines = []
+
+    def issue(i):
+        kind, off = loads[i]
+        if kind == "frag":
+            lines.append("ds_read_b128 %%[t%d], %%[addr] offset:%d" % (i % F, off))
+        else:
+            lines.append("ds_read_b64 %[pi], %[addrpi]")
+
+    for i in range(min(F, n_loads)):
+        issue(i)
+    for s in range(n_steps):
+        issued = min(s + F, n_loads)
+        lines.append("s_waitcnt lgkmcnt(%d)" % (issued - (s + 1)))
+        for u in range(2):
+            a = ("%%[a%d_%d]" % (s, u)) if s < NM else ("%%[aex_%d]" % u)
+            lines.append("v_mfma_f32_32x32x16_bf16 %%[acc%d], %s, %%[t%d], %s" % (u, a, s % F, "0" if s == 0 else "%%[acc%d]" % u))
+        if s + F < n_loads:
+            issue(s + F)
+    lines.append("s_waitcnt lgkmcnt(0)")
+    lines.append("s_nop 15")
+    lines.append("s_nop 3")
+    return NM, lines
+
+
+def emit2(D, F):
+    """the wide geometry (512 users per workgroup)"""
+    NM, lines = block_wide(D, F)
+    out = []
+    out.append("template <>")
+    out.append("struct BlockAsm2<%d> {" % D)
+    out.append("    static constexpr int kFragmentsInFlight = %d;" % F)
+    out.append("    // one 32-item half-tile against 64 user rows: acc0 / acc1 = the two row sets; every B fragment feeds two MFMAs; pi = (pop, id)")
+    out.append("    static __device__ __forceinline__ void run(f32x16& acc0, f32x16& acc1, u32x2& pi, const u32x4 (&ah)[2][%d], const u32x4 (&aex)[2], unsigned addr," % NM)
+    out.append("                                               unsigned addr_pi) {")
+    out.append("#if defined(__HIP_DEVICE_COMPILE__)")
+    out.append("        u32x4 " + ", ".join("t%d" % i for i in range(F)) + ";")
+    out.append("        asm volatile(")
+    for l in lines:
+        out.append('            "%s\\n\\t"' % l)
+    outs = ['[acc0] "=&v"(acc0)', '[acc1] "=&v"(acc1)', '[pi] "=&v"(pi)'] + ['[t%d] "=&v"(t%d)' % (i, i) for i in range(F)]
+    ins = ['[a%d_%d] "v"(ah[%d][%d])' % (m, u, u, m) for u in range(2) for m in range(NM)] + ['[aex_%d] "v"(aex[%d])' % (u, u) for u in range(2)] + \
+          ['[addr] "v"(addr)', '[addrpi] "v"(addr_pi)']
+    out.append("            : " + ", ".join(outs))
+    out.append("            : " + ", ".join(ins))
+    out.append('            : "memory");')
+    out.append("#endif")
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
 def main():
     print("// GENERATED by tools/gen_v4_block_asm.py -- do not edit.  One 64-item block of sweep4_kernel: %d fragments in flight." % F_DEFAULT)
     print("// acc0 / acc1: the two half-tiles' accumulators (the folded test included); pi = (pop, id) of half-tile 0 in .xy, of half-tile 1 in .zw.")
@@ -82,6 +143,11 @@ def main():
     print("struct BlockAsm;")
     for D in (64, 128):
         print(emit(D, F_DEFAULT))
+    print("typedef unsigned u32x2 __attribute__((ext_vector_type(2)));")
+    print("template <int D>")
+    print("struct BlockAsm2;")
+    for D in (64, 128):
+        print(emit2(D, F_WIDE))
 
 
 if __name__ == "__main__":

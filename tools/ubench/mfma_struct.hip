@@ -4,6 +4,7 @@
 // streaming tiles into two LDS slots beside the MFMA waves (no hand-over: the data is garbage, the traffic is real).
 //   A  the kernel as it is: 2 MFMA waves per SIMD x 32 user rows (UA = 1): 18 MFMAs per block and wave, then a VALU read of the
 //      block's own accumulators (the filter); 4 loader waves; 16 waves per workgroup
+//   D  2 MFMA waves per SIMD x 64 user rows: 512 users per workgroup -- half the LDS reads AND half the tile traffic per MFMA (168 VGPRs)
 //   B  1 MFMA wave per SIMD x 64 user rows (UA = 2): 36 MFMAs per block on four chains, ONE B read per two MFMAs, the filter runs
 //      on the PREVIOUS block's accumulators (double-buffered) so that it never waits for the pipe; 2 or 4 loader waves
 // build: python tools/ubench/gen_blk.py 6 > tools/ubench/blk.h && hipcc --offload-arch=gfx950 -O3 -o tools/ubench/mfma_struct tools/ubench/mfma_struct.hip
@@ -160,5 +161,7 @@ int main() {
     run<2, 4, 4, 0, true>(rows, n_bytes, d, "B' the same with 4 loaders, no idle waves");
     run<2, 4, 2, 2, false>(rows, n_bytes, d, "B0 1 MFMA wave/SIMD x 64 rows, own-block filter (stalls), 2 loaders, 2 idle");
     run<1, 4, 2, 2, false>(rows, n_bytes, d, "C  1 MFMA wave/SIMD x 32 rows, own-block filter");
+    run<2, 8, 2, 2, false>(rows, n_bytes, d, "D  2 MFMA waves/SIMD x 64 rows (512 users per workgroup), own-block filter, 2 loaders, 2 idle");
+    run<2, 8, 4, 0, false>(rows, n_bytes, d, "D' the same with 4 loaders, no idle waves");
     return 0;
 }
