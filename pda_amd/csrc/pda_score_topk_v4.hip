@@ -49,7 +49,7 @@ constexpr int kMainWaves = 8;
 #endif
 #ifdef PDA_V4_PROF
 // profiling build only (tools/build_variant.sh prof -DPDA_V4_PROF): cycle counters summed over waves
-__device__ unsigned long long pda_prof4[16];
+__device__ unsigned long long pda_prof4[24];
 #define PROF_T0(v) const long long v = __builtin_readcyclecounter()
 #define PROF_T1(v, slot) prof[slot] += (unsigned long long)(__builtin_readcyclecounter() - v)
 #define PROF_INC(slot, x) prof[slot] += (unsigned long long)(x)
@@ -312,7 +312,7 @@ __device__ __forceinline__ int split_tiles(int n_tiles, int split, int n_splits)
 // when a threshold may have changed.
 template <int CAP, bool GLB = false>
 __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t key, uint64_t* lists, int* cntl, float* taul, int row0,
-                                            int n_rows, int K, int lane, unsigned* uns = nullptr) {
+                                            int n_rows, int K, int lane, unsigned* uns = nullptr, [[maybe_unused]] unsigned long long* prof = nullptr) {
     bool changed = false;
     for (;;) {
         bool ov = false;
@@ -321,19 +321,39 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
             if (slot < CAP) lists[(size_t)lrow * CAP + slot] = key;
             else ov = true;
         }
-        if (!__any(ov)) break;
+        uint64_t todo = __ballot(ov);
+        if (todo == 0ull) break;
         list_sync<GLB>();
-        for (int base = 0; base < n_rows; base += 64) {
-            uint64_t full = __ballot(base + lane < n_rows && cntl[row0 + (base + lane < n_rows ? base + lane : 0)] >= CAP);
-            while (full) {
-                const int rr = base + __builtin_ctzll(full);
-                full &= full - 1ull;
-                compact_list<CAP, GLB>(lists + (size_t)(row0 + rr) * CAP, &cntl[row0 + rr], &taul[row0 + rr], K, lane,
-                                       uns ? &uns[(row0 + rr) >> 5] : nullptr, 1u << ((row0 + rr) & 31));
+        // the rows that overflowed are the rows of the lanes that say so (a row sits at CAP untouched until an append fails): no
+        // scan over the wave's counters -- two LDS round trips per event on the rescoring path
+        bool again = false;
+        while (todo) {
+            const int rr = __builtin_amdgcn_readlane(lrow, __builtin_ctzll(todo));
+            const uint64_t mine_m = __ballot(ov && lrow == rr);
+            todo &= ~mine_m;
+#ifdef PDA_V4_PROF
+            const long long tc0 = __builtin_readcyclecounter();
+#endif
+            const float tau = compact_list<CAP, GLB>(lists + (size_t)rr * CAP, &cntl[rr], &taul[rr], K, lane, uns ? &uns[rr >> 5] : nullptr, 1u << (rr & 31));
+#ifdef PDA_V4_PROF
+            if (prof) { prof[22] += (unsigned long long)(__builtin_readcyclecounter() - tc0); prof[23] += 1; }
+#endif
+            // the row holds K keys now and its threshold is known: the lanes that failed on it take the slots behind them directly
+            // (an atomic and a threshold read per retry were two more round trips per event)
+            const bool mine = ((mine_m >> lane) & 1ull) != 0ull;
+            const bool keep = mine && tt >= tau;
+            const uint64_t km = __ballot(keep);
+            if (km != 0ull) {
+                const int before = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0));
+                const int nk = __popcll(km);
+                if (keep && K + before < CAP) lists[(size_t)rr * CAP + K + before] = key;
+                if (keep && K + before >= CAP) again = true;            // (more than CAP - K keys for one row in one pass)
+                if (lane == 0) cntl[rr] = min(K + nk, CAP);
             }
         }
+        list_sync<GLB>();
         changed = true;
-        p = ov && (tt >= taul[lrow]);
+        p = again;
     }
     return changed;
 }
@@ -702,6 +722,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_GL
 #define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
 #endif
+#ifndef PDA_V4_RESCORE_AHEAD
+#define PDA_V4_RESCORE_AHEAD 1   // rescoring waves request the rows of the next pass before the appends of this one
+#endif
 #ifndef PDA_V4_NSLOT
 #define PDA_V4_NSLOT 4    // tile slots in LDS when the lists live in HBM (<= 5: the vote words of the early termination)
 #endif
@@ -831,7 +854,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         if constexpr (GL) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     }
 #ifdef PDA_V4_PROF
-    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long prof[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     PDA_STAMP(st1);
 
@@ -842,11 +865,11 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         const int row0 = r * RR;
         uint64_t* my_lists = lists + (size_t)row0 * kCap4;
         constexpr int NRL = (RR + 63) / 64;                  // rows per lane
-        int uidv[NRL];
+        int uidv[NRL], rblv[NRL];                            // user id and place in the caller's block (-1: padding) of the lane's rows
         float seedv[NRL];
         long long hbv[NRL], hev[NRL];
 #pragma unroll
-        for (int s2 = 0; s2 < NRL; ++s2) { uidv[s2] = 0; seedv[s2] = -INFINITY; hbv[s2] = 0; hev[s2] = 0; }
+        for (int s2 = 0; s2 < NRL; ++s2) { uidv[s2] = 0; rblv[s2] = -1; seedv[s2] = -INFINITY; hbv[s2] = 0; hev[s2] = 0; }
         // row `row` of this wave: entry row / 64 of lane row % 64
         auto row_i = [&](const int (&a)[NRL], int row) __attribute__((always_inline)) -> int {
             int v = __shfl(a[0], row & 63, 64);
@@ -875,6 +898,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             const bool ok = rl < RR && rb_s < g.n_users_blk;
             const int rb_l = ok ? orig_row(rb_s) : 0;
             uidv[s2] = ok ? g.users[rb_l] : 0;
+            rblv[s2] = ok ? rb_l : -1;
             if (g.seed != nullptr && ok) seedv[s2] = g.seed[rb_l];
             if (hist_on && ok) {
                 const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uidv[s2] : (int64_t)rb_l;
@@ -894,78 +918,150 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         int next_sort = 0;                          // rows [0, next_sort) have been sorted in idle time
         unsigned idle = 0;
         PROF_T0(tr0);
-        for (;;) {
-            if constexpr ((PDA_V4_ABL & 8) != 0) break;
-            unsigned dn = 1u, tl[kMPR];
+        // One pass = up to CPP candidates of ONE ring: their user and item rows are loaded (a round trip to L2 / HBM), the exact dot
+        // products taken, the survivors checked against the history and appended to their lists.  The rows of pass p + 1 are
+        // requested between the dot products and the appends of pass p -- the row registers are dead by then.  Cycle counters on
+        // the raw head (C3, ~330 candidates per user, the rescoring waves 98 % busy): of a pass's 8 000 cycles 3 400 were the wait
+        // for its rows, 4 300 the history check and the appends.
+        f32x4 uu[8], ii[8];
+        bool have = false;                          // a pass is in flight: its words read, its rows requested
+        int f_ring = 0;                             // (per lane: the ring its candidate came from)
+        unsigned f_word = 0u, f_bh1 = 0u, f_bh2 = 0u, f_taken = 0u;
+        uint32_t f_bw1 = 0xFFFFFFFFu, f_bw2 = 0xFFFFFFFFu;
+        float f_pv = 1.0f;
+        // A pass is filled from ALL rings of the wave (served one ring at a time, passes carried 10.8 of 16 candidates on the raw
+        // head, and a pass costs the same round trips whatever it carries).  What a pass costs IS its LDS round trips -- ~450 cycles
+        // each beside eight MFMA waves streaming B fragments, ten of them per pass -- so the ring words are read WITH the tails:
+        // the rings of a wave share the pass's slots in pairs, one ring filling its group of GS slots from the bottom, the other
+        // from the top, and every lane knows where its word would be before it knows whether there is one.  The row's threshold
+        // and seed come with the user id (one more round trip); the threshold may be one pass old -- a candidate let in against
+        // an old threshold is dropped by the next compaction of its row.
+        constexpr int NG = kMPR >= 2 ? kMPR / 2 : 1, GS = CPP / NG;
+        static_assert(kMPR == 1 || kMPR % 2 == 0, "rings share the slots of a pass in pairs");
+        bool f_valid = false;
+        float f_tau = -INFINITY, f_sd = -INFINITY;
+        auto fetch = [&](unsigned* dn_out) __attribute__((always_inline)) -> bool {
+            const int gi = ci / GS, li = ci % GS;
+            const int yA = kMPR >= 2 ? 2 * gi : 0, yB = kMPR >= 2 ? 2 * gi + 1 : 0;
+            unsigned hA = 0, hB = 0;
 #pragma unroll
-            for (int z = 0; z < kMPR; ++z) dn &= lds_ld(&s_done[kMPR * r + z]);                 // read BEFORE the tails
+            for (int y = 0; y < kMPR; ++y) { hA = yA == y ? head[y] : hA; hB = yB == y ? head[y] : hB; }
+            unsigned tl[kMPR];
+            if (dn_out != nullptr) {
+                unsigned dn = 1u;
+#pragma unroll
+                for (int z = 0; z < kMPR; ++z) dn &= lds_ld(&s_done[kMPR * r + z]);                 // read BEFORE the tails
+                *dn_out = dn;
+            }
 #pragma unroll
             for (int z = 0; z < kMPR; ++z) tl[z] = lds_ld(&s_tail[kMPR * r + z]);
-            // the next non-empty ring behind the one looked at last time
-            int pick = -1;
-            unsigned tail = 0, hd = 0;
+            PDA_CBAR();                                                                            // (the words BEHIND the tails)
+            const unsigned wA = rings[(kMPR * r + yA) * kRing4 + (hA + (unsigned)li) % kRing4];
+            const unsigned wB = kMPR >= 2 ? rings[(kMPR * r + yB) * kRing4 + (hB + (unsigned)(GS - 1 - li)) % kRing4] : 0u;
+            unsigned take[kMPR], taken = 0u, total = 0u;
+            if constexpr (kMPR == 1) {
+                take[0] = (unsigned)min((int)(tl[0] - head[0]), CPP);
+            } else {
 #pragma unroll
-            for (int z = kMPR; z >= 1; --z) {
-                const int cand = (sel + z) % kMPR;
-                unsigned tz = 0, hz = 0;
-#pragma unroll
-                for (int y = 0; y < kMPR; ++y) { tz = cand == y ? tl[y] : tz; hz = cand == y ? head[y] : hz; }
-                if (tz != hz) { pick = cand; tail = tz; hd = hz; }
-            }
-            if (pick < 0) {
-                if (dn) break;
-                if (next_sort < RR) {
-                    // nothing to rescore: put one more of the lists that came in unsorted in order (it has to be sorted for the
-                    // output anyway; done here it costs nothing, done behind the sweep it is a serial tail of the launch)
-                    const int rr = next_sort++;
-                    compact_list<kCap4, GL>(my_lists + (size_t)rr * kCap4, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5],
-                                            1u << ((row0 + rr) & 31));
-                    continue;
+                for (int gq = 0; gq < NG; ++gq) {
+                    const int avA = (int)(tl[2 * gq] - head[2 * gq]), avB = (int)(tl[2 * gq + 1] - head[2 * gq + 1]);
+                    const bool prioA = ((sel ^ gq) & 1) == 0;                                      // the pair's first claim alternates
+                    const int tA = prioA ? min(avA, GS) : min(avA, GS - min(avB, GS));
+                    const int tB = prioA ? min(avB, GS - tA) : min(avB, GS);
+                    take[2 * gq] = (unsigned)tA;
+                    take[2 * gq + 1] = (unsigned)tB;
                 }
-                if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
-                PROF_T0(ti);
-                __builtin_amdgcn_s_sleep(PDA_V4_RSLEEP);
-                PROF_T1(ti, 7);
-                continue;
             }
-            idle = 0;
-            sel = pick;
-            PROF_INC(8, 1);
-            const unsigned* ring = rings + (kMPR * r + sel) * kRing4;
-            PDA_CBAR();
-            const int n = min((int)(tail - hd), CPP);
-            n_cand += (unsigned)n;
-            const bool valid = ci < n;
-            const unsigned word = valid ? ring[(hd + (unsigned)ci) % kRing4] : 0u;
-            const int row = sel * ROWS + (int)(word >> 26);                         // row of this wave
+            unsigned tAl = 0, tBl = 0;
+#pragma unroll
+            for (int y = 0; y < kMPR; ++y) {
+                tAl = yA == y ? take[y] : tAl;
+                tBl = yB == y ? take[y] : tBl;
+                total += take[y];
+                taken |= take[y] != 0u ? 1u << y : 0u;
+            }
+            if (total == 0u) return false;
+            sel ^= 1;
+#pragma unroll
+            for (int y = 0; y < kMPR; ++y) head[y] += take[y];
+            n_cand += total;
+            const bool fromA = (unsigned)li < tAl;
+            const bool valid = fromA || (kMPR >= 2 && (unsigned)(GS - 1 - li) < tBl);
+            const int my_ring = fromA ? yA : yB;
+            const unsigned word = valid ? (fromA ? wA : wB) : 0u;
+            const int row = my_ring * ROWS + (int)(word >> 26);                     // row of this wave
             const int loc = (int)(word & 0x3FFFFFFu);                               // local item id
             const int urow = row_i(uidv, row);
+            const int rbb = row_i(rblv, row);                                       // (its place in the caller's block: the filter words)
+            f_sd = row_f(seedv, row);
+            f_tau = taul[row0 + row];
             const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)loc * D + q * 32;
-            f32x4 uu[8], ii[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
                 ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
             }
-            float pv = 1.0f;
-            if constexpr (HEAD == PDA_HEAD_POP) pv = g.pop[loc];
+            f_pv = 1.0f;
+            if constexpr (HEAD == PDA_HEAD_POP) f_pv = g.pop[loc];
             // the two filter words of (row, item), in flight with the rows
-            unsigned bh1 = 0u, bh2 = 0u;
-            uint32_t bw1 = 0xFFFFFFFFu, bw2 = 0xFFFFFFFFu;
+            f_bh1 = 0u; f_bh2 = 0u; f_bw1 = 0xFFFFFFFFu; f_bw2 = 0xFFFFFFFFu;
             if (bloom_on && valid && q == LPC - 1) {
-                const int rbs = utile * UT + row0 + row;
-                if (rbs < g.n_users_blk) {
-                    const int rbb = orig_row(rbs);
-                    bh1 = bloom_h1(g.item_offset + loc);
-                    bh2 = bloom_h2(g.item_offset + loc);
-                    bw1 = g.bloom[(size_t)rbb * 32 + (bh1 >> 5)];
-                    bw2 = g.bloom[(size_t)rbb * 32 + (bh2 >> 5)];
+                if (rbb >= 0) {
+                    f_bh1 = bloom_h1(g.item_offset + loc);
+                    f_bh2 = bloom_h2(g.item_offset + loc);
+                    f_bw1 = g.bloom[(size_t)rbb * 32 + (f_bh1 >> 5)];
+                    f_bw2 = g.bloom[(size_t)rbb * 32 + (f_bh2 >> 5)];
                 }
             }
-#pragma unroll
-            for (int y = 0; y < kMPR; ++y) head[y] += sel == y ? (unsigned)n : 0u;
             PDA_CBAR();
-            lds_st(&s_head[kMPR * r + sel], hd + (unsigned)n);              // the words are in registers: the slots are free
+#pragma unroll
+            for (int y = 0; y < kMPR; ++y)
+                if (taken & (1u << y)) lds_st(&s_head[kMPR * r + y], head[y]);      // the words are in registers: the slots are free
+            f_ring = my_ring;
+            f_taken = taken;
+            f_valid = valid;
+            f_word = word;
+            have = true;
+            return true;
+        };
+        for (;;) {
+            if constexpr ((PDA_V4_ABL & 8) != 0) break;
+            PROF_T0(tp0);
+            if (!have) {
+                unsigned dn = 1u;
+                if (!fetch(&dn)) {
+                    if (dn) break;
+                    if (next_sort < RR) {
+                        // nothing to rescore: put one more of the lists that came in unsorted in order (it has to be sorted for the
+                        // output anyway; done here it costs nothing, done behind the sweep it is a serial tail of the launch)
+                        const int rr = next_sort++;
+                        compact_list<kCap4, GL>(my_lists + (size_t)rr * kCap4, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5],
+                                                1u << ((row0 + rr) & 31));
+                        continue;
+                    }
+                    if (++idle > kSpinMax) { if (lane == 0) g.stats[0] = 3u; break; }
+                    PROF_T0(ti);
+                    __builtin_amdgcn_s_sleep(PDA_V4_RSLEEP);
+                    PROF_T1(ti, 7);
+                    continue;
+                }
+            }
+            idle = 0;
+            PROF_INC(8, 1);
+            // ---- the pass in flight
+            const unsigned c_taken = f_taken;
+            const bool valid = f_valid;
+            const float c_tau = f_tau, c_sd = f_sd;
+            const int row = f_ring * ROWS + (int)(f_word >> 26);
+            const int loc = (int)(f_word & 0x3FFFFFFu);
+            const float pv = f_pv;
+            const unsigned bh1 = f_bh1, bh2 = f_bh2;
+            const uint32_t bw1 = f_bw1, bw2 = f_bw2;
+#ifdef PDA_V4_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            PROF_T1(tp0, 16);
+            PROF_T0(tp1);
             float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
 #pragma unroll
             for (int ph = 0; ph < LPC; ++ph) {
@@ -994,34 +1090,64 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             }
             float sc = o0 + o1;                               // meaningful on the candidate's last lane
             if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
-            const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
+            float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
+            have = false;
+            PROF_T1(tp1, 17);
+#if PDA_V4_RESCORE_AHEAD
+            PROF_T0(tp4);
+            {
+                // ---- the next pass: its rows travel while this one's survivors go through the history and the lists
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(tt));                  // (the dot products first: the row registers are free only behind them)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+                fetch(nullptr);
+#if defined(__HIP_DEVICE_COMPILE__)
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            PROF_T1(tp4, 21);
+#endif
+            PROF_T0(tp2);
             const int lrow = row0 + row;
             const int item = g.item_offset + loc;
             // ">=": equal scores are decided by the key (lower item id wins) at the next compaction, so ties must get in.
             // With a seed (item-sharded evaluation: the K-th values of the OTHER shards' warm-up lists) nothing below it can be
             // in the merged top K: it stays out of this shard's list, which may then end shorter than K.
-            const float sd = row_f(seedv, row);
-            bool p = valid && q == LPC - 1 && (tt >= fmaxf(taul[lrow], sd));
+            bool p = valid && q == LPC - 1 && (tt >= fmaxf(c_tau, c_sd));
             if (hist_on) {
                 // train items are masked HERE: a binary search in the row's id-sorted history for a candidate that has passed
                 // the pre-filter and the exact threshold -- and whose two Bloom bits are set (hist_bloom4_kernel)
-                long long lo = row_l(hbv, row), hi = row_l(hev, row);
-                const long long he = hi;
-                if (p && (((bw1 >> (bh1 & 31u)) & (bw2 >> (bh2 & 31u)) & 1u) != 0u)) {
-                    while (lo < hi) {
-                        const long long mid = (lo + hi) >> 1;
-                        if (g.hist_indices[mid] < item) lo = mid + 1; else hi = mid;
+                const bool look = p && (((bw1 >> (bh1 & 31u)) & (bw2 >> (bh2 & 31u)) & 1u) != 0u);
+                if (__any(look)) {                         // (the bounds come through shuffles: every lane takes part)
+                    long long lo = row_l(hbv, row), hi = row_l(hev, row);
+                    const long long he = hi;
+                    if (look) {
+                        while (lo < hi) {
+                            const long long mid = (lo + hi) >> 1;
+                            if (g.hist_indices[mid] < item) lo = mid + 1; else hi = mid;
+                        }
+                        if (lo < he && g.hist_indices[lo] == item) p = false;
                     }
-                    if (lo < he && g.hist_indices[lo] == item) p = false;
                 }
             }
             const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+            PROF_T1(tp2, 18);
+            PROF_T0(tp3);
+            PROF_INC(20, __popcll(__ballot(p)));
+#ifdef PDA_V4_PROF
+            const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns, prof);
+#else
             const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns);
-            if (changed && lane == 0) __hip_atomic_fetch_add(&s_tver[kMPR * r + sel], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+            PROF_T1(tp3, 19);
+            if (changed && lane < kMPR && ((c_taken >> lane) & 1u) != 0u)
+                __hip_atomic_fetch_add(&s_tver[kMPR * r + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         PROF_T1(tr0, 6);
         PROF_INC(9, n_cand);
         PROF_FLUSH(6, 9);
+        PROF_FLUSH(16, 23);
         if (lane == 0) atomicAdd(g.stats + 1, n_cand);
     } else if (wave >= kMainWaves) {
         // ================================== loader ==================================
@@ -1928,9 +2054,9 @@ extern "C" int pda_topk_seed_pick(const float* bounds, const int32_t* counts, in
 }
 
 #ifdef PDA_V4_PROF
-extern "C" int pda_debug_prof4(unsigned long long* out16, int reset) {
-    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pda_prof4), sizeof(unsigned long long) * 16) != hipSuccess) return PDA_ERR_LAUNCH;
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pda_prof4), z, sizeof(z)) != hipSuccess) return PDA_ERR_LAUNCH; }
+extern "C" int pda_debug_prof4(unsigned long long* out16, int reset) {     /* 24 words */
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pda_prof4), sizeof(unsigned long long) * 24) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (reset) { unsigned long long z[24] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(pda_prof4), z, sizeof(z)) != hipSuccess) return PDA_ERR_LAUNCH; }
     return PDA_OK;
 }
 #endif

@@ -126,8 +126,9 @@ __device__ __forceinline__ void list_sync() {
 template <int CAP = kCap, bool GLB = false>
 // flag_word / flag_bit (optional): a set bit says "this list came in UNSORTED" (generation 4 hands its warm-up lists over
 // unsorted): the incremental path is off until the list has been through one full compaction, which clears the bit.
-__device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane, unsigned* flag_word = nullptr,
-                                             unsigned flag_bit = 0u) {
+// Returns the row's threshold behind the compaction (-inf while it holds fewer than K keys).
+__device__ __forceinline__ float compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane, unsigned* flag_word = nullptr,
+                                              unsigned flag_bit = 0u) {
     list_sync<GLB>();
     const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), CAP);   // failed appends may have pushed it past kCap
     bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
@@ -138,7 +139,10 @@ __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float
             if (lane == 0) *flag_word = fw & ~flag_bit;
         }
     }
-    uint64_t key = lane < c ? buf[lane] : (uint64_t)(63 - lane);  // fillers: unique, below any real key
+    // (one LDS round trip for the count, the threshold, the flag and the keys; lanes at and behind CAP read slot CAP - 1 -- a row's
+    // CAP slots are its own)
+    const uint64_t kraw = buf[lane < CAP ? lane : CAP - 1];
+    uint64_t key = lane < c ? kraw : (uint64_t)(63 - lane);      // fillers: unique, below any real key
     int rank;
     // First compaction of a row (all <= 59 keys against each other): the keys to rank against come from LDS as broadcast
     // reads, four in flight -- no SGPR round trip per key.  32 of these per wave were 40 % of the exact warm-up of a sweep.
@@ -169,10 +173,11 @@ __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float
     }
     list_sync<GLB>();
     if (lane < c && rank < K) buf[rank] = key;
+    float tau = -INFINITY;
     if (c >= K) {
         uint64_t mk = __ballot(lane < c && rank == K - 1);
         int src = __builtin_ctzll(mk);
-        const float tau = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src));
+        tau = pda_unordf((uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), src));
         if (lane == 0) {
             *tau_slot = tau;
             *cnt_slot = K;
@@ -181,6 +186,7 @@ __device__ __forceinline__ void compact_list(uint64_t* buf, int* cnt_slot, float
         *cnt_slot = c;
     }
     list_sync<GLB>();
+    return tau;
 }
 
 

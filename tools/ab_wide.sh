@@ -1,0 +1,11 @@
+# A/B of build variants on the wide geometry (dense ordered C3, 262 144 users); usage: bash tools/ab_wide.sh <out dir> <variant> ...
+out=gpurun_out/$1; shift
+mkdir -p $out
+export PDA_SCORE_LISTS=wide
+for v in base "$@" base; do
+  if [ $v = base ]; then unset PDA_HIP_LIB; else export PDA_HIP_LIB=$PWD/pda_amd/csrc/variants/libpda_hip_$v.so; fi
+  echo "== $v" >> $out/ab.txt
+  ONLY_ORDER=1 python tools/time_v4.py c3 262144 1 v4 2>&1 | grep head >> $out/ab.txt
+done
+unset PDA_HIP_LIB
+cat $out/ab.txt
