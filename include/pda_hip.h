@@ -206,6 +206,11 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        512 users per workgroup, 64 user rows per MFMA wave (two A operands per B read), lists in the workspace, four tile slots --
  *        half the LDS reads and half the tile traffic per MFMA, which on this power-limited part is clock.  Identical keys. */
 #define PDA_SWEEP_WIDE 4
+/*        bit 3 = PDA_SWEEP_MANY_CANDIDATES, the geometry hint for the opposite kind of sweep (d <= 128): hundreds of list
+ *        insertions per user -- the raw head, the popularity head in natural item order.  128 users per workgroup: four MFMA
+ *        waves, and EIGHT rescoring waves (one per 16 user rows) with the lists of 128 users and four tile slots in the LDS.
+ *        Such a sweep is bound by its rescoring waves (cycle counters: 98 % busy at four per 256 users).  Identical keys. */
+#define PDA_SWEEP_MANY_CANDIDATES 8
 #define PDA_SWEEP_WARM_TILES(n) (((n) & 7) << 4)
 size_t pda_item_prep4_bytes(int n_items_local, int d);
 int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,

@@ -722,6 +722,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_GL
 #define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
 #endif
+#ifndef PDA_V4_ROWS_INTERLEAVED
+#define PDA_V4_ROWS_INTERLEAVED 1   // rescoring: a candidate's lanes share every load (d <= 128)
+#endif
 #ifndef PDA_V4_RESCORE_AHEAD
 #define PDA_V4_RESCORE_AHEAD 1   // rescoring waves request the rows of the next pass before the appends of this one
 #endif
@@ -742,10 +745,12 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 template <int D, int GM = 0>
 struct Geo4 {
     static constexpr bool WIDE = D <= 128 && GM == 2;
-    static constexpr int UA = D <= 128 ? (WIDE ? 2 : PDA_V4_UA) : 1;  // A operands per B read: 32 UA user rows per MFMA wave
+    static constexpr bool MANY = D <= 128 && GM == 3;
+    static constexpr int MW = MANY ? 4 : kMainWaves;                  // MFMA waves
+    static constexpr int UA = D <= 128 ? (WIDE ? 2 : (MANY ? 1 : PDA_V4_UA)) : 1;  // A operands per B read: 32 UA user rows per MFMA wave
     // the exact lists in HBM (workspace) free the LDS for four tile slots (d = 256: 8.1 instead of 9.0 ms on a config-5 shard);
     // 512 users x 57 x 8 B would not fit the LDS anyway
-    static constexpr bool GL = (PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0) || GM >= 1;
+    static constexpr bool GL = (PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0) || GM == 1 || GM == 2;
 #ifdef PDA_V4_NBX   /* timing experiment only (results are wrong): NBX half-tiles per block at d <= 128 */
     static constexpr int NB = D <= 128 ? PDA_V4_NBX : 1;
 #else
@@ -754,20 +759,28 @@ struct Geo4 {
     // lives across it do not fit 168 VGPRs: hipcc spilled the accumulators behind every block; 64 rows x 32 items do)
 #endif
     static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : 2;
-    static constexpr int RESCORERS = (D <= 128 && UA == 1) ? 4 : 2;
-    static constexpr int MPR = kMainWaves / RESCORERS;   // MFMA waves per rescoring wave
-    static constexpr int WAVES = kMainWaves + LOADERS + RESCORERS;
+    static constexpr int RESCORERS = MANY ? 8 : ((D <= 128 && UA == 1) ? 4 : 2);
     static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
-    static constexpr int UT = kMainWaves * ROWS;         // user rows per workgroup
+    // candidate rings: one per MFMA wave, or (MANY) two -- rows 0..15 and 16..31 of the wave -- each with a rescoring wave of its own
+    static constexpr int NRINGS = MW > RESCORERS ? MW : RESCORERS;
+    static constexpr int RPW = NRINGS / MW;              // rings per MFMA wave
+    static constexpr int RPR = ROWS / RPW;               // user rows per ring
+    static constexpr int MPR = NRINGS / RESCORERS;       // rings per rescoring wave
+    static constexpr int WAVES = MW + LOADERS + RESCORERS;
+    static constexpr int UT = MW * ROWS;                 // user rows per workgroup
     static constexpr int RB = row_bytes(D), TB = tile_bytes(D);
     static constexpr int HB = 32 * RB;                   // one half-tile
     static constexpr int BB = NB * HB;                   // one block = one ring slot
     static constexpr int NP = (BB + 1023) / 1024;        // 1 KiB DMA pieces per block; the last one may be half a piece (32 lanes)
     static constexpr int LASTL = (BB % 1024) ? (BB % 1024) / 16 : 64;
-    static constexpr int NSLOT = GL ? PDA_V4_NSLOT : 2;
+    static constexpr int NSLOT = (GL || MANY) ? PDA_V4_NSLOT : 2;    // (MANY: 128 users' lists leave the LDS room for four slots)
     static constexpr size_t lds_tiles = NSLOT * (size_t)BB;
-    static constexpr size_t lds_lists = GL ? 0 : (size_t)UT * kCap4 * 8;
+    // list slots per user row: a full list is compacted to its best K, i.e. every CAP - K insertions (half of what a candidate costs
+    // its rescoring wave); 128 users leave the LDS room for 64
+    static constexpr int CAP = MANY ? 64 : kCap4;
+    static constexpr size_t lds_lists = GL ? 0 : (size_t)UT * CAP * 8;
     static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 512;
+    static_assert(NRINGS <= kMainWaves && RPW * MW == NRINGS && MPR * RESCORERS == NRINGS, "ring bookkeeping: eight words each");
     static_assert(NSLOT >= 2 && NSLOT <= 5, "vote timing of the early termination");
     static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
 };
@@ -777,14 +790,15 @@ struct Geo4 {
 template <int D, int HEAD, bool BF, bool ES, int GM = 0>
 __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4 g) {
     using G = Geo4<D, GM>;
-    constexpr int kLoaders = G::LOADERS, kMPR = G::MPR;
+    constexpr int kLoaders = G::LOADERS, kMPR = G::MPR, MW = G::MW, RPW = G::RPW, RPR = G::RPR;
     constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP, UA = G::UA, NSLOT = G::NSLOT;
     constexpr bool GL = G::GL;
+    constexpr int CAPL = G::CAP;                       // list slots per user row
     constexpr int NM = D / 16;
     constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tiles = smem;                                                             // NSLOT x BB
-    uint64_t* lists = GL ? g.lists_ws + (size_t)blockIdx.x * UT * kCap4                      // [UT][kCap4] exact keys
+    uint64_t* lists = GL ? g.lists_ws + (size_t)blockIdx.x * UT * CAPL                      // [UT][CAPL] exact keys
                          : reinterpret_cast<uint64_t*>(smem + G::lds_tiles);
     int* cntl = reinterpret_cast<int*>(smem + G::lds_tiles + G::lds_lists);                  // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                                       // [UT] exact K-th value (-inf until K entries)
@@ -793,7 +807,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     unsigned* s_landed = sync;                // [4]
     unsigned* s_stop = sync + 108;            // [1]  early termination: loaders leave
     unsigned* s_released = sync + 4;          // [8]
-    unsigned* s_tail = sync + 12;             // [8]  ring write positions (MFMA wave w)
+    unsigned* s_tail = sync + 12;             // [8]  ring write positions (ring RPW w + rg of MFMA wave w)
     unsigned* s_head = sync + 20;             // [8]  ring read positions
     unsigned* s_done = sync + 28;             // [8]  MFMA wave w has pushed its last candidate
     unsigned* s_tver = sync + 36;             // [8]  bumped by the rescoring wave whenever a threshold of wave w's rows rose
@@ -841,7 +855,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             const int rb = utile * UT + rr;
             const uint64_t key = keyv[q];
             const int c = __popcll(__ballot(key != 0ull));
-            if (lane < K) lists[(size_t)rr * kCap4 + lane] = key;
+            if (lane < K) lists[(size_t)rr * CAPL + lane] = key;
             uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
@@ -858,12 +872,12 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
 #endif
     PDA_STAMP(st1);
 
-    if (wave >= kMainWaves + kLoaders) {
+    if (wave >= MW + kLoaders) {
         // ============================== rescoring wave ==============================
-        constexpr int RR = kMPR * ROWS;                      // rows of this wave (128: two per lane)
-        const int r = wave - kMainWaves - kLoaders;
+        constexpr int RR = kMPR * RPR;                       // rows of this wave (128: two per lane)
+        const int r = wave - MW - kLoaders;
         const int row0 = r * RR;
-        uint64_t* my_lists = lists + (size_t)row0 * kCap4;
+        uint64_t* my_lists = lists + (size_t)row0 * CAPL;
         constexpr int NRL = (RR + 63) / 64;                  // rows per lane
         int uidv[NRL], rblv[NRL];                            // user id and place in the caller's block (-1: padding) of the lane's rows
         float seedv[NRL];
@@ -911,7 +925,8 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         unsigned head[kMPR], n_cand = 0;
 #pragma unroll
         for (int z = 0; z < kMPR; ++z) head[z] = 0;
-        constexpr int LPC = D / 32;                 // lanes per candidate: each owns 32 consecutive k
+        constexpr int LPC = D / 32;                 // lanes per candidate
+        constexpr bool kRowsInterleaved = D <= 128 && PDA_V4_ROWS_INTERLEAVED != 0;
         constexpr int CPP = 64 / LPC;               // candidates per pass
         const int q = lane % LPC, ci = lane / LPC;
         int sel = 0;                                // the ring looked at last
@@ -950,7 +965,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             if (dn_out != nullptr) {
                 unsigned dn = 1u;
 #pragma unroll
-                for (int z = 0; z < kMPR; ++z) dn &= lds_ld(&s_done[kMPR * r + z]);                 // read BEFORE the tails
+                for (int z = 0; z < kMPR; ++z) dn &= lds_ld(&s_done[(kMPR * r + z) / RPW]);         // read BEFORE the tails
                 *dn_out = dn;
             }
 #pragma unroll
@@ -989,17 +1004,22 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             const bool valid = fromA || (kMPR >= 2 && (unsigned)(GS - 1 - li) < tBl);
             const int my_ring = fromA ? yA : yB;
             const unsigned word = valid ? (fromA ? wA : wB) : 0u;
-            const int row = my_ring * ROWS + (int)(word >> 26);                     // row of this wave
+            const int row = my_ring * RPR + (int)(word >> 26);                      // row of this wave
             const int loc = (int)(word & 0x3FFFFFFu);                               // local item id
             const int urow = row_i(uidv, row);
             const int rbb = row_i(rblv, row);                                       // (its place in the caller's block: the filter words)
             f_sd = row_f(seedv, row);
             f_tau = taul[row0 + row];
-            const size_t ub = (size_t)urow * D + q * 32, ib = (size_t)loc * D + q * 32;
+            // d <= 128: the 8-float chunks of a row go round the candidate's LPC lanes (lane q: chunks q, LPC + q, 2 LPC + q, ..), so
+            // that a load touches ONE cache line per candidate.  With 32 consecutive floats per lane every load touched 64
+            // different lines, 1 024 tag look-ups per pass: the CU's vector memory pipe was what capped rescoring at ~5 candidates
+            // per 1 000 cycles, whether four or eight waves were at it (cycle counters, raw head).
+            const size_t ub = (size_t)urow * D + (kRowsInterleaved ? q * 8 : q * 32), ib = (size_t)loc * D + (kRowsInterleaved ? q * 8 : q * 32);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                uu[c] = pda_load4<BF>(g.U, ub + 4 * c);
-                ii[c] = pda_load4<BF>(g.I, ib + 4 * c);
+                const int off = kRowsInterleaved ? 8 * LPC * (c >> 1) + 4 * (c & 1) : 4 * c;
+                uu[c] = pda_load4<BF>(g.U, ub + off);
+                ii[c] = pda_load4<BF>(g.I, ib + off);
             }
             f_pv = 1.0f;
             if constexpr (HEAD == PDA_HEAD_POP) f_pv = g.pop[loc];
@@ -1035,7 +1055,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                         // nothing to rescore: put one more of the lists that came in unsorted in order (it has to be sorted for the
                         // output anyway; done here it costs nothing, done behind the sweep it is a serial tail of the launch)
                         const int rr = next_sort++;
-                        compact_list<kCap4, GL>(my_lists + (size_t)rr * kCap4, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5],
+                        compact_list<CAPL, GL>(my_lists + (size_t)rr * CAPL, &cntl[row0 + rr], &taul[row0 + rr], K, lane, &s_uns[(row0 + rr) >> 5],
                                                 1u << ((row0 + rr) & 31));
                         continue;
                     }
@@ -1052,7 +1072,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             const unsigned c_taken = f_taken;
             const bool valid = f_valid;
             const float c_tau = f_tau, c_sd = f_sd;
-            const int row = f_ring * ROWS + (int)(f_word >> 26);
+            const int row = f_ring * RPR + (int)(f_word >> 26);
             const int loc = (int)(f_word & 0x3FFFFFFu);
             const float pv = f_pv;
             const unsigned bh1 = f_bh1, bh2 = f_bh2;
@@ -1062,10 +1082,46 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
 #endif
             PROF_T1(tp0, 16);
             PROF_T0(tp1);
-            float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
+            float o0 = 0.f, o1 = 0.f;
+            if constexpr (kRowsInterleaved) {
+                // The sum order is the oracle's (oracle/pda_oracle.c dot_chain): chunk x feeds chain x & 1, the chunks of a chain in
+                // ascending order.  Lane q holds chunks LPC cq + q in its registers 2 cq, 2 cq + 1.  d = 64: lane 0 IS chain 0, lane 1
+                // chain 1.  d = 128: chain 0 alternates between lanes 0 and 2, chain 1 between lanes 1 and 3 -- eight FMAs, one DPP
+                // move across the quad, eight FMAs, one move back, per four chunks.
+                auto fma8 = [&](float acc, int cq) __attribute__((always_inline)) -> float {
 #pragma unroll
-            for (int ph = 0; ph < LPC; ++ph) {
-                o0 = c0;
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        acc = __builtin_fmaf(uu[2 * cq][sidx], ii[2 * cq][sidx], acc);
+                        acc = __builtin_fmaf(uu[2 * cq + 1][sidx], ii[2 * cq + 1][sidx], acc);
+                    }
+                    return acc;
+                };
+                float o = 0.f;
+                if constexpr (LPC == 4) {
+                    const bool hi = q >= 2;
+                    auto swap2 = [](float x) __attribute__((always_inline)) -> float {
+                        return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+                    };
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) {
+                        const float a = fma8(o, cq);                  // (lanes 0, 1: the chains behind chunks 4 cq, 4 cq + 1)
+                        const float a_sw = swap2(a);
+                        const float b = fma8(hi ? a_sw : o, cq);      // (lanes 2, 3: behind chunks 4 cq + 2, 4 cq + 3)
+                        const float b_sw = swap2(b);
+                        o = hi ? b : b_sw;
+                    }
+                } else {
+                    static_assert(LPC == 2, "d = 64");
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) o = fma8(o, cq);
+                }
+                // even lanes end with chain 0, odd lanes with chain 1
+                o0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(o), 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
+                o1 = o;
+            } else {
+            float c0 = 0.f, c1 = 0.f;
+#pragma unroll
+            for (int ph = 0; ph < LPC; ++ph) {                o0 = c0;
                 o1 = c1;
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {      // chunk 4 q + cc of the row: even chunks feed chain 0, odd ones chain 1
@@ -1087,6 +1143,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                         c1 = r1;
                     }
                 }
+            }
             }
             float sc = o0 + o1;                               // meaningful on the candidate's last lane
             if constexpr (HEAD == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
@@ -1136,25 +1193,25 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             PROF_T0(tp3);
             PROF_INC(20, __popcll(__ballot(p)));
 #ifdef PDA_V4_PROF
-            const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns, prof);
+            const bool changed = append_keys<CAPL, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns, prof);
 #else
-            const bool changed = append_keys<kCap4, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns);
+            const bool changed = append_keys<CAPL, GL>(p, lrow, tt, key, lists, cntl, taul, row0, RR, K, lane, s_uns);
 #endif
             PROF_T1(tp3, 19);
             if (changed && lane < kMPR && ((c_taken >> lane) & 1u) != 0u)
-                __hip_atomic_fetch_add(&s_tver[kMPR * r + lane], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(&s_tver[(kMPR * r + lane) / RPW], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         PROF_T1(tr0, 6);
         PROF_INC(9, n_cand);
         PROF_FLUSH(6, 9);
         PROF_FLUSH(16, 23);
         if (lane == 0) atomicAdd(g.stats + 1, n_cand);
-    } else if (wave >= kMainWaves) {
+    } else if (wave >= MW) {
         // ================================== loader ==================================
         // Issued through inline asm: hipcc counts a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
         // s_waitcnt vmcnt(0) in front of the next ds_read of ANY address (the hand-over polls): the loads would be
         // synchronous.  M0 = LDS byte address of the piece, saved and restored inside the statement.
-        const int l = wave - kMainWaves;
+        const int l = wave - MW;
         const unsigned lds_tiles0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
         __syncthreads();
         // Three or more slots: a loader keeps TWO blocks in flight -- it announces block b - 1 behind the issue of its pieces
@@ -1172,7 +1229,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                 auto min_released = [&]() __attribute__((always_inline)) -> unsigned {
                     unsigned mn = 0xFFFFFFFFu;
 #pragma unroll
-                    for (int z = 0; z < kMainWaves; ++z) mn = min(mn, lds_ld(&s_released[z]));
+                    for (int z = 0; z < MW; ++z) mn = min(mn, lds_ld(&s_released[z]));
                     return mn;
                 };
                 while (min_released() < want) {
@@ -1300,31 +1357,42 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     if (w < 4) __builtin_amdgcn_s_setprio(PDA_V4_PRIO);     // experiment: the first-dispatched MFMA wave of every SIMD goes first
 #endif
 
-    unsigned* ring = rings + w * kRing4;
-    unsigned tail = 0, head_c = 0;          // wave-uniform
-    // push the flagged registers (bit 15 - r <-> register r)
-    auto push_mask = [&](uint32_t m, int loc, int u) __attribute__((always_inline)) {
-        while (__any(m != 0)) {
-            const bool act = m != 0;
-            const int bit = 31 - __builtin_clz(m | 1u);
-            const int r = 15 - bit;
-            const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
-            m &= ~(1u << bit);
-            const uint64_t pm = __ballot(act);
-            if (tail + 64u - head_c > (unsigned)kRing4) {      // ring full: publish what is there and wait for the rescoring wave
-                PDA_CBAR();
-                lds_st(&s_tail[w], tail);
-                unsigned spin = 0;
-                PROF_T0(tq);
-                do {
-                    head_c = lds_ld(&s_head[w]);
-                    if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 2u; break; }
-                } while (tail + 64u - head_c > (unsigned)kRing4);
-                PROF_T1(tq, 2);
+    // ring RPW w + rg of this wave takes the candidates of rows rg RPR .. rg RPR + RPR - 1
+    unsigned tail[RPW], head_c[RPW];        // wave-uniform
+#pragma unroll
+    for (int rg = 0; rg < RPW; ++rg) { tail[rg] = 0u; head_c[rg] = 0u; }
+    auto publish_tails = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int rg = 0; rg < RPW; ++rg) lds_st(&s_tail[RPW * w + rg], tail[rg]);
+    };
+    // push the flagged registers (bit 15 - r <-> register r; registers 0 .. 7 are rows 0 .. 15 of the row set, 8 .. 15 rows 16 .. 31)
+    auto push_mask = [&](uint32_t m_all, int loc, int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int rg = 0; rg < RPW; ++rg) {
+            uint32_t m = RPW == 1 ? m_all : (rg == 0 ? (m_all & 0xFF00u) : (m_all & 0x00FFu));
+            unsigned* ring = rings + (RPW * w + rg) * kRing4;
+            while (__any(m != 0)) {
+                const bool act = m != 0;
+                const int bit = 31 - __builtin_clz(m | 1u);
+                const int r = 15 - bit;
+                const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h - rg * RPR;
+                m &= ~(1u << bit);
+                const uint64_t pm = __ballot(act);
+                if (tail[rg] + 64u - head_c[rg] > (unsigned)kRing4) {      // ring full: publish what is there and wait for the rescoring wave
+                    PDA_CBAR();
+                    lds_st(&s_tail[RPW * w + rg], tail[rg]);
+                    unsigned spin = 0;
+                    PROF_T0(tq);
+                    do {
+                        head_c[rg] = lds_ld(&s_head[RPW * w + rg]);
+                        if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 2u; break; }
+                    } while (tail[rg] + 64u - head_c[rg] > (unsigned)kRing4);
+                    PROF_T1(tq, 2);
+                }
+                const unsigned slot = (tail[rg] + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))) % kRing4;
+                if (act) ring[slot] = ((uint32_t)row << 26) | (uint32_t)loc;
+                tail[rg] += (unsigned)__popcll(pm);
             }
-            const unsigned slot = (tail + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))) % kRing4;
-            if (act) ring[slot] = ((uint32_t)row << 26) | (uint32_t)loc;
-            tail += (unsigned)__popcll(pm);
         }
     };
     auto ensure_landed = [&](int b) __attribute__((always_inline)) {
@@ -1409,7 +1477,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                 const unsigned* v = &s_vote[((it - kVL) & 7) * kMainWaves];
                 unsigned all = 1u;
 #pragma unroll
-                for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
+                for (int z = 0; z < MW; ++z) all &= lds_ld(&v[z]);
                 stopped = all != 0u;
             }
             PDA_CBAR();
@@ -1534,7 +1602,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             const unsigned* v = &s_vote[((it - kVL) & 7) * kMainWaves];
             unsigned all = 1u;
 #pragma unroll
-            for (int z = 0; z < kMainWaves; ++z) all &= lds_ld(&v[z]);
+            for (int z = 0; z < MW; ++z) all &= lds_ld(&v[z]);
             stopped = all != 0u;
         }
         PDA_CBAR();
@@ -1577,7 +1645,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                         }
                         push_mask(mcb, locv[cb], u);
                         PDA_CBAR();
-                        lds_st(&s_tail[w], tail);
+                        publish_tails();
                         PROF_T1(ts, 3);
                     }
                 }
@@ -1593,11 +1661,11 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     }
     PROF_T1(tm0, 0);
     PROF_INC(13, 1);
-    PROF_INC(15, tail);
+    PROF_INC(15, tail[0] + tail[RPW - 1] * (RPW - 1));
     PROF_FLUSH(0, 5);
     PROF_FLUSH(13, 15);
     PDA_CBAR();
-    lds_st(&s_tail[w], tail);
+    publish_tails();
     PDA_CBAR();
     lds_st(&s_done[w], 1u);
     if (stopped) lds_st(s_stop, 1u);
@@ -1624,8 +1692,8 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         for (int q = 0; q < EB; ++q) {
             const int rr = r0 + q * G::WAVES;
             if (rr >= UT) break;
-            uint64_t* buf = lists + (size_t)rr * kCap4;
-            compact_list<kCap4, GL>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
+            uint64_t* buf = lists + (size_t)rr * CAPL;
+            compact_list<CAPL, GL>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
             const int c = cntl[rr];
             if (rov[q] >= 0 && lane < K) {
                 const uint64_t k = lane < c ? buf[lane] : 0ull;
@@ -1802,6 +1870,9 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
             if (geometry == 2) return launch_sweep4<D, HEAD, BF, 2>(g, stream);
             if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
         }
+        if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
+            if (geometry == 3) return launch_sweep4<D, HEAD, BF, 3>(g, stream);
+        }
         return launch_sweep4<D, HEAD, BF, 0>(g, stream);
     }
     return PDA_OK;
@@ -1844,9 +1915,9 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
-    if (early_stop < 0 || (early_stop & ~0x77) != 0) return PDA_ERR_ARG;
+    if (early_stop < 0 || (early_stop & ~0x7F) != 0) return PDA_ERR_ARG;
     // geometry hints (Geo4<D, 1 | 2>): results do not depend on them.  The wide geometry needs one item split and whole waves of work
-    int geometry = (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
+    int geometry = (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;

@@ -130,18 +130,25 @@ template <int CAP = kCap, bool GLB = false>
 __device__ __forceinline__ float compact_list(uint64_t* buf, int* cnt_slot, float* tau_slot, int K, int lane, unsigned* flag_word = nullptr,
                                               unsigned flag_bit = 0u) {
     list_sync<GLB>();
-    const int c = min(__builtin_amdgcn_readfirstlane(*cnt_slot), CAP);   // failed appends may have pushed it past kCap
-    bool sorted_prefix = __builtin_amdgcn_readfirstlane(__float_as_int(*tau_slot)) != (int)0xff800000 && c >= K;
+    // ONE round trip for the count, the threshold, the flag and the keys: all four requested before the first is looked at (as four
+    // dependent trips beside eight MFMA waves streaming B fragments they were most of a compaction's 2 200 cycles; lanes at and
+    // behind CAP read slot CAP - 1 -- a row's CAP slots are its own)
+    const int cnt_v = *cnt_slot;
+    const int tau_v = __float_as_int(*tau_slot);
+    const unsigned flag_v = flag_word != nullptr ? *flag_word : 0u;
+    const uint64_t kraw = buf[lane < CAP ? lane : CAP - 1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(cnt_v), "v"(tau_v), "v"(flag_v), "v"(kraw));
+#endif
+    const int c = min(__builtin_amdgcn_readfirstlane(cnt_v), CAP);        // failed appends may have pushed it past kCap
+    bool sorted_prefix = __builtin_amdgcn_readfirstlane(tau_v) != (int)0xff800000 && c >= K;
     if (flag_word != nullptr) {
-        const unsigned fw = __builtin_amdgcn_readfirstlane(*flag_word);
+        const unsigned fw = __builtin_amdgcn_readfirstlane(flag_v);
         if (fw & flag_bit) {
             sorted_prefix = false;
             if (lane == 0) *flag_word = fw & ~flag_bit;
         }
     }
-    // (one LDS round trip for the count, the threshold, the flag and the keys; lanes at and behind CAP read slot CAP - 1 -- a row's
-    // CAP slots are its own)
-    const uint64_t kraw = buf[lane < CAP ? lane : CAP - 1];
     uint64_t key = lane < c ? kraw : (uint64_t)(63 - lane);      // fillers: unique, below any real key
     int rank;
     // First compaction of a row (all <= 59 keys against each other): the keys to rank against come from LDS as broadcast
@@ -149,7 +156,25 @@ __device__ __forceinline__ float compact_list(uint64_t* buf, int* cnt_slot, floa
     if (sorted_prefix) {
         rank = lane < K ? lane : 0;
         const uint64_t oldmask = K >= 64 ? ~0ull : ((1ull << K) - 1ull);
-        for (int jj = K; jj < c; ++jj) {
+        // the first eight new keys without a loop: their broadcasts, compares and ballots do not depend on one another (as a loop of
+        // c - K dependent rounds this was ~1 000 of a compaction's 2 200 cycles, and a compaction every seven insertions is half
+        // of what a candidate costs its rescoring wave)
+        constexpr int NU = 8;
+        const int nnew = c - K;
+        uint64_t kn[NU];
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+            const uint64_t kt = pda_readlane_u64(key, K + t < 63 ? K + t : 63);
+            kn[t] = t < nnew ? kt : 0ull;                       // (0: below every key)
+        }
+#pragma unroll
+        for (int t = 0; t < NU; ++t) rank += (kn[t] > key) ? 1 : 0;
+#pragma unroll
+        for (int t = 0; t < NU; ++t) {
+            const int olds_above = __popcll(__ballot(key > kn[t]) & oldmask);
+            rank += (lane == K + t && t < nnew) ? olds_above : 0;
+        }
+        for (int jj = K + NU; jj < c; ++jj) {
             const uint64_t kj = pda_readlane_u64(key, jj);      // (<= 9 keys: an LDS read per key would only add latency)
             rank += (kj > key) ? 1 : 0;
             const int olds_above = __popcll(__ballot(key > kj) & oldmask);

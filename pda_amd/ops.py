@@ -189,9 +189,9 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
     """Which pre-filtered kernel generation serves a call.  All of them return the same keys; the choice is by measured
     speed (65 536 users per block).  Generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
     waves, register-resident exact warm-up) for every sweep in visiting order -- C3 dense 3.40 vs 4.61 ms, early-terminating
-    0.42 vs 0.49 ms; C1/C2 0.31 vs 0.60 ms; a config-5 shard 3.2 vs 4.5 ms --; generation 3 for the candidate-heavy
-    natural-order sweeps (C3: 8.8 vs 10.7 ms; a tie at d = 64) and for the raw head at d = 256, whose visiting order by norm
-    leaves 300+ candidates per user (19.6 vs 29.3 ms: generation 4 keeps the d = 256 lists in HBM).  PDA_SCORE_KERNEL=v3|v4
+    0.42 vs 0.49 ms; C1/C2 0.31 vs 0.60 ms; a config-5 shard 3.2 vs 4.5 ms -- and, since its many-candidates geometry (round 3),
+    for the natural-order sweeps at d <= 128; generation 3 for natural order and the raw head at d = 256, whose visiting order
+    by norm leaves 300+ candidates per user (19.6 vs 29.3 ms: generation 4 keeps the d = 256 lists in HBM).  PDA_SCORE_KERNEL=v3|v4
     forces one (A/B measurements, cross-checks)."""
     import os
     forced = os.environ.get("PDA_SCORE_KERNEL", "")
@@ -200,9 +200,9 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
         return "v3"
     if forced == "v4":
         return "v4" if fits else "v3"
-    if not (fits and prune) or (d == 256 and head == HEAD_RAW):
+    if not fits or (d == 256 and (head == HEAD_RAW or not prune)):
         return "v3"
-    return "v4"
+    return "v4"        # (natural order at d <= 128 too since the many-candidates geometry: C3 65 536 users 7.0 vs 8.8 ms)
 
 
 WIDE_MIN_USERS = 131072      # below that, 512-user workgroups leave CUs idle
@@ -213,10 +213,16 @@ def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:
     behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
     four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
     forced = os.environ.get("PDA_SCORE_LISTS", "")
-    if forced in ("lds", "hbm", "wide"):
-        return {"lds": 0, "hbm": 2, "wide": 4}[forced]
+    if forced in ("lds", "hbm", "wide", "many"):
+        return {"lds": 0, "hbm": 2, "wide": 4, "many": 8}[forced]
     if head == HEAD_POP and prune == "order" and n_users >= WIDE_MIN_USERS and d in (64, 128):
         return 4            # PDA_SWEEP_WIDE: the dense sweep of a large user block (512-user workgroups, half the LDS and tile traffic per MFMA)
+    early = prune is True or (prune == 1 and prune != "order")
+    if d in (64, 128) and not early and (head == HEAD_RAW or not prune):
+        # PDA_SWEEP_MANY_CANDIDATES: hundreds of list insertions per user (raw head; popularity head in natural item order) -- 128
+        # users per workgroup with eight rescoring waves.  Same box: C3 262 144 users raw 31.3 -> 28.1 ms, natural order 34.2 ->
+        # 28.3 ms; C2 raw 3.39 -> 2.10 ms, natural 4.37 -> 2.39 ms.  (Early-terminating raw sweeps: 30.5 vs 37.8 ms, not hinted.)
+        return 8
     # Measured (round 3, config 3, 262 144 users, same box): dense sweep 12.58 vs 12.71 ms with the lists in the workspace (four
     # tile slots), early-terminating sweep 1.18 vs 1.04 ms, C1 / C2 0.28 vs 0.25 ms: the hand-over of the warm-up lists and the
     # final sort go through L2 instead of the LDS.  Not worth it: off unless forced.

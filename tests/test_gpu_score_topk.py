@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop", "k4hbm", "k4wide"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop", "k4hbm", "k4wide", "k4many"])
 def impl(request, monkeypatch):
     """Every test runs against all scoring paths: v1 = exact fp32 MFMA; v2 / v2ord / v2order_only = the pre-filtered path
     (bf16 MFMA filter + exact rescoring) in natural order / visiting order with early termination / visiting order without
@@ -30,8 +30,9 @@ def impl(request, monkeypatch):
     monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order", "k3": "1", "k4ord": "order",
                                            "k4stop": "1", "k4hbm": "1", "k4wide": "order"}.get(request.param, "0"))
     # k4hbm: generation 4 with its exact lists in the workspace and four tile slots at d <= 128 (PDA_SWEEP_FEW_CANDIDATES);
-    # k4wide: the wide geometry (PDA_SWEEP_WIDE: 512 users per workgroup, 64 user rows per MFMA wave), dense in visiting order
-    monkeypatch.setenv("PDA_SCORE_LISTS", {"k4hbm": "hbm", "k4wide": "wide"}.get(request.param, "lds"))
+    # k4wide: the wide geometry (PDA_SWEEP_WIDE: 512 users per workgroup, 64 user rows per MFMA wave), dense in visiting order;
+    # k4many: the many-candidates geometry (PDA_SWEEP_MANY_CANDIDATES: 128 users per workgroup, eight rescoring waves), natural order
+    monkeypatch.setenv("PDA_SCORE_LISTS", {"k4hbm": "hbm", "k4wide": "wide", "k4many": "many"}.get(request.param, "lds"))
     if request.param == "k3":
         monkeypatch.setenv("PDA_SCORE_KERNEL", "v3")
     elif request.param.startswith("k4"):
@@ -672,6 +673,15 @@ def test_full_size_c3_sweep_modes_agree(dev, impl):
         raw[prune] = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_RAW, None, hist, prune=prune), want="keys")
         assert_lists_match_oracle(raw[prune], *oracle[0], head=0)
     assert torch.equal(raw[None], raw[False])
+    os.environ["PDA_SCORE_LISTS"] = "many"        # the many-candidates geometry on the same block: identical keys, both heads
+    try:
+        for prune in ("order", False):
+            km = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_RAW, None, hist, prune=prune), want="keys")
+            assert torch.equal(km, raw[None]), ("many", "raw", prune)
+        km = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=False), want="keys")
+        assert torch.equal(km, k262), ("many", "pop")
+    finally:
+        os.environ["PDA_SCORE_LISTS"] = "lds"
     torch.cuda.synchronize()
 
 
