@@ -728,6 +728,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_RESCORE_AHEAD
 #define PDA_V4_RESCORE_AHEAD 1   // rescoring waves request the rows of the next pass before the appends of this one
 #endif
+#ifndef PDA_V4_NSLOT_MAX
+#define PDA_V4_NSLOT_MAX 5   // (timing experiments raise it: the votes of the early termination are then wrong)
+#endif
 #ifndef PDA_V4_NSLOT
 #define PDA_V4_NSLOT 4    // tile slots in LDS when the lists live in HBM (<= 5: the vote words of the early termination)
 #endif
@@ -781,7 +784,7 @@ struct Geo4 {
     static constexpr size_t lds_lists = GL ? 0 : (size_t)UT * CAP * 8;
     static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 512;
     static_assert(NRINGS <= kMainWaves && RPW * MW == NRINGS && MPR * RESCORERS == NRINGS, "ring bookkeeping: eight words each");
-    static_assert(NSLOT >= 2 && NSLOT <= 5, "vote timing of the early termination");
+    static_assert(NSLOT >= 2 && NSLOT <= PDA_V4_NSLOT_MAX, "vote timing of the early termination");
     static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
 };
 
