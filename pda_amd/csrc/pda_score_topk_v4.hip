@@ -89,6 +89,8 @@ struct Args4 {
     int n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, n_tiles;
     int warm_tiles;              // 1 .. kWarmTiles: 64-item tiles per split scored exactly by warm4_kernel
     int warm_sorted;             // the warm-up hands its lists over sorted (phase 1 alone: pda_topk_kth_value reads ranks) or as they are
+    uint64_t* handover;          // [n_splits, n_users_blk, kCap4] or NULL: warm-up and sweep of ONE call hand the lists over here, K .. kCap4 keys
+                                 // per row (zero-padded), instead of exactly K through out_keys
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -554,7 +556,10 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     // More than CAP survivors at the exact K-th value (ties): the general append path with its compactions.
     // Two registers (= four rows) per descent: the steps of one descent are a dependent chain (compare, ballot, popcount, select),
     // two independent chains share the wave's issue slots.
-    const int cap_t = g.warm_sorted ? CAP : K;          // unsorted hand-over: exactly K survivors (out_keys has K slots per row)
+    // unsorted hand-over through out_keys: exactly K survivors (K slots per row) -- a bisection down to the K-th value itself,
+    // ~20 rounds of ballots over the 256 scores of a row, 0.25 of the warm-up's 0.6 ms at 262 144 users.  Through the workspace
+    // (g.handover: CAP slots per row) any threshold with K .. CAP survivors will do: a handful of rounds.
+    const int cap_t = (g.warm_sorted || g.handover != nullptr) ? CAP : K;
     auto emit_row = [&](const int r, const uint32_t t, const int c_t) __attribute__((always_inline)) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         const int lrow = wave * 32 + row;
@@ -664,11 +669,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     for (int rr = 0; rr < 32; ++rr) {
         uint64_t* buf = my_lists + rr * CAP;
         // sorted hand-over, or a row that went through the general append path (ties at its K-th value) and may hold more than K
-        if (((PDA_W4_ABL & 4) == 0) && (g.warm_sorted || __builtin_amdgcn_readfirstlane(cntl[wave * 32 + rr]) > K))
+        if (((PDA_W4_ABL & 4) == 0) && (g.warm_sorted || (g.handover == nullptr && __builtin_amdgcn_readfirstlane(cntl[wave * 32 + rr]) > K)))
             compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
         const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
-        if (rb < g.n_users_blk && lane < K) {
+        if (g.handover != nullptr) {
+            if (rb < g.n_users_blk && lane < CAP) g.handover[((size_t)split * g.n_users_blk + rb) * CAP + lane] = lane < c ? buf[lane] : 0ull;
+        } else if (rb < g.n_users_blk && lane < K) {
             const uint64_t k = lane < c ? buf[lane] : 0ull;
             g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
         }
@@ -714,13 +721,14 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #define PDA_V4_LSLEEP 1     // loaders: s_sleep between polls for a free slot
 #endif
 #ifndef PDA_V4_UA
-#define PDA_V4_UA 1       // d <= 128: A operands (32 user rows each) per MFMA wave and B read.  2 = 512-user workgroups with
-                          // half the LDS reads per MFMA and the lists in HBM: measured, no faster on the large dense sweep (the
-                          // kernel runs at the chip's power limit either way) and 2 x slower on 65 536-user blocks and on the
-                          // candidate-heavy sweeps -- kept as a build option (tools/build_variant.sh)
+#define PDA_V4_UA 1       // d <= 128: A operands (32 user rows each) per MFMA wave and B read of the DEFAULT geometry.  (2 as a build
+                          // option was round 2's experiment; the 64-rows-per-wave mapping is the WIDE geometry, Geo4<D, 2>, now.)
 #endif
 #ifndef PDA_V4_GL
 #define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
+#endif
+#ifndef PDA_V4_HANDOVER_WS
+#define PDA_V4_HANDOVER_WS 1   // one-call sweeps: warm-up lists handed over through the workspace with K .. kCap4 keys per row
 #endif
 #ifndef PDA_V4_ROWS_INTERLEAVED
 #define PDA_V4_ROWS_INTERLEAVED 1   // rescoring: a candidate's lanes share every load (d <= 128)
@@ -850,7 +858,9 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
           }
 #pragma unroll
           for (int q = 0; q < PB; ++q)
-              keyv[q] = (rov[q] >= 0 && lane < K) ? g.out_keys[((size_t)split * g.n_users_blk + rov[q]) * K + lane] : 0ull;
+              keyv[q] = rov[q] < 0 ? 0ull
+                        : g.handover != nullptr ? (lane < kCap4 ? g.handover[((size_t)split * g.n_users_blk + rov[q]) * kCap4 + lane] : 0ull)
+                        : (lane < K ? g.out_keys[((size_t)split * g.n_users_blk + rov[q]) * K + lane] : 0ull);
 #pragma unroll
           for (int q = 0; q < PB; ++q) {
             const int rr = r0 + q * NW;
@@ -858,7 +868,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             const int rb = utile * UT + rr;
             const uint64_t key = keyv[q];
             const int c = __popcll(__ballot(key != 0ull));
-            if (lane < K) lists[(size_t)rr * CAPL + lane] = key;
+            if (lane < (g.handover != nullptr ? kCap4 : K)) lists[(size_t)rr * CAPL + lane] = key;
             uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
@@ -1888,7 +1898,7 @@ static bool lists_in_hbm4(int) { return true; }       // (every d may run with i
 // the workspace of the pda_score_topk4_* calls: [counters of pda_score_topk_workspace_bytes | list slots of every workgroup when the
 // lists live in HBM | Bloom filters, 128 B per user | warm-position train-item masks, 32 B per user and split | regrouping: 1024 bins, bin and sweep row of every user]
 struct Ws4 {
-    size_t lists, bloom, hmask, regroup, total;
+    size_t lists, bloom, hmask, regroup, handover, total;
 };
 static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -1902,7 +1912,8 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     w.bloom = al(b);
     w.hmask = al(w.bloom + (size_t)n_users_blk * 128);
     w.regroup = al(w.hmask + ((size_t)n_users_blk + kUserTile - 1) / kUserTile * (size_t)n_splits * kUserTile * 2 * kWarmTiles * 4);
-    w.total = w.regroup + (1024 + 4 * (size_t)n_users_blk) * 4;       // bins, bin_of, row_perm, pred_ws
+    w.handover = al(w.regroup + (1024 + 4 * (size_t)n_users_blk) * 4);       // (behind: bins, bin_of, row_perm, pred_ws)
+    w.total = w.handover + (size_t)n_splits * (size_t)n_users_blk * kCap4 * 8;
     return w;
 }
 extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
@@ -1953,6 +1964,8 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
 #else
             (phase == 1 || (L.n_tiles + n_splits - 1) / n_splits <= warm_tiles) ? 1 : 0};
 #endif
+    // warm-up and sweep in one call: K .. kCap4 keys per row through the workspace (see warm4_kernel)
+    if (phase == 3 && !g.warm_sorted && PDA_V4_HANDOVER_WS) g.handover = reinterpret_cast<uint64_t*>(wsb + W.handover);
     if (hist_indptr && (phase & 2)) {
         uint32_t* bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
         hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,
