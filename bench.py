@@ -361,8 +361,12 @@ def bench_train(args, dev, workload=None, quick=False):
 
     U, I = W.U.clone(), W.I.clone()
     loss = torch.zeros(3, device=dev)
-    out["sgd_fused"] = timed_graph(lambda i: ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, lr=lr,
-                                                          mode=ops.UPD_SGD_FUSED, loss_acc=loss, grouped=True), args.train_steps)
+    # (users are distinct inside a batch -- the sampler contract, B <= n_users --: their rows take plain stores)
+    out["sgd_fused"] = timed_graph(lambda i: ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED,
+                                                          loss_acc=loss, grouped=True, users_distinct=B <= W.n_users), args.train_steps)
+    U, I = W.U.clone(), W.I.clone()
+    out["sgd_fused_atomic_user_rows"] = timed_graph(lambda i: ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, lr=lr,
+                                                                            mode=ops.UPD_SGD_FUSED, loss_acc=loss, grouped=True), args.train_steps)
     U, I = W.U.clone(), W.I.clone()
     raw_batches = [ops.sample_triplets(W.hist_indptr, W.hist_indices, B, seed=2020, step=s_, n_pool=W.n_users,
                                        train_slots=W.hist_slots, neg_range=(0, W.n_items), pop_matrix=W.pop_train, sort_by_pos=False)

@@ -52,6 +52,11 @@ extern "C" {
 #define PDA_UPD_DENSE_GRAD 2 /* atomically sum gradients into dense gU/gI (feeds pda_adam_dense_sweep_f32)  */
 #define PDA_UPD_ANY_ORDER 0x100 /* OR into update_mode when the batch is NOT grouped by positive: equal positives are then
                                  * combined on chip wherever they sit in a workgroup (slightly slower on grouped batches) */
+#define PDA_UPD_USERS_DISTINCT 0x200 /* OR into update_mode of pda_bpr_step_f32(PDA_UPD_SGD_FUSED): the caller asserts that no user id
+                              * occurs twice in the batch (the reference's sampler draws users without replacement,
+                              * MF/train_new_api.py:380-381; pda_sample_triplets does while B <= the pool) -- the user row then
+                              * takes a plain store of (row read) - lr * gradient instead of d fp32 atomics.  With a repeated
+                              * user one of its updates is lost. */
 #define PDA_UPD_SGD_ITEMS 3  /* internal: what pda_bpr_step_shard_f32 runs (item rows updated, user grads out)   */
 #define PDA_UPD_DENSE_ITEMS 4 /* internal: pda_bpr_step_shard_f32 with gI_shard (item grads accumulated, user grads out) */
 

@@ -18,6 +18,7 @@ HEAD_RAW, HEAD_POP = 0, 1
 HIST_BY_BLOCK_ROW, HIST_BY_USER_ID = 0, 1
 UPD_NONE, UPD_SGD_FUSED, UPD_DENSE_GRAD = 0, 1, 2
 UPD_ANY_ORDER = 0x100
+UPD_USERS_DISTINCT = 0x200
 ADAM_REPLAY_FAST = 0x10
 MAX_K = 64
 TOPK_CAP = 60

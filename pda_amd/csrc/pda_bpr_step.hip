@@ -40,6 +40,7 @@ struct StepArgs {
     const void* Ufwd;  // tables the forward pass gathers from: U / I themselves (fp32) or their bf16 shadows
     const void* Ifwd;  // (pda_bpr_step_bf16: U / I are then the fp32 masters that take the update)
     int any_order;     // PDA_UPD_ANY_ORDER: equal positives are combined wherever they sit in the workgroup
+    int users_distinct;  // PDA_UPD_USERS_DISTINCT: no user id occurs twice in the batch -- its row takes a plain store
 };
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -136,7 +137,11 @@ __device__ __forceinline__ void bpr_step_body(const StepArgs& a, const int bid) 
         const f32x4 dpe_raw = dpe;
         if (a.mode == PDA_UPD_SGD_FUSED) {
             const float nlr = -a.lr;
-            atomic_add4(up, due * nlr);   // users are unique per batch (rd.sample) but atomics keep B > n_users safe
+            // users are unique per batch in the reference's sampler (MF/train_new_api.py:380-381): when the caller says so
+            // (PDA_UPD_USERS_DISTINCT) the row this triplet read is the row it writes, no atomics; otherwise atomics keep
+            // B > n_users (and any other sampler) safe
+            if (a.users_distinct && !BF && !COH) *reinterpret_cast<f32x4*>(up) = ue + due * nlr;
+            else atomic_add4(up, due * nlr);
             atomic_add4(np_, dne * nlr);  // negatives are uniform over the catalogue: duplicates are rare
             dpe = dpe * nlr;
             ptarget = pp;
@@ -731,12 +736,13 @@ extern "C" int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const 
     if (!U || !I || !users || !pos || !neg || B <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
-    update_mode &= ~PDA_UPD_ANY_ORDER;
+    [[maybe_unused]] const int users_distinct = (update_mode & PDA_UPD_USERS_DISTINCT) ? 1 : 0;
+    update_mode &= ~(PDA_UPD_ANY_ORDER | PDA_UPD_USERS_DISTINCT);
     if (update_mode < PDA_UPD_NONE || update_mode > PDA_UPD_DENSE_GRAD) return PDA_ERR_ARG;
     if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
     if (g_user && (!g_pos || !g_neg)) return PDA_ERR_ARG;
     StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, g_user, g_pos, g_neg, gU, gI, loss_acc,
-               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I, any_order};
+               B, 1.0f / (float)B, regs / reg_div, lr, update_mode, 0, d, U, I, any_order, users_distinct};
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (d) {
         case 32: return launch_step<32>(a, s);
@@ -753,7 +759,8 @@ extern "C" int pda_bpr_step_sample_f32(float* U, float* I, const int32_t* users,
     if (!U || !I || !users || !pos || !neg || B <= 0 || reg_div <= 0.f || !next) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
-    update_mode &= ~PDA_UPD_ANY_ORDER;
+    [[maybe_unused]] const int users_distinct = (update_mode & PDA_UPD_USERS_DISTINCT) ? 1 : 0;
+    update_mode &= ~(PDA_UPD_ANY_ORDER | PDA_UPD_USERS_DISTINCT);
     if (update_mode != PDA_UPD_SGD_FUSED && update_mode != PDA_UPD_NONE) return PDA_ERR_ARG;
     // the sampler job: validated like pda_sample_triplets_dev; its outputs must not be this step's inputs
     if (!next->users || !next->train_indptr || !next->train_indices || !next->pos || !next->neg || !next->step_dev || next->B <= 0 ||
@@ -784,7 +791,8 @@ extern "C" int pda_bpr_train_steps_f32(float* U, float* I, int d, float regs, fl
     if (!U || !I || !set0 || !set1 || !step_ctr || !barrier_ws || n_steps <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
     if (!loss_acc && !loss_steps) return PDA_ERR_ARG;
     const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
-    update_mode &= ~PDA_UPD_ANY_ORDER;
+    [[maybe_unused]] const int users_distinct = (update_mode & PDA_UPD_USERS_DISTINCT) ? 1 : 0;
+    update_mode &= ~(PDA_UPD_ANY_ORDER | PDA_UPD_USERS_DISTINCT);
     if (update_mode != PDA_UPD_SGD_FUSED) return PDA_ERR_ARG;
     TrainLoopArgs t{};
     const pda_sample_job* sets[2] = {set0, set1};
@@ -1077,7 +1085,8 @@ extern "C" int pda_bpr_step_bf16(const uint16_t* U_bf16, const uint16_t* I_bf16,
     if (!U_bf16 || !I_bf16 || !users || !pos || !neg || B <= 0 || reg_div <= 0.f) return PDA_ERR_ARG;
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     const int any_order = (update_mode & PDA_UPD_ANY_ORDER) ? 1 : 0;
-    update_mode &= ~PDA_UPD_ANY_ORDER;
+    [[maybe_unused]] const int users_distinct = (update_mode & PDA_UPD_USERS_DISTINCT) ? 1 : 0;
+    update_mode &= ~(PDA_UPD_ANY_ORDER | PDA_UPD_USERS_DISTINCT);
     if (update_mode < PDA_UPD_NONE || update_mode > PDA_UPD_DENSE_GRAD) return PDA_ERR_ARG;
     if (update_mode == PDA_UPD_DENSE_GRAD && (!gU || !gI)) return PDA_ERR_ARG;
     if (update_mode == PDA_UPD_SGD_FUSED && (!U_master || !I_master)) return PDA_ERR_ARG;   // bf16 rows take no atomics

@@ -208,7 +208,7 @@ class _MFBase:
             return self._train_step_bf16(users, pos, neg, pos_pop, neg_pop)
         if self.optimizer == "sgd_fused":
             ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size, lr=self.lr,
-                         mode=ops.UPD_SGD_FUSED, loss_acc=self._loss)
+                         mode=ops.UPD_SGD_FUSED, loss_acc=self._loss, users_distinct=bool(getattr(self, "users_distinct", False)))
             return self._loss
         if self.optimizer == "sgd":
             sc = getattr(self, "_sgd_scratch", None)

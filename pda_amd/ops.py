@@ -11,7 +11,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (HEAD_POP, HEAD_RAW, HIST_BY_BLOCK_ROW, HIST_BY_USER_ID, UPD_ANY_ORDER, UPD_DENSE_GRAD, UPD_NONE,  # noqa: F401
+from ._lib import (HEAD_POP, HEAD_RAW, HIST_BY_BLOCK_ROW, HIST_BY_USER_ID, UPD_ANY_ORDER, UPD_DENSE_GRAD, UPD_NONE, UPD_USERS_DISTINCT,  # noqa: F401
                    UPD_SGD_FUSED, check, ptr, stream_ptr)
 
 ADAM_BETA1, ADAM_BETA2, ADAM_EPS = 0.9, 0.999, 1e-8   # tf.train.AdamOptimizer defaults (MF/model_api.py:83)
@@ -541,9 +541,11 @@ def recommend_topk(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist=
 
 def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, lr: float = 0.0,
              mode: int = UPD_NONE, grads_out=None, gU=None, gI=None, loss_acc: Optional[torch.Tensor] = None,
-             grouped: bool = False):
+             grouped: bool = False, users_distinct: bool = False):
     """pda_bpr_step_f32.  grads_out = (g_user, g_pos, g_neg) float32 [B,d] or None.  grouped: the batch went through
-    group_triplets_by_pos / sort_triplets_by_pos (equal positives adjacent); otherwise PDA_UPD_ANY_ORDER is set."""
+    group_triplets_by_pos / sort_triplets_by_pos (equal positives adjacent); otherwise PDA_UPD_ANY_ORDER is set.
+    users_distinct: the caller's assertion that no user id repeats in the batch (the sampler contract, pda_amd.sampler
+    .distinct_users): PDA_UPD_USERS_DISTINCT, the fused step's user rows take plain stores instead of atomics."""
     lib = _lib.load()
     U = _need(U, torch.float32, "U")
     I = _need(I, torch.float32, "I")
@@ -560,8 +562,9 @@ def bpr_step(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, 
     gI = _need(gI, torch.float32, "gI", optional=True)
     loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
     check(lib.pda_bpr_step_f32(ptr(U), ptr(I), ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), B, d,
-                               float(regs), float(reg_div), float(lr), mode | (0 if grouped else UPD_ANY_ORDER), ptr(gu), ptr(gp),
-                               ptr(gn), ptr(gU), ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_f32")
+                               float(regs), float(reg_div), float(lr),
+                               mode | (0 if grouped else UPD_ANY_ORDER) | (UPD_USERS_DISTINCT if users_distinct and mode == UPD_SGD_FUSED else 0),
+                               ptr(gu), ptr(gp), ptr(gn), ptr(gU), ptr(gI), ptr(loss_acc), stream_ptr()), "pda_bpr_step_f32")
     if mode == UPD_SGD_FUSED:
         mark_modified(U, I)
 

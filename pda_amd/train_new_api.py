@@ -94,6 +94,9 @@ class DatasetApi_Model:
             self.Recommender = BPRMF(args, data_config, use_dataset_api=True, device=self.device)
         else:
             raise NotImplementedError("not implement this model: " + args.train)   # :590
+        # the device sampler draws a batch's users without replacement (like the reference, :380-381): the fused SGD step may
+        # then store its user rows plainly (PDA_UPD_USERS_DISTINCT)
+        self.Recommender.users_distinct = bool(getattr(generator_sampler, "distinct_users", False))
         self.n_items = data_config["n_items"]
         self._shard = topk_shard            # optional pda_amd.dist.ItemShardedTopK (multi-GPU evaluation)
         self.Create_Recommendation()

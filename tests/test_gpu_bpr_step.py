@@ -70,6 +70,34 @@ def test_sgd_fused_update_with_duplicate_items(dev, with_pop):
     np.testing.assert_allclose(It.cpu().numpy(), I1, atol=TOL)
 
 
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_sgd_fused_plain_user_store_with_distinct_users(dev, d):
+    """PDA_UPD_USERS_DISTINCT: with the reference sampler's contract (users drawn without replacement, MF/train_new_api.py:380-381)
+    the user rows take plain stores.  The step must still equal the oracle's SGD step, and U the atomic variant's to rounding (not
+    bit for bit: inside one launch a triplet may read an item row another triplet's atomics are half way through -- hogwild)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(23 + d)
+    nU, nI, B, regs, lr = 5000, 400, 2048, 1e-2, 0.05
+    U = (rng.standard_normal((nU, d)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.2).astype(np.float32)
+    users = rng.permutation(nU)[:B].astype(np.int32)
+    pos = rng.integers(0, nI, B).astype(np.int32)
+    neg = rng.integers(0, nI, B).astype(np.int32)
+    pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    U1, I1, _, ref_loss = po.train_step(U, I, users, pos, neg, pp, pn, regs, B, lr, optimizer="sgd")
+    res = []
+    for flag in (True, False):
+        Ut, It, ut, pt, nt, ppt, pnt = to(dev, U, I, users, pos, neg, pp, pn)
+        loss = torch.zeros(3, device=dev)
+        ops.bpr_step(Ut, It, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, mode=ops.UPD_SGD_FUSED, loss_acc=loss, users_distinct=flag)
+        np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=TOL, rtol=TOL)
+        np.testing.assert_allclose(Ut.cpu().numpy(), U1, atol=TOL)
+        np.testing.assert_allclose(It.cpu().numpy(), I1, atol=TOL)
+        res.append(Ut.cpu())
+    np.testing.assert_allclose(res[0].numpy(), res[1].numpy(), atol=1e-6)
+
+
 def _hot_batch(rng, nU, nI, B, hot_share=0.3):
     """A batch in which one positive item carries `hot_share` of the triplets and users repeat (B > nU)."""
     users = rng.integers(0, nU, B).astype(np.int32)
