@@ -330,7 +330,13 @@ int pda_bpr_step_f32(float* U, float* I, const int32_t* users, const int32_t* po
  *            (use PDA_UPD_NONE + pda_sgd_apply_f32 for such batches).
  *   pda_bpr_step_plan_bf16  the exact step on bf16 tables (config 5): forward pass on the bf16 rows, update on the fp32 masters,
  *            the touched bf16 rows re-rounded (RNE) by the same two launches (no pda_refresh_rows_bf16 afterwards). */
+/*   pda_triplet_plan_large(users, pos, neg, B, plan, workspace)   the same plan (same layout, same bytes) of ONE batch of any size
+ *            (pda_bpr_plan_large.hip: a device-wide stable radix sort of the 2B references instead of one workgroup's LDS) -- what
+ *            lets the exact step run at batch sizes where the launch floor no longer matters (B = 32 768 at config 2: see
+ *            profiles/round3_train_b_sweep.txt).  workspace: pda_triplet_plan_large_workspace_bytes(B) bytes. */
 size_t pda_triplet_plan_bytes(int B);
+size_t pda_triplet_plan_large_workspace_bytes(int B);
+int pda_triplet_plan_large(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, void* plan, void* workspace, void* stream);
 size_t pda_bpr_step_plan_scratch_bytes(int B, int d);
 int pda_triplet_plan(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int n_batches, void* plans, void* stream);
 int pda_bpr_step_plan_f32(float* U, float* I, const int32_t* users, const int32_t* pos, const int32_t* neg, const float* pos_pop,

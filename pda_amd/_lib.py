@@ -81,6 +81,8 @@ SIGNATURES = {
     "pda_triplet_plan_bytes": (_sz, [_i]),
     "pda_bpr_step_plan_scratch_bytes": (_sz, [_i, _i]),
     "pda_triplet_plan": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "pda_triplet_plan_large_workspace_bytes": (_sz, [_i]),
+    "pda_triplet_plan_large": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "pda_bpr_step_plan_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _i, _vp, _vp]),
     "pda_bpr_step_plan_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "pda_sgd_apply_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

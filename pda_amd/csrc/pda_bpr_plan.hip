@@ -30,10 +30,16 @@
 // stores, the shared item rows keep the atomics of the fused step (hogwild on those rows only).
 #include <cstdlib>
 #include "pda_common.h"
+#include "pda_plan_common.h"
 
 namespace {
 
-constexpr int kPlanMaxB = 4096;      // one workgroup sorts 2B <= 8192 references in LDS
+#ifndef PDA_PLAN_LONGU
+#define PDA_PLAN_LONGU 8      // launch B, long segments: entries per lane group and round trip
+#endif
+constexpr int kPlanMaxB = 4096;
+__host__ __device__ inline int xl_max(int B) { return (2 * B) / kXlMin + 1; }
+__host__ __device__ inline size_t scratch_floats_base(int B, int d) { return (size_t)B * (size_t)(d + 2) + 2 * ((size_t)B / 8 + 8); }      // one workgroup sorts 2B <= 8192 references in LDS
 
 struct PlanView {
     int* hdr;              // [4]: segments, "a user occurs twice", 2B, B
@@ -226,6 +232,7 @@ struct PlanStepArgs {
     int B;
     float inv_B, reg_c, lr;
     int exact;
+    int strided;           // launch B: lane group g of workgroup w takes segment g W + w (W workgroups with work) instead of w G + g
 };
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -367,6 +374,10 @@ __global__ void __launch_bounds__(512) plan_triplets_kernel(PlanStepArgs a) {
         float mf = -sm * a.inv_B;                   // -mean(maxi)          :114 / :704
         float rg = a.reg_c * 0.5f * ss;             // regs * l2 / batch    :117-120
         if (rejected) mf = rg = __int_as_float(0x7FC00000);
+        if (a.exact && blockIdx.x == 0 && a.strided) {          // (launch B's arrival counters of the very long segments)
+            int* xc = reinterpret_cast<int*>(a.scratch + scratch_floats_base(a.B, D));
+            for (int q = 0; q < xl_max(a.B); ++q) xc[q] = 0;
+        }
         if (a.exact) {
             // two plain stores per workgroup; launch B adds them up (64 workgroups x 3 float atomics on the same three words were
             // a visible share of this latency-bound launch)
@@ -381,18 +392,96 @@ __global__ void __launch_bounds__(512) plan_triplets_kernel(PlanStepArgs a) {
     }
 }
 
+// launch B, extra workgroups (large batches): workgroup j sums piece j % kXlPieces of very long segment j / kXlPieces; the last of a
+// segment's kXlPieces workgroups to arrive adds the partial sums in piece order and stores the row.
+template <int D, bool BF>
+__device__ __forceinline__ void plan_items_xl(const PlanStepArgs& a, int j, float* s_part) {
+    constexpr int L = D / 4, G = 256 / L, LONGU = PDA_PLAN_LONGU, STEP = G * LONGU;
+    __shared__ int s_last;
+    const int tid = threadIdx.x, g = tid / L, e = tid % L;
+    const int B = a.B;
+    const int k = j / kXlPieces, piece = j % kXlPieces;
+    if (a.hdr[1] != 0) return;                                      // rejected batch
+    const int n_xl = a.seg_start[2 * B + 1];
+    if (k >= n_xl) return;
+    const int sidx = a.seg_item[2 * B - 1 - k];                       // (the list of very long segments grows from the end of seg_item)
+    const int x = a.seg_item[sidx], b0 = a.seg_start[sidx], b1 = a.seg_start[sidx + 1];
+    const int len = b1 - b0;
+    const int r0 = b0 + (int)((long long)len * piece / kXlPieces), r1 = b0 + (int)((long long)len * (piece + 1) / kXlPieces);
+    const float* __restrict__ coef = a.scratch + (size_t)B * D;
+    const float* __restrict__ rows_old = a.scratch;
+    const int* __restrict__ entries = a.entries;
+    int* xl_cnt = reinterpret_cast<int*>(a.scratch + scratch_floats_base(B, D));
+    float* xl_part = a.scratch + scratch_floats_base(B, D) + xl_max(B);
+    f32x4 part = {0.f, 0.f, 0.f, 0.f};
+    for (int i0 = r0 + g; i0 < r1; i0 += STEP) {
+        int en2[LONGU];
+#pragma unroll
+        for (int q = 0; q < LONGU; ++q) en2[q] = entries[min(i0 + q * G, 2 * B - 1)];
+        float w2[LONGU];
+        f32x4 u2[LONGU];
+#pragma unroll
+        for (int q = 0; q < LONGU; ++q) {
+            const bool on = i0 + q * G < r1;
+            const int t = en2[q] < B ? en2[q] : en2[q] - B;
+            const float2 co = *reinterpret_cast<const float2*>(coef + 2 * (size_t)t);
+            w2[q] = on ? (en2[q] < B ? co.x : -co.y) : 0.f;
+            u2[q] = *reinterpret_cast<const f32x4*>(rows_old + (size_t)t * D + 4 * e);
+        }
+#pragma unroll
+        for (int q = 0; q < LONGU; ++q) part += u2[q] * w2[q];
+    }
+    *reinterpret_cast<f32x4*>(s_part + g * D + 4 * e) = part;
+    __syncthreads();
+    if (g == 0) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < G; ++q) sum += *reinterpret_cast<const f32x4*>(s_part + q * D + 4 * e);       // group order
+        *reinterpret_cast<f32x4*>(xl_part + ((size_t)k * kXlPieces + piece) * D + 4 * e) = sum;
+    }
+    __threadfence();                                                // the partial row is visible device-wide before the count
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&xl_cnt[k], 1) == kXlPieces - 1 ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                                // (acquire: the other workgroups' partial rows)
+    if (g == 0) {
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < kXlPieces; ++q)
+            sum += *reinterpret_cast<const volatile f32x4*>(xl_part + ((size_t)k * kXlPieces + q) * D + 4 * e);      // piece order
+        const f32x4 row = pda_load4<BF>(a.Ifwd, (size_t)x * D + 4 * e);
+        f32x4 old = row;
+        if constexpr (BF) old = *reinterpret_cast<const f32x4*>(a.I + (size_t)x * D + 4 * e);
+        const float cc = a.reg_c * (float)len;
+        const f32x4 nw = old - (sum + row * cc) * a.lr;
+        *reinterpret_cast<f32x4*>(a.I + (size_t)x * D + 4 * e) = nw;
+        if constexpr (BF) store_bf16x4(a.Ish + (size_t)x * D + 4 * e, nw);
+    }
+}
+
 // launch B: one segment (one distinct item row) per D/4 lanes.  The launch is a chain of dependent loads -- segment -> entries ->
 // coefficients and old user rows -> the row's store --, so every level is issued for ALL of a lane group's entries at once
 // (branch-free, clamped indices): three round trips for a segment of up to 8 entries, one more per 4 further entries and group.
 template <int D, bool BF>
-__global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_parts) {
-    constexpr int L = D / 4, G = 256 / L, SHORT = 8, LONGU = 4;
+__global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_parts, int n_normal) {
+    constexpr int L = D / 4, G = 256 / L, SHORT = 8, LONGU = PDA_PLAN_LONGU;
     __shared__ __attribute__((aligned(16))) float s_part[G * D];
     __shared__ int s_long[G];
     __shared__ int s_nlong;
     const int tid = threadIdx.x, g = tid / L, e = tid % L;
-    const int s = (int)blockIdx.x * G + g;
+    if ((int)blockIdx.x >= n_normal) {
+        plan_items_xl<D, BF>(a, (int)blockIdx.x - n_normal, s_part);
+        return;
+    }
+    // Which segment.  Small batches (LDS plan: segments in hash-bucket order): w G + g, known without a load.  Large batches (plan
+    // sorted by item id: the hot items -- neighbours wherever ids follow popularity -- would all fall to the first workgroups, each
+    // long segment a serial loop of its workgroup: launch B 80 of a 91 us step at B = 32 768): g W + w, neighbours apart.
     const int B = a.B;
+    int s = (int)blockIdx.x * G + g, n_wg = 0;
+    if (a.strided) {
+        n_wg = (a.hdr[0] + G - 1) / G;
+        s = g * n_wg + (int)blockIdx.x;
+        if (s >= 2 * B) s = 2 * B - 1;             // (the loads below are in bounds whatever they return)
+    }
     const float* __restrict__ coef = a.scratch + (size_t)B * D;
     const float* __restrict__ rows_old = a.scratch;
     const int* __restrict__ entries = a.entries;
@@ -419,10 +508,10 @@ __global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_p
         }
     }
     if (rejected != 0) return;                        // rejected batch (uniform over the grid)
-    if ((int)blockIdx.x * G >= n_seg) return;
+    if (a.strided ? (int)blockIdx.x >= n_wg : (int)blockIdx.x * G >= n_seg) return;
     if (tid == 0) s_nlong = 0;
     __syncthreads();
-    const bool have = s < n_seg;
+    const bool have = (a.strided ? g * n_wg + (int)blockIdx.x : s) < n_seg;
     const int x = have ? x_raw : 0, b0 = have ? b0_raw : 0, b1 = have ? b1_raw : 0;
     // level 2: the first SHORT entries and the row itself
     int en[SHORT];
@@ -445,22 +534,26 @@ __global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_p
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < SHORT; ++i) sum += ur[i] * w[i];          // plan order: bit-reproducible
-    if (have && b1 - b0 > SHORT && e == 0) s_long[atomicAdd(&s_nlong, 1)] = g;
+    const bool is_xl = a.strided != 0 && have && b1 - b0 >= kXlMin;          // (summed and stored by the extra workgroups of the launch)
+    if (have && !is_xl && b1 - b0 > SHORT && e == 0) s_long[atomicAdd(&s_nlong, 1)] = g;
     __syncthreads();
     const int nl = s_nlong;
     for (int k = 0; k < nl; ++k) {
         // a long segment: every lane group takes every G-th of its remaining entries, LONGU of them per round trip; the owner
         // adds the G partial sums in group order (which long segment comes first does not matter: each sum is formed the same way)
         const int og = s_long[k];
-        const int so = (int)blockIdx.x * G + og;
+        const int so = a.strided ? og * n_wg + (int)blockIdx.x : (int)blockIdx.x * G + og;
         const int ob0 = a.seg_start[so] + SHORT, ob1 = a.seg_start[so + 1];
         f32x4 part = {0.f, 0.f, 0.f, 0.f};
-        for (int i0 = ob0 + g; i0 < ob1; i0 += G * LONGU) {
-            int en2[LONGU];
+        // Two dependent loads per round (the entry, then its coefficient and old user row): pipelined over the rounds -- the rows
+        // of round r + 1 and the entries of round r + 2 are requested before round r is summed.  (Unpipelined, the one 3 000-entry
+        // segment of a Zipf batch of 32 768 triplets was 70 of the step's 90 us: 24 rounds of two round trips in one workgroup.)
+        constexpr int STEP = G * LONGU;
+        auto load_entries = [&](int i0, int (&en2)[LONGU]) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < LONGU; ++q) en2[q] = entries[min(i0 + q * G, 2 * B - 1)];
-            float w2[LONGU];
-            f32x4 u2[LONGU];
+        };
+        auto load_rows = [&](int i0, const int (&en2)[LONGU], float (&w2)[LONGU], f32x4 (&u2)[LONGU]) __attribute__((always_inline)) {
 #pragma unroll
             for (int q = 0; q < LONGU; ++q) {
                 const bool on = i0 + q * G < ob1;
@@ -469,8 +562,35 @@ __global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_p
                 w2[q] = on ? (en2[q] < B ? co.x : -co.y) : 0.f;
                 u2[q] = *reinterpret_cast<const f32x4*>(rows_old + (size_t)t * D + 4 * e);
             }
+        };
+        {
+            // (two buffer sets used in turn: a register copy from one to the other would wait for the very loads it is meant to hide)
+            int i0 = ob0 + g;
+            int enA[LONGU], enB[LONGU];
+            float wA[LONGU], wB[LONGU];
+            f32x4 uA[LONGU], uB[LONGU];
+            if (i0 < ob1) {
+                load_entries(i0, enA);
+                load_rows(i0, enA, wA, uA);                          // round 0
+                load_entries(i0 + STEP, enB);                        // entries of round 1
+            }
+            while (i0 < ob1) {
+                if (i0 + STEP < ob1) {
+                    load_rows(i0 + STEP, enB, wB, uB);               // rows of the next round
+                    load_entries(i0 + 2 * STEP, enA);                // entries of the one after
+                }
 #pragma unroll
-            for (int q = 0; q < LONGU; ++q) part += u2[q] * w2[q];
+                for (int q = 0; q < LONGU; ++q) part += uA[q] * wA[q];      // (round order, as before: the sum is unchanged)
+                i0 += STEP;
+                if (i0 >= ob1) break;
+                if (i0 + STEP < ob1) {
+                    load_rows(i0 + STEP, enA, wA, uA);
+                    load_entries(i0 + 2 * STEP, enB);
+                }
+#pragma unroll
+                for (int q = 0; q < LONGU; ++q) part += uB[q] * wB[q];
+                i0 += STEP;
+            }
         }
         *reinterpret_cast<f32x4*>(s_part + g * D + 4 * e) = part;
         __syncthreads();
@@ -479,7 +599,7 @@ __global__ void __launch_bounds__(256) plan_items_kernel(PlanStepArgs a, int n_p
         }
         __syncthreads();
     }
-    if (have) {
+    if (have && !is_xl) {
         const float cc = a.reg_c * (float)(b1 - b0);
         const f32x4 nw = old - (sum + row * cc) * a.lr;
         *reinterpret_cast<f32x4*>(a.I + (size_t)x * D + 4 * e) = nw;
@@ -496,7 +616,8 @@ int launch_plan_step(const PlanStepArgs& a, hipStream_t s) {
     if (PDA_PLAN_ONLY != 2) hipLaunchKernelGGL((plan_triplets_kernel<D, BF>), dim3((unsigned)((a.B + TPB - 1) / TPB)), dim3(512), 0, s, a);
     PDA_CHECK_LAUNCH();
     if (a.exact && PDA_PLAN_ONLY != 1) {
-        hipLaunchKernelGGL((plan_items_kernel<D, BF>), dim3((unsigned)((2 * a.B + G - 1) / G)), dim3(256), 0, s, a, (a.B + TPB - 1) / TPB);
+        const int n_normal = (2 * a.B + G - 1) / G, n_xl_wg = a.strided ? xl_max(a.B) * kXlPieces : 0;
+        hipLaunchKernelGGL((plan_items_kernel<D, BF>), dim3((unsigned)(n_normal + n_xl_wg)), dim3(256), 0, s, a, (a.B + TPB - 1) / TPB, n_normal);
         PDA_CHECK_LAUNCH();
     }
     return PDA_OK;
@@ -505,13 +626,13 @@ int launch_plan_step(const PlanStepArgs& a, hipStream_t s) {
 int run_plan_step(float* U, float* I, const void* Ufwd, const void* Ifwd, uint16_t* Ush, uint16_t* Ish, bool bf, const int32_t* users,
                   const int32_t* pos, const int32_t* neg, const float* pos_pop, const float* neg_pop, int B, int d, float regs, float reg_div,
                   float lr, const void* plan, float* scratch, int exact, float* loss_acc, hipStream_t s) {
-    if (!U || !I || !users || !pos || !neg || !plan || B <= 0 || B > kPlanMaxB || reg_div <= 0.f) return PDA_ERR_ARG;
+    if (!U || !I || !users || !pos || !neg || !plan || B <= 0 || B > (1 << 24) || reg_div <= 0.f) return PDA_ERR_ARG;     // (plans of B > 4096: pda_triplet_plan_large)
     if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
     if (exact && !scratch) return PDA_ERR_ARG;
     if (!exact && bf) return PDA_ERR_UNSUPPORTED;
     const PlanView pv = plan_view(const_cast<void*>(plan), B);
     const PlanStepArgs a{U, I, Ufwd, Ifwd, Ush, Ish, users, pos, neg, pos_pop, neg_pop, pv.hdr, pv.seg_item, pv.seg_start, pv.entries, pv.flags,
-                         scratch, loss_acc, B, 1.0f / (float)B, regs / reg_div, lr, exact ? 1 : 0};
+                         scratch, loss_acc, B, 1.0f / (float)B, regs / reg_div, lr, exact ? 1 : 0, B > kPlanMaxB ? 1 : 0};
     switch (d) {
         case 32: return bf ? launch_plan_step<32, true>(a, s) : launch_plan_step<32, false>(a, s);
         case 64: return bf ? launch_plan_step<64, true>(a, s) : launch_plan_step<64, false>(a, s);
@@ -526,7 +647,8 @@ int run_plan_step(float* U, float* I, const void* Ufwd, const void* Ifwd, uint16
 extern "C" size_t pda_triplet_plan_bytes(int B) { return B > 0 ? plan_bytes(B) : 0; }
 // old user rows [B][d], coefficients [B][2], one (mf, reg) pair per workgroup of launch A (at most B / 8 + 1 of them: d = 256)
 extern "C" size_t pda_bpr_step_plan_scratch_bytes(int B, int d) {
-    return (B > 0 && d > 0) ? ((size_t)B * (size_t)(d + 2) + 2 * ((size_t)B / 8 + 8)) * 4 : 0;
+    // ... then (large batches) one counter and kXlPieces partial rows per very long segment
+    return (B > 0 && d > 0) ? (scratch_floats_base(B, d) + (size_t)xl_max(B) * (1 + (size_t)kXlPieces * d)) * 4 : 0;
 }
 
 extern "C" int pda_triplet_plan(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int n_batches, void* plans, void* stream) {

@@ -585,13 +585,18 @@ def sgd_step_exact(U, I, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: f
     return scratch
 
 
+PLAN_LDS_MAX_B = 4096     # pda_triplet_plan sorts a batch inside one workgroup's LDS up to here
+_PLAN_WS = {}
+
+
 def triplet_plan_bytes(B: int) -> int:
     return _lib.load().pda_triplet_plan_bytes(B)
 
 
 def triplet_plan(users, pos, neg, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """pda_triplet_plan: users / pos / neg int32 [B] or [n, B] -> uint8 [n, pda_triplet_plan_bytes(B)] (one plan per batch; the
-    plan of batch j is out[j]).  B <= 4096."""
+    plan of batch j is out[j]).  B <= 4096: one workgroup per batch; larger batches: pda_triplet_plan_large, a device-wide sort
+    per batch (same plan bytes)."""
     lib = _lib.load()
     users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
     B = users.shape[-1]
@@ -601,6 +606,15 @@ def triplet_plan(users, pos, neg, out: Optional[torch.Tensor] = None) -> torch.T
         out = torch.empty((n, nb), dtype=torch.uint8, device=users.device)
     elif out.shape != (n, nb) or out.dtype != torch.uint8 or not out.is_contiguous():
         raise ValueError("out must be contiguous uint8 [n_batches, pda_triplet_plan_bytes(B)]")
+    if B > PLAN_LDS_MAX_B:
+        key = (B, users.device)
+        ws = _PLAN_WS.get(key)
+        if ws is None:
+            ws = _PLAN_WS[key] = torch.empty(lib.pda_triplet_plan_large_workspace_bytes(B), dtype=torch.uint8, device=users.device)
+        u2, p2, n2 = users.reshape(n, B), pos.reshape(n, B), neg.reshape(n, B)
+        for j in range(n):
+            check(lib.pda_triplet_plan_large(ptr(u2[j]), ptr(p2[j]), ptr(n2[j]), B, ptr(out[j]), ptr(ws), stream_ptr()), "pda_triplet_plan_large")
+        return out
     check(lib.pda_triplet_plan(ptr(users), ptr(pos), ptr(neg), B, n, ptr(out), stream_ptr()), "pda_triplet_plan")
     return out
 

@@ -100,7 +100,7 @@ class DeviceSampler:
         ops.sample_batches_into(self._queue, self.indptr, self.indices, seed=self.seed, step_dev=self._ctr, parity=self._calls & 1,
                                 user_pool=self.pool, n_pool=self.pool.numel(), train_slots=self.slots if self.with_pop else None,
                                 neg_range=self.neg_range, pop_matrix=self.pop)
-        if self.with_plan and B <= 4096:
+        if self.with_plan:
             # the plans of the whole queue in ONE launch (one workgroup per batch), like the batches themselves
             if self._plans is None:
                 nb = ops.triplet_plan_bytes(B)
@@ -116,7 +116,7 @@ class DeviceSampler:
                                                   step=self.step, user_pool=self.pool, n_pool=self.pool.numel(),
                                                   train_slots=self.slots if self.with_pop else None,
                                                   neg_range=self.neg_range, pop_matrix=self.pop)
-            self.plan = ops.triplet_plan(u, p, n)[0] if (self.with_plan and self.data.batch_size <= 4096) else None
+            self.plan = ops.triplet_plan(u, p, n)[0] if self.with_plan else None
             return (u, p, n, pp, pn) if self.with_pop else (u, p, n)
         if self._left == 0:
             self._refill()

@@ -40,11 +40,12 @@ def parse_plan(plan, B):
     return hdr, seg_item, seg_start, entries, flags
 
 
-@pytest.mark.parametrize("B", [1, 37, 2048, 4096])
+@pytest.mark.parametrize("B", [1, 37, 2048, 4096, 4097, 20000])
 def test_triplet_plan_is_the_sorted_segmentation_of_pos_and_neg(dev, B):
+    """(B > 4096: pda_triplet_plan_large, the device-wide sort -- same layout, same checks)"""
     from pda_amd import ops
     rng = np.random.default_rng(B)
-    nU, nI = 9000, 700
+    nU, nI = max(9000, B + 1000), 700
     n = 3
     us, ps, ns = [], [], []
     for _ in range(n):
@@ -106,6 +107,52 @@ def test_planned_exact_sgd_equals_the_oracle_on_a_hot_item_batch(dev, d, with_po
     touched = np.zeros(nI, bool)
     touched[pos] = touched[neg] = True
     assert torch.equal(out[0][1].cpu()[~torch.from_numpy(touched)], torch.from_numpy(I[~touched]))
+
+
+@pytest.mark.parametrize("B,d", [(8192, 64), (16384, 128), (32768, 32)])
+def test_planned_exact_sgd_on_large_batches(dev, B, d):
+    """Batches beyond one workgroup's LDS sort (pda_triplet_plan_large): the exact step equals the oracle's mini-batch SGD step on a
+    hot-item batch (30 % of the batch on one positive: a segment of thousands of references) and is bit-reproducible."""
+    from pda_amd import ops
+    rng = np.random.default_rng(7 + B)
+    nU, nI, regs, lr = B + 5000, 3000, 1e-2, 0.05
+    U = (rng.standard_normal((nU, d)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.2).astype(np.float32)
+    users, pos, neg = hot_batch(rng, nU, nI, B)
+    pp = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    pn = (rng.uniform(0, 1, B) ** 0.22).astype(np.float32)
+    U1, I1, _, ref_loss = po.train_step(U, I, users, pos, neg, pp, pn, regs, B, lr, optimizer="sgd")
+    out = []
+    for rep in range(2):
+        Ut, It, ut, pt, nt, ppt, pnt = to(dev, U, I, users, pos, neg, pp, pn)
+        loss = torch.zeros(3, device=dev)
+        plan = ops.triplet_plan(ut, pt, nt)[0]
+        assert ops.plan_header(plan)[1:] == (0, 2 * B, B)
+        ops.bpr_step_plan(Ut, It, ut, pt, nt, ppt, pnt, regs=regs, reg_div=B, lr=lr, plan=plan, loss_acc=loss)
+        np.testing.assert_allclose(loss.cpu().numpy(), ref_loss, atol=1e-5, rtol=1e-5)
+        np.testing.assert_allclose(Ut.cpu().numpy(), U1, atol=1e-6)
+        np.testing.assert_allclose(It.cpu().numpy(), I1, atol=2e-6)       # (the hot row: a sum of ~0.3 B terms)
+        out.append((Ut.clone(), It.clone()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
+def test_large_plan_path_gives_the_same_tables_as_the_lds_plan(dev, monkeypatch):
+    """The two plan builders order their segments differently (hash buckets vs item id) but sum every segment in the same order:
+    the step's tables must agree bit for bit."""
+    from pda_amd import ops
+    rng = np.random.default_rng(5)
+    nU, nI, B, d, regs, lr = 9000, 900, 2048, 64, 1e-2, 0.05
+    U = (rng.standard_normal((nU, d)) * 0.2).astype(np.float32)
+    I = (rng.standard_normal((nI, d)) * 0.2).astype(np.float32)
+    users, pos, neg = hot_batch(rng, nU, nI, B)
+    res = []
+    for large in (False, True):
+        monkeypatch.setattr(ops, "PLAN_LDS_MAX_B", 0 if large else 4096)
+        Ut, It, ut, pt, nt = to(dev, U, I, users, pos, neg)
+        plan = ops.triplet_plan(ut, pt, nt)[0]
+        ops.bpr_step_plan(Ut, It, ut, pt, nt, regs=regs, reg_div=B, lr=lr, plan=plan)
+        res.append((Ut.cpu(), It.cpu()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
 
 
 def test_planned_one_launch_step_plain_stores_on_unshared_rows(dev):
