@@ -668,7 +668,27 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
     from oracle import cpu_baseline as cb
     budget = budget or args.cpu_budget
     W = ev_res["W"]
-    cores = torch.get_num_threads()
+    # The threads that can actually run: the container's CPU quota, not the machine's logical CPUs (the GPU boxes of round 3 show
+    # 256 logical CPUs under a cgroup quota of 16 -- 128 threads there are 16 cores' worth of time, throttled).
+    logical = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            quota = float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        try:
+            qq, pp = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()), int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = qq / pp if qq > 0 else None
+        except (OSError, ValueError):
+            quota = None
+    cores = max(1, min(torch.get_num_threads(), logical, int(quota + 0.5) if quota else logical))
+    torch.set_num_threads(cores)
+    try:
+        import ctypes as _C0
+        _C0.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        pass
     U, pop = W.U.float().cpu(), W.pop_last.cpu()
     I = W.I.float().cpu()
     indptr, indices = W.hist_indptr.cpu(), W.hist_indices.cpu()
@@ -694,6 +714,7 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
     except OSError:
         pass
     out = {"value": rate, "unit": "users/s", "cores": cores, "kind": "port", "cpu_model": cpu_model,
+           "host_logical_cpus": logical, "cgroup_cpu_quota": quota,
            "protocol": "3 warm-up blocks, median of the timed 2048-user blocks (up to 10, bounded by the budget)",
            "sample": "%d users in 2048-user reference blocks x full %d-item catalogue, d=%d; C / OpenMP port of the path "
                      "(oracle/pda_cpu_port.c: fused score + head + mask + heap top-K, AVX2 + FMA, 32 users x 4 items cache blocks) on "
