@@ -5,13 +5,16 @@
 // What v3's profile said (profiles/round1k_pmc.txt): matrix pipe 39 % busy, ~11 non-MFMA instructions per MFMA, 35 % of
 // the wave cycles waiting -- every wave amortised its B reads, barriers and loop control over 32 user rows only, and every
 // ring drain (a chain of dependent gathers) stopped the MFMAs of its wave.  v4 therefore
-//   * gives each MFMA wave 64 user rows (UA = 2 A operands per B read: half the LDS reads, half the per-tile bookkeeping
-//     per MFMA; d = 256 keeps 32 rows -- its A operand alone is 128 VGPRs);
-//   * splits the workgroup into 4 MFMA waves and 4 RESCORING waves (wave w + 4 serves wave w: it owns the rows' lists,
-//     drains the candidate ring, gathers the exact rows, runs the fp32 fmaf chains, appends, compacts, publishes the
+//   * splits the workgroup into MFMA waves, LOADER waves and RESCORING waves (a rescoring wave owns the lists of its rows,
+//     drains their candidate rings, gathers the exact rows, runs the fp32 fmaf chains, appends, compacts, publishes the
 //     thresholds).  The MFMA waves never wait for a gather: the latency-bound half of the algorithm runs beside them on the
 //     same SIMDs.  Results do not depend on the timing: a stale threshold is a LOWER threshold (more candidates, never
-//     fewer), every candidate is rescored exactly, and the lists keep the exact best K;
+//     fewer), every candidate is rescored exactly, and the lists keep the exact best K.  Four geometries (Geo4<D, GM>, chosen by
+//     the caller's hint, identical keys): 8 MFMA x 32 rows + 4 loaders + 4 rescoring waves with the lists in the LDS (default,
+//     d <= 128); the same with the lists in the workspace and four tile slots (d = 256: 8 + 2 + 2; PDA_SWEEP_FEW_CANDIDATES);
+//     WIDE: 8 MFMA x 64 rows (two A operands per B read), 512 users per workgroup -- the dense sweep of large blocks, power-
+//     limited, wants the fewest LDS reads and DMA bytes per MFMA; MANY: 4 MFMA x 32 rows + 4 loaders + 8 rescoring waves, 128
+//     users per workgroup -- the raw head and natural order, hundreds of list insertions per user, are bound by rescoring;
 //   * has no s_barrier in the loop (it would tie the rescoring waves to the tile cadence): the MFMA waves hand tiles to each
 //     other through one monotonic LDS counter -- "my share of tile i+1 has landed and I am done reading tile i" -- which
 //     orders both the RAW and the WAR side of the two tile buffers;
