@@ -209,7 +209,8 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
 #define PDA_SWEEP_FEW_CANDIDATES 2
 /*        bit 2 = PDA_SWEEP_WIDE, a second geometry hint for the same kind of sweep on LARGE user blocks (>= 131 072 users, d <= 128):
  *        512 users per workgroup, 64 user rows per MFMA wave (two A operands per B read), lists in the workspace, four tile slots --
- *        half the LDS reads and half the tile traffic per MFMA, which on this power-limited part is clock.  Identical keys. */
+ *        half the LDS reads and half the tile traffic per MFMA, which on this power-limited part is clock.  Identical keys.
+ *        Dense sweeps only: with bit 0 set the hint is ignored. */
 #define PDA_SWEEP_WIDE 4
 /*        bit 3 = PDA_SWEEP_MANY_CANDIDATES, the geometry hint for the opposite kind of sweep (d <= 128): hundreds of list
  *        insertions per user -- the raw head, the popularity head in natural item order.  128 users per workgroup: four MFMA

@@ -730,6 +730,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_GL
 #define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
 #endif
+#ifndef PDA_V4_WIDE_PREFETCH
+#define PDA_V4_WIDE_PREFETCH 1   // wide geometry, d = 128: the next block's first B fragments are read under this block's last MFMAs
+#endif
 #ifndef PDA_V4_HANDOVER_WS
 #define PDA_V4_HANDOVER_WS 1   // one-call sweeps: warm-up lists handed over through the workspace with K .. kCap4 keys per row
 #endif
@@ -738,6 +741,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #endif
 #ifndef PDA_V4_RESCORE_AHEAD
 #define PDA_V4_RESCORE_AHEAD 1   // rescoring waves request the rows of the next pass before the appends of this one
+#endif
+#ifndef PDA_V4_NSLOT_WIDE
+#define PDA_V4_NSLOT_WIDE 8   // tile slots of the wide geometry (32-item blocks of 9.5 KiB)
 #endif
 #ifndef PDA_V4_NSLOT_MAX
 #define PDA_V4_NSLOT_MAX 5   // (timing experiments raise it: the votes of the early termination are then wrong)
@@ -787,7 +793,9 @@ struct Geo4 {
     static constexpr int BB = NB * HB;                   // one block = one ring slot
     static constexpr int NP = (BB + 1023) / 1024;        // 1 KiB DMA pieces per block; the last one may be half a piece (32 lanes)
     static constexpr int LASTL = (BB % 1024) ? (BB % 1024) / 16 : 64;
-    static constexpr int NSLOT = (GL || MANY) ? PDA_V4_NSLOT : 2;    // (MANY: 128 users' lists leave the LDS room for four slots)
+    // (MANY: 128 users' lists leave the LDS room for four slots; WIDE: eight -- its MFMA waves want block b + 1 landed before they
+    // start block b, see the cross-block prefetch: with four slots they waited for tiles a quarter of their time)
+    static constexpr int NSLOT = WIDE ? PDA_V4_NSLOT_WIDE : (GL || MANY) ? PDA_V4_NSLOT : 2;
     static constexpr size_t lds_tiles = NSLOT * (size_t)BB;
     // list slots per user row: a full list is compacted to its best K, i.e. every CAP - K insertions (half of what a candidate costs
     // its rescoring wave); 128 users leave the LDS room for 64
@@ -795,7 +803,7 @@ struct Geo4 {
     static constexpr size_t lds_lists = GL ? 0 : (size_t)UT * CAP * 8;
     static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 512;
     static_assert(NRINGS <= kMainWaves && RPW * MW == NRINGS && MPR * RESCORERS == NRINGS, "ring bookkeeping: eight words each");
-    static_assert(NSLOT >= 2 && NSLOT <= PDA_V4_NSLOT_MAX, "vote timing of the early termination");
+    static_assert(NSLOT >= 2 && (NSLOT <= PDA_V4_NSLOT_MAX || WIDE), "vote timing of the early termination (the wide geometry has no early-terminating instance)");
     static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
 };
 
@@ -1459,6 +1467,16 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     constexpr bool kAsmGeo = PDA_V4_ASM != 0 && D <= 128 && ((UA == 1 && NB == 2) || (UA == 2 && NB == 1 && G::WIDE));     // the block as one asm statement (below)
     constexpr bool PFX = !kAsmGeo && NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
     u32x4 bq[PF];
+    // wide geometry, d = 128, dense sweep: cross-block prefetch of the B fragments (pda_v4_block_asm.h, BlockAsm2P)
+    constexpr bool kPrefetchGeo = kAsmGeo && G::WIDE && D == 128 && !ES && PDA_V4_WIDE_PREFETCH != 0;
+    [[maybe_unused]] u32x4 tqa[3] = {}, tqb[3] = {};
+    [[maybe_unused]] bool swp = false;
+    if constexpr (kPrefetchGeo) {
+        if (n_blk > 0) {
+            ensure_landed(0);
+            BlockAsm2Pro<D>::run(tqa[0], tqa[1], tqa[2], lane_base_lds);
+        }
+    }
     int dead_from = 0x7FFFFFFF;                // first tile from which no row of this wave can be reached (early termination)
     for (int b = 0; b < n_blk && !stopped; ++b) {
         const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
@@ -1505,11 +1523,13 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         // With three slots the first B fragments of block b + 1 are read while the MFMAs of block b are still being issued: the
         // wave comes back from the accumulator test of block b with its operands in registers.
         const bool has_next = (PFX || kAsmGeo) && b + 1 < n_blk;
-        if (b == 0 || !PFX) ensure_landed(b);       // (asm path: a poll only when the answer read under the previous block said "not yet")
+        if constexpr (kPrefetchGeo) ensure_landed(b + 1 < n_blk ? b + 1 : b);      // (this block's statement reads the start of the next)
+        else if (b == 0 || !PFX) ensure_landed(b);       // (asm path: a poll only when the answer read under the previous block said "not yet")
         // "has block b + 1 landed?" is asked here and looked at half a block later, in front of the first read of block b + 1:
         // a synchronous poll costs an LDS round trip per block (440 cycles of a block's 1 600 on a busy LDS)
         unsigned lnd[kLoaders];
-        const bool asked = has_next && landed_c < (unsigned)(b + 2);
+        // (with the cross-block prefetch the answer is wanted a block earlier: "has block b + 2 landed?")
+        const bool asked = has_next && landed_c < (unsigned)min(b + (kPrefetchGeo ? 3 : 2), n_blk);
         if (asked) {
 #pragma unroll
             for (int z = 0; z < kLoaders; ++z) lnd[z] = lds_ld(&s_landed[z]);
@@ -1540,6 +1560,24 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                     locv[0] = (int)piq[1];
                     popv[NB - 1] = __uint_as_float(piq[2]);
                     locv[NB - 1] = (int)piq[3];
+                } else if constexpr (kPrefetchGeo) {
+                    // The first three B fragments of block b + 1 are read under the last MFMAs of block b (the wave waits for that block
+                    // to have landed first): a wave comes back from its accumulator test with operands in registers.  (A block of
+                    // this geometry is 576 cycles of MFMAs per wave; what a wave does between two blocks -- drain, test, hand-over,
+                    // the first LDS round trip -- has to fit under the OTHER wave's 576 for the pipe to stay busy.)
+                    u32x2 pid;
+                    const unsigned an = lane_base_lds + (unsigned)(((b + 1 < n_blk ? b + 1 : b) % NSLOT) * BB);      // (last block: itself, unused)
+                    const unsigned api = a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32);
+#define PDA_BLK2P(PRE, NXT)                                                                                                            \
+    do {                                                                                                                               \
+        if (!swp) BlockAsm2P<D, PRE, NXT>::run(acc[0][0], acc[UA - 1][0], pid, tqa[0], tqa[1], tqa[2], tqb[0], tqb[1], tqb[2], ah, aex, a0, api, an); \
+        else BlockAsm2P<D, PRE, NXT>::run(acc[0][0], acc[UA - 1][0], pid, tqb[0], tqb[1], tqb[2], tqa[0], tqa[1], tqa[2], ah, aex, a0, api, an);      \
+    } while (0)
+                    PDA_BLK2P(true, true);
+#undef PDA_BLK2P
+                    swp = !swp;                            // (the triple that took the next block's fragments is that block's own)
+                    popv[0] = __uint_as_float(pid[0]);
+                    locv[0] = (int)pid[1];
                 } else {
                     u32x2 pid;
                     BlockAsm2<D>::run(acc[0][0], acc[UA - 1][0], pid, ah, aex, a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
@@ -1831,34 +1869,47 @@ __global__ void __launch_bounds__(1024) stop_scatter4_kernel(const int* __restri
 template <int D, int HEAD, bool BF, int GM>
 int launch_sweep4(const Args4& g, hipStream_t stream) {
     using G = Geo4<D, GM>;
+    constexpr bool kHasES = GM != 2;         // (the wide geometry is a dense sweep's: launch4 sends early-terminating sweeps elsewhere)
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false, GM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)G::lds_total) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true, GM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)G::lds_total) != hipSuccess)
             return PDA_ERR_LAUNCH;
+        if constexpr (kHasES) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, true, GM>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)G::lds_total) != hipSuccess)
+                return PDA_ERR_LAUNCH;
+        }
         attr_set = 1;
     }
     const int utiles = (g.n_users_blk + G::UT - 1) / G::UT;
-    if (g.sufA != nullptr && g.regroup_ws != nullptr) {
-        Args4 gp = g;
-        int* bins = g.regroup_ws;
-        int* bin_of = bins + 1024;
-        int32_t* perm = bin_of + g.n_users_blk;
-        if (hipMemsetAsync(bins, 0, 1024 * sizeof(int), stream) != hipSuccess) return PDA_ERR_LAUNCH;
-        hipLaunchKernelGGL((stop_predict4_kernel<D, BF>), dim3((unsigned)((g.n_users_blk + 31) / 32)), dim3(256), 0, stream, g, bin_of);
-        const unsigned hb = (unsigned)((g.n_users_blk + 4095) / 4096);
-        hipLaunchKernelGGL(stop_hist4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, g.n_users_blk, bins);
-        hipLaunchKernelGGL(stop_scan4_kernel, dim3(1), dim3(1024), 0, stream, bins);
-        hipLaunchKernelGGL(stop_scatter4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, bins, g.n_users_blk, perm);
-        PDA_CHECK_LAUNCH();
-        gp.row_perm = perm;
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
-    } else if (g.sufA != nullptr)
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
-    else
-        hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+    if constexpr (kHasES) {
+        if (g.sufA != nullptr && g.regroup_ws != nullptr) {
+            Args4 gp = g;
+            int* bins = g.regroup_ws;
+            int* bin_of = bins + 1024;
+            int32_t* perm = bin_of + g.n_users_blk;
+            if (hipMemsetAsync(bins, 0, 1024 * sizeof(int), stream) != hipSuccess) return PDA_ERR_LAUNCH;
+            hipLaunchKernelGGL((stop_predict4_kernel<D, BF>), dim3((unsigned)((g.n_users_blk + 31) / 32)), dim3(256), 0, stream, g, bin_of);
+            const unsigned hb = (unsigned)((g.n_users_blk + 4095) / 4096);
+            hipLaunchKernelGGL(stop_hist4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, g.n_users_blk, bins);
+            hipLaunchKernelGGL(stop_scan4_kernel, dim3(1), dim3(1024), 0, stream, bins);
+            hipLaunchKernelGGL(stop_scatter4_kernel, dim3(hb), dim3(1024), 0, stream, bin_of, bins, g.n_users_blk, perm);
+            PDA_CHECK_LAUNCH();
+            gp.row_perm = perm;
+            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, gp);
+            PDA_CHECK_LAUNCH();
+            return PDA_OK;
+        }
+        if (g.sufA != nullptr) {
+            hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, true, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
+            PDA_CHECK_LAUNCH();
+            return PDA_OK;
+        }
+    } else if (g.sufA != nullptr) {
+        return PDA_ERR_ARG;
+    }
+    hipLaunchKernelGGL((sweep4_kernel<D, HEAD, BF, false, GM>), dim3((unsigned)(utiles * g.n_splits)), dim3(64 * G::WAVES), G::lds_total, stream, g);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -1883,7 +1934,7 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
     if (phase & 2) {
         // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
-            if (geometry == 2) return launch_sweep4<D, HEAD, BF, 2>(g, stream);
+            if (geometry == 2 && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
             if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
         }
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {

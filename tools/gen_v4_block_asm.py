@@ -135,6 +135,74 @@ def emit2(D, F):
     return "\n".join(out)
 
 
+def block_wide_pf(D, pre, nxt):
+    """block_wide with cross-block prefetch (d = 128: nine fragment reads per block, six registers).  Registers p0..p2 carry own
+    fragments 0..2 and 6..8, q0..q2 own fragments 3..5 -- and, behind them (NXT), fragments 0..2 of the NEXT block, read under
+    this block's last MFMAs: the caller passes them as p0..p2 of the next block (PRE), i.e. the two triples swap roles from block to
+    block.  Every wait is counted on the simulated issue order; the statement ends with lgkmcnt(0): nothing is pending when the
+    compiler gets the registers back."""
+    NM = D // 16
+    assert NM == 8
+    own = [("frag", 32 * m) for m in range(NM)] + [("frag", 2 * D)] + [("pi", 0)]
+    n_frag = NM + 1
+    reg = lambda i: ("p%d" % (i % 3)) if (i % 6) < 3 else ("q%d" % (i % 3))
+    lines, order = [], []
+
+    def issue_own(i):
+        kind, off = own[i]
+        lines.append(("ds_read_b128 %%[%s], %%[addr] offset:%d" % (reg(i), off)) if kind == "frag" else "ds_read_b64 %[pi], %[addrpi]")
+        order.append(("own", i))
+
+    def issue_next(j):
+        lines.append("ds_read_b128 %%[q%d], %%[addrn] offset:%d" % (j, own[j][1]))
+        order.append(("next", j))
+
+    for i in range(3 if pre else 0, 6):
+        issue_own(i)
+    nj = 0
+    for s in range(n_frag):
+        if not (pre and s < 3):
+            pos = order.index(("own", s))
+            lines.append("s_waitcnt lgkmcnt(%d)" % (len(order) - (pos + 1)))
+        for u in range(2):
+            a = ("%%[a%d_%d]" % (s, u)) if s < NM else ("%%[aex_%d]" % u)
+            lines.append("v_mfma_f32_32x32x16_bf16 %%[acc%d], %s, %%[%s], %s" % (u, a, reg(s), "0" if s == 0 else "%%[acc%d]" % u))
+        if s + 6 < len(own):
+            issue_own(s + 6)
+        if nxt and nj < 3 and s >= 3 + nj:          # q(nj) held own fragment 3 + nj: free once its MFMAs have been issued
+            issue_next(nj)
+            nj += 1
+    assert not nxt or nj == 3
+    lines.append("s_waitcnt lgkmcnt(0)")
+    lines.append("s_nop 15")
+    lines.append("s_nop 3")
+    return NM, lines
+
+
+def emit2pf(D, pre, nxt):
+    NM, lines = block_wide_pf(D, pre, nxt)
+    out = []
+    out.append("template <>")
+    out.append("struct BlockAsm2P<%d, %s, %s> {" % (D, "true" if pre else "false", "true" if nxt else "false"))
+    out.append("    // p0..p2: PRE: fragments 0..2 of this block on entry.  q0..q2: NXT: fragments 0..2 of the next block on exit.")
+    out.append("    static __device__ __forceinline__ void run(f32x16& acc0, f32x16& acc1, u32x2& pi, u32x4& p0, u32x4& p1, u32x4& p2, u32x4& q0, u32x4& q1, u32x4& q2,")
+    out.append("                                               const u32x4 (&ah)[2][%d], const u32x4 (&aex)[2], unsigned addr, unsigned addr_pi, unsigned addrn) {" % NM)
+    out.append("#if defined(__HIP_DEVICE_COMPILE__)")
+    out.append("        asm volatile(")
+    for l in lines:
+        out.append('            "%s\\n\\t"' % l)
+    outs = ['[acc0] "=&v"(acc0)', '[acc1] "=&v"(acc1)', '[pi] "=&v"(pi)'] + ['[p%d] "+v"(p%d)' % (i, i) for i in range(3)] + ['[q%d] "=&v"(q%d)' % (i, i) for i in range(3)]
+    ins = ['[a%d_%d] "v"(ah[%d][%d])' % (m, u, u, m) for u in range(2) for m in range(NM)] + ['[aex_%d] "v"(aex[%d])' % (u, u) for u in range(2)] + \
+          ['[addr] "v"(addr)', '[addrpi] "v"(addr_pi)', '[addrn] "v"(addrn)']
+    out.append("            : " + ", ".join(outs))
+    out.append("            : " + ", ".join(ins))
+    out.append('            : "memory");')
+    out.append("#endif")
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
 def main():
     print("// GENERATED by tools/gen_v4_block_asm.py -- do not edit.  One 64-item block of sweep4_kernel: %d fragments in flight." % F_DEFAULT)
     print("// acc0 / acc1: the two half-tiles' accumulators (the folded test included); pi = (pop, id) of half-tile 0 in .xy, of half-tile 1 in .zw.")
@@ -148,6 +216,25 @@ def main():
     print("struct BlockAsm2;")
     for D in (64, 128):
         print(emit2(D, F_WIDE))
+    assert F_WIDE == 6
+    print("// the wide block with cross-block prefetch (see block_wide_pf in the generator)")
+    print("template <int D, bool PRE, bool NXT>")
+    print("struct BlockAsm2P;")
+    for D in (128,):                 # (d = 64 has five fragment reads per block: it keeps BlockAsm2)
+        # only <true, true> is used: with self-loading variants beside it in the loop hipcc spilled 108 registers.  The kernel reads
+        # fragments 0..2 of its first block with BlockAsm2Pro and waits for block b + 1 to have landed before it runs block b.
+        print(emit2pf(D, True, True))
+        print("template <int D>")
+        print("struct BlockAsm2Pro;")
+        print("template <>")
+        print("struct BlockAsm2Pro<%d> {" % D)
+        print("    static __device__ __forceinline__ void run(u32x4& p0, u32x4& p1, u32x4& p2, unsigned addr) {")
+        print("#if defined(__HIP_DEVICE_COMPILE__)")
+        print('        asm volatile("ds_read_b128 %0, %3\\n\\tds_read_b128 %1, %3 offset:32\\n\\tds_read_b128 %2, %3 offset:64\\n\\ts_waitcnt lgkmcnt(0)"')
+        print('                     : "=&v"(p0), "=&v"(p1), "=&v"(p2) : "v"(addr) : "memory");')
+        print("#endif")
+        print("    }")
+        print("};")
 
 
 if __name__ == "__main__":
