@@ -742,6 +742,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_RESCORE_AHEAD
 #define PDA_V4_RESCORE_AHEAD 1   // rescoring waves request the rows of the next pass before the appends of this one
 #endif
+#ifndef PDA_V4_RING_MANY
+#define PDA_V4_RING_MANY 128   // candidate ring entries of the many-candidates geometry (256 / 512: no faster -- later thresholds, more candidates)
+#endif
 #ifndef PDA_V4_NSLOT_WIDE
 #define PDA_V4_NSLOT_WIDE 8   // tile slots of the wide geometry (32-item blocks of 9.5 KiB)
 #endif
@@ -801,7 +804,8 @@ struct Geo4 {
     // its rescoring wave); 128 users leave the LDS room for 64
     static constexpr int CAP = MANY ? 64 : kCap4;
     static constexpr size_t lds_lists = GL ? 0 : (size_t)UT * CAP * 8;
-    static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * kRing4 * 4 + 512;
+    static constexpr int RING = MANY ? PDA_V4_RING_MANY : kRing4;      // entries per candidate ring (a push needs 64 free)
+    static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * RING * 4 + 512;
     static_assert(NRINGS <= kMainWaves && RPW * MW == NRINGS && MPR * RESCORERS == NRINGS, "ring bookkeeping: eight words each");
     static_assert(NSLOT >= 2 && (NSLOT <= PDA_V4_NSLOT_MAX || WIDE), "vote timing of the early termination (the wide geometry has no early-terminating instance)");
     static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
@@ -816,6 +820,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     constexpr int NB = G::NB, ROWS = G::ROWS, UT = G::UT, RB = G::RB, HB = G::HB, BB = G::BB, NP = G::NP, UA = G::UA, NSLOT = G::NSLOT;
     constexpr bool GL = G::GL;
     constexpr int CAPL = G::CAP;                       // list slots per user row
+    constexpr int RINGL = G::RING;                     // entries per candidate ring
     constexpr int NM = D / 16;
     constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -824,8 +829,8 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                          : reinterpret_cast<uint64_t*>(smem + G::lds_tiles);
     int* cntl = reinterpret_cast<int*>(smem + G::lds_tiles + G::lds_lists);                  // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                                       // [UT] exact K-th value (-inf until K entries)
-    unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [8][kRing4]
-    unsigned* sync = rings + kMainWaves * kRing4;
+    unsigned* rings = reinterpret_cast<unsigned*>(taul + UT);                                // [8][RINGL]
+    unsigned* sync = rings + kMainWaves * RINGL;
     unsigned* s_landed = sync;                // [4]
     unsigned* s_stop = sync + 108;            // [1]  early termination: loaders leave
     unsigned* s_released = sync + 4;          // [8]
@@ -995,8 +1000,8 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
 #pragma unroll
             for (int z = 0; z < kMPR; ++z) tl[z] = lds_ld(&s_tail[kMPR * r + z]);
             PDA_CBAR();                                                                            // (the words BEHIND the tails)
-            const unsigned wA = rings[(kMPR * r + yA) * kRing4 + (hA + (unsigned)li) % kRing4];
-            const unsigned wB = kMPR >= 2 ? rings[(kMPR * r + yB) * kRing4 + (hB + (unsigned)(GS - 1 - li)) % kRing4] : 0u;
+            const unsigned wA = rings[(kMPR * r + yA) * RINGL + (hA + (unsigned)li) % RINGL];
+            const unsigned wB = kMPR >= 2 ? rings[(kMPR * r + yB) * RINGL + (hB + (unsigned)(GS - 1 - li)) % RINGL] : 0u;
             unsigned take[kMPR], taken = 0u, total = 0u;
             if constexpr (kMPR == 1) {
                 take[0] = (unsigned)min((int)(tl[0] - head[0]), CPP);
@@ -1394,7 +1399,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
 #pragma unroll
         for (int rg = 0; rg < RPW; ++rg) {
             uint32_t m = RPW == 1 ? m_all : (rg == 0 ? (m_all & 0xFF00u) : (m_all & 0x00FFu));
-            unsigned* ring = rings + (RPW * w + rg) * kRing4;
+            unsigned* ring = rings + (RPW * w + rg) * RINGL;
             while (__any(m != 0)) {
                 const bool act = m != 0;
                 const int bit = 31 - __builtin_clz(m | 1u);
@@ -1402,7 +1407,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                 const int row = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h - rg * RPR;
                 m &= ~(1u << bit);
                 const uint64_t pm = __ballot(act);
-                if (tail[rg] + 64u - head_c[rg] > (unsigned)kRing4) {      // ring full: publish what is there and wait for the rescoring wave
+                if (tail[rg] + 64u - head_c[rg] > (unsigned)RINGL) {      // ring full: publish what is there and wait for the rescoring wave
                     PDA_CBAR();
                     lds_st(&s_tail[RPW * w + rg], tail[rg]);
                     unsigned spin = 0;
@@ -1410,10 +1415,10 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
                     do {
                         head_c[rg] = lds_ld(&s_head[RPW * w + rg]);
                         if (++spin > kSpinMax) { if (lane == 0) g.stats[0] = 2u; break; }
-                    } while (tail[rg] + 64u - head_c[rg] > (unsigned)kRing4);
+                    } while (tail[rg] + 64u - head_c[rg] > (unsigned)RINGL);
                     PROF_T1(tq, 2);
                 }
-                const unsigned slot = (tail[rg] + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))) % kRing4;
+                const unsigned slot = (tail[rg] + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0))) % RINGL;
                 if (act) ring[slot] = ((uint32_t)row << 26) | (uint32_t)loc;
                 tail[rg] += (unsigned)__popcll(pm);
             }
