@@ -231,7 +231,14 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
         # the threshold test), survivors rescored exactly in fp32.
         gen = ops.score_kernel(W.d, args.K, n_local, "order" if use_order else False)
         kname = ("sweep4_kernel" if gen == "v4" else "score_topk_v3_kernel")
+        hint = ops.few_candidates_hint(head, "order" if use_order else False, Bu_rank, W.d) if gen == "v4" else 0
+        geo = {0: "256 users per workgroup, lists in LDS (Geo4<D, 0>)", 2: "lists in the workspace (Geo4<D, 1>)", 4: "wide: 512 users per workgroup (Geo4<D, 2>)",
+               8: "many candidates: 128 users per workgroup (Geo4<D, 3>)"}.get(hint, "")
+        if W.d == 256:
+            geo = "256 users per workgroup, lists in the workspace, 8 + 2 + 2 waves (Geo4<256, 0>)"
         roof = {"kernel": "%s<%d,%s,%s>%s" % (kname, W.d, hd, td_name, " visiting order, early_stop=0" if use_order else " natural order"),
+                "kernel_template": ("sweep4_kernel<%d, %d, %s, false, %d>" % (W.d, 1 if head else 0, "true" if td_name == "bf16" else "false", {0: 0, 2: 1, 4: 2, 8: 3}.get(hint, 0))) if gen == "v4" else None,
+                "geometry": geo,
                 "bound": "mfma", "achieved": alg_tf,
                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_BF16_MFMA_TFLOPS,
                 "traffic": profile_traffic(kname, workload if (world_all == 1 and Bu == 262144) else "none"), "kernel_ms": k_ms, "flops_per_launch": flops,
