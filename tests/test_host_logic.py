@@ -87,3 +87,35 @@ def test_unknown_modes_raise_like_the_reference():
     a = parse.parse_args(["--train", "temp_pop"])
     with pytest.raises(NotImplementedError):
         t.DatasetApi_Model(a, {"n_users": 4, "n_items": 4}, 16, lambda: iter(()), device="cpu")
+
+
+def test_sweep_kernel_and_geometry_selection(monkeypatch):
+    """Which kernel generation and which workgroup geometry a score call gets (pda_amd.ops.score_kernel / few_candidates_hint):
+    pure host logic, results never depend on it -- but the measured defaults should not drift unnoticed."""
+    from pda_amd import ops
+    for var in ("PDA_SCORE_KERNEL", "PDA_SCORE_LISTS", "PDA_SCORE_PRUNE"):
+        monkeypatch.delenv(var, raising=False)
+    P, R = ops.HEAD_POP, ops.HEAD_RAW
+    # generation: v4 wherever it fits, except natural order / raw head at d = 256
+    assert ops.score_kernel(128, 50, 200000, True, P) == "v4"
+    assert ops.score_kernel(128, 50, 200000, "order", P) == "v4"
+    assert ops.score_kernel(128, 50, 200000, False, P) == "v4"          # natural order: many-candidates geometry (round 3)
+    assert ops.score_kernel(64, 50, 20000, "order", R) == "v4"
+    assert ops.score_kernel(256, 50, 250000, True, P) == "v4"
+    assert ops.score_kernel(256, 50, 250000, False, P) == "v3"
+    assert ops.score_kernel(256, 50, 250000, "order", R) == "v3"
+    assert ops.score_kernel(32, 50, 1000, True, P) == "v3"
+    # geometry hints (bits of early_stop): 4 = wide, 8 = many candidates, 0 = default
+    assert ops.few_candidates_hint(P, "order", 262144, 128) == 4          # the headline: dense sweep of a large block
+    assert ops.few_candidates_hint(P, "order", 131072, 64) == 4
+    assert ops.few_candidates_hint(P, "order", 131071, 128) == 0          # 512-user workgroups would leave CUs idle
+    assert ops.few_candidates_hint(P, "order", 262144, 256) == 0
+    assert ops.few_candidates_hint(P, True, 262144, 128) == 0             # early-terminating: a warm-up and a sort
+    assert ops.few_candidates_hint(P, False, 50000, 64) == 8              # natural order
+    assert ops.few_candidates_hint(R, "order", 262144, 128) == 8          # raw head by norm
+    assert ops.few_candidates_hint(R, False, 65536, 128) == 8
+    assert ops.few_candidates_hint(R, True, 65536, 128) == 0
+    assert ops.few_candidates_hint(R, "order", 65536, 256) == 0
+    assert ops.prune_default(P, 128) is True and ops.prune_default(R, 128) == "order" and ops.prune_default(R, 256) is False
+    monkeypatch.setenv("PDA_SCORE_LISTS", "many")
+    assert ops.few_candidates_hint(P, "order", 262144, 128) == 8
