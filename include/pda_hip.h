@@ -207,7 +207,7 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        An item shard of an R-rank job wants 4 / R: the R warm-ups cover R x 64 n items between them, and the warm-up is the
  *        per-rank cost that does not shrink with the shard. */
 #define PDA_SWEEP_FEW_CANDIDATES 2
-/*        bit 2 = PDA_SWEEP_WIDE, a second geometry hint for the same kind of sweep on LARGE user blocks (>= 131 072 users, d <= 128):
+/*        bit 2 = PDA_SWEEP_WIDE, a second geometry hint for the same kind of sweep on LARGE user blocks (> 65 536 users, d <= 128):
  *        512 users per workgroup, 64 user rows per MFMA wave (two A operands per B read), lists in the workspace, four tile slots --
  *        half the LDS reads and half the tile traffic per MFMA, which on this power-limited part is clock.  Identical keys.
  *        Dense sweeps only: with bit 0 set the hint is ignored. */

@@ -205,7 +205,9 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
     return "v4"        # (natural order at d <= 128 too since the many-candidates geometry: C3 65 536 users 7.0 vs 8.8 ms)
 
 
-WIDE_MIN_USERS = 131072      # below that, 512-user workgroups leave CUs idle
+# The wide geometry pays as soon as the 256-user geometry needs a second round of workgroups (> 256 x 256 users): measured at config 3,
+# 98 304 users 5.22 vs 5.78 ms, 131 072 x 50 000 items 1.75 vs 1.84 ms; at 65 536 users (one round of 256 workgroups) 5.00 vs 3.55 ms.
+WIDE_MIN_USERS = 65537
 
 
 def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:

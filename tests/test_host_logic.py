@@ -108,7 +108,8 @@ def test_sweep_kernel_and_geometry_selection(monkeypatch):
     # geometry hints (bits of early_stop): 4 = wide, 8 = many candidates, 0 = default
     assert ops.few_candidates_hint(P, "order", 262144, 128) == 4          # the headline: dense sweep of a large block
     assert ops.few_candidates_hint(P, "order", 131072, 64) == 4
-    assert ops.few_candidates_hint(P, "order", 131071, 128) == 0          # 512-user workgroups would leave CUs idle
+    assert ops.few_candidates_hint(P, "order", 98304, 128) == 4           # (the 256-user geometry would need a second round of workgroups)
+    assert ops.few_candidates_hint(P, "order", 65536, 128) == 0           # one round of 256 workgroups: the 256-user geometry
     assert ops.few_candidates_hint(P, "order", 262144, 256) == 0
     assert ops.few_candidates_hint(P, True, 262144, 128) == 0             # early-terminating: a warm-up and a sort
     assert ops.few_candidates_hint(P, False, 50000, 64) == 8              # natural order
