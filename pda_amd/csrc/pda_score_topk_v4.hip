@@ -745,6 +745,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_RING_MANY
 #define PDA_V4_RING_MANY 128   // candidate ring entries of the many-candidates geometry (256 / 512: no faster -- later thresholds, more candidates)
 #endif
+#ifndef PDA_V4_ASM256
+#define PDA_V4_ASM256 1       // d = 256: the block as one asm statement too (config-5 shard: 29.15 -> 28.24 ms dense, 5.43 -> 5.08 ms early-terminating)
+#endif
+#ifndef PDA_V4_NB256
+#define PDA_V4_NB256 2        // d = 256: half-tiles per block.  64-item blocks = two accumulator chains per wave: config-5 shard 30.65 -> 29.10 ms dense,
+                              // 5.87 -> 5.39 ms early-terminating (one chain per wave, two waves per SIMD, left the matrix pipe waiting on dependent MFMAs)
+#endif
 #ifndef PDA_V4_NSLOT_WIDE
 #define PDA_V4_NSLOT_WIDE 8   // tile slots of the wide geometry (32-item blocks of 9.5 KiB)
 #endif
@@ -777,7 +784,7 @@ struct Geo4 {
 #ifdef PDA_V4_NBX   /* timing experiment only (results are wrong): NBX half-tiles per block at d <= 128 */
     static constexpr int NB = D <= 128 ? PDA_V4_NBX : 1;
 #else
-    static constexpr int NB = (D <= 128 && UA == 1) ? 2 : 1;          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
+    static constexpr int NB = (D <= 128 && UA == 1) ? 2 : (D > 128 ? PDA_V4_NB256 : 1);          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
     // (wide: 64 rows x 64 items per block would hold 64 + 64 registers of A operands and accumulators -- the block statement and what
     // lives across it do not fit 168 VGPRs: hipcc spilled the accumulators behind every block; 64 rows x 32 items do)
 #endif
@@ -1469,7 +1476,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         sb_nx = g.sufB[tn];
     }
     constexpr int S = NB * NM, PF = S < PDA_V4_PF ? S : PDA_V4_PF;
-    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && D <= 128 && ((UA == 1 && NB == 2) || (UA == 2 && NB == 1 && G::WIDE));     // the block as one asm statement (below)
+    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && (D <= 128 || PDA_V4_ASM256 != 0) && ((UA == 1 && NB == 2) || (UA == 2 && NB == 1 && G::WIDE));     // the block as one asm statement (below)
     constexpr bool PFX = !kAsmGeo && NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
     u32x4 bq[PF];
     // wide geometry, d = 128, dense sweep: cross-block prefetch of the B fragments (pda_v4_block_asm.h, BlockAsm2P)

@@ -209,7 +209,7 @@ def main():
     print("#pragma once")
     print("template <int D>")
     print("struct BlockAsm;")
-    for D in (64, 128):
+    for D in (64, 128, 256):
         print(emit(D, F_DEFAULT))
     print("typedef unsigned u32x2 __attribute__((ext_vector_type(2)));")
     print("template <int D>")
