@@ -745,6 +745,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_RING_MANY
 #define PDA_V4_RING_MANY 128   // candidate ring entries of the many-candidates geometry (256 / 512: no faster -- later thresholds, more candidates)
 #endif
+#ifndef PDA_V4_LWIDE
+#define PDA_V4_LWIDE 2         // wide geometry: loader waves (of the four waves beside the eight MFMA waves; the rest rescore)
+#endif
+#ifndef PDA_V4_L256
+#define PDA_V4_L256 3          // d = 256: loader waves (three: config-5 shard 27.78 -> 26.21 ms dense, 0.51 of the roof; 35 DMA pieces per 64-item block were
+                              // too many for two) (of the four waves beside the eight MFMA waves; the rest rescore)
+#endif
 #ifndef PDA_V4_ASM256
 #define PDA_V4_ASM256 1       // d = 256: the block as one asm statement too (config-5 shard: 29.15 -> 28.24 ms dense, 5.43 -> 5.08 ms early-terminating)
 #endif
@@ -788,8 +795,8 @@ struct Geo4 {
     // (wide: 64 rows x 64 items per block would hold 64 + 64 registers of A operands and accumulators -- the block statement and what
     // lives across it do not fit 168 VGPRs: hipcc spilled the accumulators behind every block; 64 rows x 32 items do)
 #endif
-    static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : 2;
-    static constexpr int RESCORERS = MANY ? 8 : ((D <= 128 && UA == 1) ? 4 : 2);
+    static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : (D > 128 ? PDA_V4_L256 : PDA_V4_LWIDE);
+    static constexpr int RESCORERS = MANY ? 8 : ((D <= 128 && UA == 1) ? 4 : (D > 128 ? 4 - PDA_V4_L256 : 4 - PDA_V4_LWIDE));
     static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
     // candidate rings: one per MFMA wave, or (MANY) two -- rows 0..15 and 16..31 of the wave -- each with a rescoring wave of its own
     static constexpr int NRINGS = MW > RESCORERS ? MW : RESCORERS;
