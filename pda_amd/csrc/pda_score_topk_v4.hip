@@ -730,6 +730,9 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_GL
 #define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
 #endif
+#ifndef PDA_V4_WIDE_DOUBLE
+#define PDA_V4_WIDE_DOUBLE 1     // wide geometry, d = 128: two half-tiles per asm statement, accumulators tested inside it
+#endif
 #ifndef PDA_V4_WIDE_PREFETCH
 #define PDA_V4_WIDE_PREFETCH 1   // wide geometry, d = 128: the next block's first B fragments are read under this block's last MFMAs
 #endif
@@ -1497,7 +1500,94 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         }
     }
     int dead_from = 0x7FFFFFFF;                // first tile from which no row of this wave can be reached (early termination)
-    for (int b = 0; b < n_blk && !stopped; ++b) {
+    // ---- wide geometry, d = 128, dense sweep: TWO half-tiles per statement (BlockAsm2D).  36 MFMAs per wave and statement instead of
+    // 18: what a wave does between two statements has twice the time to hide under the other wave's MFMAs (the config-5 shard, whose
+    // statements are that long, keeps the pipe 79 % busy).  The accumulators stay inside the statement -- it hands back the OR of
+    // their bit patterns per half-tile and row set; a half-tile with a set sign bit (next to none in a dense sweep in visiting
+    // order) is scored again on its own (BlockAsm2) and goes through the usual test and push.
+    constexpr bool kDoubleGeo = kPrefetchGeo && PDA_V4_WIDE_DOUBLE != 0;
+    if constexpr (kDoubleGeo) {
+        for (int b = 0; b < n_blk; b += 2) {
+            const unsigned pr_tv = lds_ld(&s_tver[w]);
+            const int bn = b + 2 < n_blk ? b + 2 : b + 1;           // the block whose first fragments this statement reads ahead
+            ensure_landed(bn);
+            unsigned lnd[kLoaders];
+            const bool asked = b + 2 < n_blk && landed_c < (unsigned)min(b + 5, n_blk);
+            if (asked) {
+#pragma unroll
+                for (int z = 0; z < kLoaders; ++z) lnd[z] = lds_ld(&s_landed[z]);
+            } else {
+#pragma unroll
+                for (int z = 0; z < kLoaders; ++z) lnd[z] = 0xFFFFFFFFu;
+            }
+            const unsigned a0 = lane_base_lds + (unsigned)((b % NSLOT) * BB), a1 = lane_base_lds + (unsigned)(((b + 1) % NSLOT) * BB);
+            const unsigned an = lane_base_lds + (unsigned)((bn % NSLOT) * BB);
+            const unsigned api0 = a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32), api1 = a1 - 16u * (unsigned)h + (unsigned)(2 * D + 32);
+            unsigned mo00, mo01, mo10, mo11;
+            u32x2 pi0, pi1;
+            BlockAsm2D<D>::run(mo00, mo01, mo10, mo11, pi0, pi1, tqa[0], tqa[1], tqa[2], ah, aex, a0, a1, api0, api1, an);
+            if (asked) {
+                unsigned mn = 0xFFFFFFFFu;
+#pragma unroll
+                for (int z = 0; z < kLoaders; ++z) mn = min(mn, lnd[z]);
+                landed_c = mn;
+            }
+            const float pv0 = __uint_as_float(pi0[0]), pv1 = __uint_as_float(pi1[0]);
+            bool c0 = (int)(mo00 | mo01) < 0, c1 = (int)(mo10 | mo11) < 0;
+            if constexpr (HEAD == PDA_HEAD_POP) {
+                const float tm = fminf(thr_min[0], thr_min[UA - 1]);
+                c0 = c0 || pv0 > tm;
+                c1 = c1 || pv1 > tm;
+            }
+            const bool hit0 = __any(c0), hit1 = __any(c1);
+            if (__builtin_expect(hit0 || hit1, 0)) {
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    if (hh == 0 ? !hit0 : !hit1) continue;
+                    f32x16 accr[2];
+                    u32x2 pid;
+                    BlockAsm2<D>::run(accr[0], accr[1], pid, ah, aex, hh == 0 ? a0 : a1, hh == 0 ? api0 : api1);
+                    const float popv1 = __uint_as_float(pid[0]);
+                    const int locv1 = (int)pid[1];
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        uint32_t mo = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mo |= (uint32_t)__float_as_int(accr[u][r]);
+                        bool clampy = false;
+                        if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv1 > thr_min[u]);
+                        if (__any((int)mo < 0) || clampy) {
+                            uint32_t mcb = 0;
+                            if (__any((int)mo < 0)) {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(accr[u][r]), 31);
+                            }
+                            if (clampy) {
+                                int hv = h;
+#if defined(__HIP_DEVICE_COMPILE__)
+                                asm volatile("" : "+v"(hv));
+#endif
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) mcb |= (popv1 > thr_of(r, hv, u)) ? (1u << (15 - r)) : 0u;
+                            }
+                            push_mask(mcb, locv1, u);
+                            PDA_CBAR();
+                            publish_tails();
+                        }
+                    }
+                }
+            }
+            PDA_CBAR();
+            lds_st(&s_released[w], (unsigned)(b + 2));
+            PDA_CBAR();
+            if (pr_tv != tver_seen) {
+                tver_seen = pr_tv;
+                refresh_thr();
+            }
+            ++n_done;                              // a 64-item tile is complete
+        }
+    }
+    for (int b = kDoubleGeo ? n_blk : 0; b < n_blk && !stopped; ++b) {
         const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
         // ---- early termination.  In front of the last block of tile i every wave votes "nothing at or behind tile i + kVL
         // can reach my rows" (candidates still in the ring can only raise thresholds) -- BEFORE it releases that block.  Once

@@ -203,6 +203,102 @@ def emit2pf(D, pre, nxt):
     return "\n".join(out)
 
 
+ACC_BASE = 136        # hard accumulator registers of BlockAsm2D: v[136:151] (row set 0), v[152:167] (row set 1) of the 168 a wave of the
+                      # wide geometry has (12 waves per CU)
+
+
+def block_wide_double(D):
+    """TWO 32-item half-tiles against 64 user rows in one statement (the wide geometry, d = 128): 36 MFMAs, the accumulators in hard
+    registers that never leave the statement -- what leaves is, per half-tile and row set, the OR of the accumulators' bit patterns
+    (sign bit = "some pair of this lane passed the folded test"), and the (pop, id) pairs.  A block with a set sign bit (next to none
+    in a dense sweep in visiting order) is scored again on its own by BlockAsm2.  p0..p2 hold fragments 0..2 of the first half-tile on
+    entry and those of the NEXT tile's first half on exit (18 fragment reads per statement: the ring of six registers comes round)."""
+    NM = D // 16
+    assert NM == 8
+    n_frag = 2 * (NM + 1)
+    frag_off = lambda i: 32 * (i % (NM + 1)) if (i % (NM + 1)) < NM else 2 * D
+    reg = lambda i: ("p%d" % (i % 3)) if (i % 6) < 3 else ("q%d" % (i % 3))
+    acc = lambda u: "v[%d:%d]" % (ACC_BASE + 16 * u, ACC_BASE + 16 * u + 15)
+    lines, order = [], []
+
+    def issue_own(i):
+        lines.append("ds_read_b128 %%[%s], %%[addr%d] offset:%d" % (reg(i), i // (NM + 1), frag_off(i)))
+        order.append(("own", i))
+
+    def issue_pi(hh):
+        lines.append("ds_read_b64 %%[pi%d], %%[addrpi%d]" % (hh, hh))
+        order.append(("pi", hh))
+
+    def issue_next(j):
+        lines.append("ds_read_b128 %%[p%d], %%[addrn] offset:%d" % (j, frag_off(j)))
+        order.append(("next", j))
+
+    def or_phase(hh):
+        lines.append("s_nop 15")          # XDL write -> VALU read of the accumulators
+        lines.append("s_nop 3")
+        for u in range(2):
+            b = ACC_BASE + 16 * u
+            lines.append("v_or_b32 %%[mo%d%d], v%d, v%d" % (hh, u, b, b + 1))
+            for r in range(2, 16, 2):
+                lines.append("v_or3_b32 %%[mo%d%d], v%d, v%d, %%[mo%d%d]" % (hh, u, b + r, b + r + 1, hh, u))
+
+    for i in range(3, 6):
+        issue_own(i)
+    nj = 0
+    for s in range(n_frag):
+        hh, m = s // (NM + 1), s % (NM + 1)
+        if s >= 3:
+            pos = order.index(("own", s))
+            lines.append("s_waitcnt lgkmcnt(%d)" % (len(order) - (pos + 1)))
+        for u in range(2):
+            a = ("%%[a%d_%d]" % (m, u)) if m < NM else ("%%[aex_%d]" % u)
+            lines.append("v_mfma_f32_32x32x16_bf16 %s, %s, %%[%s], %s" % (acc(u), a, reg(s), "0" if m == 0 else acc(u)))
+        if s + 6 < n_frag:
+            issue_own(s + 6)
+        if s == 2:
+            issue_pi(0)
+        if s == 10:
+            issue_pi(1)
+        if nj < 3 and s >= 12 + nj:         # p(nj) held own fragment 12 + nj
+            issue_next(nj)
+            nj += 1
+        if m == NM:
+            or_phase(hh)
+    assert nj == 3
+    lines.append("s_waitcnt lgkmcnt(0)")
+    return NM, lines
+
+
+def emit2d(D):
+    NM, lines = block_wide_double(D)
+    out = []
+    out.append("template <int D>")
+    out.append("struct BlockAsm2D;")
+    out.append("template <>")
+    out.append("struct BlockAsm2D<%d> {" % D)
+    out.append("    static constexpr int kAccBase = %d;      // v[kAccBase .. kAccBase + 31] are clobbered" % ACC_BASE)
+    out.append("    static __device__ __forceinline__ void run(unsigned& mo00, unsigned& mo01, unsigned& mo10, unsigned& mo11, u32x2& pi0, u32x2& pi1,")
+    out.append("                                               u32x4& p0, u32x4& p1, u32x4& p2, const u32x4 (&ah)[2][%d], const u32x4 (&aex)[2], unsigned addr0," % NM)
+    out.append("                                               unsigned addr1, unsigned addr_pi0, unsigned addr_pi1, unsigned addrn) {")
+    out.append("#if defined(__HIP_DEVICE_COMPILE__)")
+    out.append("        u32x4 q0, q1, q2;")
+    out.append("        asm volatile(")
+    for l in lines:
+        out.append('            "%s\\n\\t"' % l)
+    outs = ['[mo%d%d] "=&v"(mo%d%d)' % (hh, u, hh, u) for hh in range(2) for u in range(2)] + ['[pi0] "=&v"(pi0)', '[pi1] "=&v"(pi1)'] + \
+           ['[p%d] "+v"(p%d)' % (i, i) for i in range(3)] + ['[q%d] "=&v"(q%d)' % (i, i) for i in range(3)]
+    ins = ['[a%d_%d] "v"(ah[%d][%d])' % (m, u, u, m) for u in range(2) for m in range(NM)] + ['[aex_%d] "v"(aex[%d])' % (u, u) for u in range(2)] + \
+          ['[addr0] "v"(addr0)', '[addr1] "v"(addr1)', '[addrpi0] "v"(addr_pi0)', '[addrpi1] "v"(addr_pi1)', '[addrn] "v"(addrn)']
+    clob = ['"memory"'] + ['"v%d"' % r for r in range(ACC_BASE, ACC_BASE + 32)]
+    out.append("            : " + ", ".join(outs))
+    out.append("            : " + ", ".join(ins))
+    out.append("            : " + ", ".join(clob) + ");")
+    out.append("#endif")
+    out.append("    }")
+    out.append("};")
+    return "\n".join(out)
+
+
 def main():
     print("// GENERATED by tools/gen_v4_block_asm.py -- do not edit.  One 64-item block of sweep4_kernel: %d fragments in flight." % F_DEFAULT)
     print("// acc0 / acc1: the two half-tiles' accumulators (the folded test included); pi = (pop, id) of half-tile 0 in .xy, of half-tile 1 in .zw.")
@@ -235,6 +331,7 @@ def main():
         print("#endif")
         print("    }")
         print("};")
+        print(emit2d(D))
 
 
 if __name__ == "__main__":
