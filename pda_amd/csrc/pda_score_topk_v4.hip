@@ -1507,6 +1507,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     // order) is scored again on its own (BlockAsm2) and goes through the usual test and push.
     constexpr bool kDoubleGeo = kPrefetchGeo && PDA_V4_WIDE_DOUBLE != 0;
     if constexpr (kDoubleGeo) {
+        static_assert(G::WAVES <= 12 && BlockAsm2D<D>::kAccBase + 32 <= 168, "BlockAsm2D keeps its accumulators in v136 .. v167: 168 VGPRs per wave");
         for (int b = 0; b < n_blk; b += 2) {
             const unsigned pr_tv = lds_ld(&s_tver[w]);
             const int bn = b + 2 < n_blk ? b + 2 : b + 1;           // the block whose first fragments this statement reads ahead
