@@ -763,7 +763,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
                               // 5.87 -> 5.39 ms early-terminating (one chain per wave, two waves per SIMD, left the matrix pipe waiting on dependent MFMAs)
 #endif
 #ifndef PDA_V4_NSLOT_WIDE
-#define PDA_V4_NSLOT_WIDE 8   // tile slots of the wide geometry (32-item blocks of 9.5 KiB)
+#define PDA_V4_NSLOT_WIDE 12  // tile slots of the wide geometry (32-item blocks of 9.5 KiB; 8 -> 12: -1 %, same box)
 #endif
 #ifndef PDA_V4_NSLOT_MAX
 #define PDA_V4_NSLOT_MAX 5   // (timing experiments raise it: the votes of the early termination are then wrong)
