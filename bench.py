@@ -63,6 +63,16 @@ def parse():
     return p.parse_args()
 
 
+def dist_world_size():
+    import torch.distributed as dist
+    return dist.get_world_size()
+
+
+def dist_backend():
+    import torch.distributed as dist
+    return dist.get_backend()
+
+
 def profile_traffic(kernel_substr, workload=None):
     """HBM bytes per launch of the dominant kernel from the committed PMC summary of this round (rocprofv3 --pmc FETCH_SIZE
     / WRITE_SIZE in separate passes; FETCH_SIZE doubled per the gfx950 note in guides/MI355X_MICROARCH.md).  None when no
@@ -106,6 +116,62 @@ class TimedScore:
 
     def mean_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.events) / max(1, len(self.events))
+
+
+def bench_reference_block_protocol(args, dev, workload):
+    """What a maintainer who keeps MF/train_new_api.py and swaps only the model wrapper sees (INTEGRATION.md route 2):
+    DatasetApi_Model.do_recommendation called exactly as evaluation.generator_Rec_result_fast calls it (MF/train_new_api.py:780-794)
+    -- blocks of 2 048 user ids as a Python list (:703,724-726), items = list(range(I)) (:785), pos_pop an ndarray [I] (:788), the
+    train mask as the (int64 [nnz, 2], [-inf] * nnz, shape) triple built once per set_evaluate_obj_pre (:730-739), the result
+    fetched to the host as an int32 ndarray [2048, 50] (:792).  Everything do_recommendation does is inside the timed region: list
+    -> device conversions, the COO -> CSR conversion, the sweep, the merge, the copy back."""
+    import numpy as np
+    from pda_amd import ops, parse, synthetic
+    from pda_amd import train_new_api as t
+    W = synthetic.make_workload(workload, dev)
+    a = parse.parse_args(["--train", "s_condition", "--test", "s_condition", "--embed_size", str(W.d), "--batch_size", "2048", "--verbose", "0"])
+    small = {"n_users": 64, "n_items": 64}              # (tables replaced below: no second 600 MB allocation)
+    m = t.DatasetApi_Model(a, small, 2048, None, dev)
+    m.Recommender.weights = {"user_embedding": W.U, "item_embedding": W.I}
+    m.Recommender.n_users, m.Recommender.n_items, m.n_items = W.n_users, W.n_items, W.n_items
+    Bu, nb = 2048, (8 if workload == "tiny" else 48)
+    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
+    items = list(range(W.n_items))
+    pop = W.pop_last.cpu().numpy()
+    blocks = []
+    for b in range(nb + 2):
+        u0 = (b * 9973 * 7) % max(1, W.n_users - Bu)
+        users = list(range(u0, u0 + Bu))
+        lens = (ip[u0 + 1:u0 + Bu + 1] - ip[u0:u0 + Bu]).astype(np.int64)
+        rows = np.repeat(np.arange(Bu, dtype=np.int64), lens)
+        cols = ix[ip[u0]:ip[u0 + Bu]].astype(np.int64)
+        index = np.stack([rows, cols], axis=1)
+        blocks.append((users, (index, np.array([-np.inf] * len(rows)).astype(np.float32), np.array([Bu, W.n_items]).astype(np.int64))))
+    for users, mask in blocks[:2]:
+        m.do_recommendation(None, users, items, "condition", pop, mask)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for users, mask in blocks[2:]:
+        out = m.do_recommendation(None, users, items, "condition", pop[items], mask)      # (a fresh ndarray per block, like :788)
+    dt = time.perf_counter() - t0
+    assert out.shape == (Bu, 50) and out.dtype == np.int32
+    # the kernels alone on the same blocks (device-resident inputs): what the host conversions cost on top
+    hs = [ops.HistoryCSR.from_coo(mask[0], Bu, dev) for _, mask in blocks[2:]]
+    us = [torch.as_tensor(np.asarray(users, dtype=np.int32), device=dev) for users, _ in blocks[2:]]
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for u, h in zip(us, hs):
+        ops.recommend_topk(W.U, W.I, u, 50, ops.HEAD_POP, W.pop_last, h)
+    torch.cuda.synchronize()
+    dk = time.perf_counter() - t1
+    fl = 2.0 * Bu * W.n_items * W.d
+    return {"users_per_s": Bu * nb / dt, "ms_per_block": dt / nb * 1e3, "blocks": nb, "users_per_block": Bu,
+            "roofline_frac": fl / (dt / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+            "device_only": {"users_per_s": Bu * nb / dk, "ms_per_block": dk / nb * 1e3, "roofline_frac": fl / (dk / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS},
+            "nnz_per_block": int(np.mean([len(mk[0]) for _, mk in blocks])),
+            "note": "DatasetApi_Model.do_recommendation called like MF/train_new_api.py:792: Python lists in, COO mask triple, int32 ndarray "
+                    "out, blocking; product-default sweep (early-terminating); device_only = the same blocks with ids and CSR already in HBM"}
+
 
 
 def table_dtype_of(args, workload):
@@ -241,7 +307,11 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
                 "geometry": geo,
                 "bound": "mfma", "achieved": alg_tf,
                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_BF16_MFMA_TFLOPS,
-                "traffic": profile_traffic(kname, workload if (world_all == 1 and Bu == 262144) else "none"), "kernel_ms": k_ms, "flops_per_launch": flops,
+                "traffic": profile_traffic(kname, workload if (world_all == 1 and Bu == 262144) else "none"), "kernel_ms": k_ms,
+                # N = 1: HIP events around every score call on its launch stream; N > 1: the pipelined multi-rank path is not wrapped
+                # per call -- the figure is then WALL time per step (max over ranks), collectives included
+                "kernel_ms_source": "hip_events_per_call" if world_all == 1 else "wall_time_per_step_max_over_ranks",
+                "flops_per_launch": flops,
                 # the folded threshold test is one more MFMA k-step per tile (d/16 + 1 instead of d/16): executed > algorithmic
                 "executed": {"bf16_mfma_TFLOPs": alg_tf * (W.d / 16 + 1) / (W.d / 16),
                              "frac_of_bf16_peak": alg_tf * (W.d / 16 + 1) / (W.d / 16) / PEAK_BF16_MFMA_TFLOPS,
@@ -631,7 +701,7 @@ def bench_adam_big_tables(args, dev, workload):
     out["replay_fast_graph"] = run_graph(True, 1536 if workload != "tiny" else 128)
     out["replay_fast_graph"]["note"] = "the three launches of a step in HIP graphs of 64 steps, the step counter in device memory (pda_adam_lazy_dev_f32)"
     out["replay_fast"] = run(True, 1536 if workload != "tiny" else 64, fast=True)
-    out["replay_fast"]["note"] = ("PDA_ADAM_REPLAY_FAST (the product's default above 64 MB of tables): the same catch-up to 1e-6 on x instead of bit "
+    out["replay_fast"]["note"] = ("PDA_ADAM_REPLAY_FAST (--adam_sweep replay_fast, an explicit opt-in; the default above 64 MB of tables is the bit-identical replay): the same catch-up to 1e-6 on x instead of bit "
                                   "for bit -- running sqrt, hardware reciprocal, closed-form powers for m and v")
     return out
 
@@ -816,6 +886,10 @@ def main():
             from pda_amd import synthetic as _syn
             train_pack[0][key] = sgd_rates_on_tables(args, dev, _syn.make_workload(args.workload, dev, table_dtype=td))
             torch.cuda.empty_cache()
+    block2048 = None
+    if world == 1 and not args.headline_only and args.workload in ("c3", "c2", "c1", "tiny") and args.head == "condition":
+        block2048 = bench_reference_block_protocol(args, dev, args.workload)
+        torch.cuda.empty_cache()
     cpu = None
     if world == 1 and rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, ev, train_pack)
@@ -857,11 +931,14 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": ev["table_dtype"],
             "data": "synthetic",
-            "config": {"workload": "%s: synthetic %d users x %d items, embed_dim=%d, %s head, history-masked top-K@%d"
+            # (kept under 120 characters: the driver's record truncates longer strings)
+            "config": {"workload": "%s: synthetic %d users x %d items, d=%d, %s head, masked top-K@%d"
                                    % (args.workload.upper(), W.n_users, W.n_items, W.d,
                                       "PDA condition ((elu+1)*pop^%.2f)" % W.gamma if args.head == "condition" else "raw",
                                       args.K),
                        "users_per_step": ev["Bu"],
+                       # what torch.distributed itself reports: a SCALE record shows that RCCL ("nccl") saw N ranks
+                       "ranks_seen": (dist_world_size() if world > 1 else 1), "backend": (dist_backend() if world > 1 else None),
                        "sharding": ("%d user group(s) x %d item shards: inside a group item-parallel (every rank owns an item slice), one RCCL "
                                     "all-to-all of the partial top-K lists per step, result sharded by user slice; the groups split the users "
                                     "of a step" % (ev["layout"]["user_groups"], ev["layout"]["item_shards"])) if world > 1 else "single GPU",
@@ -873,6 +950,7 @@ def main():
                                       "kernel on the widened tables; the bf16 MFMA pass is a pre-filter with a rigorous error bound")},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "dense_natural_order": ev["natural"],
             "ordered_sweep": ev["ordered"], "raw_head": ev["raw_head"], "item_sharded_only": ev_items, "prep": ev["prep"], "per_config": per_config,
+            "eval_block_2048": block2048,
             "train": train_pack[0] if train_pack else ({"item_parallel_sgd": sharded_train} if sharded_train else None),
         }
         print(json.dumps(line))

@@ -39,7 +39,9 @@ namespace {
 #endif
 constexpr int kPlanMaxB = 4096;
 __host__ __device__ inline int xl_max(int B) { return (2 * B) / kXlMin + 1; }
-__host__ __device__ inline size_t scratch_floats_base(int B, int d) { return (size_t)B * (size_t)(d + 2) + 2 * ((size_t)B / 8 + 8); }      // one workgroup sorts 2B <= 8192 references in LDS
+// (rounded up to whole f32x4: the multi-workgroup segments' partial sums behind it are stored and read as f32x4)
+__host__ __device__ inline size_t scratch_floats_base(int B, int d) { return ((size_t)B * (size_t)(d + 2) + 2 * ((size_t)B / 8 + 8) + 3) & ~(size_t)3; }
+__host__ __device__ inline int xl_cnt_floats(int B) { return (xl_max(B) + 3) & ~3; }        // the arrival counters in front of xl_part, 16-byte granular
 
 struct PlanView {
     int* hdr;              // [4]: segments, "a user occurs twice", 2B, B
@@ -412,7 +414,7 @@ __device__ __forceinline__ void plan_items_xl(const PlanStepArgs& a, int j, floa
     const float* __restrict__ rows_old = a.scratch;
     const int* __restrict__ entries = a.entries;
     int* xl_cnt = reinterpret_cast<int*>(a.scratch + scratch_floats_base(B, D));
-    float* xl_part = a.scratch + scratch_floats_base(B, D) + xl_max(B);
+    float* xl_part = a.scratch + scratch_floats_base(B, D) + xl_cnt_floats(B);
     f32x4 part = {0.f, 0.f, 0.f, 0.f};
     for (int i0 = r0 + g; i0 < r1; i0 += STEP) {
         int en2[LONGU];
@@ -648,7 +650,7 @@ extern "C" size_t pda_triplet_plan_bytes(int B) { return B > 0 ? plan_bytes(B) :
 // old user rows [B][d], coefficients [B][2], one (mf, reg) pair per workgroup of launch A (at most B / 8 + 1 of them: d = 256)
 extern "C" size_t pda_bpr_step_plan_scratch_bytes(int B, int d) {
     // ... then (large batches) one counter and kXlPieces partial rows per very long segment
-    return (B > 0 && d > 0) ? (scratch_floats_base(B, d) + (size_t)xl_max(B) * (1 + (size_t)kXlPieces * d)) * 4 : 0;
+    return (B > 0 && d > 0) ? (scratch_floats_base(B, d) + (size_t)xl_cnt_floats(B) + (size_t)xl_max(B) * (size_t)kXlPieces * d) * 4 : 0;
 }
 
 extern "C" int pda_triplet_plan(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, int n_batches, void* plans, void* stream) {

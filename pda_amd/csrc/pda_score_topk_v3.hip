@@ -672,6 +672,9 @@ __global__ void __launch_bounds__(kThreads, 2) score_topk_v3_kernel(ScoreArgs2 a
         if (iteration(k, pA_h)) break;
     }
     if (tid == 0) atomicAdd(aa.visited, (unsigned long long)n32);
+    // kernel identity (workspace + 16; tests read it back to prove WHICH kernel a call ran): generation 3 | ORD | HEAD | BF | d / 64
+    if (tid == 0 && blockIdx.x == 0)
+        reinterpret_cast<unsigned*>(aa.visited)[2] = (3u << 28) | ((ORD ? 1u : 0u) << 12) | ((unsigned)HEAD << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     if (ring_cnt > 0) process_ring();
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned*>(aa.visited) - 1, n_cand);   // workspace + 4: u32 "pairs rescored"
 

@@ -875,6 +875,10 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
 #define PDA_STAMP(x)
 #endif
     if (tid < 128) sync[tid] = tid >= 112 ? 0xFFFFFFFFu : 0u;       // (words 112 .. 127: every list comes in unsorted, see s_uns)
+    // kernel identity (workspace + 16; tests read it back to prove WHICH kernel and geometry a call ran):
+    // generation 4 | geometry << 8 | early-terminating << 12 | head << 13 | bf16 tables << 14 | d / 64
+    if (tid == 0 && blockIdx.x == 0)
+        g.stats[4] = (4u << 28) | ((unsigned)GM << 8) | ((ES ? 1u : 0u) << 12) | ((unsigned)HEAD << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // The lists of the warm-up -> LDS (or the workspace), their counts and K-th values: ALL waves share the rows (the MFMA
     // waves wait for the thresholds behind the barrier: 64 rows per rescoring wave, one after the other, were 50 us of every
     // workgroup's life -- 13 % of an early-terminating sweep).  A list may come in unsorted: its K-th value is the smallest key.
@@ -2094,7 +2098,8 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
     if (early_stop < 0 || (early_stop & ~0x7F) != 0) return PDA_ERR_ARG;
-    // geometry hints (Geo4<D, 1 | 2>): results do not depend on them.  The wide geometry needs one item split and whole waves of work
+    // geometry hints (Geo4<D, 1 | 2 | 3>): results do not depend on them, and every geometry takes any n_splits and any user count
+    // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks); the wide geometry only PAYS on large blocks
     int geometry = (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;

@@ -139,6 +139,8 @@ class ItemShardedTopK:
         per user block."""
         n = self.I_shard.shape[0]
         if pop_full is None:
+            if self.pop_shard is not None:
+                self._pop_epoch = getattr(self, "_pop_epoch", 0) + 1
             self.pop_shard, self._pop_src = None, None
             return
         src = getattr(self, "_pop_src", None)
@@ -147,6 +149,9 @@ class ItemShardedTopK:
         if pop_full.numel() < self.item_offset + n:
             raise ValueError("popularity vector has %d entries, this shard needs items up to %d" % (pop_full.numel(), self.item_offset + n))
         self.pop_shard = pop_full[self.item_offset:self.item_offset + n].contiguous()
+        # (what _validate_once keys on: a count of re-slicings, the same on every rank -- object ids are recycled, and a rank that
+        # hit a stale id would skip the flag all-reduce the other ranks issue)
+        self._pop_epoch = getattr(self, "_pop_epoch", 0) + 1
         import weakref
         self._pop_src = (weakref.ref(pop_full), pop_full._version)
 
@@ -170,8 +175,8 @@ class ItemShardedTopK:
     def _validate_once(self, head):
         """Conditions that differ from rank to rank (the shard's size, its popularity slice) are checked on every rank BEFORE the
         first collective of a seeded sweep and the verdict is shared: a rank that raised alone would leave the others waiting in
-        an all-reduce forever.  Once per (popularity version, head)."""
-        key = (head, id(self.pop_shard), None if self.pop_shard is None else self.pop_shard._version)
+        an all-reduce forever.  Once per (set_popularity epoch, head)."""
+        key = (head, getattr(self, "_pop_epoch", 0))          # rank-invariant: every rank makes the same set_popularity calls
         if getattr(self, "_validated", None) == key:
             return
         err = ""

@@ -84,9 +84,12 @@ class _MFBase:
             raise NotImplementedError("adam_sweep must be auto | sweep | replay | replay_fast")
         if forced is None and mode != "auto":
             forced = mode != "sweep"
-        # replay: bit-identical to the sweeps; replay_fast (and auto, above 64 MB of tables): the same catch-up to 1e-6
-        # (PDA_ADAM_REPLAY_FAST: running sqrt, hardware reciprocal, closed-form powers for m and v) -- ~4 x less arithmetic
-        self.adam_replay_fast = mode in ("auto", "replay_fast")
+        # replay (and auto, above 64 MB of tables): bit-identical to the sweeps -- the reference-parity optimiser and the checkpoints
+        # written behind sync_optimizer stay bit-equal to the dense-decay Adam.  replay_fast is an explicit opt-in: the same catch-up
+        # with a running sqrt, the hardware reciprocal and closed-form powers for m and v (PDA_ADAM_REPLAY_FAST, ~4 x less
+        # arithmetic); x to 1e-6 per catch-up against the sweep (tests/test_gpu_bpr_step.py), NOT bit-equal, and the per-catch-up
+        # error (~4e-8 |x|: the geometric tail is ~10 x the last term) accumulates over the row's touches of a long run
+        self.adam_replay_fast = mode == "replay_fast"
         table_bytes = (self.n_users + self.n_items) * self.emb_dim * 4
         self.adam_exact_lazy = (table_bytes > self.ADAM_SWEEP_MAX_BYTES) if forced is None else bool(forced)
         self._lazy = None

@@ -55,15 +55,19 @@ class HistoryCSR:
 
     @staticmethod
     def from_coo(index, n_rows: int, device) -> "HistoryCSR":
-        """The reference's sparse mask triple index int64[nnz,2] = (row, item) (MF/train_new_api.py:736)."""
+        """The reference's sparse mask triple index int64[nnz,2] = (row, item) (MF/train_new_api.py:736), built per 2 048-user
+        block and handed over with every do_recommendation call (:791): one host -> device copy, then sorted and counted ON THE
+        DEVICE (one 64-bit sort of row << 32 | item, a bincount, a cumsum) -- a numpy lexsort of the ~100 000 entries of a block
+        cost more than the block's sweep."""
         import numpy as np
-        index = np.asarray(index, dtype=np.int64).reshape(-1, 2)
-        order = np.lexsort((index[:, 1], index[:, 0]))
-        rows, items = index[order, 0], index[order, 1].astype(np.int32)
-        indptr = np.zeros(n_rows + 1, dtype=np.int64)
-        np.add.at(indptr, rows + 1, 1)
-        np.cumsum(indptr, out=indptr)
-        return HistoryCSR(torch.from_numpy(indptr).to(device), torch.from_numpy(items).to(device), by_user=False)
+        idx = torch.from_numpy(np.ascontiguousarray(np.asarray(index, dtype=np.int64).reshape(-1, 2))).to(device, non_blocking=True)
+        if idx.shape[0] == 0:
+            return HistoryCSR(torch.zeros(n_rows + 1, dtype=torch.int64, device=device), torch.zeros(0, dtype=torch.int32, device=device), by_user=False)
+        key = torch.sort((idx[:, 0] << 32) | idx[:, 1]).values
+        items = (key & 0xFFFFFFFF).to(torch.int32)
+        indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
+        torch.cumsum(torch.bincount(key >> 32, minlength=n_rows)[:n_rows], 0, out=indptr[1:])
+        return HistoryCSR(indptr, items, by_user=False)
 
 
 def auto_splits(n_users_blk: int, n_items_local: int) -> int:
@@ -405,6 +409,7 @@ def seeded_finish(c: SeededCall) -> torch.Tensor:
         c.stats["tiles_scored"] = c.ws[8:16].view(torch.int64)
         c.stats["pairs_rescored"] = c.ws[4:8].view(torch.int32)
         c.stats["tiles_dense"] = ((c.nloc + 31) // 32) * ((c.nu + 127) // 128)
+        c.stats["kernel_id"] = c.ws[16:20].view(torch.int32)
     out, c.keep = c.out, None
     return out
 
@@ -480,6 +485,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["pairs_rescored"] = ws[4:8].view(torch.int32)
             stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)
+            stats["kernel_id"] = ws[16:20].view(torch.int32)     # written by the sweep kernel itself: see kernel_identity()
         return out
     if impl == "v2" and prune:
         prep, order = item_prep_ordered(I_shard, pop_shard if head == HEAD_POP else None)
@@ -495,6 +501,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["pairs_rescored"] = ws[4:8].view(torch.int32)        # v3 kernel only (0 otherwise)
             stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)
+            stats["kernel_id"] = ws[16:20].view(torch.int32)
         return out
     if impl == "v2":
         prep = item_prep(I_shard)
@@ -510,6 +517,20 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
                                  hist.mode if hist else 0, K, head, n_splits, ptr(out), stream_ptr()),
           "pda_score_topk_f32")
     return out
+
+
+GEOMETRY_NAMES = {0: "lds", 1: "hbm", 2: "wide", 3: "many", 4: "huge"}
+
+
+def kernel_identity(word) -> dict:
+    """Decodes the word the sweep kernels write at workspace + 16 (stats["kernel_id"]): which kernel generation, geometry and
+    template instance a score_topk_keys call actually ran.  Synchronising when given the device tensor.  0 = no pre-filtered
+    sweep ran (every split ended inside its warm-up, or generation 1)."""
+    w = int(word) & 0xFFFFFFFF
+    if w == 0:
+        return {"generation": 0}
+    return {"generation": w >> 28, "geometry": GEOMETRY_NAMES.get((w >> 8) & 15, "?") if (w >> 28) == 4 else None,
+            ("early_stop" if (w >> 28) == 4 else "visiting_order"): bool((w >> 12) & 1), "head": (w >> 13) & 1, "bf16": bool((w >> 14) & 1), "d": (w & 15) * 64}
 
 
 def topk_merge(keys: torch.Tensor, users=None, hist: Optional[HistoryCSR] = None, want="idx_val"):

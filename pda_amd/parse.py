@@ -68,7 +68,7 @@ _REFERENCE_FLAGS = [
 
 _EXTENSION_FLAGS = [
     ("optimizer", str, "adam", "adam = TF-1.14 dense-decay Adam (reference, MF/model_api.py:83) | lazy_adam | sgd (exact mini-batch step) | sgd_fused (one launch, asynchronous in-kernel update)"),
-    ("adam_sweep", str, "auto", "how --optimizer adam applies the reference's dense decay: sweep = one pass over both tables per step | replay = the same arithmetic without the sweep (idle rows replay their decay when next needed; bit-identical after the sync) | replay_fast = that catch-up to 1e-6 instead of bit for bit (~4x less arithmetic) | auto = replay_fast once the tables exceed 64 MB"),
+    ("adam_sweep", str, "auto", "how --optimizer adam applies the reference's dense decay: sweep = one pass over both tables per step | replay = the same arithmetic without the sweep (idle rows replay their decay when next needed; bit-identical after the sync) | replay_fast = that catch-up to 1e-6 instead of bit for bit (~4x less arithmetic; explicit opt-in) | auto = sweep up to 64 MB of tables, the bit-identical replay above"),
     ("sampler", str, "device", "device = HIP counter-based sampler | host = the reference's Python generators"),
     ("table_dtype", str, "f32", "f32 | bf16 (BASELINE config 5): bf16 embedding tables for the forward pass and the evaluation, fp32 masters take the updates"),
     ("eval_block", int, 262144, "users per score+top-K launch (the reference always uses 2048, MF/train_new_api.py:703); large blocks balance the early-terminating sweep: 92 M users/s at 65536, 109 M at 262144 (C3)"),

@@ -50,6 +50,12 @@ def test_bench_emits_one_contract_line(dev):
     big = t["sgd_on_headline_tables"]
     assert big["B2048"]["exact_planned"]["triplets_per_s"] > 0 and big["B2048"]["fused_hogwild"]["hbm_frac"] > 0
     assert c["torch_intraop_threads"]["value"] > 0
+    # round 4: the reference's own block protocol (do_recommendation on 2 048-user blocks, MF/train_new_api.py:703,792), what
+    # torch.distributed saw, and where kernel_ms comes from
+    b = d["eval_block_2048"]
+    assert b["users_per_block"] == 2048 and b["users_per_s"] > 0 and b["device_only"]["users_per_s"] >= b["users_per_s"] * 0.5
+    assert d["config"]["ranks_seen"] == 1 and d["config"]["backend"] is None and len(d["config"]["workload"]) <= 120
+    assert r["kernel_ms_source"] == "hip_events_per_call"
 
 
 def test_bench_bf16_tables_line(dev):

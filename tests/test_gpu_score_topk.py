@@ -583,168 +583,6 @@ def test_negative_popularity_is_rejected(dev):
         ops.score_topk_keys(U, I, torch.arange(8, dtype=torch.int32, device=dev), 5, 1, pop)
 
 
-def oracle_sample_lists(W, users_t, head, n=256):
-    """c_oracle.score_topk (the fp32 fmaf chain of the kernels, order=1) on the first n of `users_t` against the WHOLE
-    catalogue of workload W with the users' real train rows; bf16 tables are widened (that is how their scores are defined)."""
-    sub = users_t[:n].cpu().numpy()
-    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
-    rows = [ix[ip[u]:ip[u + 1]] for u in sub]
-    bip, bix = csr(rows)
-    Uw, Iw = W.U[users_t[:n].long()].float().cpu().numpy(), W.I.float().cpu().numpy()
-    pop = W.pop_last.cpu().numpy() if head else None
-    return c_oracle.score_topk(Uw, Iw, np.arange(len(sub), dtype=np.int32), 50, head, pop, bip, bix, order=1, want_scores=True)
-
-
-def assert_lists_match_oracle(keys, ridx, rval, sc, head):
-    """Merged packed keys of the kernels against the oracle's lists: raw head bit-exact; popularity head 1e-5 on the values and
-    any list disagreement a near-tie inside that tolerance (hardware v_exp_f32 vs libm expf in the last ulp)."""
-    from pda_amd import ops
-    idx, val = ops.unpack_keys(keys[:len(ridx)])
-    if head == 0:
-        np.testing.assert_array_equal(val, rval)
-        np.testing.assert_array_equal(idx, ridx)
-        return
-    np.testing.assert_allclose(val, rval, rtol=TOL, atol=TOL)
-    for r, k in np.argwhere(idx != ridx):
-        a, b = idx[r, k], ridx[r, k]
-        assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b)
-
-
-def test_full_size_c3_sweep_modes_agree(dev, impl):
-    """BASELINE config 3 at full size (1M users x 200k items, d=128, PDA head, real history CSR of 49M entries): the
-    natural-order, visiting-order and early-terminating sweeps return identical merged keys for 16 384 users, and the exact
-    fp32-MFMA kernel agrees on a 2 048-user subset.  (Runs once: the `impl` fixture's modes are set explicitly here.)"""
-    if impl != "v2":
-        pytest.skip("sweep modes are chosen explicitly in this test")
-    from pda_amd import ops, synthetic
-    W = synthetic.make_workload("c3", dev)
-    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
-    users = torch.arange(500_000, 500_000 + 16384, dtype=torch.int32, device=dev)
-    out = {}
-    for name, prune in (("natural", False), ("order", "order"), ("stop", True)):
-        st = {}
-        keys = ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune, stats=st)
-        out[name] = ops.topk_merge(keys, want="keys")
-        if name == "stop":
-            assert float(st["tiles_scored"][0]) < 0.2 * st["tiles_dense"]
-    assert torch.equal(out["natural"], out["order"]) and torch.equal(out["natural"], out["stop"])
-    sub = users[:2048].contiguous()
-    exact = ops.topk_merge(ops.score_topk_keys(W.U, W.I, sub, 50, ops.HEAD_POP, W.pop_last, hist, impl="v1"), want="keys")
-    assert torch.equal(exact, out["natural"][:2048])
-    idx, val = ops.unpack_keys(out["stop"][:64])
-    assert (np.diff(val, axis=1) <= 0).all() and (idx >= 0).all() and (idx < W.n_items).all()
-    # a block of the size the product evaluates (131 072 users: the warm-up's train-item masks come from their own kernel from
-    # 98 304 users on), both kernel generations, early-terminating and dense in visiting order
-    big = torch.arange(200_000, 200_000 + 131072, dtype=torch.int32, device=dev)
-    got = {}
-    old = os.environ.get("PDA_SCORE_KERNEL")
-    try:
-        for kern in ("v3", "v4"):
-            os.environ["PDA_SCORE_KERNEL"] = kern
-            for prune in (True, "order"):
-                got[(kern, prune)] = ops.topk_merge(ops.score_topk_keys(W.U, W.I, big, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
-    finally:
-        if old is None:
-            os.environ.pop("PDA_SCORE_KERNEL", None)
-        else:
-            os.environ["PDA_SCORE_KERNEL"] = old
-    ref = got[("v3", True)]
-    for k, v in got.items():
-        assert torch.equal(ref, v), k
-    # ---- the operating point of bench.py's headline: a 262 144-user block (MF/train_new_api.py:780-794 at the product's
-    # --eval_block), both heads, product-default sweep mode and the dense sweep in visiting order.  (a) the first 256 lists
-    # equal the oracle's on config 3's real history; (b) the keys of the users shared with the 131 072-user block are the same.
-    huge = torch.arange(200_000, 200_000 + 262144, dtype=torch.int32, device=dev)
-    oracle = {h: oracle_sample_lists(W, huge, h) for h in (0, 1)}
-    for prune in ("order", True):
-        k262 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
-        assert torch.equal(k262[:131072], ref), prune
-        assert_lists_match_oracle(k262, *oracle[1], head=1)
-    for geo, prunes in (("hbm", ("order",)), ("wide", ("order", True))):     # the other geometries on the same block: identical keys
-        os.environ["PDA_SCORE_LISTS"] = geo
-        try:
-            for prune in prunes:
-                kg = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
-                assert torch.equal(kg, k262), (geo, prune)
-        finally:
-            os.environ["PDA_SCORE_LISTS"] = "lds"
-    raw = {}
-    for prune in (None, False):                   # raw head: the product default (visiting order by norm) and natural order
-        raw[prune] = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_RAW, None, hist, prune=prune), want="keys")
-        assert_lists_match_oracle(raw[prune], *oracle[0], head=0)
-    assert torch.equal(raw[None], raw[False])
-    os.environ["PDA_SCORE_LISTS"] = "many"        # the many-candidates geometry on the same block: identical keys, both heads
-    try:
-        for prune in ("order", False):
-            km = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_RAW, None, hist, prune=prune), want="keys")
-            assert torch.equal(km, raw[None]), ("many", "raw", prune)
-        km = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=False), want="keys")
-        assert torch.equal(km, k262), ("many", "pop")
-    finally:
-        os.environ["PDA_SCORE_LISTS"] = "lds"
-    torch.cuda.synchronize()
-
-
-def test_full_size_c5_shard_bf16(dev, impl):
-    """One rank's share of BASELINE config 5 at full size (250 000 item rows x d = 256, bf16 tables, 1M-user replica of the
-    user table, 50M-entry history CSR): the three sweep modes of both kernel generations return identical merged keys for
-    8 192 users; a 256-user sample equals the oracle on the widened tables (popularity head: 1e-5 + near-tie rule); lists
-    are sorted, in range and free of train items."""
-    if impl != "v2":
-        pytest.skip("sweep modes are chosen explicitly in this test")
-    import os
-    from pda_amd import ops, synthetic
-    W = synthetic.make_workload("c5shard", dev, table_dtype=torch.bfloat16)
-    assert W.U.dtype == torch.bfloat16 and W.I.shape == (250_000, 256)
-    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
-    users = torch.arange(300_000, 300_000 + 8192, dtype=torch.int32, device=dev)
-    out = {}
-    old = os.environ.get("PDA_SCORE_KERNEL")
-    try:
-        for kern in ("v3", "v4"):
-            os.environ["PDA_SCORE_KERNEL"] = kern
-            for name, prune in (("natural", False), ("order", "order"), ("stop", True)):
-                st = {}
-                keys = ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune, stats=st)
-                out[kern + name] = ops.topk_merge(keys, want="keys")
-                if name == "stop":
-                    assert float(st["tiles_scored"][0]) < st["tiles_dense"]          # (8 192 users are few user tiles: many item splits, each stopping on its own)
-    finally:
-        if old is None:
-            os.environ.pop("PDA_SCORE_KERNEL", None)
-        else:
-            os.environ["PDA_SCORE_KERNEL"] = old
-    ref = out["v3natural"]
-    for k, v in out.items():
-        assert torch.equal(ref, v), k
-    idx, val = ops.unpack_keys(ref)
-    assert (np.diff(val, axis=1) <= 0).all() and (idx >= 0).all() and (idx < W.n_items).all()
-    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
-    for r in range(0, 8192, 512):
-        u = 300_000 + r
-        assert not set(idx[r]) & set(ix[ip[u]:ip[u + 1]])
-    # oracle sample on the widened tables
-    sub = users[:256].cpu().numpy()
-    Uw, Iw = W.U[users[:256].long()].float().cpu().numpy(), W.I.float().cpu().numpy()
-    rows = [ix[ip[u]:ip[u + 1]] for u in sub]
-    bip, bix = csr(rows)
-    ridx, rval, sc = c_oracle.score_topk(Uw, Iw, np.arange(256, dtype=np.int32), 50, 1, W.pop_last.cpu().numpy(), bip, bix, order=1,
-                                         want_scores=True)
-    np.testing.assert_allclose(val[:256], rval, rtol=TOL, atol=TOL)
-    bad = np.argwhere(idx[:256] != ridx)
-    for r, k in bad:
-        a, b = idx[r, k], ridx[r, k]
-        assert abs(sc[r, a] - sc[r, b]) <= TOL * max(1.0, abs(sc[r, b])), (r, k, a, b)
-    # ---- the block size bench.py --workload c5shard times (262 144 users; the regrouping and the masks' own kernel start at
-    # 98 304): dense in visiting order and early-terminating, generation 4 -- the users shared with the 8 192-user block above
-    # carry the same keys, and the first 256 lists equal the oracle's
-    huge = torch.arange(300_000, 300_000 + 262144, dtype=torch.int32, device=dev)
-    for prune in ("order", True):
-        k262 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, ops.HEAD_POP, W.pop_last, hist, prune=prune), want="keys")
-        assert torch.equal(k262[:8192], ref), prune
-        assert_lists_match_oracle(k262, ridx, rval, sc, head=1)
-
-
 class FakeCollectives:
     """all_reduce among R threads of this process, one per emulated item shard (what pda_amd.dist does over RCCL)."""
 

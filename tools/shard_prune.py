@@ -30,7 +30,7 @@ for name, seeded, rounds in (("own K-th value only", False, 0), ("plain seed", T
         s2 = {}
         kw = {}
         if seeded:
-            kw = {"seed_reduce": lambda mx, mn: (coll.all_reduce(r, mx, "max"), coll.all_reduce(r, mn, "min")),
+            kw = {"seed_reduce": lambda b: coll.all_reduce(r, b, "max"),          # float32 [3, Bu]: (K-th, ceil(K / R)-th, minus the latter)
                   "seed_sum": lambda c: coll.all_reduce(r, c, "sum"), "seed_shards": R}
         k = ops.score_topk_keys(W.U, I_s, users, 50, ops.HEAD_POP, pop_s, hist, item_offset=lo, prune=True, n_splits=1, stats=s2, **kw)
         return ops.topk_merge(k, want="keys"), float(s2["tiles_scored"][0])
