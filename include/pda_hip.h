@@ -217,6 +217,12 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        waves, and EIGHT rescoring waves (one per 16 user rows) with the lists of 128 users and four tile slots in the LDS.
  *        Such a sweep is bound by its rescoring waves (cycle counters: 98 % busy at four per 256 users).  Identical keys. */
 #define PDA_SWEEP_MANY_CANDIDATES 8
+/*        bit 7 = PDA_SWEEP_HUGE, the geometry hint for the dense sweep of the popularity head in visiting order on VERY large user
+ *        blocks (d <= 128; a prep built with the popularity the call passes): 1 024 users per workgroup, four waves of 512
+ *        registers, 256 users each -- the users' bf16 rows in AGPRs, every item fragment read from the LDS feeds EIGHT MFMAs, the
+ *        product transposed so that the threshold test is a per-lane compare (no test k-step), the item image pre-scaled by the
+ *        popularity (pda_v5_sweep.h).  Identical keys.  Dense sweeps only (with bit 0 set: ignored); other heads: the wide geometry. */
+#define PDA_SWEEP_HUGE 128
 #define PDA_SWEEP_WARM_TILES(n) (((n) & 7) << 4)
 size_t pda_item_prep4_bytes(int n_items_local, int d);
 int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,

@@ -94,13 +94,20 @@ struct Args4 {
     int warm_sorted;             // the warm-up hands its lists over sorted (phase 1 alone: pda_topk_kth_value reads ranks) or as they are
     uint64_t* handover;          // [n_splits, n_users_blk, kCap4] or NULL: warm-up and sweep of ONE call hand the lists over here, K .. kCap4 keys
                                  // per row (zero-padded), instead of exactly K through out_keys
+    // the huge geometry (pda_v5_sweep.h): the popularity-scaled, swizzled item image and its per-half-tile (pmax, nmax); the user block as
+    // bf16 MFMA operands and the users' padded norms (workspace)
+    const unsigned char* rows5;
+    const float* meta5;
+    const unsigned char* ufrag;
+    const float* unorm;
+    int prep_hdr_pop;            // host copy of "the prep was built with a popularity" (the image is scaled by it): set by the entry points
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // prep: padded rows in visiting order
 // ---------------------------------------------------------------------------------------------------------------------
 struct Prep4Layout {
-    size_t hdr, pos_of, sufA, sufB, sufR, rows, total;
+    size_t hdr, pos_of, sufA, sufB, sufR, rows, rows5, meta5, total;
     int n_tiles;
 };
 Prep4Layout prep4_layout(int n, int d) {
@@ -114,6 +121,14 @@ Prep4Layout prep4_layout(int n, int d) {
     L.sufR = L.sufB + al((size_t)L.n_tiles * 4);
     L.rows = L.sufR + al((size_t)L.n_tiles * 4);
     L.total = L.rows + (size_t)L.n_tiles * tile_bytes(d);
+    // d <= 128: the image of the huge geometry -- rows scaled by the popularity, bf16, 16-byte chunks XOR-swizzled, 32-item half-tiles of
+    // 64 d bytes -- and (pmax, nmax) per half-tile
+    L.rows5 = al(L.total);
+    L.meta5 = L.rows5;
+    if (d <= 128) {
+        L.meta5 = L.rows5 + al((size_t)L.n_tiles * 2 * 64 * (size_t)d);
+        L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 8);
+    }
     return L;
 }
 
@@ -121,7 +136,7 @@ Prep4Layout prep4_layout(int n, int d) {
 template <int D, bool BF>
 __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, const float* __restrict__ pop, const int* __restrict__ order,
                                                     int n, int n_pad, unsigned char* __restrict__ rows, int* __restrict__ pos_of,
-                                                    int* __restrict__ hdr) {
+                                                    int* __restrict__ hdr, unsigned char* __restrict__ rows5, int* __restrict__ meta5) {
     constexpr int TPR = D / 8, RB = row_bytes(D);
     const int pos = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
     if (pos >= n_pad) return;
@@ -145,14 +160,39 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
         *reinterpret_cast<u32x4*>(rp + 16 * e) = hq;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ss += a[k] * a[k] + b[k] * b[k];
+        if constexpr (D <= 128) {
+            // the huge geometry's image: chunk e of row pos & 31 of half-tile pos >> 5, scaled by the popularity (NaN: a zero row -- such an
+            // item never ranks), at the swizzled place the MFMA waves read it from (pda_v5_sweep.h)
+            const float pv = pop ? ((popv == popv) ? popv : 0.f) : 1.0f;
+            f32x4 as = a, bs = b;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { as[k] *= pv; bs[k] *= pv; }
+            u32x4 hs, ls;
+            split8(as, bs, hs, ls);
+            const int r5 = pos & 31;
+            const int sw = D >= 128 ? (r5 & 15) : ((r5 >> 1) & 7);
+            *reinterpret_cast<u32x4*>(rows5 + (size_t)(pos >> 5) * (64 * D) + r5 * (2 * D) + ((e ^ sw) << 4)) = hs;
+        }
     } else {
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(rp + 16 * e) = z;
+        if constexpr (D <= 128) {
+            const int r5 = pos & 31;
+            const int sw = D >= 128 ? (r5 & 15) : ((r5 >> 1) & 7);
+            *reinterpret_cast<u32x4*>(rows5 + (size_t)(pos >> 5) * (64 * D) + r5 * (2 * D) + ((e ^ sw) << 4)) = z;
+        }
     }
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (e == 0) {
         const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
+        if constexpr (D <= 128) {
+            if (pos < n) {                                   // (pmax, nmax) of the half-tile: maxima of non-negative floats = maxima of their bit patterns
+                const float pv = pop ? ((popv == popv) ? popv : 0.f) : 1.0f;
+                atomicMax(&meta5[2 * (pos >> 5)], __float_as_int(pop ? pv : 0.f));
+                atomicMax(&meta5[2 * (pos >> 5) + 1], __float_as_int(pv * v * 1.000001f));
+            }
+        }
         // the B side of the extra k-step (see pda_score_topk_v2.hip:item_prep_kernel): k 0..7 pieces of (1/pop)' rounded
         // down (1 for the raw head), k 8 the constant 1 (raw: 8e-6), k 9 8e-6 (raw: 0), k 10 the padded norm rounded up
         uint32_t p1 = 0x3F80u, p2 = 0, p3 = 0, k1 = 0, k2 = 0;
@@ -272,12 +312,15 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     if (order && hipMemsetAsync(hdr + 2, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;          // header word 2 := 1: a visiting order was given
     if (pop && hipMemsetAsync(hdr + 1, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;            // header word 1 := 1: the test operands carry 1/pop pieces
     const int n_pad = L.n_tiles * 64;
+    if (d <= 128 && hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 8, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    unsigned char* r5 = pb + L.rows5;
+    int* m5 = reinterpret_cast<int*>(pb + L.meta5);
 #define PDA_P4(DD)                                                                                                              \
     case DD: {                                                                                                                  \
         constexpr int RPB = 256 / (DD / 8);                                                                                     \
         const dim3 grid((unsigned)((n_pad + RPB - 1) / RPB));                                                                   \
-        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr); \
-        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr);    \
+        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5); \
+        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5);    \
         break;                                                                                                                  \
     }
     switch (d) { PDA_P4(64) PDA_P4(128) PDA_P4(256) }
@@ -1980,6 +2023,8 @@ __global__ void __launch_bounds__(1024) stop_scatter4_kernel(const int* __restri
         if (b[i] >= 0) perm[sh[b[i]] + r[i]] = (int)blockIdx.x * 4096 + i * 1024 + t;
 }
 
+#include "pda_v5_sweep.h"
+
 template <int D, int HEAD, bool BF, int GM>
 int launch_sweep4(const Args4& g, hipStream_t stream) {
     using G = Geo4<D, GM>;
@@ -2048,7 +2093,9 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
     if (phase & 2) {
         // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
-            if (geometry == 2 && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
+            // the huge geometry (pda_v5_sweep.h): dense sweeps of the popularity head on a prep built WITH that popularity
+            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF>(g, stream);
+            if ((geometry == 2 || geometry == 4) && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
             if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
         }
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
@@ -2066,7 +2113,7 @@ static bool lists_in_hbm4(int) { return true; }       // (every d may run with i
 // the workspace of the pda_score_topk4_* calls: [counters of pda_score_topk_workspace_bytes | list slots of every workgroup when the
 // lists live in HBM | Bloom filters, 128 B per user | warm-position train-item masks, 32 B per user and split | regrouping: 1024 bins, bin and sweep row of every user]
 struct Ws4 {
-    size_t lists, bloom, hmask, regroup, handover, total;
+    size_t lists, bloom, hmask, regroup, handover, ufrag, unorm, total;
 };
 static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2074,7 +2121,7 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     w.lists = al(pda_score_topk_workspace_bytes(n_users_blk));
     size_t b = w.lists;
     if (lists_in_hbm4(d)) {
-        const size_t ut = 512;          // (the widest user tile of any geometry)
+        const size_t ut = 1024;         // (the widest user tile of any geometry: the huge one's)
         b += ((size_t)n_users_blk + ut - 1) / ut * (size_t)n_splits * ut * kCap4 * 8 + 256;
     }
     w.bloom = al(b);
@@ -2082,6 +2129,14 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     w.regroup = al(w.hmask + ((size_t)n_users_blk + kUserTile - 1) / kUserTile * (size_t)n_splits * kUserTile * 2 * kWarmTiles * 4);
     w.handover = al(w.regroup + (1024 + 4 * (size_t)n_users_blk) * 4);       // (behind: bins, bin_of, row_perm, pred_ws)
     w.total = w.handover + (size_t)n_splits * (size_t)n_users_blk * kCap4 * 8;
+    // the huge geometry (d <= 128): the user block as bf16 MFMA operands (whole 1 024-user workgroups) and the users' padded norms
+    w.ufrag = al(w.total);
+    w.unorm = w.ufrag;
+    if (d <= 128) {
+        const size_t n_pad = ((size_t)n_users_blk + kUT5 - 1) / kUT5 * kUT5;
+        w.unorm = w.ufrag + al(n_pad * 2 * (size_t)d);
+        w.total = w.unorm + al(n_pad * 4);
+    }
     return w;
 }
 extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
@@ -2097,10 +2152,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
-    if (early_stop < 0 || (early_stop & ~0x7F) != 0) return PDA_ERR_ARG;
+    if (early_stop < 0 || (early_stop & ~0xFF) != 0) return PDA_ERR_ARG;
     // geometry hints (Geo4<D, 1 | 2 | 3>): results do not depend on them, and every geometry takes any n_splits and any user count
     // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks); the wide geometry only PAYS on large blocks
-    int geometry = (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
+    int geometry = (early_stop & PDA_SWEEP_HUGE) ? 4 : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
@@ -2129,12 +2184,18 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
             reinterpret_cast<unsigned*>(workspace), reinterpret_cast<uint64_t*>(wsb + W.lists), nullptr, nullptr, nullptr, nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr), seed, n_users_blk, item_offset, n_items_local, hist_row_mode, K, n_splits, L.n_tiles, warm_tiles,
             // sorted hand-over when nobody sorts behind the warm-up: phase 1 alone, or a catalogue that ends inside the warm-up
 #ifdef PDA_V4_WARM_SORTED
-            1};
+            1, nullptr, pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), nullptr, nullptr, 0};
 #else
-            (phase == 1 || (L.n_tiles + n_splits - 1) / n_splits <= warm_tiles) ? 1 : 0};
+            (phase == 1 || (L.n_tiles + n_splits - 1) / n_splits <= warm_tiles) ? 1 : 0, nullptr,
+            pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), nullptr, nullptr, 0};
 #endif
     // warm-up and sweep in one call: K .. kCap4 keys per row through the workspace (see warm4_kernel)
     if (phase == 3 && !g.warm_sorted && PDA_V4_HANDOVER_WS) g.handover = reinterpret_cast<uint64_t*>(wsb + W.handover);
+    g.ufrag = wsb + W.ufrag;
+    g.unorm = reinterpret_cast<const float*>(wsb + W.unorm);
+    // (the prep is the caller's, built by pda_item_prep4_* with the SAME pop_shard it passes here for the popularity head: ops.item_prep4
+    // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
+    g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
     if (hist_indptr && (phase & 2)) {
         uint32_t* bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
         hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,

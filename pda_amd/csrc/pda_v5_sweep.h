@@ -1,0 +1,331 @@
+// The "huge" geometry of the sweep (round 4): sweep5_kernel -- included by pda_score_topk_v4.hip behind the shared device pieces.
+//
+// What generation 4's wide geometry is bound by: the chip is power-limited on the block loop, and what the MFMAs are fed
+// from decides the clock -- one ds_read_b128 per two MFMAs 1 500 TFLOP/s executed, register operands 2 050.  And 1/9 of the MFMAs it
+// executes (1/5 at d = 64) are the folded threshold test.  This geometry removes both (tools/ubench/mfma_struct5.hip measured the
+// mapping first: 1 777 TFLOP/s, all of it algorithmic, against 1 364 algorithmic for the wide mapping on the same box):
+//   * FOUR waves per workgroup, one per SIMD, 512 registers each; a wave owns 256 users, whose bf16 rows sit in AGPRs as eight MFMA
+//     operands of 32 users (re-loaded from the user image at every entry of the asm loop: the
+//     compiler spills into AGPRs between the statements) -- every item fragment read from the LDS feeds EIGHT MFMAs, and a 32-item half-tile is DMA-ed into the LDS
+//     once per 1 024 users;
+//   * the product is TRANSPOSED (A = item fragment, B = user fragment): an accumulator lane holds 16 items of ONE user, so the test
+//     "could this pair reach the user's threshold" is a per-lane compare of the lane's maximum (VALU in the MFMA shadow) -- no test k-step;
+//   * the item image is PRE-SCALED by the popularity: i' = pop * i, so that for s > 0 the head (s + 1) pop = u . i' + pop, and the
+//     per-item terms (pop, the bf16 error bound eps ||u|| ||i'||) are replaced by their maxima over the 32-item half-tile (pmax, nmax:
+//     8 bytes of meta per half-tile; in visiting order the popularities of a half-tile are all but equal):
+//         flag  <=>  max(max_i s~'(u, i) + pmax + eps_w nmax, pmax) > thr'(u)         (eps_w = eps x the wave's largest ||u||)
+//     which is implied by "some pair of the half-tile has an exact head >= the user's K-th value" (s <= 0: the head is <= pop <= pmax);
+//   * no loader and no rescoring waves: the MFMA waves issue the LDS-DMA themselves (two 1 KiB pieces per wave and half-tile at
+//     d = 128), and a wave whose half-tile raised a flag leaves its asm loop, scores that half-tile again with compiler-visible
+//     MFMAs, rescores the candidates exactly (the fp32 chain of the oracle, generation 4's lists and compaction) and re-enters.  In a
+//     dense sweep in visiting order that is a fraction of a candidate per user behind the exact warm-up.
+// Everything else is generation 4's: warm4_kernel's exact lists (handed over through the workspace), the packed keys, the epilogue.
+// Popularity head, d = 64 / 128, dense sweeps (no early termination); selected by the caller's hint PDA_SWEEP_HUGE.
+#pragma once
+#include "pda_v5_loop_asm.h"
+
+constexpr int kUT5 = 1024;            // users per workgroup
+constexpr int kNSlot5 = 8;            // half-tile slots in the LDS (pda_v5_loop_asm.h: NSLOT)
+constexpr int kRing5 = 192;           // candidate ring entries per wave (u64 each); a push needs 64 free
+
+__host__ __device__ constexpr int half_bytes5(int d) { return 64 * d; }       // 32 rows of 2 d bytes, 16-byte chunks XOR-swizzled
+template <int D>
+__device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((row >> 1) & 7); }
+
+// ---- the user image: the block's rows as bf16 MFMA operands, in the order the waves load them into their AGPRs ------------------
+// fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes; lane l holds user 32 u + (l & 31), elements 16 k + 8 (l >> 5) .. + 7
+template <int D, bool BF>
+__global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U, const int32_t* __restrict__ users, int n_users_blk, int n_pad,
+                                                     unsigned char* __restrict__ ufrag, float* __restrict__ unorm) {
+    constexpr int TPR = D / 8, NK = D / 16;
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int rb = gid / TPR, c = gid % TPR;
+    if (rb >= n_pad) return;
+    f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
+    if (rb < n_users_blk) {
+        const int uid = users[rb];
+        x = pda_load4<BF>(U, (size_t)uid * D + 8 * c);
+        y = pda_load4<BF>(U, (size_t)uid * D + 8 * c + 4);
+    }
+    u32x4 hq, lq;
+    split8(x, y, hq, lq);
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
+#pragma unroll
+    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const int wgw = rb >> 8, u = (rb >> 5) & 7, j = rb & 31, k = c >> 1, hh = c & 1;
+    *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 8 + u) * NK + k) * 64 + (j + 32 * hh)) * 16) = hq;
+    if (c == 0) unorm[rb] = sqrtf(ss) * 1.0009765625f * 1.0001f;          // padded ||u|| (as generation 4's nu_row)
+}
+
+template <int D, bool BF>
+__global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
+    constexpr int NK = D / 16, HB = half_bytes5(D), UT = kUT5, CAPL = kCap4, RB4 = row_bytes(D);
+    constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
+    constexpr float kEps5 = BF ? 2.01171875e-3f : 4.0234375e-3f;         // 2^-9 x 1.03 (only the scaled items are rounded)  |  2^-8 x 1.03
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* tiles = smem;                                         // kNSlot5 x HB
+    int* cntl = reinterpret_cast<int*>(smem + kNSlot5 * HB);            // [UT]
+    float* taul = reinterpret_cast<float*>(cntl + UT);                   // [UT]
+    uint64_t* crings = reinterpret_cast<uint64_t*>(taul + UT);           // [4][kRing5]  (user row of the wave << 32 | visiting position)
+    unsigned* sync = reinterpret_cast<unsigned*>(crings + 4 * kRing5);   // landed[4], released[4]
+    unsigned* s_uns = sync + 8;                                          // [32] one bit per user row: its list came in unsorted
+    uint64_t* lists = g.lists_ws + (size_t)blockIdx.x * UT * CAPL;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    const int K = g.K;
+    const int nt = split_tiles(g.n_tiles, split, g.n_splits);
+    const int n_it = max(0, nt - g.warm_tiles);                          // 64-item tiles behind the warm-up
+    const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
+    if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;
+    // kernel identity (workspace + 16): generation 4 | geometry 4 << 8 | head << 13 | bf16 tables << 14 | d / 64
+    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | (4u << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
+    // ---- the lists of the warm-up -> the workspace, their counts and K-th values -> LDS (all waves; as sweep4_kernel)
+    {
+        constexpr int NW = 4, PB = 8;
+        for (int r0 = wave; r0 < UT; r0 += PB * NW) {
+            uint64_t keyv[PB];
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int rr = r0 + q * NW, rb = utile * UT + rr;
+                keyv[q] = (rr >= UT || rb >= g.n_users_blk) ? 0ull
+                          : g.handover != nullptr ? (lane < kCap4 ? g.handover[((size_t)split * g.n_users_blk + rb) * kCap4 + lane] : 0ull)
+                          : (lane < K ? g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] : 0ull);
+            }
+#pragma unroll
+            for (int q = 0; q < PB; ++q) {
+                const int rr = r0 + q * NW;
+                if (rr >= UT) break;
+                const int rb = utile * UT + rr;
+                const uint64_t key = keyv[q];
+                const int c = __popcll(__ballot(key != 0ull));
+                if (lane < (g.handover != nullptr ? kCap4 : K)) lists[(size_t)rr * CAPL + lane] = key;
+                uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+                if (lane == 0) {
+                    cntl[rr] = c;
+                    taul[rr] = rb < g.n_users_blk ? (c >= K ? pda_unordf(mn) : -INFINITY) : INFINITY;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    }
+    __syncthreads();
+
+    unsigned n_cand = 0;
+    if (hend > 0) {
+        const int row0 = wave * 256;                                     // this wave's user rows of the workgroup
+        const int j = lane & 31, hh = lane >> 5;
+        const unsigned lane16 = (unsigned)lane * 16u;
+        const unsigned char* my_ufrag = g.ufrag + ((size_t)utile * 4 + wave) * (size_t)(8 * NK * 1024);
+        // the wave's largest padded ||u||, the external seeds and the history bounds of the lane's users (block u: row 32 u + j)
+        float eu = 0.f, seedv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int rb = utile * UT + row0 + 32 * u + j;
+            eu = fmaxf(eu, rb < g.n_users_blk ? g.unorm[rb] : 0.f);
+            seedv[u] = (g.seed != nullptr && rb < g.n_users_blk) ? g.seed[rb] : -INFINITY;
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) eu = fmaxf(eu, __shfl_xor(eu, o, 64));
+        eu = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(eu * (kEps5 * 1.001f))));       // eps x the wave's largest ||u||, wave-uniform
+        const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
+        const unsigned sync_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(sync);
+        uint64_t* my_ring = crings + wave * kRing5;
+        unsigned ring_n = 0;                                             // wave-uniform: entries in my_ring
+        const unsigned t0 = (unsigned)(split + g.warm_tiles * g.n_splits);
+        const size_t img = (size_t)g.rows5, meta = (size_t)g.meta5;
+        const bool hist_on = g.hist_indptr != nullptr;
+
+        // the lowered threshold of the lane's user of block u: strictly below the exact K-th value (ties must pass) and below the fp32
+        // roundings between the bound and the rescored head; +-1e30 stand for +-inf
+        auto thr_of = [&](int u) __attribute__((always_inline)) -> float {
+            const float tq = fmaxf(taul[row0 + 32 * u + j], seedv[u]);
+            float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
+            return fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
+        };
+        // ---- exact rescoring of the ring's candidates: the fp32 chain of the oracle (oracle/pda_oracle.c dot_chain; sweep4_kernel's
+        // interleaved row loads), the train-item check, the append.  CPP candidates per pass, LPC lanes each.
+        auto rescore_ring = [&]() __attribute__((always_inline)) {
+            const int q = lane % LPC, ci = lane / LPC;
+            for (unsigned base = 0; base < ring_n; base += CPP) {
+                const bool have = base + (unsigned)ci < ring_n;
+                const uint64_t e = have ? my_ring[base + ci] : 0ull;
+                const int row = (int)(e >> 32);
+                const unsigned pos = (unsigned)e;
+                bool valid = have && pos < (unsigned)g.n_items_local;
+                const unsigned char* tail = g.rows + (size_t)(valid ? pos : 0u) * RB4 + 2 * D + 32;
+                const float pv = *reinterpret_cast<const float*>(tail);
+                const int loc = *reinterpret_cast<const int*>(tail + 4);
+                const int rb = utile * UT + row0 + row;
+                valid = valid && rb < g.n_users_blk;
+                const int uid = valid ? g.users[rb] : 0;
+                const float c_sd = (g.seed != nullptr && valid) ? g.seed[rb] : -INFINITY;
+                const float c_tau = taul[row0 + (valid ? row : 0)];
+                f32x4 uu[8], ii[8];
+                const size_t ub = (size_t)uid * D + q * 8, ib = (size_t)(valid ? loc : 0) * D + q * 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const int off = 8 * LPC * (c >> 1) + 4 * (c & 1);
+                    uu[c] = pda_load4<BF>(g.U, ub + off);
+                    ii[c] = pda_load4<BF>(g.I, ib + off);
+                }
+                long long hb = 0, he = 0;
+                if (hist_on && valid) {
+                    const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)uid : (int64_t)rb;
+                    hb = g.hist_indptr[hr];
+                    he = g.hist_indptr[hr + 1];
+                }
+                auto fma8 = [&](float acc, int cq) __attribute__((always_inline)) -> float {
+#pragma unroll
+                    for (int sidx = 0; sidx < 4; ++sidx) {
+                        acc = __builtin_fmaf(uu[2 * cq][sidx], ii[2 * cq][sidx], acc);
+                        acc = __builtin_fmaf(uu[2 * cq + 1][sidx], ii[2 * cq + 1][sidx], acc);
+                    }
+                    return acc;
+                };
+                float o = 0.f;
+                if constexpr (LPC == 4) {
+                    const bool hi = q >= 2;
+                    auto swap2 = [](float x) __attribute__((always_inline)) -> float {
+                        return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+                    };
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) {
+                        const float a = fma8(o, cq);
+                        const float a_sw = swap2(a);
+                        const float b = fma8(hi ? a_sw : o, cq);
+                        const float b_sw = swap2(b);
+                        o = hi ? b : b_sw;
+                    }
+                } else {
+                    static_assert(LPC == 2, "d = 64");
+#pragma unroll
+                    for (int cq = 0; cq < 4; ++cq) o = fma8(o, cq);
+                }
+                const float o0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(o), 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
+                float sc = o0 + o;                                  // meaningful on the candidate's last lane
+                sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
+                const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
+                const int item = g.item_offset + loc;
+                bool p = valid && q == LPC - 1 && (tt >= fmaxf(c_tau, c_sd));
+                if (hist_on && p) {                                 // train items are masked here: a binary search in the row's id-sorted history
+                    long long lo = hb, hi2 = he;
+                    while (lo < hi2) {
+                        const long long mid = (lo + hi2) >> 1;
+                        if (g.hist_indices[mid] < item) lo = mid + 1; else hi2 = mid;
+                    }
+                    if (lo < he && g.hist_indices[lo] == item) p = false;
+                }
+                const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+                append_keys<CAPL, true>(p, row0 + row, tt, key, lists, cntl, taul, row0, 256, K, lane, s_uns);
+            }
+            n_cand += ring_n;
+            ring_n = 0;
+        };
+        // ---- a half-tile that raised a flag, scored again with compiler-visible MFMAs: every pair whose bound reaches the user's
+        // threshold -> the ring
+        auto extract = [&](unsigned ft) __attribute__((always_inline)) {
+            const unsigned T = t0 + (ft >> 1) * (unsigned)g.n_splits;                   // its 64-item tile
+            const unsigned pos0 = T * 64u + (ft & 1u) * 32u;                            // visiting position of its first item
+            const float2 mt = *reinterpret_cast<const float2*>(g.meta5 + 2 * (size_t)(2u * T + (ft & 1u)));
+            const float ct = __builtin_fmaf(eu, mt.y, mt.x);
+            const unsigned char* tb = tiles + (ft & (kNSlot5 - 1)) * HB + j * (2 * D);
+            u32x4 af[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) af[k] = *reinterpret_cast<const u32x4*>(tb + (((2 * k + hh) ^ swz5<D>(j)) << 4));
+            for (int u = 0; u < 8; ++u) {
+                const float tl = thr_of(u);
+                const bool clampy = mt.x > tl;
+                f32x16 acc = zero16v();
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const u32x4 bf = *reinterpret_cast<const u32x4*>(my_ufrag + (((size_t)u * NK + k) * 64 + lane) * 16);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+                }
+                uint32_t m = 0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m |= (acc[r] + ct > tl) ? (1u << r) : 0u;
+                if (__any(clampy)) {
+                    // (rare: a user whose threshold lies below a popularity of this half-tile -- a head pop x exp(s), s <= 0, may qualify)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const unsigned pp = pos0 + 8u * (r >> 2) + 4u * hh + (r & 3);
+                        const float pi = clampy ? *reinterpret_cast<const float*>(g.rows + (size_t)pp * RB4 + 2 * D + 32) : 0.f;
+                        m |= (clampy && pi > tl) ? (1u << r) : 0u;
+                    }
+                }
+                while (__any(m != 0u)) {
+                    if (ring_n + 64u > (unsigned)kRing5) rescore_ring();
+                    const bool act = m != 0u;
+                    const int r = __builtin_ctz(m | 0x10000u);
+                    m &= ~(1u << r);
+                    const uint64_t pm = __ballot(act);
+                    const unsigned slot = ring_n + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
+                    if (act) my_ring[slot] = ((uint64_t)(unsigned)(32 * u + j) << 32) | (uint64_t)(pos0 + 8u * (r >> 2) + 4u * hh + (r & 3));
+                    ring_n += (unsigned)__popcll(pm);
+                }
+            }
+        };
+
+        unsigned h = 0, issued = 0, n_entries = 0;
+        for (unsigned guard = 0; guard < 2u * hend + 8u; ++guard) {
+            ++n_entries;
+            float thr[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) thr[u] = thr_of(u);
+            unsigned reason = 0;
+            Loop5<D>::run(h, issued, reason, hend, ring_lds, sync_lds, sync_lds + 4u * (unsigned)wave, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
+                          (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, my_ufrag, thr, lane16);
+            if (reason == 0u) break;
+            if (reason != 1u) { if (lane == 0) g.stats[0] = 5u; break; }
+            if (h >= 1u && h - 1u < hend) extract(h - 1u);
+            // (thresholds rise only through the lists: rescoring a ring that holds a pass's worth keeps them fresh enough)
+            if (ring_n >= (unsigned)CPP) rescore_ring();
+        }
+        if (ring_n > 0u) rescore_ring();
+        if (lane == 0) atomicAdd(g.stats + 1, n_cand);
+        if (lane == 0) atomicAdd(g.stats + 5, n_entries);                  // (workspace + 20: entries of the asm loop, summed over the waves)
+        if (lane == 0 && wave == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * n_it * (UT / kUserTile)));
+    }
+    // ================================== all waves: sort and emit ==================================
+    __syncthreads();
+    constexpr int EB = 8;
+    for (int r0 = wave; r0 < UT; r0 += EB * 4) {
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int rr = r0 + q * 4;
+            if (rr >= UT) break;
+            const int rb = utile * UT + rr;
+            uint64_t* buf = lists + (size_t)rr * CAPL;
+            compact_list<CAPL, true>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
+            const int c = cntl[rr];
+            if (rb < g.n_users_blk && lane < K) {
+                const uint64_t k = lane < c ? buf[lane] : 0ull;
+                g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+            }
+        }
+    }
+}
+
+template <int D, bool BF>
+int launch_sweep5(const Args4& g, hipStream_t stream) {
+    constexpr size_t lds = (size_t)kNSlot5 * half_bytes5(D) + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 8 * 4 + 32 * 4 + 64;
+    static int attr_set = 0;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PDA_ERR_LAUNCH;
+        attr_set = 1;
+    }
+    const int utiles = (g.n_users_blk + kUT5 - 1) / kUT5, n_pad = utiles * kUT5;
+    hipLaunchKernelGGL((uprep5_kernel<D, BF>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, stream, g.U, g.users, g.n_users_blk, n_pad,
+                       const_cast<unsigned char*>(g.ufrag), const_cast<float*>(g.unorm));
+    PDA_CHECK_LAUNCH();
+    hipLaunchKernelGGL((sweep5_kernel<D, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}

@@ -212,6 +212,8 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
 # The wide geometry pays as soon as the 256-user geometry needs a second round of workgroups (> 256 x 256 users): measured at config 3,
 # 98 304 users 5.22 vs 5.78 ms, 131 072 x 50 000 items 1.75 vs 1.84 ms; at 65 536 users (one round of 256 workgroups) 5.00 vs 3.55 ms.
 WIDE_MIN_USERS = 65537
+# The huge geometry (pda_v5_sweep.h) wants a workgroup of 1 024 users on every CU: from 256 x 1 024 users on (measured: see DESIGN 3.1h)
+HUGE_MIN_USERS = 196609
 
 
 def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:
@@ -219,8 +221,10 @@ def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:
     behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
     four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
     forced = os.environ.get("PDA_SCORE_LISTS", "")
-    if forced in ("lds", "hbm", "wide", "many"):
-        return {"lds": 0, "hbm": 2, "wide": 4, "many": 8}[forced]
+    if forced in ("lds", "hbm", "wide", "many", "huge"):
+        return {"lds": 0, "hbm": 2, "wide": 4, "many": 8, "huge": 128}[forced]
+    if head == HEAD_POP and prune == "order" and n_users >= HUGE_MIN_USERS and d in (64, 128):
+        return 128          # PDA_SWEEP_HUGE: 1 024-user workgroups of four 512-register waves, eight MFMAs per LDS read, no test k-step
     if head == HEAD_POP and prune == "order" and n_users >= WIDE_MIN_USERS and d in (64, 128):
         return 4            # PDA_SWEEP_WIDE: the dense sweep of a large user block (512-user workgroups, half the LDS and tile traffic per MFMA)
     early = prune is True or (prune == 1 and prune != "order")
@@ -410,6 +414,7 @@ def seeded_finish(c: SeededCall) -> torch.Tensor:
         c.stats["pairs_rescored"] = c.ws[4:8].view(torch.int32)
         c.stats["tiles_dense"] = ((c.nloc + 31) // 32) * ((c.nu + 127) // 128)
         c.stats["kernel_id"] = c.ws[16:20].view(torch.int32)
+        c.stats["error"] = c.ws[0:4].view(torch.int32)
     out, c.keep = c.out, None
     return out
 
@@ -481,11 +486,17 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,
                  K, head, es, n_splits, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4")
+        if os.environ.get("PDA_CHECK_SWEEP_ERRORS"):          # (tests: synchronising) a bounded wait of the sweep ran out, or the huge geometry's self-check failed
+            err = int(ws[0:4].view(torch.int32)[0])
+            if err != 0:
+                raise RuntimeError("pda_score_topk4: the sweep reported protocol error %d" % err)
         if stats is not None:
             stats["tiles_scored"] = ws[8:16].view(torch.int64)
             stats["pairs_rescored"] = ws[4:8].view(torch.int32)
             stats["tiles_dense"] = ((nloc + 31) // 32) * ((nu + 127) // 128)
             stats["kernel_id"] = ws[16:20].view(torch.int32)     # written by the sweep kernel itself: see kernel_identity()
+            stats["huge_entries"] = ws[20:24].view(torch.int32)  # huge geometry: entries of its asm loop, summed over the waves (1 per wave + 1 per flagged half-tile)
+            stats["error"] = ws[0:4].view(torch.int32)           # 0, or which bounded wait of the sweep ran out (1 .. 4: hand-over words; 5, 6: huge geometry)
         return out
     if impl == "v2" and prune:
         prep, order = item_prep_ordered(I_shard, pop_shard if head == HEAD_POP else None)

@@ -64,6 +64,7 @@ def run(ops, W, hist, users, head, prune, expect, **kw):
     keys = ops.score_topk_keys(W.U, W.I, users, 50, head, W.pop_last if head else None, hist, prune=prune, stats=st, **kw)
     out = ops.topk_merge(keys, want="keys")
     ident = ops.kernel_identity(st["kernel_id"][0]) if "kernel_id" in st else {"generation": None}
+    assert "error" not in st or int(st["error"][0]) == 0, ("the sweep reported a protocol error", int(st["error"][0]))
     for k, v in expect.items():
         assert ident.get(k) == v, (expect, ident)
     return out, st
@@ -105,14 +106,15 @@ def test_full_size_c3(dev, monkeypatch):
         assert torch.equal(ref, v), k
 
     # ---- the operating point of bench.py's headline: a 262 144-user block, NO PDA_* variable set -- the library's own choice of
-    # kernel and geometry, asserted: the dense sweep of the popularity head in visiting order runs the wide geometry
-    # (sweep4_kernel<128, 1, false, false, 2>), the raw head and the natural-order sweeps the many-candidates geometry (<.., 3>).
+    # kernel and geometry, asserted: the dense sweep of the popularity head in visiting order runs the huge geometry
+    # (sweep5_kernel<128, false>; the wide one, sweep4_kernel<128, 1, false, false, 2>, from 65 537 users on), the raw head and the
+    # natural-order sweeps the many-candidates geometry (<.., 3>).
     # (a) the first 256 lists equal the oracle's on config 3's real history, both heads; (b) the users shared with the
     # 131 072-user block carry the same keys.
     huge = torch.arange(200_000, 200_000 + 262144, dtype=torch.int32, device=dev)
     oracle = {h: oracle_sample_lists(W, huge, h) for h in (0, 1)}
     k262 = {}
-    for prune, exp in (("order", {"generation": 4, "geometry": "wide", "early_stop": False, "head": 1, "d": 128, "bf16": False}),
+    for prune, exp in (("order", {"generation": 4, "geometry": "huge", "early_stop": False, "head": 1, "d": 128, "bf16": False}),
                        (True, {"generation": 4, "geometry": "lds", "early_stop": True, "head": 1}),
                        (False, {"generation": 4, "geometry": "many", "early_stop": False, "head": 1})):
         k262[prune], st = run(ops, W, hist, huge, POP, prune, exp)
@@ -135,8 +137,8 @@ def test_full_size_c3(dev, monkeypatch):
 
     # ---- every other geometry forced on the same 262 144-user block: identical keys
     monkeypatch.setenv("PDA_SCORE_KERNEL", "v4")
-    for geo, cases in (("lds", ((POP, "order"),)), ("hbm", ((POP, "order"), (POP, True))), ("wide", ((POP, True),)),
-                       ("many", ((POP, "order"), (RAW, "order")))):
+    for geo, cases in (("lds", ((POP, "order"),)), ("hbm", ((POP, "order"), (POP, True))), ("wide", ((POP, "order"), (POP, True))),
+                       ("many", ((POP, "order"), (RAW, "order"))), ("huge", ((POP, "order"),))):
         monkeypatch.setenv("PDA_SCORE_LISTS", geo)
         for head, prune in cases:
             # (the wide geometry has no early-terminating instance: the library falls back to the default geometry there)

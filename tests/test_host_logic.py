@@ -105,8 +105,9 @@ def test_sweep_kernel_and_geometry_selection(monkeypatch):
     assert ops.score_kernel(256, 50, 250000, False, P) == "v3"
     assert ops.score_kernel(256, 50, 250000, "order", R) == "v3"
     assert ops.score_kernel(32, 50, 1000, True, P) == "v3"
-    # geometry hints (bits of early_stop): 4 = wide, 8 = many candidates, 0 = default
-    assert ops.few_candidates_hint(P, "order", 262144, 128) == 4          # the headline: dense sweep of a large block
+    # geometry hints (bits of early_stop): 128 = huge, 4 = wide, 8 = many candidates, 0 = default
+    assert ops.few_candidates_hint(P, "order", 262144, 128) == 128        # the headline: dense sweep of a very large block (1 024-user workgroups)
+    assert ops.few_candidates_hint(P, "order", 196608, 128) == 4          # (below 192 x 1 024 + 1 users the wide geometry fills the chip better)
     assert ops.few_candidates_hint(P, "order", 131072, 64) == 4
     assert ops.few_candidates_hint(P, "order", 98304, 128) == 4           # (the 256-user geometry would need a second round of workgroups)
     assert ops.few_candidates_hint(P, "order", 65536, 128) == 0           # one round of 256 workgroups: the 256-user geometry
