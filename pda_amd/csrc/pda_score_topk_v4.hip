@@ -127,7 +127,7 @@ Prep4Layout prep4_layout(int n, int d) {
     L.meta5 = L.rows5;
     if (d <= 128) {
         L.meta5 = L.rows5 + al((size_t)L.n_tiles * 2 * 64 * (size_t)d);
-        L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 8);
+        L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 16);          // (pmax, nmax, 0, 0) per half-tile: one 16-byte LDS-DMA lane
     }
     return L;
 }
@@ -189,8 +189,8 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
         if constexpr (D <= 128) {
             if (pos < n) {                                   // (pmax, nmax) of the half-tile: maxima of non-negative floats = maxima of their bit patterns
                 const float pv = pop ? ((popv == popv) ? popv : 0.f) : 1.0f;
-                atomicMax(&meta5[2 * (pos >> 5)], __float_as_int(pop ? pv : 0.f));
-                atomicMax(&meta5[2 * (pos >> 5) + 1], __float_as_int(pv * v * 1.000001f));
+                atomicMax(&meta5[4 * (pos >> 5)], __float_as_int(pop ? pv : 0.f));
+                atomicMax(&meta5[4 * (pos >> 5) + 1], __float_as_int(pv * v * 1.000001f));
             }
         }
         // the B side of the extra k-step (see pda_score_topk_v2.hip:item_prep_kernel): k 0..7 pieces of (1/pop)' rounded
@@ -312,7 +312,7 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     if (order && hipMemsetAsync(hdr + 2, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;          // header word 2 := 1: a visiting order was given
     if (pop && hipMemsetAsync(hdr + 1, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;            // header word 1 := 1: the test operands carry 1/pop pieces
     const int n_pad = L.n_tiles * 64;
-    if (d <= 128 && hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 8, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (d <= 128 && hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 16, s) != hipSuccess) return PDA_ERR_LAUNCH;
     unsigned char* r5 = pb + L.rows5;
     int* m5 = reinterpret_cast<int*>(pb + L.meta5);
 #define PDA_P4(DD)                                                                                                              \
@@ -2370,6 +2370,13 @@ extern "C" int pda_topk_seed_pick(const float* bounds, const int32_t* counts, in
     return PDA_OK;
 }
 
+#ifdef PDA_V5_LOG
+extern "C" int pda_debug_v5_log(unsigned* out, int n_words, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pda_v5_log), (size_t)n_words * 4) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (reset) { unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(pda_v5_log), &z, 4) != hipSuccess) return PDA_ERR_LAUNCH; }
+    return PDA_OK;
+}
+#endif
 #ifdef PDA_V4_PROF
 extern "C" int pda_debug_prof4(unsigned long long* out16, int reset) {     /* 24 words */
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(pda_prof4), sizeof(unsigned long long) * 24) != hipSuccess) return PDA_ERR_LAUNCH;

@@ -16,9 +16,10 @@
 //         flag  <=>  max(max_i s~'(u, i) + pmax + eps_w nmax, pmax) > thr'(u)         (eps_w = eps x the wave's largest ||u||)
 //     which is implied by "some pair of the half-tile has an exact head >= the user's K-th value" (s <= 0: the head is <= pop <= pmax);
 //   * no loader and no rescoring waves: the MFMA waves issue the LDS-DMA themselves (two 1 KiB pieces per wave and half-tile at
-//     d = 128), and a wave whose half-tile raised a flag leaves its asm loop, scores that half-tile again with compiler-visible
-//     MFMAs, rescores the candidates exactly (the fp32 chain of the oracle, generation 4's lists and compaction) and re-enters.  In a
-//     dense sweep in visiting order that is a fraction of a candidate per user behind the exact warm-up.
+//     d = 128) and run in step, one s_barrier per half-tile; when a half-tile raised a flag in any of them, all four leave their asm
+//     loop together, score that half-tile (and the one behind it) again with compiler-visible MFMAs, rescore the candidates exactly
+//     (the fp32 chain of the oracle, generation 4's lists and compaction) and re-enter.  In a dense sweep in visiting order that is a
+//     fraction of a candidate per user behind the exact warm-up.
 // Everything else is generation 4's: warm4_kernel's exact lists (handed over through the workspace), the packed keys, the epilogue.
 // Popularity head, d = 64 / 128, dense sweeps (no early termination); selected by the caller's hint PDA_SWEEP_HUGE.
 #pragma once
@@ -26,6 +27,13 @@
 
 constexpr int kUT5 = 1024;            // users per workgroup
 constexpr int kNSlot5 = 8;            // half-tile slots in the LDS (pda_v5_loop_asm.h: NSLOT)
+#ifdef PDA_V5_LOG
+__device__ unsigned pda_v5_log[1 << 18];      // debug build: [0] = entries used; then (block << 8 | wave, kind, a, b) per event
+#define V5LOG(kind, a, b) do { if (lane == 0) { const unsigned i_ = atomicAdd(&pda_v5_log[0], 1u); if (i_ < (1u << 16) - 1u) { \
+    pda_v5_log[4 * i_ + 4] = ((unsigned)blockIdx.x << 8) | (unsigned)wave; pda_v5_log[4 * i_ + 5] = (kind); pda_v5_log[4 * i_ + 6] = (a); pda_v5_log[4 * i_ + 7] = (b); } } } while (0)
+#else
+#define V5LOG(kind, a, b) do {} while (0)
+#endif
 constexpr int kRing5 = 192;           // candidate ring entries per wave (u64 each); a push needs 64 free
 
 __host__ __device__ constexpr int half_bytes5(int d) { return 64 * d; }       // 32 rows of 2 d bytes, 16-byte chunks XOR-swizzled
@@ -69,8 +77,9 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     int* cntl = reinterpret_cast<int*>(smem + kNSlot5 * HB);            // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                   // [UT]
     uint64_t* crings = reinterpret_cast<uint64_t*>(taul + UT);           // [4][kRing5]  (user row of the wave << 32 | visiting position)
-    unsigned* sync = reinterpret_cast<unsigned*>(crings + 4 * kRing5);   // landed[4], released[4]
+    unsigned* sync = reinterpret_cast<unsigned*>(crings + 4 * kRing5);   // [4] the shared flag words of the last four half-tiles (pda_v5_loop_asm.h)
     unsigned* s_uns = sync + 8;                                          // [32] one bit per user row: its list came in unsorted
+    unsigned* metal = sync + 48;                                         // [8][4] the LDS meta ring: (pmax, nmax, 0, 0) of the half-tiles in the slots
     uint64_t* lists = g.lists_ws + (size_t)blockIdx.x * UT * CAPL;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -80,7 +89,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - g.warm_tiles);                          // 64-item tiles behind the warm-up
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
-    if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;
+    if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;          // (words 0 .. 3: the shared flag words; 8 .. 39: every list comes in unsorted)
     // kernel identity (workspace + 16): generation 4 | geometry 4 << 8 | head << 13 | bf16 tables << 14 | d / 64
     if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | (4u << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the lists of the warm-up -> the workspace, their counts and K-th values -> LDS (all waves; as sweep4_kernel)
@@ -134,7 +143,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         for (int o = 32; o >= 1; o >>= 1) eu = fmaxf(eu, __shfl_xor(eu, o, 64));
         eu = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(eu * (kEps5 * 1.001f))));       // eps x the wave's largest ||u||, wave-uniform
         const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)tiles;
-        const unsigned sync_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(sync);
+        const unsigned flags_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(sync);
         uint64_t* my_ring = crings + wave * kRing5;
         unsigned ring_n = 0;                                             // wave-uniform: entries in my_ring
         const unsigned t0 = (unsigned)(split + g.warm_tiles * g.n_splits);
@@ -232,7 +241,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         auto extract = [&](unsigned ft) __attribute__((always_inline)) {
             const unsigned T = t0 + (ft >> 1) * (unsigned)g.n_splits;                   // its 64-item tile
             const unsigned pos0 = T * 64u + (ft & 1u) * 32u;                            // visiting position of its first item
-            const float2 mt = *reinterpret_cast<const float2*>(g.meta5 + 2 * (size_t)(2u * T + (ft & 1u)));
+            const float2 mt = *reinterpret_cast<const float2*>(g.meta5 + 4 * (size_t)(2u * T + (ft & 1u)));
             const float ct = __builtin_fmaf(eu, mt.y, mt.x);
             const unsigned char* tb = tiles + (ft & (kNSlot5 - 1)) * HB + j * (2 * D);
             u32x4 af[NK];
@@ -273,17 +282,39 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         };
 
         unsigned h = 0, issued = 0, n_entries = 0;
+        const unsigned metal_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(metal);
         for (unsigned guard = 0; guard < 2u * hend + 8u; ++guard) {
             ++n_entries;
             float thr[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) thr[u] = thr_of(u);
             unsigned reason = 0;
-            Loop5<D>::run(h, issued, reason, hend, ring_lds, sync_lds, sync_lds + 4u * (unsigned)wave, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
-                          (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, my_ufrag, thr, lane16);
+            Loop5<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
+                          (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), metal_lds, eu, my_ufrag, thr, lane16);
+            V5LOG(reason, h, issued);
             if (reason == 0u) break;
             if (reason != 1u) { if (lane == 0) g.stats[0] = 5u; break; }
+#ifdef PDA_V5_LOG
+            // LDS integrity: the half-tiles about to be scored again and the one in progress, in their slots, against the image
+            for (unsigned tq = (h >= 2u ? h - 2u : 0u); tq <= h && tq < hend; ++tq) {
+                const unsigned Tq = t0 + (tq >> 1) * (unsigned)g.n_splits;
+                const unsigned char* gsrc = g.rows5 + ((size_t)(2u * Tq + (tq & 1u))) * HB;
+                const unsigned char* lsrc = tiles + (tq & (kNSlot5 - 1)) * HB;
+                unsigned pieces = 0;
+                for (int i = 0; i < HB / 1024; ++i) {
+                    const u32x4 a4 = *reinterpret_cast<const u32x4*>(gsrc + i * 1024 + lane * 16);
+                    const u32x4 b4 = *reinterpret_cast<const u32x4*>(lsrc + i * 1024 + lane * 16);
+                    if (__ballot(((a4[0] ^ b4[0]) | (a4[1] ^ b4[1]) | (a4[2] ^ b4[2]) | (a4[3] ^ b4[3])) != 0u) != 0ull) pieces |= 1u << i;
+                }
+                if (pieces != 0u) V5LOG(13u, (tq << 8) | (h - tq), pieces);
+            }
+#endif
+            // every wave of the workgroup left at half-tile h because SOME wave's lanes flagged h - 2; the flags of h - 1 were still being
+            // worked out: both are scored again here (a half-tile without a candidate of this wave costs its 8 NK MFMAs)
+            [[maybe_unused]] const unsigned before = ring_n + n_cand;
+            if (h >= 2u && h - 2u < hend) extract(h - 2u);
             if (h >= 1u && h - 1u < hend) extract(h - 1u);
+            V5LOG(10u, h, ring_n + n_cand - before);
             // (thresholds rise only through the lists: rescoring a ring that holds a pass's worth keeps them fresh enough)
             if (ring_n >= (unsigned)CPP) rescore_ring();
         }
@@ -314,7 +345,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
 
 template <int D, bool BF>
 int launch_sweep5(const Args4& g, hipStream_t stream) {
-    constexpr size_t lds = (size_t)kNSlot5 * half_bytes5(D) + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 8 * 4 + 32 * 4 + 64;
+    constexpr size_t lds = (size_t)kNSlot5 * half_bytes5(D) + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 48 * 4 + kNSlot5 * 16 + 64;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
