@@ -23,10 +23,14 @@
 // Everything else is generation 4's: warm4_kernel's exact lists (handed over through the workspace), the packed keys, the epilogue.
 // Popularity head, d = 64 / 128, dense sweeps (no early termination); selected by the caller's hint PDA_SWEEP_HUGE.
 #pragma once
+#ifdef PDA_V5_LOOP_HEADER          // a timing-only A/B build of the loop (tools/ab_huge.sh)
+#include PDA_V5_LOOP_HEADER
+#else
 #include "pda_v5_loop_asm.h"
+#endif
 
 constexpr int kUT5 = 1024;            // users per workgroup
-constexpr int kNSlot5 = 8;            // half-tile slots in the LDS (pda_v5_loop_asm.h: NSLOT)
+constexpr int kNSlot5 = 8;            // half-tile slots in the LDS (pda_v5_loop_asm.h: NSLOT), Loop5<D>::kSlotBytes each: the rows, then the meta entry
 #ifdef PDA_V5_LOG
 __device__ unsigned pda_v5_log[1 << 18];      // debug build: [0] = entries used; then (block << 8 | wave, kind, a, b) per event
 #define V5LOG(kind, a, b) do { if (lane == 0) { const unsigned i_ = atomicAdd(&pda_v5_log[0], 1u); if (i_ < (1u << 16) - 1u) { \
@@ -69,17 +73,17 @@ __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U,
 
 template <int D, bool BF>
 __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
-    constexpr int NK = D / 16, HB = half_bytes5(D), UT = kUT5, CAPL = kCap4, RB4 = row_bytes(D);
+    [[maybe_unused]] constexpr int HB = half_bytes5(D);
+    constexpr int NK = D / 16, SS = Loop5<D>::kSlotBytes, UT = kUT5, CAPL = kCap4, RB4 = row_bytes(D);
     constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
     constexpr float kEps5 = BF ? 2.01171875e-3f : 4.0234375e-3f;         // 2^-9 x 1.03 (only the scaled items are rounded)  |  2^-8 x 1.03
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* tiles = smem;                                         // kNSlot5 x HB
-    int* cntl = reinterpret_cast<int*>(smem + kNSlot5 * HB);            // [UT]
+    unsigned char* tiles = smem;                                         // kNSlot5 x SS (at LDS address 0: the loop XORs fragment offsets into slot addresses)
+    int* cntl = reinterpret_cast<int*>(smem + kNSlot5 * SS);            // [UT]
     float* taul = reinterpret_cast<float*>(cntl + UT);                   // [UT]
     uint64_t* crings = reinterpret_cast<uint64_t*>(taul + UT);           // [4][kRing5]  (user row of the wave << 32 | visiting position)
-    unsigned* sync = reinterpret_cast<unsigned*>(crings + 4 * kRing5);   // [4] the shared flag words of the last four half-tiles (pda_v5_loop_asm.h)
+    unsigned* sync = reinterpret_cast<unsigned*>(crings + 4 * kRing5);   // [2] the shared flag words, one per half-tile parity (pda_v5_loop_asm.h)
     unsigned* s_uns = sync + 8;                                          // [32] one bit per user row: its list came in unsorted
-    unsigned* metal = sync + 48;                                         // [8][4] the LDS meta ring: (pmax, nmax, 0, 0) of the half-tiles in the slots
     uint64_t* lists = g.lists_ws + (size_t)blockIdx.x * UT * CAPL;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -89,7 +93,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - g.warm_tiles);                          // 64-item tiles behind the warm-up
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
-    if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;          // (words 0 .. 3: the shared flag words; 8 .. 39: every list comes in unsorted)
+    if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;          // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted)
     // kernel identity (workspace + 16): generation 4 | geometry 4 << 8 | head << 13 | bf16 tables << 14 | d / 64
     if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | (4u << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the lists of the warm-up -> the workspace, their counts and K-th values -> LDS (all waves; as sweep4_kernel)
@@ -243,7 +247,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
             const unsigned pos0 = T * 64u + (ft & 1u) * 32u;                            // visiting position of its first item
             const float2 mt = *reinterpret_cast<const float2*>(g.meta5 + 4 * (size_t)(2u * T + (ft & 1u)));
             const float ct = __builtin_fmaf(eu, mt.y, mt.x);
-            const unsigned char* tb = tiles + (ft & (kNSlot5 - 1)) * HB + j * (2 * D);
+            const unsigned char* tb = tiles + (ft & (kNSlot5 - 1)) * SS + j * (2 * D);
             u32x4 af[NK];
 #pragma unroll
             for (int k = 0; k < NK; ++k) af[k] = *reinterpret_cast<const u32x4*>(tb + (((2 * k + hh) ^ swz5<D>(j)) << 4));
@@ -282,15 +286,16 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         };
 
         unsigned h = 0, issued = 0, n_entries = 0;
-        const unsigned metal_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(metal);
-        for (unsigned guard = 0; guard < 2u * hend + 8u; ++guard) {
+        bool hend_ok = true;
+        if ((ring_lds & 255u) != 0u) { if (lane == 0) g.stats[0] = 6u; hend_ok = false; }      // (the slots must start at multiples of 256)
+        for (unsigned guard = 0; hend_ok && guard < 2u * hend + 8u; ++guard) {
             ++n_entries;
             float thr[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) thr[u] = thr_of(u);
             unsigned reason = 0;
             Loop5<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
-                          (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), metal_lds, eu, my_ufrag, thr, lane16);
+                          (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, my_ufrag, thr, lane16);
             V5LOG(reason, h, issued);
             if (reason == 0u) break;
             if (reason != 1u) { if (lane == 0) g.stats[0] = 5u; break; }
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
             for (unsigned tq = (h >= 2u ? h - 2u : 0u); tq <= h && tq < hend; ++tq) {
                 const unsigned Tq = t0 + (tq >> 1) * (unsigned)g.n_splits;
                 const unsigned char* gsrc = g.rows5 + ((size_t)(2u * Tq + (tq & 1u))) * HB;
-                const unsigned char* lsrc = tiles + (tq & (kNSlot5 - 1)) * HB;
+                const unsigned char* lsrc = tiles + (tq & (kNSlot5 - 1)) * SS;
                 unsigned pieces = 0;
                 for (int i = 0; i < HB / 1024; ++i) {
                     const u32x4 a4 = *reinterpret_cast<const u32x4*>(gsrc + i * 1024 + lane * 16);
@@ -345,7 +350,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
 
 template <int D, bool BF>
 int launch_sweep5(const Args4& g, hipStream_t stream) {
-    constexpr size_t lds = (size_t)kNSlot5 * half_bytes5(D) + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 48 * 4 + kNSlot5 * 16 + 64;
+    constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 48 * 4 + 64;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
