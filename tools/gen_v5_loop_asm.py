@@ -136,14 +136,14 @@ def gen(D):
         q = 1 - p
         # -- fixed places first
         # slot 0: the last fragment of THIS half-tile (its register set was in use until the end of h - 1) and its meta pair
-        ev(p, 0, "lds", ("frag", p, NK - 1), frag_read(NK - 1, 0))
+        ev(p, 0, "lds", ("frag", p, NK - 1), frag_read(NK - 1, 0), "frag")
         ev(p, 0, "lds", ("meta", p), ["ds_read_b64 %s, %s offset:%d" % (metapair(p), vsb, HB)], "flag")
         # slot 1: the flag word of h - 2's parity (complete behind the barrier that ended h - 1); reads now go to the slot of h + 1
         ev(p, 1, "lds", ("flag", p), ["ds_read_b32 %s, %s offset:%d" % (vflag, vfb, 4 * p)], "flag")
-        ev(p, 1, "valu", None, ["v_add_u32 %s, s95, %s" % (vrd, voff0), "v_mov_b32 %s, s95" % vsb])
+        ev(p, 1, "valu", None, ["v_add_u32 %s, s95, %s" % (vrd, voff0), "v_mov_b32 %s, s95" % vsb], "salu")
         # fragments 0 .. NK - 2 of h + 1: right behind the last MFMA of this half-tile that reads the register set
         for k in range(NK - 1):
-            ev(p, slot_of(G - 1, k, GU - 1) + 1, "lds", ("frag", q, k), frag_read(k, k))
+            ev(p, slot_of(G - 1, k, GU - 1) + 1, "lds", ("frag", q, k), frag_read(k, k), "frag")
         # tests: chain (g, j) is final behind slot_of(g, NK - 1, j) and restarts n_half - (NK - 1) GU slots later: its eight maxima (which
         # read the accumulator) spread over that window; the add, maximum, compare and OR (which do not) behind it, two slots per chain
         for g in range(G):
@@ -180,7 +180,7 @@ def gen(D):
         # ct of THIS half-tile from its meta pair (pmax, nmax): the slack between the bf16 product and a bound of the exact head
         ev(p, s0 + 1, "check", ("meta", p), ["v_fma_f32 %s, %%[eu], %s, %s" % (ct(p), metan(p), metap(p))], "flag")
         # the LDS slot of h + 2 (s95 was read in slot 1)
-        s1 = spread(p, s0 + 1, s0 + 4, [["s_add_u32 s97, %[h], 2"] + slot_addr("s95", "s97")])
+        s1 = spread(p, s0 + 1, s0 + 4, [] if "nosalu" in VARIANT else [["s_add_u32 s97, %[h], 2"] + slot_addr("s95", "s97")])
         # the pieces (and the meta entry) of h + PFD -- their slot held h + PFD - 8 -- and the pointers' step to the next half-tile: none
         # past the end; behind an even half-tile the tile's other half, behind an odd one the split's next tile
         x_odd = (p + PFD) & 1
@@ -188,7 +188,7 @@ def gen(D):
                 "s_cselect_b32 s87, %s, 0" % ("s91" if x_odd else "16")]
         adv = [["s_add_u32 s84, s84, s86", "s_addc_u32 s85, s85, 0"], ["s_add_u32 s88, s88, s87", "s_addc_u32 s89, s89, 0", "s_mov_b32 %[issued], s80"]]
         lastdma = min(PUB - 2, slot_of(G - 1, 0, GU - 1)) if D >= 128 else n_half - 2
-        spread(p, s1, lastdma, [["s_add_u32 s81, %%[h], %d" % PFD]] + dma_ops("s81") + [step[:2], step[2:]] + adv)
+        spread(p, s1, lastdma, [] if "nosalu" in VARIANT else [["s_add_u32 s81, %%[h], %d" % PFD]] + dma_ops("s81") + [step[:2], step[2:]] + adv)
         # my own flags of h - 1 are complete: publish them (h + 2 into the word of h - 1's parity when any is set), start afresh
         ev(p, PUB, "valu", None, ["s_add_u32 s97, %[h], 2", "s_cmp_lg_u64 s[92:93], 0", "s_cselect_b32 s98, s97, 0", "s_mov_b64 s[92:93], 0"], "flag")
         ev(p, PUB + 1, "valu", None, ["v_mov_b32 %s, s98" % vpub, "s_mov_b64 exec, 1"], "flag")
