@@ -223,6 +223,10 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        product transposed so that the threshold test is a per-lane compare (no test k-step), the item image pre-scaled by the
  *        popularity (pda_v5_sweep.h).  Identical keys.  Dense sweeps only (with bit 0 set: ignored); other heads: the wide geometry. */
 #define PDA_SWEEP_HUGE 128
+/*        bit 8 = PDA_SWEEP_HUGE_32X32, with bit 7: the first form of that loop, on v_mfma_f32_32x32x16_bf16 (eight user blocks of 32
+ *        per wave) instead of v_mfma_f32_16x16x32_bf16 (sixteen of 16: half the accumulator registers moved per MAC, which on this
+ *        power-limited part is clock).  Kept for A/B measurements.  Identical keys. */
+#define PDA_SWEEP_HUGE_32X32 256
 #define PDA_SWEEP_WARM_TILES(n) (((n) & 7) << 4)
 size_t pda_item_prep4_bytes(int n_items_local, int d);
 int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,

@@ -2094,8 +2094,9 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
         // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
             // the huge geometry (pda_v5_sweep.h): dense sweeps of the popularity head on a prep built WITH that popularity
-            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF>(g, stream);
-            if ((geometry == 2 || geometry == 4) && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
+            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true>(g, stream);
+            if (geometry == 5 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, false>(g, stream);
+            if ((geometry == 2 || geometry == 4 || geometry == 5) && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
             if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
         }
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
@@ -2152,10 +2153,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
-    if (early_stop < 0 || (early_stop & ~0xFF) != 0) return PDA_ERR_ARG;
+    if (early_stop < 0 || (early_stop & ~0x1FF) != 0) return PDA_ERR_ARG;
     // geometry hints (Geo4<D, 1 | 2 | 3>): results do not depend on them, and every geometry takes any n_splits and any user count
     // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks); the wide geometry only PAYS on large blocks
-    int geometry = (early_stop & PDA_SWEEP_HUGE) ? 4 : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
+    int geometry = (early_stop & PDA_SWEEP_HUGE) ? ((early_stop & PDA_SWEEP_HUGE_32X32) ? 5 : 4) : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;

@@ -28,6 +28,11 @@
 #else
 #include "pda_v5_loop_asm.h"
 #endif
+#ifdef PDA_V6_LOOP_HEADER
+#include PDA_V6_LOOP_HEADER
+#else
+#include "pda_v6_loop_asm.h"           // the same loop on v_mfma_f32_16x16x32_bf16 (S16 below; tools/gen_v6_loop_asm.py)
+#endif
 
 constexpr int kUT5 = 1024;            // users per workgroup
 constexpr int kNSlot5 = 8;            // half-tile slots in the LDS (pda_v5_loop_asm.h: NSLOT), Loop5<D>::kSlotBytes each: the rows, then the meta entry
@@ -46,10 +51,11 @@ __device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((
 
 // ---- the user image: the block's rows as bf16 MFMA operands, in the order the waves load them into their AGPRs ------------------
 // fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes; lane l holds user 32 u + (l & 31), elements 16 k + 8 (l >> 5) .. + 7
-template <int D, bool BF>
+// S16 (the 16 x 16 x 32 loop): fragment (wg, w, u, k) is 16 users x 32 elements; lane l holds user 16 u + (l & 15), elements 32 k + 8 (l >> 4) .. + 7
+template <int D, bool BF, bool S16>
 __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U, const int32_t* __restrict__ users, int n_users_blk, int n_pad,
                                                      unsigned char* __restrict__ ufrag, float* __restrict__ unorm) {
-    constexpr int TPR = D / 8, NK = D / 16;
+    constexpr int TPR = D / 8;
     const int gid = blockIdx.x * 256 + threadIdx.x;
     const int rb = gid / TPR, c = gid % TPR;
     if (rb >= n_pad) return;
@@ -66,15 +72,25 @@ __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U,
     for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    const int wgw = rb >> 8, u = (rb >> 5) & 7, j = rb & 31, k = c >> 1, hh = c & 1;
-    *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 8 + u) * NK + k) * 64 + (j + 32 * hh)) * 16) = hq;
+    if constexpr (S16) {
+        constexpr int NK = D / 32;
+        const int wgw = rb >> 8, u = (rb >> 4) & 15, j = rb & 15, k = c >> 2, g4 = c & 3;
+        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 16 + u) * NK + k) * 64 + (j + 16 * g4)) * 16) = hq;
+    } else {
+        constexpr int NK = D / 16;
+        const int wgw = rb >> 8, u = (rb >> 5) & 7, j = rb & 31, k = c >> 1, hh = c & 1;
+        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 8 + u) * NK + k) * 64 + (j + 32 * hh)) * 16) = hq;
+    }
     if (c == 0) unorm[rb] = sqrtf(ss) * 1.0009765625f * 1.0001f;          // padded ||u|| (as generation 4's nu_row)
 }
 
-template <int D, bool BF>
+template <int D, bool BF, bool S16>
 __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     [[maybe_unused]] constexpr int HB = half_bytes5(D);
-    constexpr int NK = D / 16, SS = Loop5<D>::kSlotBytes, UT = kUT5, CAPL = kCap4, RB4 = row_bytes(D);
+    static_assert(Loop5<D>::kSlotBytes == Loop6<D>::kSlotBytes, "one LDS image for both loops");
+    // NK k-steps per product, NU user blocks of UBW users per wave (S16: 16 x 16 x 32 MFMAs -- 16 blocks of 16; else 32 x 32 x 16 -- 8 of 32)
+    constexpr int NK = S16 ? D / 32 : D / 16, NU = S16 ? 16 : 8, UBW = S16 ? 16 : 32;
+    constexpr int SS = Loop5<D>::kSlotBytes, UT = kUT5, CAPL = kCap4, RB4 = row_bytes(D);
     constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
     constexpr float kEps5 = BF ? 2.01171875e-3f : 4.0234375e-3f;         // 2^-9 x 1.03 (only the scaled items are rounded)  |  2^-8 x 1.03
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -94,8 +110,8 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     const int n_it = max(0, nt - g.warm_tiles);                          // 64-item tiles behind the warm-up
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
     if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;          // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted)
-    // kernel identity (workspace + 16): generation 4 | geometry 4 << 8 | head << 13 | bf16 tables << 14 | d / 64
-    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | (4u << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
+    // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
+    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((S16 ? 4u : 5u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the lists of the warm-up -> the workspace, their counts and K-th values -> LDS (all waves; as sweep4_kernel)
     {
         constexpr int NW = 4, PB = 8;
@@ -132,14 +148,14 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     unsigned n_cand = 0;
     if (hend > 0) {
         const int row0 = wave * 256;                                     // this wave's user rows of the workgroup
-        const int j = lane & 31, hh = lane >> 5;
+        const int j = lane & (UBW - 1), hh = lane / UBW;               // the lane's user of a block; its 8-element group of a fragment's k-range
         const unsigned lane16 = (unsigned)lane * 16u;
-        const unsigned char* my_ufrag = g.ufrag + ((size_t)utile * 4 + wave) * (size_t)(8 * NK * 1024);
-        // the wave's largest padded ||u||, the external seeds and the history bounds of the lane's users (block u: row 32 u + j)
-        float eu = 0.f, seedv[8];
+        const unsigned char* my_ufrag = g.ufrag + ((size_t)utile * 4 + wave) * (size_t)(NU * NK * 1024);
+        // the wave's largest padded ||u||, the external seeds and the history bounds of the lane's users (block u: row UBW u + j)
+        float eu = 0.f, seedv[NU];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int rb = utile * UT + row0 + 32 * u + j;
+        for (int u = 0; u < NU; ++u) {
+            const int rb = utile * UT + row0 + UBW * u + j;
             eu = fmaxf(eu, rb < g.n_users_blk ? g.unorm[rb] : 0.f);
             seedv[u] = (g.seed != nullptr && rb < g.n_users_blk) ? g.seed[rb] : -INFINITY;
         }
@@ -157,7 +173,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         // the lowered threshold of the lane's user of block u: strictly below the exact K-th value (ties must pass) and below the fp32
         // roundings between the bound and the rescored head; +-1e30 stand for +-inf
         auto thr_of = [&](int u) __attribute__((always_inline)) -> float {
-            const float tq = fmaxf(taul[row0 + 32 * u + j], seedv[u]);
+            const float tq = fmaxf(taul[row0 + UBW * u + j], seedv[u]);
             float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
             return fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
         };
@@ -248,26 +264,52 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
             const float2 mt = *reinterpret_cast<const float2*>(g.meta5 + 4 * (size_t)(2u * T + (ft & 1u)));
             const float ct = __builtin_fmaf(eu, mt.y, mt.x);
             const unsigned char* tb = tiles + (ft & (kNSlot5 - 1)) * SS + j * (2 * D);
-            u32x4 af[NK];
+            // accumulator register r of the lane <-> item of the half-tile (S16: r = 4 ib + register of chain ib)
+            auto item_of = [&](int r) __attribute__((always_inline)) -> unsigned {
+                return S16 ? 16u * (r >> 2) + 4u * hh + (r & 3) : 8u * (r >> 2) + 4u * hh + (r & 3);
+            };
+            constexpr int NR = S16 ? 8 : 16;
+            u32x4 af[S16 ? 2 * NK : NK];
+            if constexpr (S16) {
 #pragma unroll
-            for (int k = 0; k < NK; ++k) af[k] = *reinterpret_cast<const u32x4*>(tb + (((2 * k + hh) ^ swz5<D>(j)) << 4));
-            for (int u = 0; u < 8; ++u) {
+                for (int ib = 0; ib < 2; ++ib)
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) af[ib * NK + k] = *reinterpret_cast<const u32x4*>(tb + ib * 16 * (2 * D) + (((4 * k + hh) ^ swz5<D>(j)) << 4));
+            } else {
+#pragma unroll
+                for (int k = 0; k < NK; ++k) af[k] = *reinterpret_cast<const u32x4*>(tb + (((2 * k + hh) ^ swz5<D>(j)) << 4));
+            }
+            for (int u = 0; u < NU; ++u) {
                 const float tl = thr_of(u);
                 const bool clampy = mt.x > tl;
-                f32x16 acc = zero16v();
-#pragma unroll
-                for (int k = 0; k < NK; ++k) {
-                    const u32x4 bf = *reinterpret_cast<const u32x4*>(my_ufrag + (((size_t)u * NK + k) * 64 + lane) * 16);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
-                }
                 uint32_t m = 0;
+                if constexpr (S16) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m |= (acc[r] + ct > tl) ? (1u << r) : 0u;
+                    for (int ib = 0; ib < 2; ++ib) {
+                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+                            const u32x4 bf = *reinterpret_cast<const u32x4*>(my_ufrag + (((size_t)u * NK + k) * 64 + lane) * 16);
+                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ib * NK + k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m |= (acc[r] + ct > tl) ? (1u << (4 * ib + r)) : 0u;
+                    }
+                } else {
+                    f32x16 acc = zero16v();
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const u32x4 bf = *reinterpret_cast<const u32x4*>(my_ufrag + (((size_t)u * NK + k) * 64 + lane) * 16);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m |= (acc[r] + ct > tl) ? (1u << r) : 0u;
+                }
                 if (__any(clampy)) {
                     // (rare: a user whose threshold lies below a popularity of this half-tile -- a head pop x exp(s), s <= 0, may qualify)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const unsigned pp = pos0 + 8u * (r >> 2) + 4u * hh + (r & 3);
+                    for (int r = 0; r < NR; ++r) {
+                        const unsigned pp = pos0 + item_of(r);
                         const float pi = clampy ? *reinterpret_cast<const float*>(g.rows + (size_t)pp * RB4 + 2 * D + 32) : 0.f;
                         m |= (clampy && pi > tl) ? (1u << r) : 0u;
                     }
@@ -279,7 +321,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
                     m &= ~(1u << r);
                     const uint64_t pm = __ballot(act);
                     const unsigned slot = ring_n + (unsigned)__builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
-                    if (act) my_ring[slot] = ((uint64_t)(unsigned)(32 * u + j) << 32) | (uint64_t)(pos0 + 8u * (r >> 2) + 4u * hh + (r & 3));
+                    if (act) my_ring[slot] = ((uint64_t)(unsigned)(UBW * u + j) << 32) | (uint64_t)(pos0 + item_of(r));
                     ring_n += (unsigned)__popcll(pm);
                 }
             }
@@ -290,12 +332,23 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         if ((ring_lds & 255u) != 0u) { if (lane == 0) g.stats[0] = 6u; hend_ok = false; }      // (the slots must start at multiples of 256)
         for (unsigned guard = 0; hend_ok && guard < 2u * hend + 8u; ++guard) {
             ++n_entries;
-            float thr[8];
+            float thr[NU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) thr[u] = thr_of(u);
+            for (int u = 0; u < NU; ++u) thr[u] = thr_of(u);
             unsigned reason = 0;
-            Loop5<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
-                          (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, my_ufrag, thr, lane16);
+            if constexpr (S16) {
+                // the wave's lowest threshold: the clamp test (a popularity of the half-tile above a user's threshold) is wave-uniform
+                float tmin = thr[0];
+#pragma unroll
+                for (int u = 1; u < NU; ++u) tmin = fminf(tmin, thr[u]);
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+                tmin = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmin)));
+                Loop6<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
+                              (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, tmin, my_ufrag, thr, lane16);
+            } else
+                Loop5<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
+                              (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, my_ufrag, thr, lane16);
             V5LOG(reason, h, issued);
             if (reason == 0u) break;
             if (reason != 1u) { if (lane == 0) g.stats[0] = 5u; break; }
@@ -348,20 +401,20 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     }
 }
 
-template <int D, bool BF>
+template <int D, bool BF, bool S16>
 int launch_sweep5(const Args4& g, hipStream_t stream) {
     constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 48 * 4 + 64;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (g.n_users_blk + kUT5 - 1) / kUT5, n_pad = utiles * kUT5;
-    hipLaunchKernelGGL((uprep5_kernel<D, BF>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, stream, g.U, g.users, g.n_users_blk, n_pad,
+    hipLaunchKernelGGL((uprep5_kernel<D, BF, S16>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, stream, g.U, g.users, g.n_users_blk, n_pad,
                        const_cast<unsigned char*>(g.ufrag), const_cast<float*>(g.unorm));
     PDA_CHECK_LAUNCH();
-    hipLaunchKernelGGL((sweep5_kernel<D, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((sweep5_kernel<D, BF, S16>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
