@@ -101,6 +101,8 @@ struct Args4 {
     const unsigned char* ufrag;
     const float* unorm;
     int prep_hdr_pop;            // host copy of "the prep was built with a popularity" (the image is scaled by it): set by the entry points
+    int warm_final;              // the huge geometry behind a one-call warm-up: warm4_kernel hands SORTED lists of K keys over and writes them to
+                                 // out_keys as well -- the sweep then sorts and emits only the rows it appended to (a few per cent)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -715,12 +717,14 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     for (int rr = 0; rr < 32; ++rr) {
         uint64_t* buf = my_lists + rr * CAP;
         // sorted hand-over, or a row that went through the general append path (ties at its K-th value) and may hold more than K
-        if (((PDA_W4_ABL & 4) == 0) && (g.warm_sorted || (g.handover == nullptr && __builtin_amdgcn_readfirstlane(cntl[wave * 32 + rr]) > K)))
+        if (((PDA_W4_ABL & 4) == 0) && (g.warm_sorted || g.warm_final || (g.handover == nullptr && __builtin_amdgcn_readfirstlane(cntl[wave * 32 + rr]) > K)))
             compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
         const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
         if (g.handover != nullptr) {
             if (rb < g.n_users_blk && lane < CAP) g.handover[((size_t)split * g.n_users_blk + rb) * CAP + lane] = lane < c ? buf[lane] : 0ull;
+            // (warm_final: the row is sorted and holds at most K keys -- it is the final answer unless the sweep appends to it)
+            if (g.warm_final && rb < g.n_users_blk && lane < K) g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = lane < c ? buf[lane] : 0ull;
         } else if (rb < g.n_users_blk && lane < K) {
             const uint64_t k = lane < c ? buf[lane] : 0ull;
             g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
@@ -2197,6 +2201,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // (the prep is the caller's, built by pda_item_prep4_* with the SAME pop_shard it passes here for the popularity head: ops.item_prep4
     // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
+    g.warm_final = ((geometry == 4 || geometry == 5) && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop && d <= 128) ? 1 : 0;
     if (hist_indptr && (phase & 2)) {
         uint32_t* bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
         hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,

@@ -100,19 +100,43 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     uint64_t* crings = reinterpret_cast<uint64_t*>(taul + UT);           // [4][kRing5]  (user row of the wave << 32 | visiting position)
     unsigned* sync = reinterpret_cast<unsigned*>(crings + 4 * kRing5);   // [2] the shared flag words, one per half-tile parity (pda_v5_loop_asm.h)
     unsigned* s_uns = sync + 8;                                          // [32] one bit per user row: its list came in unsorted
-    uint64_t* lists = g.lists_ws + (size_t)blockIdx.x * UT * CAPL;
-
+    unsigned* touched = sync + 40;                                       // [32] one bit per user row: the sweep appended to its list
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    // the exact lists: the hand-over rows of the warm-up IN PLACE (a one-call sweep; the rows of the workgroup's padding do not exist
+    // and are never touched: no candidate, no output), else the workgroup's rows of the workspace
+    uint64_t* lists = g.handover != nullptr ? g.handover + ((size_t)split * g.n_users_blk + (size_t)utile * UT) * kCap4
+                                            : g.lists_ws + (size_t)blockIdx.x * UT * CAPL;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int n_it = max(0, nt - g.warm_tiles);                          // 64-item tiles behind the warm-up
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
-    if (tid < 40) sync[tid] = tid < 8 ? 0u : 0xFFFFFFFFu;          // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted)
+    // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted -- unless the warm-up sorted them: warm_final; 40 .. 71: no row touched)
+    if (tid < 72) sync[tid] = (tid < 8 || tid >= 40 || g.warm_final) ? 0u : 0xFFFFFFFFu;
     // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
     if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((S16 ? 4u : 5u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
-    // ---- the lists of the warm-up -> the workspace, their counts and K-th values -> LDS (all waves; as sweep4_kernel)
+    // ---- the counts and K-th values of the warm-up's lists -> LDS (all waves); without a hand-over buffer the lists themselves -> the workspace
+    if (g.warm_final) {
+        // sorted lists of at most K keys (warm4_kernel): a LANE per row -- its K-th key says everything (0: fewer than K keys; count them)
+        for (int rr = tid; rr < UT; rr += 256) {
+            const int rb = utile * UT + rr;
+            int c = 0;
+            float tau = INFINITY;
+            if (rb < g.n_users_blk) {
+                const uint64_t kl = lists[(size_t)rr * CAPL + (K - 1)];
+                c = K;
+                tau = pda_unordf((uint32_t)(kl >> 32));
+                if (kl == 0ull) {
+                    tau = -INFINITY;
+                    for (c = 0; c < K - 1 && lists[(size_t)rr * CAPL + c] != 0ull; ++c) {}
+                }
+            }
+            cntl[rr] = c;
+            taul[rr] = tau;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    } else
     {
         constexpr int NW = 4, PB = 8;
         for (int r0 = wave; r0 < UT; r0 += PB * NW) {
@@ -131,7 +155,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
                 const int rb = utile * UT + rr;
                 const uint64_t key = keyv[q];
                 const int c = __popcll(__ballot(key != 0ull));
-                if (lane < (g.handover != nullptr ? kCap4 : K)) lists[(size_t)rr * CAPL + lane] = key;
+                if (g.handover == nullptr && lane < K) lists[(size_t)rr * CAPL + lane] = key;
                 uint32_t mn = key != 0ull ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
@@ -251,6 +275,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
                     if (lo < he && g.hist_indices[lo] == item) p = false;
                 }
                 const uint64_t key = pda_pack_key(tt, (uint32_t)item);
+                if (p) atomicOr(&touched[(row0 + row) >> 5], 1u << ((row0 + row) & 31));
                 append_keys<CAPL, true>(p, row0 + row, tt, key, lists, cntl, taul, row0, 256, K, lane, s_uns);
             }
             n_cand += ring_n;
@@ -382,20 +407,59 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         if (lane == 0 && wave == 0) atomicAdd(reinterpret_cast<unsigned long long*>(g.stats + 2), (unsigned long long)(2 * n_it * (UT / kUserTile)));
     }
     // ================================== all waves: sort and emit ==================================
+    // Every list comes out of the warm-up unsorted with K .. kCap4 keys, and all but a few per cent of them are untouched since: the
+    // final top-K selection and sort of all 1 024 rows is a fixed cost of the launch.  With one wave per SIMD nothing hides a round
+    // trip, so: the keys of eight rows are requested together, and a row is ranked out of the LDS (the row's keys written once, then
+    // read back as broadcasts, two keys per ds_read_b128) -- ~150 instructions per row where compact_list's loop over the list in
+    // global memory was a dependent round trip per four keys (0.87 ms of a 9.0 ms launch -> 0.2).  A wave emits its own 256 rows.
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __syncthreads();
-    constexpr int EB = 8;
-    for (int r0 = wave; r0 < UT; r0 += EB * 4) {
+    {
+        constexpr int EB = 8;
+        uint64_t* scr = crings + wave * kRing5;                          // (the rings are empty now)
+        auto emit_row = [&](int rb, int cnt, uint64_t kraw) __attribute__((always_inline)) {
+            const int c = min(__builtin_amdgcn_readfirstlane(cnt), CAPL);                    // (failed appends may have pushed it past the capacity)
+            const uint64_t key = lane < c ? kraw : (uint64_t)(63 - lane);                    // fillers: unique, below any real key
+            scr[lane] = key;
+            pda_wave_sync();
+            int rank = 0;
+            for (int jj = 0; jj < c; jj += 4) {
+                const uint64_t k0 = scr[jj], k1 = scr[jj + 1], k2 = scr[jj + 2], k3 = scr[jj + 3];
+                rank += ((k0 > key) ? 1 : 0) + ((k1 > key) ? 1 : 0) + ((k2 > key) ? 1 : 0) + ((k3 > key) ? 1 : 0);
+            }
+            pda_wave_sync();
+            uint64_t* orow = g.out_keys + ((size_t)split * g.n_users_blk + rb) * K;
+            if (lane < c && rank < K) orow[rank] = key;
+            if (lane >= c && lane < K) orow[lane] = 0ull;
+        };
+        if (g.warm_final) {
+            // out_keys holds the warm-up's sorted rows: only the rows the sweep appended to are ranked and written again
+            for (int w = 0; w < 8; ++w) {
+                unsigned m = touched[wave * 8 + w];
+                while (m != 0u) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const int rr = wave * 256 + 32 * w + b;
+                    emit_row(utile * UT + rr, cntl[rr], lists[(size_t)rr * CAPL + (lane < CAPL ? lane : CAPL - 1)]);
+                }
+            }
+        } else {
+            for (int i0 = 0; i0 < 256; i0 += EB) {
+                uint64_t kraw[EB];
+                int cv[EB];
 #pragma unroll
-        for (int q = 0; q < EB; ++q) {
-            const int rr = r0 + q * 4;
-            if (rr >= UT) break;
-            const int rb = utile * UT + rr;
-            uint64_t* buf = lists + (size_t)rr * CAPL;
-            compact_list<CAPL, true>(buf, &cntl[rr], &taul[rr], K, lane, &s_uns[rr >> 5], 1u << (rr & 31));
-            const int c = cntl[rr];
-            if (rb < g.n_users_blk && lane < K) {
-                const uint64_t k = lane < c ? buf[lane] : 0ull;
-                g.out_keys[((size_t)split * g.n_users_blk + rb) * K + lane] = k;
+                for (int q = 0; q < EB; ++q) {
+                    const int rr = wave * 256 + i0 + q, rb = utile * UT + rr;
+                    const bool ok = rb < g.n_users_blk;
+                    kraw[q] = ok ? lists[(size_t)rr * CAPL + (lane < CAPL ? lane : CAPL - 1)] : 0ull;
+                    cv[q] = ok ? cntl[rr] : 0;
+                }
+#pragma unroll
+                for (int q = 0; q < EB; ++q) {
+                    const int rb = utile * UT + wave * 256 + i0 + q;
+                    if (rb >= g.n_users_blk) break;
+                    emit_row(rb, cv[q], kraw[q]);
+                }
             }
         }
     }
@@ -403,7 +467,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
 
 template <int D, bool BF, bool S16>
 int launch_sweep5(const Args4& g, hipStream_t stream) {
-    constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 48 * 4 + 64;
+    constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 80 * 4 + 64;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -1,5 +1,5 @@
 """The huge geometry against the wide one on a bench workload: time per block, loop entries, candidates (HIP events around the call).
-usage: time_huge.py [workload=c3] [users per block=262144] [geometries=wide,huge]"""
+usage: time_huge.py [workload=c3] [users per block=262144] [geometries=wide,huge] [n_items override: the fixed cost of a call]"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from pda_amd import ops, synthetic
@@ -7,7 +7,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 Bu = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
 geos = (sys.argv[3] if len(sys.argv) > 3 else "wide,huge").split(",")
 dev = torch.device('cuda')
-W = synthetic.make_workload(wl, dev)
+W = synthetic.make_workload(wl, dev, n_items=int(sys.argv[4]) if len(sys.argv) > 4 else None)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 Bu = min(Bu, W.n_users)
 blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in range(0, min(W.n_users - Bu + 1, 3 * Bu), Bu)]
