@@ -227,6 +227,10 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        per wave) instead of v_mfma_f32_16x16x32_bf16 (sixteen of 16: half the accumulator registers moved per MAC, which on this
  *        power-limited part is clock).  Kept for A/B measurements.  Identical keys. */
 #define PDA_SWEEP_HUGE_32X32 256
+/*        bit 9 = PDA_SWEEP_HUGE_2WG, with bit 7: TWO 512-user workgroups per CU (eight waves of 256 registers, 128 users each: a SIMD's
+ *        second wave has the matrix pipe while the first runs its VALU tests) instead of one 1 024-user workgroup.  Measured slower on
+ *        large blocks (the pipe is busier, the clock lower: twice the LDS traffic per MFMA); kept for A/B measurements.  Identical keys. */
+#define PDA_SWEEP_HUGE_2WG 512
 #define PDA_SWEEP_WARM_TILES(n) (((n) & 7) << 4)
 size_t pda_item_prep4_bytes(int n_items_local, int d);
 int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,

@@ -2098,9 +2098,10 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
         // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
             // the huge geometry (pda_v5_sweep.h): dense sweeps of the popularity head on a prep built WITH that popularity
-            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true>(g, stream);
-            if (geometry == 5 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, false>(g, stream);
-            if ((geometry == 2 || geometry == 4 || geometry == 5) && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
+            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, 256>(g, stream);
+            if (geometry == 6 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, 128>(g, stream);
+            if (geometry == 5 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, false, 256>(g, stream);
+            if ((geometry == 2 || geometry >= 4) && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
             if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
         }
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
@@ -2157,10 +2158,10 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
-    if (early_stop < 0 || (early_stop & ~0x1FF) != 0) return PDA_ERR_ARG;
+    if (early_stop < 0 || (early_stop & ~0x3FF) != 0) return PDA_ERR_ARG;
     // geometry hints (Geo4<D, 1 | 2 | 3>): results do not depend on them, and every geometry takes any n_splits and any user count
     // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks); the wide geometry only PAYS on large blocks
-    int geometry = (early_stop & PDA_SWEEP_HUGE) ? ((early_stop & PDA_SWEEP_HUGE_32X32) ? 5 : 4) : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
+    int geometry = (early_stop & PDA_SWEEP_HUGE) ? ((early_stop & PDA_SWEEP_HUGE_32X32) ? 5 : (early_stop & PDA_SWEEP_HUGE_2WG) ? 6 : 4) : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
@@ -2201,7 +2202,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // (the prep is the caller's, built by pda_item_prep4_* with the SAME pop_shard it passes here for the popularity head: ops.item_prep4
     // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
-    g.warm_final = ((geometry == 4 || geometry == 5) && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop && d <= 128) ? 1 : 0;
+    g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop && d <= 128) ? 1 : 0;
     if (hist_indptr && (phase & 2)) {
         uint32_t* bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
         hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,

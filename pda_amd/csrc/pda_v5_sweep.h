@@ -52,7 +52,7 @@ __device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((
 // ---- the user image: the block's rows as bf16 MFMA operands, in the order the waves load them into their AGPRs ------------------
 // fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes; lane l holds user 32 u + (l & 31), elements 16 k + 8 (l >> 5) .. + 7
 // S16 (the 16 x 16 x 32 loop): fragment (wg, w, u, k) is 16 users x 32 elements; lane l holds user 16 u + (l & 15), elements 32 k + 8 (l >> 4) .. + 7
-template <int D, bool BF, bool S16>
+template <int D, bool BF, bool S16, int UPW>
 __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U, const int32_t* __restrict__ users, int n_users_blk, int n_pad,
                                                      unsigned char* __restrict__ ufrag, float* __restrict__ unorm) {
     constexpr int TPR = D / 8;
@@ -73,24 +73,31 @@ __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U,
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if constexpr (S16) {
-        constexpr int NK = D / 32;
-        const int wgw = rb >> 8, u = (rb >> 4) & 15, j = rb & 15, k = c >> 2, g4 = c & 3;
-        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 16 + u) * NK + k) * 64 + (j + 16 * g4)) * 16) = hq;
+        constexpr int NK = D / 32, NU = UPW / 16;                        // (wgw: the wave's index among all waves of the launch)
+        const int wgw = rb / UPW, u = (rb >> 4) & (NU - 1), j = rb & 15, k = c >> 2, g4 = c & 3;
+        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * NU + u) * NK + k) * 64 + (j + 16 * g4)) * 16) = hq;
     } else {
         constexpr int NK = D / 16;
+        static_assert(S16 || UPW == 256, "the 32 x 32 x 16 loop: 256 users per wave");
         const int wgw = rb >> 8, u = (rb >> 5) & 7, j = rb & 31, k = c >> 1, hh = c & 1;
         *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 8 + u) * NK + k) * 64 + (j + 32 * hh)) * 16) = hq;
     }
     if (c == 0) unorm[rb] = sqrtf(ss) * 1.0009765625f * 1.0001f;          // padded ||u|| (as generation 4's nu_row)
 }
 
-template <int D, bool BF, bool S16>
-__global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
+// UPW users per wave: 256 -- one 1 024-user workgroup per CU, 512 registers per wave -- or (S16) 128: 512-user workgroups, TWO per CU, 256
+// registers per wave.  With one wave per SIMD nothing overlaps the wave's own VALU tests, LDS reads and scalar work with its MFMAs (PMC, UPW
+// = 256: matrix pipe 77 % busy at 2.03 GHz, 87 % without the tests); two independent workgroups per CU give every SIMD a second wave --
+// measured (profiles/round4_huge_variants.txt): the pipe is 82 % busy then, but at 1.86 GHz: twice the LDS reads and LDS-DMA per MFMA
+// cost more clock than the overlap buys (8.38 vs 8.18 ms).  UPW = 256 is the product; 128 stays selectable (PDA_SWEEP_HUGE_2WG).
+template <int D, bool BF, bool S16, int UPW>
+__global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g) {
     [[maybe_unused]] constexpr int HB = half_bytes5(D);
-    static_assert(Loop5<D>::kSlotBytes == Loop6<D>::kSlotBytes, "one LDS image for both loops");
-    // NK k-steps per product, NU user blocks of UBW users per wave (S16: 16 x 16 x 32 MFMAs -- 16 blocks of 16; else 32 x 32 x 16 -- 8 of 32)
-    constexpr int NK = S16 ? D / 32 : D / 16, NU = S16 ? 16 : 8, UBW = S16 ? 16 : 32;
-    constexpr int SS = Loop5<D>::kSlotBytes, UT = kUT5, CAPL = kCap4, RB4 = row_bytes(D);
+    static_assert(Loop5<D>::kSlotBytes == Loop6<D, 16>::kSlotBytes && Loop5<D>::kSlotBytes == Loop6<D, 8>::kSlotBytes, "one LDS image for all loops");
+    static_assert(UPW == 256 || (S16 && UPW == 128), "users per wave");
+    // NK k-steps per product, NU user blocks of UBW users per wave (S16: 16 x 16 x 32 MFMAs -- blocks of 16; else 32 x 32 x 16 -- 8 of 32)
+    constexpr int NK = S16 ? D / 32 : D / 16, UBW = S16 ? 16 : 32, NU = UPW / UBW;
+    constexpr int SS = Loop5<D>::kSlotBytes, UT = 4 * UPW, CAPL = kCap4, RB4 = row_bytes(D);
     constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
     constexpr float kEps5 = BF ? 2.01171875e-3f : 4.0234375e-3f;         // 2^-9 x 1.03 (only the scaled items are rounded)  |  2^-8 x 1.03
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -114,8 +121,8 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
     // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted -- unless the warm-up sorted them: warm_final; 40 .. 71: no row touched)
     if (tid < 72) sync[tid] = (tid < 8 || tid >= 40 || g.warm_final) ? 0u : 0xFFFFFFFFu;
-    // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
-    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((S16 ? 4u : 5u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
+    // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, one 1 024-user workgroup per CU; 6: the same, two 512-user workgroups; 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
+    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((!S16 ? 5u : UPW == 256 ? 4u : 6u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the counts and K-th values of the warm-up's lists -> LDS (all waves); without a hand-over buffer the lists themselves -> the workspace
     if (g.warm_final) {
         // sorted lists of at most K keys (warm4_kernel): a LANE per row -- its K-th key says everything (0: fewer than K keys; count them)
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
 
     unsigned n_cand = 0;
     if (hend > 0) {
-        const int row0 = wave * 256;                                     // this wave's user rows of the workgroup
+        const int row0 = wave * UPW;                                     // this wave's user rows of the workgroup
         const int j = lane & (UBW - 1), hh = lane / UBW;               // the lane's user of a block; its 8-element group of a fragment's k-range
         const unsigned lane16 = (unsigned)lane * 16u;
         const unsigned char* my_ufrag = g.ufrag + ((size_t)utile * 4 + wave) * (size_t)(NU * NK * 1024);
@@ -276,7 +283,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
                 }
                 const uint64_t key = pda_pack_key(tt, (uint32_t)item);
                 if (p) atomicOr(&touched[(row0 + row) >> 5], 1u << ((row0 + row) & 31));
-                append_keys<CAPL, true>(p, row0 + row, tt, key, lists, cntl, taul, row0, 256, K, lane, s_uns);
+                append_keys<CAPL, true>(p, row0 + row, tt, key, lists, cntl, taul, row0, UPW, K, lane, s_uns);
             }
             n_cand += ring_n;
             ring_n = 0;
@@ -369,7 +376,7 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
                 tmin = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmin)));
-                Loop6<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
+                Loop6<D, NU>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
                               (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, tmin, my_ufrag, thr, lane16);
             } else
                 Loop5<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
@@ -434,29 +441,29 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
         };
         if (g.warm_final) {
             // out_keys holds the warm-up's sorted rows: only the rows the sweep appended to are ranked and written again
-            for (int w = 0; w < 8; ++w) {
-                unsigned m = touched[wave * 8 + w];
+            for (int w = 0; w < UPW / 32; ++w) {
+                unsigned m = touched[wave * (UPW / 32) + w];
                 while (m != 0u) {
                     const int b = __builtin_ctz(m);
                     m &= m - 1u;
-                    const int rr = wave * 256 + 32 * w + b;
+                    const int rr = wave * UPW + 32 * w + b;
                     emit_row(utile * UT + rr, cntl[rr], lists[(size_t)rr * CAPL + (lane < CAPL ? lane : CAPL - 1)]);
                 }
             }
         } else {
-            for (int i0 = 0; i0 < 256; i0 += EB) {
+            for (int i0 = 0; i0 < UPW; i0 += EB) {
                 uint64_t kraw[EB];
                 int cv[EB];
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
-                    const int rr = wave * 256 + i0 + q, rb = utile * UT + rr;
+                    const int rr = wave * UPW + i0 + q, rb = utile * UT + rr;
                     const bool ok = rb < g.n_users_blk;
                     kraw[q] = ok ? lists[(size_t)rr * CAPL + (lane < CAPL ? lane : CAPL - 1)] : 0ull;
                     cv[q] = ok ? cntl[rr] : 0;
                 }
 #pragma unroll
                 for (int q = 0; q < EB; ++q) {
-                    const int rb = utile * UT + wave * 256 + i0 + q;
+                    const int rb = utile * UT + wave * UPW + i0 + q;
                     if (rb >= g.n_users_blk) break;
                     emit_row(rb, cv[q], kraw[q]);
                 }
@@ -465,20 +472,22 @@ __global__ void __launch_bounds__(256) sweep5_kernel(Args4 g) {
     }
 }
 
-template <int D, bool BF, bool S16>
+template <int D, bool BF, bool S16, int UPW>
 int launch_sweep5(const Args4& g, hipStream_t stream) {
-    constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)kUT5 * 8 + 4 * kRing5 * 8 + 80 * 4 + 64;
+    constexpr int UT = 4 * UPW;
+    constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)UT * 8 + 4 * kRing5 * 8 + 80 * 4 + 64;
+    static_assert(UPW == 256 || 2 * lds <= 160 * 1024, "two workgroups per CU");
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF, S16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF, S16, UPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
-    const int utiles = (g.n_users_blk + kUT5 - 1) / kUT5, n_pad = utiles * kUT5;
-    hipLaunchKernelGGL((uprep5_kernel<D, BF, S16>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, stream, g.U, g.users, g.n_users_blk, n_pad,
+    const int utiles = (g.n_users_blk + UT - 1) / UT, n_pad = utiles * UT;
+    hipLaunchKernelGGL((uprep5_kernel<D, BF, S16, UPW>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, stream, g.U, g.users, g.n_users_blk, n_pad,
                        const_cast<unsigned char*>(g.ufrag), const_cast<float*>(g.unorm));
     PDA_CHECK_LAUNCH();
-    hipLaunchKernelGGL((sweep5_kernel<D, BF, S16>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((sweep5_kernel<D, BF, S16, UPW>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

@@ -221,8 +221,8 @@ def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:
     behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
     four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
     forced = os.environ.get("PDA_SCORE_LISTS", "")
-    if forced in ("lds", "hbm", "wide", "many", "huge", "huge32"):
-        return {"lds": 0, "hbm": 2, "wide": 4, "many": 8, "huge": 128, "huge32": 128 | 256}[forced]
+    if forced in ("lds", "hbm", "wide", "many", "huge", "huge32", "huge2"):
+        return {"lds": 0, "hbm": 2, "wide": 4, "many": 8, "huge": 128, "huge32": 128 | 256, "huge2": 128 | 512}[forced]
     if head == HEAD_POP and prune == "order" and n_users >= HUGE_MIN_USERS and d in (64, 128):
         return 128          # PDA_SWEEP_HUGE: 1 024-user workgroups of four 512-register waves, eight MFMAs per LDS read, no test k-step
     if head == HEAD_POP and prune == "order" and n_users >= WIDE_MIN_USERS and d in (64, 128):
@@ -530,7 +530,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     return out
 
 
-GEOMETRY_NAMES = {0: "lds", 1: "hbm", 2: "wide", 3: "many", 4: "huge", 5: "huge32"}
+GEOMETRY_NAMES = {0: "lds", 1: "hbm", 2: "wide", 3: "many", 4: "huge", 5: "huge32", 6: "huge2"}
 
 
 def kernel_identity(word) -> dict:

@@ -27,28 +27,35 @@ import sys
 
 VARIANT = set(filter(None, os.environ.get("V5_VARIANT", "").split(",")))     # timing-only A/B knobs; the product build has none
 
-UB, GU, IB = 16, 8, 2                # user blocks of 16 per wave; user blocks per group; 16-item blocks per half-tile
-ACC0, FRAG0 = 128, 96                # acc: v[128:255] (chain (u, ib): 4 registers at 128 + 4 (2 u + ib)); fragment sets: v[96 : 96 + 8 NK)
-THR0, M0T = 80, 64                   # thr[16], m[16]
-LO_CLOBBER = 34
-CTQ0 = 34                            # two quads (one per half-tile parity) holding ct in all four registers: the C operand of a chain's first MFMA
-VFLAG, VPUB, VRD, VSB, VFB, VOFF0, VGOFF0, VZERO = 42, 43, 44, 45, 46, 47, 48, 50     # (VGOFF0: two registers)
-CT0, NCT0, META0, ATMP0 = 52, 54, 56, 60       # ct[2], pmax - ct [2], meta pairs (pmax, nmax)[2], address temporaries[2]
+GU, IB = 8, 2                        # user blocks per group; 16-item blocks per half-tile
 NSLOT = 8
 PFD = int(os.environ.get("V5_PFD", "4"))     # half-tile h issues the pieces of h + PFD
+RD = int(os.environ.get("V6_RD", "10"))      # slots between a chain's last MFMA and the first VALU read of its accumulator
 
 
-def acc(u, ib):
-    c = ACC0 + 4 * (2 * u + ib)
-    return "v[%d:%d]" % (c, c + 3)
-
-
-def accr(u, ib, r):
-    return "v%d" % (ACC0 + 4 * (2 * u + ib) + r)
-
-
-def gen(D):
+def gen(D, UB):
+    """UB = 16: a wave owns 256 users (one 1 024-user workgroup per CU, 512 registers per wave).  UB = 8: 128 users (512-user
+    workgroups, TWO per CU, 256 registers per wave: while one wave's VALU tests run, the other wave of the SIMD has the matrix pipe)."""
     NK = D // 32
+    if UB == 16:
+        ACC0, FRAG0, THR0, M0T, MISC0 = 128, 96, 80, 64, 34
+        NSETK = NK                       # fragment register sets per 16-item block: the whole half-tile
+    else:
+        ACC0, FRAG0, THR0, M0T, MISC0 = 64, 48, 40, 32, 8
+        NSETK = min(NK, 2)               # two k-steps in registers: fragment (k, ib) is read while k - 2 .. k - 1 run
+    LO_CLOBBER = MISC0
+    # two quads (one per half-tile parity) holding ct in all four registers: the C operand of a chain's first MFMA | ... | meta pairs
+    # (pmax, nmax)[2] | address temporaries[2]
+    CTQ0, VFLAG, VPUB, VRD, VSB, VFB, VOFF0, VGOFF0, VZERO, VRDB, META0, ATMP0 = (MISC0 + x for x in (0, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 22))
+    assert MISC0 + 24 <= M0T and M0T + UB <= THR0 and THR0 + UB <= FRAG0 and FRAG0 + 8 * NSETK <= ACC0
+
+    def acc(u, ib):
+        c = ACC0 + 4 * (2 * u + ib)
+        return "v[%d:%d]" % (c, c + 3)
+
+    def accr(u, ib, r):
+        return "v%d" % (ACC0 + 4 * (2 * u + ib) + r)
+
     HB = 32 * 2 * D                      # one half-tile: 32 rows of 2 D bytes, 16-byte chunks XOR-swizzled (no padding)
     SS = HB + 256                        # LDS slot: the rows, then the half-tile's meta entry (pmax, nmax, 0, 0); a multiple of 256
     PW = HB // 1024 // 4                 # LDS-DMA pieces per wave and half-tile (2 at d = 128, 1 at d = 64)
@@ -56,7 +63,7 @@ def gen(D):
     G = UB // GU
     n_half = NK * IB * UB                # MFMA slots per half-tile (16 cycles each)
     usr = lambda u, k: "a[%d:%d]" % (4 * (u * NK + k), 4 * (u * NK + k) + 3)
-    frag = lambda k, ib: "v[%d:%d]" % (FRAG0 + 4 * (2 * k + ib), FRAG0 + 4 * (2 * k + ib) + 3)
+    frag = lambda k, ib: "v[%d:%d]" % (FRAG0 + 4 * (2 * (k % NSETK) + ib), FRAG0 + 4 * (2 * (k % NSETK) + ib) + 3)
     thr = lambda u: "v%d" % (THR0 + u)
     mt = lambda u: "v%d" % (M0T + u)
     ctq = lambda p: "v[%d:%d]" % (CTQ0 + 4 * p, CTQ0 + 4 * p + 3)
@@ -64,7 +71,7 @@ def gen(D):
     metap = lambda p: "v%d" % (META0 + 2 * p)
     metan = lambda p: "v%d" % (META0 + 2 * p + 1)
     metapair = lambda p: "v[%d:%d]" % (META0 + 2 * p, META0 + 2 * p + 1)
-    vflag, vpub, vrd, vsb, vfb, voff0, vzero = ("v%d" % x for x in (VFLAG, VPUB, VRD, VSB, VFB, VOFF0, VZERO))
+    vflag, vpub, vrd, vsb, vfb, voff0, vzero, vrdb = ("v%d" % x for x in (VFLAG, VPUB, VRD, VSB, VFB, VOFF0, VZERO, VRDB))
     vgoff = lambda j: "v%d" % (VGOFF0 + j)
     atmp = lambda i: "v%d" % (ATMP0 + (i & 1))
 
@@ -74,14 +81,16 @@ def gen(D):
     def slot_addr(dst, idx_sgpr):
         return ["s_and_b32 %s, %s, %d" % (dst, idx_sgpr, NSLOT - 1), "s_mul_i32 %s, %s, %d" % (dst, dst, SS), "s_add_u32 %s, %s, %%[ring]" % (dst, dst)]
 
-    def frag_read(k, ib, i):
-        """fragment (k, ib) of the half-tile whose slot address (+ the lane's swizzled offset of row l & 15, chunk l >> 4) is in vrd:
+    def frag_read(k, ib, i, base=None):
+        """fragment (k, ib) of the half-tile whose slot address (+ the lane's swizzled offset of row l & 15, chunk l >> 4) is in `base`
+        (vrd: the half-tile in progress; vrdb: the next one, from slot 1 on):
         chunk 4 k + (l >> 4) sits at offset_0 ^ (k << 6) -- the XOR of the swizzle touches bits 4 .. 7 only, and slots start at multiples
         of 256; the second 16 rows are 16 x 2 D bytes behind the first (same swizzle: it depends on row & 15 / (row >> 1) & 7 only)"""
         off = (" offset:%d" % (16 * 2 * D)) if ib else ""
+        base = base or vrdb
         if k == 0:
-            return ["ds_read_b128 %s, %s%s" % (frag(0, ib), vrd, off)]
-        return ["v_xor_b32 %s, %d, %s" % (atmp(i), 64 * k, vrd), "ds_read_b128 %s, %s%s" % (frag(k, ib), atmp(i), off)]
+            return ["ds_read_b128 %s, %s%s" % (frag(0, ib), base, off)]
+        return ["v_xor_b32 %s, %d, %s" % (atmp(i), 64 * k, base), "ds_read_b128 %s, %s%s" % (frag(k, ib), atmp(i), off)]
 
     def pointers_from_scratch():
         """s[84:85], s[88:89] := the sources of local half-tile %[issued] (clamped to the split's last: the loop runs two half-tiles past
@@ -128,7 +137,7 @@ def gen(D):
     # the maxima of user block (g, j): chain ib is final behind slot_of(g, NK - 1, ib, j) (+ 2: the XDL write has landed) and restarts at
     # n_half + slot_of(g, 0, ib, j); W0 slots between "both final" and the restart of chain 0
     W0 = n_half - slot_of(0, NK - 1, 1, 0) - 2
-    PUB = n_half // 2 - 6                # the wave's flags of h - 1 are published here (in half-tile h): every compare of h - 1 lies in front of it
+    PUB = n_half // 2 - 6 if n_half >= 64 else n_half // 2 + 2     # the wave's flags of h - 1 are published here (in half-tile h): every compare of h - 1 lies in front of it
     TESTS = []          # the wave's flags of h - 1 are complete here (in half-tile h)
     AHEAD = []                           # fragments the body reads in the half-tile BEFORE theirs
     for p in range(2):
@@ -136,22 +145,29 @@ def gen(D):
         # -- fixed places first
         # slot 1: the flag word of h - 2's parity (complete behind the barrier that ended h - 1); reads now go to the slot of h + 1
         ev(p, 1, "lds", ("flag", p), ["ds_read_b32 %s, %s offset:%d" % (vflag, vfb, 4 * p)], "flag")
-        ev(p, 1, "valu", None, ["v_add_u32 %s, s95, %s" % (vrd, voff0), "v_mov_b32 %s, s95" % vsb], "salu")
+        ev(p, 0, "valu", None, ["v_mov_b32 %s, %s" % (vrd, vrdb)], "salu")                   # (the next half-tile has become this one)
+        ev(p, 1, "valu", None, ["v_add_u32 %s, s95, %s" % (vrdb, voff0), "v_mov_b32 %s, s95" % vsb], "salu")
         # slot 2: the meta pair (pmax, nmax) of the NEXT half-tile: its ct is the C operand of that half-tile's first MFMAs
         ev(p, 2, "lds", ("meta", q), ["ds_read_b64 %s, %s offset:%d" % (metapair(q), vsb, HB)], "flag")
-        # fragment (k, ib) of the NEXT half-tile right behind the last MFMA of this one that reads the register set (the very last set
-        # frees up at the end of the half-tile: it is read in slot 0 of its own half-tile, before vrd moves on)
+        # fragment (k, ib) is read right behind the last MFMA that reads the register set it goes into: the set's previous occupant is
+        # fragment (k - NSETK, ib) of this half-tile, or (k < NSETK) fragment (NK - NSETK + k, ib) of the previous one -- read in the
+        # half-tile BEFORE its own then, through vrdb (the very last set frees up at the end of the half-tile: read in slot 0 of its own)
         n_rd = 0
         for k in range(NK):
             for ib in range(IB):
-                s = slot_of(G - 1, k, ib, GU - 1) + 1
-                if s == n_half:
-                    ev(p, 0, "lds", ("frag", p, k, ib), frag_read(k, ib, n_rd), "frag")
+                if k >= NSETK:
+                    s = slot_of(G - 1, k - NSETK, ib, GU - 1) + 1
+                    assert 1 <= s < slot_of(0, k, ib, 0) - 4
+                    ev(p, s, "lds", ("frag", p, k, ib), frag_read(k, ib, n_rd, vrd), "frag")
                 else:
-                    assert s >= 2
-                    ev(p, s, "lds", ("frag", q, k, ib), frag_read(k, ib, n_rd), "frag")
-                    if p == 0:
-                        AHEAD.append((k, ib))
+                    s = slot_of(G - 1, NK - NSETK + k, ib, GU - 1) + 1
+                    if s == n_half:
+                        ev(p, 0, "lds", ("frag", p, k, ib), frag_read(k, ib, n_rd, vrd), "frag")
+                    else:
+                        assert s >= 2
+                        ev(p, s, "lds", ("frag", q, k, ib), frag_read(k, ib, n_rd, vrdb), "frag")
+                        if p == 0:
+                            AHEAD.append((k, ib))
                 n_rd += 1
         TESTS.append([])
         for g in range(G):
@@ -166,14 +182,33 @@ def gen(D):
                 # half-tile, below); what is left per user block is the maximum of its 8 accumulator registers and one compare.
                 # (earliest slot, last slot, lines): placed below, every operation into the least loaded slot of its window
                 cmp_lo, cmp_hi = max(PUB, c1 + 6), min(PUB + n_half - 1, c0 + n_half + 1)      # (the next half-tile's first maximum overwrites m)
-                mx = [(c0 + 2, r0 - 1, ["v_max3_f32 %s, %s, %s, %s" % (mt(u), a(0), a(1), a(2))]),
-                      (c1 + 2, r0 - 1, ["v_max3_f32 %s, %s, %s, %s" % (mt(u), mt(u), a(3), b(0))]),
-                      (c1 + 2, r1 - 1, ["v_max3_f32 %s, %s, %s, %s" % (mt(u), mt(u), b(1), b(2))]),
-                      (c1 + 2, r1 - 1, ["v_max_f32 %s, %s, %s" % (mt(u), mt(u), b(3))])]
+                # (RD slots behind the chain's last MFMA: a VALU read of an accumulator holds its wave until the matrix pipe has worked its
+                # way up to that MFMA -- the further behind, the further the wave may run ahead of the pipe)
+                rd = RD if n_half - slot_of(0, NK - 1, 0, 0) - RD >= 12 else 2
+                mx = [(c0 + rd, r0 - 1, ["v_max3_f32 %s, %s, %s, %s" % (mt(u), a(0), a(1), a(2))]),
+                      (c0 + rd, r0 - 1, ["v_max_f32 %s, %s, %s" % (mt(u), mt(u), a(3))]),
+                      (c1 + rd, r1 - 1, ["v_max3_f32 %s, %s, %s, %s" % (mt(u), mt(u), b(0), b(1))]),
+                      (c1 + rd, r1 - 1, ["v_max3_f32 %s, %s, %s, %s" % (mt(u), mt(u), b(2), b(3))])]
                 mx = [(lo, min(hi, cmp_hi - (4 - i)), ln) for i, (lo, hi, ln) in enumerate(mx)]
                 TESTS[p].append(mx + [(cmp_lo, cmp_hi, ["v_cmp_gt_f32 vcc, %s, %s" % (mt(u), thr(u)), "s_or_b64 s[92:93], s[92:93], vcc"])])
         # the clamp of THIS half-tile (its pmax is in the parity's meta pair until slot 2 of the next half-tile reads h + 2's)
         ev(p, PUB + 2, "valu", None, ["v_cmp_lt_f32 vcc, %%[tmin], %s" % metap(p), "s_or_b64 s[92:93], s[92:93], vcc"], "test")
+    # ---- the tests (tight windows: before what may move): every operation into the least loaded slot of its window (in order within a user block)
+    if "notest" not in VARIANT:
+        for p in range(2):
+            for seq in sorted(TESTS[p], key=lambda q_: q_[0][0]):
+                prev = -1
+                for i, (lo, hi, lines) in enumerate(seq):
+                    lo = max(lo, prev + 1)
+                    hi = min(seq[t][1] - (t - i) for t in range(i, len(seq)))        # (leave a slot for each operation behind this one)
+                    assert lo <= hi, (D, p, i, lo, hi)
+                    load = lambda sl: LOAD[(p + sl // n_half) % 2][sl % n_half]
+                    best = min(range(lo, hi + 1), key=lambda sl: (load(sl), sl))
+                    if i == len(seq) - 1:
+                        assert PUB <= best < PUB + n_half            # (every compare of half-tile h between the publish of h - 1 and of h)
+                    ev(p, best, "valu", None, lines)
+                    prev = best
+
     for p in range(2):
         q = 1 - p
         # -- then what may move
@@ -188,7 +223,6 @@ def gen(D):
         ev(p, s0, "check", ("flag", p), chk)
         # ct of the NEXT half-tile from its meta pair (pmax, nmax) -- the slack between the bf16 product and a bound of the exact head --
         # into all four registers of that parity's quad (this half-tile's last reader of it: the first MFMAs of its second group)
-        assert s0 + 1 > slot_of(0, 0, 1, GU - 1) if G == 1 else True
         sq = slot_of(G - 1, 0, 1, GU - 1) + 2
         ev(p, sq, "check", ("meta", q), ["v_fma_f32 %s, %%[eu], %s, %s" % (ctr(q, 0), metan(q), metap(q))], "flag")
         ev(p, sq + 1, "valu", None, ["v_mov_b32 %s, %s" % (ctr(q, r), ctr(q, 0)) for r in (1, 2, 3)], "flag")
@@ -200,8 +234,8 @@ def gen(D):
         step = ["s_add_u32 s80, %%[h], %d" % (PFD + 1), "s_cmp_lt_u32 s80, %[hend]", "s_cselect_b32 s86, %s, 0" % ("s90" if x_odd else "%d" % HB),
                 "s_cselect_b32 s87, %s, 0" % ("s91" if x_odd else "16")]
         adv = [["s_add_u32 s84, s84, s86", "s_addc_u32 s85, s85, 0"], ["s_add_u32 s88, s88, s87", "s_addc_u32 s89, s89, 0", "s_mov_b32 %[issued], s80"]]
-        lastdma = min(PUB - 2, n_half // 2)
-        assert lastdma > s1 + 4
+        lastdma = n_half - 3
+        assert lastdma > s1 + 4 and s0 not in (PUB, PUB + 1)
         spread(p, s1, lastdma, [] if "nosalu" in VARIANT else [["s_add_u32 s81, %%[h], %d" % PFD]] + dma_ops("s81") + [step[:2], step[2:]] + adv)
         # my own flags of h - 1 are complete: publish them (h + 2 into the word of h - 1's parity when any is set), start afresh
         # (s94: 0 until the first publish behind an entry -- the compares in front of it looked at what the code outside left in the
@@ -211,22 +245,6 @@ def gen(D):
         ev(p, PUB + 1, "valu", None, ["v_mov_b32 %s, s98" % vpub, "s_mov_b64 exec, 1"], "flag")
         ev(p, PUB + 1, "lds", ("pub", p), ["ds_max_u32 %s, %s offset:%d" % (vfb, vpub, 4 * q)], "flag")
         ev(p, PUB + 1, "valu", None, ["s_mov_b64 exec, -1"], "flag")
-
-    # ---- the tests, last: every operation into the least loaded slot of its window (in order within a user block)
-    if "notest" not in VARIANT:
-        for p in range(2):
-            for seq in sorted(TESTS[p], key=lambda q_: q_[0][0]):
-                prev = -1
-                for i, (lo, hi, lines) in enumerate(seq):
-                    lo = max(lo, prev + 1)
-                    hi = min(hi, min(h2 for _, h2, _ in seq[i:]) - (0 if i == len(seq) - 1 else 1))
-                    assert lo <= hi, (D, p, i, lo, hi)
-                    load = lambda sl: LOAD[(p + sl // n_half) % 2][sl % n_half]
-                    best = min(range(lo, hi + 1), key=lambda sl: (load(sl), sl))
-                    if i == len(seq) - 1:
-                        assert PUB <= best < PUB + n_half            # (every compare of half-tile h between the publish of h - 1 and of h)
-                    ev(p, best, "valu", None, lines)
-                    prev = best
 
     def build_body(state_in):
         lg = list(state_in)
@@ -273,8 +291,7 @@ def gen(D):
     # ---- prologue (every entry) ------------------------------------------------------------------------------------------------
     P = []
     P += ["s_mov_b32 %[m0save], m0", "s_waitcnt vmcnt(0) lgkmcnt(0)", "v_mov_b32 %s, 0" % vzero, "v_mov_b32 %s, %%[flags]" % vfb]
-    for u in range(UB):
-        P.append("v_mov_b32 %s, %%[thr%d]" % (thr(u), u))
+    # (the thresholds come in in v[THR0 : THR0 + UB): physical-register inputs)
     for j in range(PW):
         P.append("v_add_u32 %s, %d, %%[lane16]" % (vgoff(j), 4096 * j))
         P.append("v_add_u32 %s, %%[w1024], %s" % (vgoff(j), vgoff(j)))
@@ -304,7 +321,7 @@ def gen(D):
     P += pointers_from_scratch()                             # the running pointers of the body: half-tile h + PFD
     # everything issued has landed; behind the barrier everybody's has
     P += ["s_waitcnt vmcnt(0) lgkmcnt(0)", "s_barrier"]
-    P += slot_addr("s97", "%[h]") + ["v_add_u32 %s, s97, %s" % (vrd, voff0), "v_mov_b32 %s, s97" % vsb, "s_add_u32 s97, %[h], 1"] + slot_addr("s95", "s97")
+    P += slot_addr("s97", "%[h]") + ["v_add_u32 %s, s97, %s" % (vrdb, voff0), "v_mov_b32 %s, s97" % vsb, "s_add_u32 s97, %[h], 1"] + slot_addr("s95", "s97")
     P += ["s_mov_b64 s[92:93], 0", "s_mov_b32 s94, 0"]
     # the entry half-tile's ct quad (both parities' registers: the branch below picks the parity), from its meta pair
     P += ["ds_read_b64 %s, %s offset:%d" % (metapair(0), vsb, HB), "s_waitcnt lgkmcnt(0)", "v_fma_f32 %s, %%[eu], %s, %s" % (ctr(0, 0), metan(0), metap(0))]
@@ -312,7 +329,7 @@ def gen(D):
     P += ["v_mov_b32 %s, %s" % (metap(1), metap(0))]
     # every fragment the body reads AHEAD of the half-tile it belongs to
     for i, (k, ib) in enumerate(AHEAD):
-        P += frag_read(k, ib, i)
+        P += frag_read(k, ib, i, vrdb)
     P += ["s_bitcmp1_b32 %[h], 0", "s_cbranch_scc1 9f"]
     for par in range(2):
         # (the first slots of the entry half-tile carry the tail of the PREVIOUS half-tile's tests: -inf makes them fail)
@@ -326,22 +343,22 @@ def gen(D):
     E += ["92:", "s_mov_b32 %[reason], 0"] + drain + ["99:"]                   # the sweep is over
     if os.environ.get("V5_LOADS"):
         for p in range(2):
-            print("D=%d parity %d fillers per slot: %s" % (D, p, " ".join("%d" % x for x in LOAD[p])), file=sys.stderr)
-    return P + b2 + E
+            print("D=%d UB=%d parity %d fillers per slot: %s" % (D, UB, p, " ".join("%d" % x for x in LOAD[p])), file=sys.stderr)
+    return P + b2 + E, THR0, LO_CLOBBER
 
 
-def emit(D):
-    L = gen(D)
+def emit(D, UB):
+    L, THR0, LO = gen(D, UB)
     out = []
     out.append("template <>")
-    out.append("struct Loop6<%d> {" % D)
+    out.append("struct Loop6<%d, %d> {" % (D, UB))
     out.append("    static constexpr int kSlotBytes = %d, kPfd = %d;" % (64 * D + 256, PFD))
     out.append("    // h: the local half-tile to run next (in: where to (re)start; out: the half-tile in progress when the statement left).")
     out.append("    // issued: half-tiles whose pieces this wave has issued.  reason: 0 = the sweep is over, 1 = half-tile h - 2 raised a flag in some")
     out.append("    // wave of the workgroup (all four leave together; h - 1 has not been looked at).")
     out.append("    static __device__ __forceinline__ void run(unsigned& h, unsigned& issued, unsigned& reason, unsigned hend, unsigned ring, unsigned flags, unsigned w1024,")
     out.append("                                               unsigned t0, unsigned nsplit, unsigned imglo, unsigned imghi, unsigned metalo, unsigned metahi, float eu, float tmin, const void* ufrag,")
-    out.append("                                               const float (&thr)[16], unsigned lane16) {")
+    out.append("                                               const float (&thr)[%d], unsigned lane16) {" % UB)
     out.append("#if defined(__HIP_DEVICE_COMPILE__)")
     out.append("        unsigned m0save;")
     out.append("        asm volatile(")
@@ -350,10 +367,10 @@ def emit(D):
     out.append('            : [h] "+s"(h), [issued] "+s"(issued), [reason] "=&s"(reason), [m0save] "=&s"(m0save)')
     ins = ['[hend] "s"(hend)', '[ring] "s"(ring)', '[flags] "s"(flags)', '[w1024] "s"(w1024)', '[t0] "s"(t0)', '[nsplit] "s"(nsplit)',
            '[imglo] "s"(imglo)', '[imghi] "s"(imghi)', '[metalo] "s"(metalo)', '[metahi] "s"(metahi)', '[eu] "s"(eu)', '[tmin] "s"(tmin)', '[ufrag] "s"(ufrag)', '[lane16] "v"(lane16)']
-    ins += ['[thr%d] "v"(thr[%d])' % (u, u) for u in range(UB)]
+    ins += ['"{v%d}"(thr[%d])' % (THR0 + u, u) for u in range(UB)]
     out.append("            : " + ", ".join(ins))
-    clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % r for r in range(80, 100)] + ['"v%d"' % r for r in range(LO_CLOBBER, 256)] + \
-           ['"a%d"' % r for r in range(4 * UB * (D // 32))]
+    clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % r for r in range(80, 100)] + \
+           ['"v%d"' % r for r in range(LO, 16 * UB) if not THR0 <= r < THR0 + UB] + ['"a%d"' % r for r in range(4 * UB * (D // 32))]
     out.append("            : " + ", ".join(clob) + ");")
     out.append("#endif")
     out.append("    }")
@@ -364,9 +381,10 @@ def emit(D):
 def main():
     print("// GENERATED by tools/gen_v6_loop_asm.py -- do not edit.")
     print("#pragma once")
-    print("template <int D> struct Loop6;")
-    for D in (64, 128):
-        print(emit(D))
+    print("template <int D, int UB> struct Loop6;")
+    for UB in (16, 8):
+        for D in (64, 128):
+            print(emit(D, UB))
 
 
 if __name__ == "__main__":
