@@ -212,17 +212,40 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
 # The wide geometry pays as soon as the 256-user geometry needs a second round of workgroups (> 256 x 256 users): measured at config 3,
 # 98 304 users 5.22 vs 5.78 ms, 131 072 x 50 000 items 1.75 vs 1.84 ms; at 65 536 users (one round of 256 workgroups) 5.00 vs 3.55 ms.
 WIDE_MIN_USERS = 65537
-# The huge geometry (pda_v5_sweep.h) wants a workgroup of 1 024 users on every CU: from 256 x 1 024 users on (measured: see DESIGN 3.1h)
+# The huge geometry (pda_v5_sweep.h) wants a workgroup of 1 024 users on every CU: from 192 x 1 024 users on with one item split
+# (measured: see DESIGN 3.1h); smaller blocks fill the chip with ITEM SPLITS instead (huge_splits below)
 HUGE_MIN_USERS = 196609
+HUGE_MIN_WORKGROUPS = 128       # of 256 CUs (129 .. 255 workgroups of 1 024 users: the 512-user geometry would need a second round)
+HUGE_SPLIT_MIN_USERS = 40960    # below: the 256-user geometry (32 768 users: equal; 16 384: 1.07 vs 1.28 ms)
+HUGE_MIN_TILES_PER_SPLIT = 512  # 64-item tiles: every split pays its own exact warm-up, hand-over and merge
 
 
-def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0) -> int:
+def huge_splits(n_users: int, n_items_local: int) -> int:
+    """Item splits with which the huge geometry fills the chip on a block of n_users (one workgroup = 1 024 users x one split), or 0
+    when it cannot (then the wide geometry does better).  Measured, config 3 (profiles/round4_huge_splits.txt): 65 536 users 4 splits
+    2.77 ms (wide 3.11 - 4.37), 98 304 users 2 splits 4.15 (wide 4.86), 131 072 users 2 splits 4.65 (wide 5.62), 163 840 users one
+    split 7.49 (wide, two rounds of workgroups: 10.3), 50 000 users 5 splits 2.41 (256-user geometry 3.01); a 20 000-item catalogue
+    (config 2) is too short to split: the 256-user geometry stays."""
+    if n_users < HUGE_SPLIT_MIN_USERS:
+        return 0
+    utiles = -(-n_users // 1024)
+    s = max(1, 256 // max(1, utiles))
+    tiles = -(-n_items_local // 64)
+    while s > 1 and tiles // s < HUGE_MIN_TILES_PER_SPLIT:
+        s -= 1
+    return s if utiles * s >= HUGE_MIN_WORKGROUPS and tiles // s >= HUGE_MIN_TILES_PER_SPLIT else 0
+
+
+def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0, n_items_local: int = 0, n_splits: int = 0) -> int:
     """PDA_SWEEP_FEW_CANDIDATES for pda_score_topk4_*: the popularity head swept in visiting order meets next to no candidates
     behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
     four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
     forced = os.environ.get("PDA_SCORE_LISTS", "")
     if forced in ("lds", "hbm", "wide", "many", "huge", "huge32", "huge2"):
         return {"lds": 0, "hbm": 2, "wide": 4, "many": 8, "huge": 128, "huge32": 128 | 256, "huge2": 128 | 512}[forced]
+    if head == HEAD_POP and prune == "order" and d in (64, 128) and n_items_local > 0 and n_splits > 0 \
+            and n_splits == huge_splits(n_users, n_items_local):
+        return 128          # (the caller splits the catalogue as huge_splits says: score_topk_keys with n_splits left to the library)
     if head == HEAD_POP and prune == "order" and n_users >= HUGE_MIN_USERS and d in (64, 128):
         return 128          # PDA_SWEEP_HUGE: 1 024-user workgroups of four 512-register waves, eight MFMAs per LDS read, no test k-step
     if head == HEAD_POP and prune == "order" and n_users >= WIDE_MIN_USERS and d in (64, 128):
@@ -479,9 +502,11 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
         if n_splits_auto and out_given is None:
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
+            if head == HEAD_POP and prune == "order" and d in (64, 128) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
+                n_splits = huge_splits(nu, nloc) or n_splits          # the huge geometry on a block that does not fill the chip by itself
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
-        es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
+        es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
         fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
         check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,

@@ -127,18 +127,23 @@ def test_full_size_c3(dev, monkeypatch):
         raw[prune], _ = run(ops, W, hist, huge, RAW, prune, exp)
         assert_lists_match_oracle(raw[prune], *oracle[0], head=0)
     assert torch.equal(raw[None], raw[False])
-    # 98 304 users (the smallest block the library gives the wide geometry and the regrouped early-terminating sweep), again unforced
+    # 98 304 users (the regrouped early-terminating sweep starts here; the dense sweep fills the chip with TWO item splits of the huge
+    # geometry: ops.huge_splits), again unforced; 53 248 users: five splits
     mid = huge[:98304].contiguous()
-    for prune, exp in (("order", {"generation": 4, "geometry": "wide"}), (True, {"generation": 4, "early_stop": True})):
+    assert ops.huge_splits(98304, W.n_items) == 2 and ops.huge_splits(53248, W.n_items) == 4 and ops.huge_splits(16384, W.n_items) == 0
+    for prune, exp in (("order", {"generation": 4, "geometry": "huge"}), (True, {"generation": 4, "early_stop": True})):
         k98, _ = run(ops, W, hist, mid, POP, prune, exp)
         assert torch.equal(k98, k262["order"][:98304]), prune
+    k53, _ = run(ops, W, hist, huge[:53248].contiguous(), POP, "order", {"generation": 4, "geometry": "huge"})
+    assert torch.equal(k53, k262["order"][:53248])
     k98r, _ = run(ops, W, hist, mid, RAW, None, {"generation": 4, "geometry": "many", "head": 0})
     assert torch.equal(k98r, raw[None][:98304])
 
     # ---- every other geometry forced on the same 262 144-user block: identical keys
     monkeypatch.setenv("PDA_SCORE_KERNEL", "v4")
     for geo, cases in (("lds", ((POP, "order"),)), ("hbm", ((POP, "order"), (POP, True))), ("wide", ((POP, "order"), (POP, True))),
-                       ("many", ((POP, "order"), (RAW, "order"))), ("huge", ((POP, "order"),))):
+                       ("many", ((POP, "order"), (RAW, "order"))), ("huge", ((POP, "order"),)), ("huge32", ((POP, "order"),)),
+                       ("huge2", ((POP, "order"),))):
         monkeypatch.setenv("PDA_SCORE_LISTS", geo)
         for head, prune in cases:
             # (the wide geometry has no early-terminating instance: the library falls back to the default geometry there)
