@@ -1,10 +1,9 @@
 """One rank's step time at the shapes the 8-GPU layouts give it: config 3, users x items per rank, dense
-sweep in the shard's visiting order and the early-terminating sweep.  usage: shard_scaling.py  (prints the table of profiles/round3_shard_scaling.txt)"""
+sweep in the shard's visiting order and the early-terminating sweep.  usage: shard_scaling.py  (prints the table of profiles/round4_shard_scaling.txt)"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from pda_amd import ops, synthetic
 dev = torch.device("cuda")
-os.environ["PDA_SCORE_KERNEL"] = "v4"
 W = synthetic.make_workload("c3", dev)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 def t(users, I, pop, prune, n=5, warm_tiles=0):

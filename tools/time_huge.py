@@ -9,6 +9,7 @@ geos = (sys.argv[3] if len(sys.argv) > 3 else "wide,huge").split(",")
 dev = torch.device('cuda')
 W = synthetic.make_workload(wl, dev, n_items=(int(sys.argv[4]) or None) if len(sys.argv) > 4 else None)
 NS = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+WT = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 Bu = min(Bu, W.n_users)
 blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in range(0, min(W.n_users - Bu + 1, 3 * Bu), Bu)]
@@ -17,14 +18,14 @@ ref = None
 for geo in geos:
     os.environ["PDA_SCORE_LISTS"] = geo
     st = {}
-    k = ops.score_topk_keys(W.U, W.I, blocks[0], 50, ops.HEAD_POP, W.pop_last, hist, prune="order", stats=st, n_splits=NS)
+    k = ops.score_topk_keys(W.U, W.I, blocks[0], 50, ops.HEAD_POP, W.pop_last, hist, prune="order", stats=st, n_splits=NS, warm_tiles=WT)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n = 4
     e0.record()
     for i in range(n):
         for b in blocks:
-            k = ops.score_topk_keys(W.U, W.I, b, 50, ops.HEAD_POP, W.pop_last, hist, prune="order", stats=st, n_splits=NS)
+            k = ops.score_topk_keys(W.U, W.I, b, 50, ops.HEAD_POP, W.pop_last, hist, prune="order", stats=st, n_splits=NS, warm_tiles=WT)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / (n * len(blocks))
     keys = ops.topk_merge(k, want="keys")
