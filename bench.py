@@ -155,6 +155,10 @@ def bench_reference_block_protocol(args, dev, workload):
         out = m.do_recommendation(None, users, items, "condition", pop[items], mask)      # (a fresh ndarray per block, like :788)
     dt = time.perf_counter() - t0
     assert out.shape == (Bu, 50) and out.dtype == np.int32
+    t2 = time.perf_counter()
+    for _ in range(4):
+        pop[items]                       # the caller's own line :788 (a 200 000-entry Python list as a fancy index), timed alone
+    caller_ms = (time.perf_counter() - t2) / 4 * 1e3
     # the kernels alone on the same blocks (device-resident inputs): what the host conversions cost on top
     hs = [ops.HistoryCSR.from_coo(mask[0], Bu, dev) for _, mask in blocks[2:]]
     us = [torch.as_tensor(np.asarray(users, dtype=np.int32), device=dev) for users, _ in blocks[2:]]
@@ -169,8 +173,10 @@ def bench_reference_block_protocol(args, dev, workload):
             "roofline_frac": fl / (dt / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
             "device_only": {"users_per_s": Bu * nb / dk, "ms_per_block": dk / nb * 1e3, "roofline_frac": fl / (dk / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS},
             "nnz_per_block": int(np.mean([len(mk[0]) for _, mk in blocks])),
+            "caller_pop_gather_ms": caller_ms,
             "note": "DatasetApi_Model.do_recommendation called like MF/train_new_api.py:792: Python lists in, COO mask triple, int32 ndarray "
-                    "out, blocking; product-default sweep (early-terminating); device_only = the same blocks with ids and CSR already in HBM"}
+                    "out, blocking; product-default sweep (early-terminating); device_only = the same blocks with ids and CSR already in HBM; "
+                    "caller_pop_gather_ms = testing_popularity[batch_item] of the reference's loop (:788), part of ms_per_block, not of this library"}
 
 
 

@@ -231,6 +231,12 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        second wave has the matrix pipe while the first runs its VALU tests) instead of one 1 024-user workgroup.  Measured slower on
  *        large blocks (the pipe is busier, the clock lower: twice the LDS traffic per MFMA); kept for A/B measurements.  Identical keys. */
 #define PDA_SWEEP_HUGE_2WG 512
+/*        bit 10 = PDA_SWEEP_WARM_PER_SPLIT.  By default a one-call sweep (warm-up + sweep in one entry point) over n_splits > 1 item
+ *        splits runs ONE exact warm-up per user -- on the first warm tiles of the whole visiting order, handed to split 0 -- and every
+ *        other split starts with an empty list and that warm-up's K-th value as its seed (a lower bound of the user's final K-th
+ *        value: pairs below it stay out of the split's list, which may end shorter than K; the merged lists are the same).  With this
+ *        bit every split warms up on its own first tiles as before round 4 (A/B measurements, cross-checks). */
+#define PDA_SWEEP_WARM_PER_SPLIT 1024
 #define PDA_SWEEP_WARM_TILES(n) (((n) & 7) << 4)
 size_t pda_item_prep4_bytes(int n_items_local, int d);
 int pda_item_prep4_f32(const float* I_shard, const float* pop_shard, const int32_t* order, int n_items_local, int d, void* prep,

@@ -393,9 +393,15 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(MergeArgs a) {
         }
         if (lane < K) outl[lane] = 0ull;
         pda_wave_sync();
+        // the largest K-th key of any list bounds the answer from below: K keys of that list are at least as large, so a smaller
+        // key has rank >= K and needs no search (32 full lists: 50 + a few survivors of 1 600 keys)
+        uint64_t floor_key = 0ull;
+        for (int r = lane; r < a.R; r += 64) floor_key = max(floor_key, keys[r * K + K - 1]);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) floor_key = max(floor_key, (uint64_t)__shfl_xor((unsigned long long)floor_key, o, 64));
         for (int e = lane; e < n; e += 64) {
             const uint64_t key = keys[e];
-            if (key == 0ull) continue;
+            if (key == 0ull || key < floor_key) continue;
             const int r = e / K, p = e - r * K;
             int rank = p;  // own list is sorted and keys are unique
             for (int r2 = 0; r2 < a.R; ++r2) {

@@ -103,6 +103,9 @@ struct Args4 {
     int prep_hdr_pop;            // host copy of "the prep was built with a popularity" (the image is scaled by it): set by the entry points
     int warm_final;              // the huge geometry behind a one-call warm-up: warm4_kernel hands SORTED lists of K keys over and writes them to
                                  // out_keys as well -- the sweep then sorts and emits only the rows it appended to (a few per cent)
+    int warm_shared;             // n_splits > 1, one call: ONE warm-up per user on tiles 0 .. warm_tiles - 1 of the whole visiting order, handed to
+                                 // split 0; the other splits start empty and prune against its K-th value (seed); see warm_tiles_of
+    float* seed_out;             // [n_users_blk] or NULL: warm4_kernel leaves a lower bound of every row's K-th value here (the shared warm-up's seed)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -356,6 +359,11 @@ __device__ __forceinline__ f32x16 zero16v() {
 // the tiles of split s: s, s + S, s + 2 S, ...
 __device__ __forceinline__ int split_tiles(int n_tiles, int split, int n_splits) {
     return split < n_tiles ? (n_tiles - split + n_splits - 1) / n_splits : 0;
+}
+// how many of split s's first tiles the warm-up has scored: warm_tiles of its own -- or, behind a shared warm-up (tiles 0 .. warm_tiles - 1
+// of the whole order), those of them that are the split's: s, s + S, ... below warm_tiles
+__device__ __forceinline__ int warm_tiles_of(const Args4& g, int split) {
+    return !g.warm_shared ? g.warm_tiles : (split < g.warm_tiles ? (g.warm_tiles - split + g.n_splits - 1) / g.n_splits : 0);
 }
 
 // append one exact key per flagged lane to its row's list; compaction (whole wave) when a list is full.  Returns true
@@ -721,6 +729,13 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
             compact_list<CAP>(buf, &cntl[wave * 32 + rr], &taul[wave * 32 + rr], K, lane);
         const int c = cntl[wave * 32 + rr];
         const int rb = utile * kUserTile + wave * 32 + rr;
+        if (g.seed_out != nullptr) {
+            // the shared warm-up's seed: the smallest of the row's (>= K) keys -- at least K items reach it; -inf for a shorter list
+            uint32_t mn = lane < c ? (uint32_t)(buf[lane] >> 32) : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) mn = min(mn, (uint32_t)__shfl_xor((int)mn, o, 64));
+            if (lane == 0 && rb < g.n_users_blk) g.seed_out[rb] = c >= K ? pda_unordf(mn) : -INFINITY;
+        }
         if (g.handover != nullptr) {
             if (rb < g.n_users_blk && lane < CAP) g.handover[((size_t)split * g.n_users_blk + rb) * CAP + lane] = lane < c ? buf[lane] : 0ull;
             // (warm_final: the row is sorted and holds at most K keys -- it is the final answer unless the sweep appends to it)
@@ -910,7 +925,9 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
-    const int n_it = max(0, nt - g.warm_tiles);                    // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (kWarmTiles + i) S
+    const int wt = warm_tiles_of(g, split);                        // the split's tiles the warm-up has scored
+    const bool starts_empty = g.warm_shared && split > 0;          // shared warm-up: its lists went to split 0, this split has the seed only
+    const int n_it = max(0, nt - wt);                              // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (wt + i) S
     const int n_blk = NB > 2 ? (2 * n_it) / NB : n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
     // block row of sweep row rb (rb < n_users_blk): the users of an early-terminating sweep are regrouped (stop_predict4_kernel)
     auto orig_row = [&](int rb) __attribute__((always_inline)) -> int { if constexpr (!ES) return rb; else return (g.row_perm != nullptr && rb < g.n_users_blk) ? g.row_perm[rb] : rb; };
@@ -942,7 +959,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
           }
 #pragma unroll
           for (int q = 0; q < PB; ++q)
-              keyv[q] = rov[q] < 0 ? 0ull
+              keyv[q] = (rov[q] < 0 || starts_empty) ? 0ull
                         : g.handover != nullptr ? (lane < kCap4 ? g.handover[((size_t)split * g.n_users_blk + rov[q]) * kCap4 + lane] : 0ull)
                         : (lane < K ? g.out_keys[((size_t)split * g.n_users_blk + rov[q]) * K + lane] : 0ull);
 #pragma unroll
@@ -1339,7 +1356,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             PROF_T1(tl0, 10);
             PROF_T0(tl1);
             const int hf0 = b * NB;                                // first half-tile of the block
-            const int t = split + (g.warm_tiles + (hf0 >> 1)) * g.n_splits;
+            const int t = split + (wt + (hf0 >> 1)) * g.n_splits;
             [[maybe_unused]] const unsigned char* src = g.rows + (size_t)t * G::TB + (size_t)(hf0 & 1) * HB + lane * 16;
             [[maybe_unused]] const unsigned dst = lds_tiles0 + (unsigned)((b % NSLOT) * BB);
 #pragma unroll
@@ -1532,7 +1549,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     float sa_nx = 0.0f, sb_nx = 0.0f;          // suffix bounds at tile it + kVL of the coming vote
     bool nx_ok = ES && kVoteEvery - 1 + kVL < n_it;
     if (nx_ok) {
-        const int tn = split + (g.warm_tiles + kVoteEvery - 1 + kVL) * g.n_splits;
+        const int tn = split + (wt + kVoteEvery - 1 + kVL) * g.n_splits;
         sa_nx = g.sufA[tn];
         sb_nx = g.sufB[tn];
     }
@@ -1658,7 +1675,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
             if (lane == 0) lds_st(&s_vote[(it & 7) * kMainWaves + w], alldead ? 1u : 0u);
             // the bounds of the next vote: loaded a tile ahead
             const int inx = it + kVoteEvery + kVL;
-            const int tn = split + (g.warm_tiles + min(inx, max(n_it - 1, 0))) * g.n_splits;
+            const int tn = split + (wt + min(inx, max(n_it - 1, 0))) * g.n_splits;
             sa_nx = g.sufA[tn];               // (no use before the next vote: the loads stay in flight over the block)
             sb_nx = g.sufB[tn];
             nx_ok = inx < n_it;
@@ -2078,6 +2095,9 @@ int launch_sweep4(const Args4& g, hipStream_t stream) {
 }
 
 template <int D, int HEAD, bool BF>
+int launch4_sweep(const Args4& g, hipStream_t stream, int geometry);
+
+template <int D, int HEAD, bool BF>
 int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      // phase: 1 = warm-up only, 2 = sweep only, 3 = both
     if (phase & 1) {
         constexpr int CAP = kCap4;
@@ -2090,11 +2110,26 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
             attr_set = 1;
         }
         const int utiles = (g.n_users_blk + kUserTile - 1) / kUserTile;
-        hipLaunchKernelGGL((warm4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * g.n_splits)), dim3(kThreads), smem, stream, g);
+        Args4 gw = g;
+        if (g.warm_shared) {             // ONE warm-up per user: "split 0 of 1" scores tiles 0 .. warm_tiles - 1 of the whole order
+            gw.n_splits = 1;
+            gw.warm_shared = 0;
+        }
+        hipLaunchKernelGGL((warm4_kernel<D, HEAD, BF>), dim3((unsigned)(utiles * gw.n_splits)), dim3(kThreads), smem, stream, gw);
         PDA_CHECK_LAUNCH();
     }
     if ((g.n_tiles + g.n_splits - 1) / g.n_splits <= g.warm_tiles) return PDA_OK;      // every split ends inside its warm-up
     if (phase & 2) {
+        Args4 gs = g;
+        if (g.warm_shared) gs.seed = g.seed_out;      // every split prunes against the shared warm-up's K-th value
+        return launch4_sweep<D, HEAD, BF>(gs, stream, geometry);
+    }
+    return PDA_OK;
+}
+
+template <int D, int HEAD, bool BF>
+int launch4_sweep(const Args4& g, hipStream_t stream, int geometry) {
+    {
         // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
             // the huge geometry (pda_v5_sweep.h): dense sweeps of the popularity head on a prep built WITH that popularity
@@ -2119,7 +2154,7 @@ static bool lists_in_hbm4(int) { return true; }       // (every d may run with i
 // the workspace of the pda_score_topk4_* calls: [counters of pda_score_topk_workspace_bytes | list slots of every workgroup when the
 // lists live in HBM | Bloom filters, 128 B per user | warm-position train-item masks, 32 B per user and split | regrouping: 1024 bins, bin and sweep row of every user]
 struct Ws4 {
-    size_t lists, bloom, hmask, regroup, handover, ufrag, unorm, total;
+    size_t lists, bloom, hmask, regroup, handover, ufrag, unorm, seed, total;
 };
 static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
@@ -2143,6 +2178,8 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
         w.unorm = w.ufrag + al(n_pad * 2 * (size_t)d);
         w.total = w.unorm + al(n_pad * 4);
     }
+    w.seed = w.total;                                   // the shared warm-up's seed: one float per user
+    w.total = w.seed + al((size_t)n_users_blk * 4);
     return w;
 }
 extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_local, int d, int n_splits) {
@@ -2158,7 +2195,8 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
-    if (early_stop < 0 || (early_stop & ~0x3FF) != 0) return PDA_ERR_ARG;
+    if (early_stop < 0 || (early_stop & ~0x7FF) != 0) return PDA_ERR_ARG;
+    const bool warm_per_split = (early_stop & PDA_SWEEP_WARM_PER_SPLIT) != 0;
     // geometry hints (Geo4<D, 1 | 2 | 3>): results do not depend on them, and every geometry takes any n_splits and any user count
     // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks); the wide geometry only PAYS on large blocks
     int geometry = (early_stop & PDA_SWEEP_HUGE) ? ((early_stop & PDA_SWEEP_HUGE_32X32) ? 5 : (early_stop & PDA_SWEEP_HUGE_2WG) ? 6 : 4) : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
@@ -2203,6 +2241,11 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
     g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop && d <= 128) ? 1 : 0;
+    // one call over several item splits: ONE exact warm-up per user instead of one per split (warm_tiles_of; PDA_SWEEP_WARM_PER_SPLIT)
+    if (phase == 3 && n_splits > 1 && seed == nullptr && !warm_per_split && L.n_tiles > n_splits * warm_tiles) {
+        g.warm_shared = 1;
+        g.seed_out = reinterpret_cast<float*>(wsb + W.seed);
+    }
     if (hist_indptr && (phase & 2)) {
         uint32_t* bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
         hipLaunchKernelGGL(hist_bloom4_kernel, dim3((unsigned)((n_users_blk + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices,
@@ -2215,7 +2258,12 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
         // 1.35 -> 1.29 ms per early-terminating sweep of 262 144 users, but 0.267 -> 0.277 ms at 50 000
         uint32_t* hm = reinterpret_cast<uint32_t*>(wsb + W.hmask);
         const int utiles = (n_users_blk + kUserTile - 1) / kUserTile;
-        hipLaunchKernelGGL(warm_mask4_kernel, dim3((unsigned)(utiles * n_splits)), dim3(kThreads), 0, s, g, hm);
+        Args4 gm = g;
+        if (g.warm_shared) {
+            gm.n_splits = 1;
+            gm.warm_shared = 0;
+        }
+        hipLaunchKernelGGL(warm_mask4_kernel, dim3((unsigned)(utiles * gm.n_splits)), dim3(kThreads), 0, s, gm, hm);
         PDA_CHECK_LAUNCH();
         g.hmask_ws = hm;
     }

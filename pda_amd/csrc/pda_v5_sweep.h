@@ -117,14 +117,23 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
                                             : g.lists_ws + (size_t)blockIdx.x * UT * CAPL;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
-    const int n_it = max(0, nt - g.warm_tiles);                          // 64-item tiles behind the warm-up
+    const int wt = warm_tiles_of(g, split);                              // the split's tiles the warm-up has scored
+    const bool starts_empty = g.warm_shared && split > 0;                // shared warm-up: its lists went to split 0; this split has the seed and empty lists
+    const bool warm_final = g.warm_final && !starts_empty;               // (an empty split writes every row of its out_keys itself)
+    const int n_it = max(0, nt - wt);                                    // 64-item tiles behind the warm-up
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles
     // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted -- unless the warm-up sorted them: warm_final; 40 .. 71: no row touched)
-    if (tid < 72) sync[tid] = (tid < 8 || tid >= 40 || g.warm_final) ? 0u : 0xFFFFFFFFu;
+    if (tid < 72) sync[tid] = (tid < 8 || tid >= 40 || warm_final || starts_empty) ? 0u : 0xFFFFFFFFu;
     // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, one 1 024-user workgroup per CU; 6: the same, two 512-user workgroups; 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
     if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((!S16 ? 5u : UPW == 256 ? 4u : 6u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the counts and K-th values of the warm-up's lists -> LDS (all waves); without a hand-over buffer the lists themselves -> the workspace
-    if (g.warm_final) {
+    if (starts_empty) {
+        for (int rr = tid; rr < UT; rr += 256) {
+            cntl[rr] = 0;
+            taul[rr] = utile * UT + rr < g.n_users_blk ? -INFINITY : INFINITY;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    } else if (warm_final) {
         // sorted lists of at most K keys (warm4_kernel): a LANE per row -- its K-th key says everything (0: fewer than K keys; count them)
         for (int rr = tid; rr < UT; rr += 256) {
             const int rb = utile * UT + rr;
@@ -197,7 +206,7 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
         const unsigned flags_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)reinterpret_cast<unsigned char*>(sync);
         uint64_t* my_ring = crings + wave * kRing5;
         unsigned ring_n = 0;                                             // wave-uniform: entries in my_ring
-        const unsigned t0 = (unsigned)(split + g.warm_tiles * g.n_splits);
+        const unsigned t0 = (unsigned)(split + wt * g.n_splits);
         const size_t img = (size_t)g.rows5, meta = (size_t)g.meta5;
         const bool hist_on = g.hist_indptr != nullptr;
 
@@ -439,8 +448,23 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
             if (lane < c && rank < K) orow[rank] = key;
             if (lane >= c && lane < K) orow[lane] = 0ull;
         };
-        if (g.warm_final) {
+        if (warm_final) {
             // out_keys holds the warm-up's sorted rows: only the rows the sweep appended to are ranked and written again
+            for (int w = 0; w < UPW / 32; ++w) {
+                unsigned m = touched[wave * (UPW / 32) + w];
+                while (m != 0u) {
+                    const int b = __builtin_ctz(m);
+                    m &= m - 1u;
+                    const int rr = wave * UPW + 32 * w + b;
+                    emit_row(utile * UT + rr, cntl[rr], lists[(size_t)rr * CAPL + (lane < CAPL ? lane : CAPL - 1)]);
+                }
+            }
+        } else if (starts_empty) {
+            // an empty split behind a shared warm-up: every row is written here -- zeros, then the few rows the sweep appended to
+            const int rb0 = utile * UT + wave * UPW, nv = max(0, min(UPW, g.n_users_blk - rb0));
+            uint64_t* ob = g.out_keys + ((size_t)split * g.n_users_blk + rb0) * K;
+            for (int i = lane; i < nv * K; i += 64) ob[i] = 0ull;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // (the same wave writes the touched rows again below)
             for (int w = 0; w < UPW / 32; ++w) {
                 unsigned m = touched[wave * (UPW / 32) + w];
                 while (m != 0u) {

@@ -157,6 +157,7 @@ def item_prep_ordered(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], 
 
 
 _PREP4_CACHE = {}      # id(I_shard) -> (weakref(I), I._version, order|None, pop weakref|None, pop _version, prep buffer)
+SWEEP_WARM_PER_SPLIT = 1024   # PDA_SWEEP_WARM_PER_SPLIT (include/pda_hip.h)
 TOPK_K_V4 = 54         # pda_score_topk4_*: K <= 54 (57 list slots per user)
 
 
@@ -507,6 +508,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
         es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
+        if os.environ.get("PDA_WARM_PER_SPLIT"):      # A/B measurements and cross-checks: every item split warms up on its own tiles (before round 4)
+            es |= SWEEP_WARM_PER_SPLIT
         fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32
         check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
                  ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0,

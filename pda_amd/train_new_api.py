@@ -136,7 +136,8 @@ class DatasetApi_Model:
         >= 0 check, the visiting order, the item image) is keyed on the tensor object."""
         arr = np.ascontiguousarray(np.asarray(pos_pop, dtype=np.float32).reshape(-1))
         hit = getattr(self, "_pop_cache", None)
-        if hit is not None and hit[0].shape == arr.shape and np.array_equal(hit[0], arr, equal_nan=True):
+        # (bit patterns: NaN-safe, and 20 x cheaper than array_equal(equal_nan=True) -- 0.9 ms per 200 000 items, more than the block's sweep)
+        if hit is not None and hit[0].shape == arr.shape and np.array_equal(hit[0].view(np.uint32), arr.view(np.uint32)):
             return hit[1]
         t = torch.as_tensor(arr, device=self.device)
         self._pop_cache = (arr.copy(), t)

@@ -711,3 +711,41 @@ def test_regrouped_early_terminating_sweep(dev, impl, head):
         assert torch.equal(ops.topk_merge(torch.stack(parts), want="keys"), ref)
     finally:
         os.environ.pop("PDA_SCORE_KERNEL", None)
+
+
+@pytest.mark.parametrize("mode", ["order", True])
+@pytest.mark.parametrize("n_splits", [2, 3, 5, 8, 16, 32])
+def test_shared_warm_up_equals_one_warm_up_per_split(dev, monkeypatch, mode, n_splits, impl):
+    """A one-call sweep over several item splits runs ONE exact warm-up per user (tiles 0 .. 3 of the whole visiting order, handed to
+    split 0; the other splits start empty and prune against its K-th value: PDA_SWEEP_WARM_PER_SPLIT in include/pda_hip.h restores one
+    warm-up per split).  The merged keys must be those of the per-split warm-up and of one split -- dense and early-terminating, every
+    generation-4 geometry, ragged blocks, rows with fewer than K unmasked items (seed = -inf), exact ties (duplicate item rows)."""
+    from pda_amd import ops
+    if not impl.startswith("k4") or impl in ("k4nat", "k4many"):
+        pytest.skip("generation 4 in visiting order")
+    rng = np.random.default_rng(100 * n_splits + (1 if mode is True else 0))
+    for d, nU, nI, K in ((64, 1300, 9000, 50), (128, 517, 6100, 20)):
+        U, I, pop, hist = make_case(rng, nU, nI, d)
+        I[100:140] = I[60:100]                       # exact ties between item rows
+        pop[100:140] = pop[60:100]
+        hist[3] = np.arange(nI, dtype=np.int32)[: nI - 7]          # 7 unmasked items: every list ends short
+        hist[4] = np.arange(nI, dtype=np.int32)                    # none
+        ip, ix = csr(hist)
+        h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+        args = (torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.from_numpy(np.arange(nU, dtype=np.int32)).to(dev), K, 1,
+                torch.from_numpy(pop).to(dev), h, 0)
+        st = {}
+        shared = ops.score_topk_keys(*args, n_splits=n_splits, prune=mode, stats=st)
+        assert int(st["error"][0]) == 0
+        monkeypatch.setenv("PDA_WARM_PER_SPLIT", "1")
+        per_split = ops.score_topk_keys(*args, n_splits=n_splits, prune=mode)
+        monkeypatch.delenv("PDA_WARM_PER_SPLIT")
+        one = ops.score_topk_keys(*args, n_splits=1, prune=mode)
+        assert shared.shape == per_split.shape == (n_splits, nU, K)
+        m_sh, m_ps, m_one = (ops.topk_merge(k, want="keys") for k in (shared, per_split, one))
+        assert torch.equal(m_sh, m_ps), (d, n_splits, int((m_sh != m_ps).sum()))
+        assert torch.equal(m_sh, m_one)
+        if nI // 64 > n_splits * 4:
+            # the shared warm-up really ran: the splits behind the first hold only what reaches its K-th value (user 3 has no seed: -inf)
+            assert not torch.equal(shared[1:], per_split[1:])
+            assert (shared[1:] != 0).sum().item() <= (per_split[1:] != 0).sum().item()

@@ -10,7 +10,7 @@ from pda_amd import ops, synthetic
 dev = torch.device("cuda:0")
 W = synthetic.make_workload(sys.argv[1] if len(sys.argv) > 1 else "c3", dev)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
-blocks = [torch.arange(s, s + 2048, dtype=torch.int32, device=dev) for s in range(0, 2048 * 40, 2048)]
+blocks = [torch.arange(s, s + 2048, dtype=torch.int32, device=dev) for s in range(0, min(2048 * 40, W.n_users - 2047), 2048)]
 for b in blocks[:4]:
     ops.recommend_topk(W.U, W.I, b, 50, ops.HEAD_POP, W.pop_last, hist)
 torch.cuda.synchronize()
