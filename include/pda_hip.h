@@ -274,6 +274,10 @@ int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void*
  *            all-reduces counts (SUM); mode 1: lo/hi updated from the summed counts (>= K entries at or above mid make it
  *            a bound), next mid and counts; mode 2: the last update only.  Three rounds bring eight shards of config 3 from
  *            1.78 x to 1.03 x the tiles of one GPU (4 more bytes per user and round).
+ *   phase 4  (round 4) the sweep of the WHOLE shard from EMPTY lists against the caller's seed (required; -inf = no bound for that
+ *            user): no warm-up ran on this catalogue -- it ran elsewhere, on replicated hot items (pda_amd/dist.py: the 256 globally
+ *            most popular rows live on every rank and are taken OUT of the shards; a rank warms up 1 / R of the users on them and
+ *            the K-th values are all-gathered as the seed).  out_keys needs no initialisation; warm_tiles is ignored.
  * Without it every rank prunes against its own shard's K-th value only and scores 8 x 32 % instead of 3.9 % of the
  * catalogue (config 3, eight shards).  n_splits must be the same (> 0) in both phases. */
 int pda_topk_kth_value(const uint64_t* keys, int n_splits, int n_users_blk, int K, int pos, float* out, void* stream);

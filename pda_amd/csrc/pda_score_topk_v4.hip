@@ -106,6 +106,8 @@ struct Args4 {
     int warm_shared;             // n_splits > 1, one call: ONE warm-up per user on tiles 0 .. warm_tiles - 1 of the whole visiting order, handed to
                                  // split 0; the other splits start empty and prune against its K-th value (seed); see warm_tiles_of
     float* seed_out;             // [n_users_blk] or NULL: warm4_kernel leaves a lower bound of every row's K-th value here (the shared warm-up's seed)
+    int lists_empty;             // phase 4: no warm-up ran on this catalogue -- every split starts with empty lists and sweeps ALL its tiles against
+                                 // the caller's seed (the warm-up ran elsewhere: on replicated hot items, pda_amd.dist)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -926,7 +928,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int wt = warm_tiles_of(g, split);                        // the split's tiles the warm-up has scored
-    const bool starts_empty = g.warm_shared && split > 0;          // shared warm-up: its lists went to split 0, this split has the seed only
+    const bool starts_empty = g.lists_empty || (g.warm_shared && split > 0);   // shared warm-up: its lists went to split 0, this split has the seed only
     const int n_it = max(0, nt - wt);                              // 64-item tiles of the pre-filtered loop: local index i <-> tile split + (wt + i) S
     const int n_blk = NB > 2 ? (2 * n_it) / NB : n_it * (2 / NB);                           // blocks: block b = half-tiles NB b .. NB b + NB - 1 of that sequence
     // block row of sweep row rb (rb < n_users_blk): the users of an early-terminating sweep are regrouped (stop_predict4_kernel)
@@ -1976,7 +1978,7 @@ __global__ void __launch_bounds__(256) stop_predict4_kernel(Args4 g, int* __rest
     uint32_t mn = 0xFFFFFFFFu;
     int cnt = 0;
     for (int k = sub; k < g.K; k += 8) {
-        const uint64_t key = g.out_keys[(size_t)u * g.K + k];
+        const uint64_t key = g.lists_empty ? 0ull : g.out_keys[(size_t)u * g.K + k];
         if (key != 0ull) { mn = min(mn, (uint32_t)(key >> 32)); ++cnt; }
     }
 #pragma unroll
@@ -2213,10 +2215,19 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
 #define PDA_V4_WARM_DEFAULT kWarmTiles
 #endif
     if (warm_tiles == 0) warm_tiles = d <= 128 ? PDA_V4_WARM_DEFAULT : kWarmTiles;
+    // phase 4: a sweep of the WHOLE shard from empty lists against the caller's seed (no warm-up on this catalogue)
+    const bool from_empty = phase == 4;
+    if (from_empty) {
+        if (seed == nullptr) return PDA_ERR_ARG;
+        phase = 2;
+        warm_tiles = 0;
+    } else if (phase < 1 || phase > 3) {
+        return PDA_ERR_ARG;
+    }
     if (n_splits <= 0) n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
     const Prep4Layout L = prep4_layout(n_items_local, d);
     const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
-    if ((phase & 1) && hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (((phase & 1) || from_empty) && hipMemsetAsync(workspace, 0, pda_score_topk_workspace_bytes(n_users_blk), s) != hipSuccess) return PDA_ERR_LAUNCH;
     const Ws4 W = ws4_layout(n_users_blk, d, n_splits);
     unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
     const float* sA = reinterpret_cast<const float*>(pb + (head == PDA_HEAD_POP ? L.sufA : L.sufB));
@@ -2241,6 +2252,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
     g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop && d <= 128) ? 1 : 0;
+    g.lists_empty = from_empty ? 1 : 0;
     // one call over several item splits: ONE exact warm-up per user instead of one per split (warm_tiles_of; PDA_SWEEP_WARM_PER_SPLIT)
     if (phase == 3 && n_splits > 1 && seed == nullptr && !warm_per_split && L.n_tiles > n_splits * warm_tiles) {
         g.warm_shared = 1;

@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int wt = warm_tiles_of(g, split);                              // the split's tiles the warm-up has scored
-    const bool starts_empty = g.warm_shared && split > 0;                // shared warm-up: its lists went to split 0; this split has the seed and empty lists
+    const bool starts_empty = g.lists_empty || (g.warm_shared && split > 0);   // shared warm-up: its lists went to split 0; this split has the seed and empty lists
     const bool warm_final = g.warm_final && !starts_empty;               // (an empty split writes every row of its out_keys itself)
     const int n_it = max(0, nt - wt);                                    // 64-item tiles behind the warm-up
     const unsigned hend = 2u * (unsigned)n_it;                           // 32-item half-tiles

@@ -213,28 +213,33 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
 # The wide geometry pays as soon as the 256-user geometry needs a second round of workgroups (> 256 x 256 users): measured at config 3,
 # 98 304 users 5.22 vs 5.78 ms, 131 072 x 50 000 items 1.75 vs 1.84 ms; at 65 536 users (one round of 256 workgroups) 5.00 vs 3.55 ms.
 WIDE_MIN_USERS = 65537
-# The huge geometry (pda_v5_sweep.h) wants a workgroup of 1 024 users on every CU: from 192 x 1 024 users on with one item split
-# (measured: see DESIGN 3.1h); smaller blocks fill the chip with ITEM SPLITS instead (huge_splits below)
-HUGE_MIN_USERS = 196609
-HUGE_MIN_WORKGROUPS = 128       # of 256 CUs (129 .. 255 workgroups of 1 024 users: the 512-user geometry would need a second round)
-HUGE_SPLIT_MIN_USERS = 40960    # below: the 256-user geometry (32 768 users: equal; 16 384: 1.07 vs 1.28 ms)
-HUGE_MIN_TILES_PER_SPLIT = 512  # 64-item tiles: every split pays its own exact warm-up, hand-over and merge
+# The huge geometry (pda_v5_sweep.h) wants a workgroup of 1 024 users on every CU: a block of fewer than 256 x 1 024 users fills the chip
+# with ITEM SPLITS (huge_splits below) -- cheap since round 4's shared warm-up (one exact warm-up per user, not per split)
+HUGE_MIN_USERS = 196609         # (kept for callers that pass their own n_splits: from here on the hint is given whatever the split count)
+HUGE_MIN_WORKGROUPS = 128       # of 256 CUs
+HUGE_SPLIT_MIN_USERS = 4096     # below: the 256-user geometry
+HUGE_MIN_TILES_PER_SPLIT = 32   # 64-item tiles: a workgroup's prologue (1 024 thresholds, 256 AGPRs per wave) wants a sweep behind it
 
 
 def huge_splits(n_users: int, n_items_local: int) -> int:
-    """Item splits with which the huge geometry fills the chip on a block of n_users (one workgroup = 1 024 users x one split), or 0
-    when it cannot (then the wide geometry does better).  Measured, config 3 (profiles/round4_huge_splits.txt): 65 536 users 4 splits
-    2.77 ms (wide 3.11 - 4.37), 98 304 users 2 splits 4.15 (wide 4.86), 131 072 users 2 splits 4.65 (wide 5.62), 163 840 users one
-    split 7.49 (wide, two rounds of workgroups: 10.3), 50 000 users 5 splits 2.41 (256-user geometry 3.01); a 20 000-item catalogue
-    (config 2) is too short to split: the 256-user geometry stays."""
+    """Item splits with which the huge geometry runs a block of n_users (one workgroup = 1 024 users x one split), or 0 when it should
+    not (then the 256-user / wide geometry serves the call).  The time of a launch follows rounds of 256 workgroups x tiles per split:
+    cost(S) = ceil(user tiles x S / 256) x (fixed cost of a workgroup + 1 / S), plus a little per split (the merge, the empty splits'
+    output rows); the smallest S at the minimum wins.  Measured, config 3, with the shared warm-up (profiles/round4_shared_warm.txt): 8 192 users x 32 splits 0.47 ms
+    (256-user geometry 0.58), 16 384 x 16 0.72 (1.01), 32 768 x 8 1.21 (1.82), 65 536 x 4 2.30 (wide 3.1), 131 072 x 2 4.27 (5.6);
+    config 2 / config 1 (313 / 407 tiles) x 5 splits 0.37 / 0.39 ms (0.46 / 0.50)."""
     if n_users < HUGE_SPLIT_MIN_USERS:
         return 0
     utiles = -(-n_users // 1024)
-    s = max(1, 256 // max(1, utiles))
     tiles = -(-n_items_local // 64)
-    while s > 1 and tiles // s < HUGE_MIN_TILES_PER_SPLIT:
-        s -= 1
-    return s if utiles * s >= HUGE_MIN_WORKGROUPS and tiles // s >= HUGE_MIN_TILES_PER_SPLIT else 0
+    smax = max(1, min(64, tiles // HUGE_MIN_TILES_PER_SPLIT))
+    best, best_cost = 1, None
+    for s in range(1, smax + 1):
+        # rounds x (a workgroup's fixed cost + its share of the catalogue) + the empty splits' output rows and the merge
+        cost = -(-utiles * s // 256) * (0.02 + 1.0 / s) + 0.004 * s * (n_users / 262144.0)
+        if best_cost is None or cost < best_cost - 1e-9:
+            best, best_cost = s, cost
+    return best if utiles * best >= HUGE_MIN_WORKGROUPS else 0
 
 
 def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0, n_items_local: int = 0, n_splits: int = 0) -> int:
@@ -413,6 +418,51 @@ def seeded_begin(U, I_shard, users, K, head, pop_shard, hist, item_offset=0, n_s
     check(lib.pda_topk_seed_bounds(ptr(c.out), n_splits, nu, K, m, ptr(c.bounds), stream_ptr()), "pda_topk_seed_bounds")
     c.n_thr, c.counts = seed_thresholds(seed_shards), None
     return c
+
+
+def sweep_from_seed(U, I_shard, users, K, head, pop_shard, hist, item_offset, seed: torch.Tensor, n_splits: int = 0, prune="order",
+                    stats: Optional[dict] = None) -> torch.Tensor:
+    """pda_score_topk4_phase_* with phase 4: the sweep of the whole shard from EMPTY lists against `seed` (float32 [Bu]: a lower
+    bound of every user's final K-th value, -inf = none) -- no warm-up on this shard.  -> packed keys int64 [n_splits, Bu, K] of the
+    pairs at or above the seed (a list may end shorter than K, or empty)."""
+    lib = _lib.load()
+    bf = I_shard.dtype == torch.bfloat16
+    U = _need(U, torch.bfloat16 if bf else torch.float32, "U")
+    I_shard = _need(I_shard, torch.bfloat16 if bf else torch.float32, "I_shard")
+    users = _need(users, torch.int32, "users")
+    seed = _need(seed, torch.float32, "seed")
+    pop_shard = _need(pop_shard, torch.float32, "pop_shard", optional=True)
+    nu, nloc, d = users.numel(), I_shard.shape[0], I_shard.shape[1]
+    if seed.numel() != nu:
+        raise ValueError("seed must have one entry per user of the block")
+    if d not in (64, 128, 256) or K > TOPK_K_V4:
+        raise ValueError("sweep_from_seed: embed dim 64/128/256 and K <= %d" % TOPK_K_V4)
+    if head == HEAD_POP and pop_shard is not None:
+        _check_pop(pop_shard)
+    if hist is not None and hist.indices.numel() == 0:
+        hist = None
+    order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
+    prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
+    if n_splits <= 0:
+        n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
+        if head == HEAD_POP and prune == "order" and d in (64, 128) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
+            n_splits = huge_splits(nu, nloc) or n_splits
+    out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
+    ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
+    es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits)
+    fn = lib.pda_score_topk4_phase_bf16 if bf else lib.pda_score_topk4_phase_f32
+    check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(pop_shard), ptr(users), nu, item_offset, nloc, d,
+             ptr(hist.indptr) if hist else None, ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, head, es, n_splits,
+             4, 0, ptr(seed), ptr(out), ptr(ws), stream_ptr()), "pda_score_topk4_phase (sweep from a seed)")
+    if os.environ.get("PDA_CHECK_SWEEP_ERRORS"):
+        err = int(ws[0:4].view(torch.int32)[0])
+        if err != 0:
+            raise RuntimeError("pda_score_topk4_phase: the sweep reported protocol error %d" % err)
+    if stats is not None:
+        stats["pairs_rescored"] = ws[4:8].view(torch.int32)
+        stats["kernel_id"] = ws[16:20].view(torch.int32)
+        stats["error"] = ws[0:4].view(torch.int32)
+    return out
 
 
 def seeded_counts(c: SeededCall) -> Optional[torch.Tensor]:

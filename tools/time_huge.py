@@ -16,7 +16,11 @@ blocks = [torch.arange(s, s + Bu, dtype=torch.int32, device=dev) for s in range(
 os.environ["PDA_SCORE_KERNEL"] = "v4"
 ref = None
 for geo in geos:
-    os.environ["PDA_SCORE_LISTS"] = geo
+    if geo == "auto":                    # the library's own choice of kernel, geometry and item splits
+        os.environ.pop("PDA_SCORE_LISTS", None)
+        os.environ.pop("PDA_SCORE_KERNEL", None)
+    else:
+        os.environ["PDA_SCORE_LISTS"] = geo
     st = {}
     k = ops.score_topk_keys(W.U, W.I, blocks[0], 50, ops.HEAD_POP, W.pop_last, hist, prune="order", stats=st, n_splits=NS, warm_tiles=WT)
     torch.cuda.synchronize()
