@@ -281,6 +281,10 @@ int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void*
  * Without it every rank prunes against its own shard's K-th value only and scores 8 x 32 % instead of 3.9 % of the
  * catalogue (config 3, eight shards).  n_splits must be the same (> 0) in both phases. */
 int pda_topk_kth_value(const uint64_t* keys, int n_splits, int n_users_blk, int K, int pos, float* out, void* stream);
+/* Packed keys whose item field holds LOCAL row ids of a gathered table -> the same keys with gid[local] in it, in place (empty slots
+ * stay 0; n_keys keys, gid int32 [n_gid]).  The replicated-hot-items path of pda_amd/dist.py scores a hot table and a cold shard
+ * that are row subsets of the catalogue; gid ascends with the local id, so sorted lists stay sorted, ties included. */
+int pda_topk_remap_items(uint64_t* keys, size_t n_keys, const int32_t* gid, int n_gid, void* stream);
 /* The same exchange in TWO collectives per user block (round 3; replaces kth_value x 3 + MAX + MIN + three sequential SUM rounds):
  *   pda_topk_seed_bounds  bounds f32 [3][n_users_blk] := (value at rank K - 1, value at rank m - 1, MINUS the value at rank
  *            m - 1) of the shard's warm-up lists, m = ceil(K / R).  ONE all-reduce MAX over the 3 n_users_blk floats (min x =

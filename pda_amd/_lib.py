@@ -70,6 +70,7 @@ SIGNATURES = {
     "pda_peak_mfma_lds_bf16": (_i, [_vp, _sz, _vp, _i, _vp]),
     "pda_peak_copy": (_i, [_vp, _vp, _sz, _vp]),
     "pda_topk_kth_value": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "pda_topk_remap_items": (_i, [_vp, _sz, _vp, _i, _vp]),
     "pda_topk_seed_refine": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_topk_seed_bounds": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "pda_topk_seed_counts": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _vp]),

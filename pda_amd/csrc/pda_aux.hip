@@ -86,6 +86,26 @@ __global__ void __launch_bounds__(64) sample_batches_kernel(SampleArgs a, int n_
 
 }  // namespace
 
+namespace {
+__global__ void __launch_bounds__(256) remap_items_kernel(uint64_t* __restrict__ keys, size_t n, const int32_t* __restrict__ gid, int n_gid) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    if (k == 0ull) return;
+    const uint32_t local = 0xFFFFFFFFu - (uint32_t)k;
+    if (local >= (uint32_t)n_gid) return;                     // (not a row of the table: left as it is)
+    keys[i] = (k & 0xFFFFFFFF00000000ull) | (uint64_t)(0xFFFFFFFFu - (uint32_t)gid[local]);
+}
+}  // namespace
+
+extern "C" int pda_topk_remap_items(uint64_t* keys, size_t n_keys, const int32_t* gid, int n_gid, void* stream) {
+    if (!keys || !gid || n_gid <= 0) return PDA_ERR_ARG;
+    if (n_keys == 0) return PDA_OK;
+    hipLaunchKernelGGL(remap_items_kernel, dim3((unsigned)((n_keys + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys, n_keys, gid, n_gid);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
 extern "C" int pda_abi_version(void) { return PDA_ABI_VERSION; }
 
 extern "C" const char* pda_error_string(int code) {

@@ -2512,7 +2512,7 @@ extern "C" int pda_score_topk4_phase_f32(const float* U, const float* I_shard, c
                                          int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr,
                                          const int32_t* hist_indices, int hist_row_mode, int K, int head, int early_stop, int n_splits,
                                          int phase, int warm_tiles, const float* seed, uint64_t* out_keys, void* workspace, void* stream) {
-    if (phase != 1 && phase != 2) return PDA_ERR_ARG;
+    if (phase != 1 && phase != 2 && phase != 4) return PDA_ERR_ARG;
     return run_score4(U, I_shard, false, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices,
                       hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace, reinterpret_cast<hipStream_t>(stream), phase, seed, warm_tiles);
 }
@@ -2521,7 +2521,7 @@ extern "C" int pda_score_topk4_phase_bf16(const uint16_t* U, const uint16_t* I_s
                                           const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
                                           int early_stop, int n_splits, int phase, int warm_tiles, const float* seed, uint64_t* out_keys,
                                           void* workspace, void* stream) {
-    if (phase != 1 && phase != 2) return PDA_ERR_ARG;
+    if (phase != 1 && phase != 2 && phase != 4) return PDA_ERR_ARG;
     return run_score4(U, I_shard, true, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices,
                       hist_row_mode, K, head, early_stop, n_splits, out_keys, workspace, reinterpret_cast<hipStream_t>(stream), phase, seed, warm_tiles);
 }

@@ -420,6 +420,24 @@ def seeded_begin(U, I_shard, users, K, head, pop_shard, hist, item_offset=0, n_s
     return c
 
 
+def kth_value(keys: torch.Tensor, pos: int) -> torch.Tensor:
+    """pda_topk_kth_value: keys int64 [S, Bu, K] (sorted lists) -> float32 [Bu], the value at rank `pos` (0-based; the largest over
+    the S lists, -inf where no list is that long)."""
+    keys = _need(keys, torch.int64, "keys")
+    S, nu, K = keys.shape
+    out = torch.empty(nu, dtype=torch.float32, device=keys.device)
+    check(_lib.load().pda_topk_kth_value(ptr(keys), S, nu, K, int(pos), ptr(out), stream_ptr()), "pda_topk_kth_value")
+    return out
+
+
+def remap_key_items(keys: torch.Tensor, gid: torch.Tensor) -> torch.Tensor:
+    """pda_topk_remap_items, IN PLACE: the item field of packed keys from local row ids of a gathered table to gid[local]."""
+    keys = _need(keys, torch.int64, "keys")
+    gid = _need(gid, torch.int32, "gid")
+    check(_lib.load().pda_topk_remap_items(ptr(keys), keys.numel(), ptr(gid), gid.numel(), stream_ptr()), "pda_topk_remap_items")
+    return keys
+
+
 def sweep_from_seed(U, I_shard, users, K, head, pop_shard, hist, item_offset, seed: torch.Tensor, n_splits: int = 0, prune="order",
                     stats: Optional[dict] = None) -> torch.Tensor:
     """pda_score_topk4_phase_* with phase 4: the sweep of the whole shard from EMPTY lists against `seed` (float32 [Bu]: a lower

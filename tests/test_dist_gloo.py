@@ -380,3 +380,96 @@ def test_seeded_item_shards_with_an_empty_shard_gloo(world):
     assert res[0][4] == (7 if world == 4 else 0)
     want = 3 if world == 4 else 2                      # MAX (+ SUM) + the exchange of the lists
     assert all(r[5] == want and r[6] == want for r in res), res
+
+
+# ---- replicated hot items (round 4): item shards without a warm-up per rank ------------------------------------------------------
+def _worker_hot(rank, world, port, q):
+    """The hot_items most popular rows are replicated (ONE all-reduce per weight version) and taken out of the shards; per block a
+    rank scores its slice of the users against them, the K-th values are all-gathered as the seed, every rank sweeps its cold shard
+    from empty lists against the seed, and the all-to-all + merge follow: TWO collectives per block, lists equal to the oracle's.
+    world 3 leaves rank 2 without items (60 items = two 32-item tiles)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from pda_amd.dist import ItemShardedTopK
+    rng = np.random.default_rng(21)
+    nU, nI, d, K = 48, (60 if world == 3 else 330), 32, 10
+    U = rng.standard_normal((nU, d), dtype=np.float32) * 0.3
+    I = rng.standard_normal((nI, d), dtype=np.float32) * 0.3
+    I[7] = I[40]                                    # an exact tie between a hot and a cold candidate
+    pop = (rng.uniform(0.05, 1, nI) ** 2).astype(np.float32)
+    pop[7] = pop[40] = 0.9
+    pop[rng.choice(nI, 11, replace=False)] += 3.0   # a popularity head: the seed of most users keeps the cold shards' lists short
+    rows = [np.unique(rng.integers(0, nI, rng.integers(0, 12))).astype(np.int32) for _ in range(nU)]
+    rows[5] = np.arange(nI, dtype=np.int32)[: nI - 4]              # four unmasked items: seed = -inf, every list short
+    ip = np.zeros(nU + 1, np.int64)
+    ip[1:] = np.cumsum([len(r) for r in rows])
+    ix = np.concatenate(rows)
+    seen = {"sweeps": 0, "kept": 0, "slots": 0}
+
+    def score(U_, I_, users, K_, head, pop_, hist, off, n_splits, prune=None):
+        return score_double(U_, I_, users, K_, head, pop_, hist, off, n_splits)
+
+    def sweep_seed(U_, I_, users, K_, head, pop_, hist, off, seed):
+        keys = score_double(U_, I_, users, K_, head, pop_, hist, off, 1).numpy()[0].copy()
+        v, i = _unpack(keys)
+        with np.errstate(invalid="ignore"):
+            keys[(v < seed.numpy()[:, None]) | (i < 0) | ~np.isfinite(v)] = 0
+        seen["sweeps"] += 1
+        seen["kept"] += int((keys != 0).sum())
+        seen["slots"] += keys.size
+        return torch.from_numpy(keys)[None]
+
+    def kth(keys, pos):
+        k = keys.numpy()[0]
+        v, i = _unpack(k)
+        with np.errstate(invalid="ignore"):
+            return torch.from_numpy(np.where((k[:, pos] != 0) & np.isfinite(v[:, pos]), v[:, pos], -np.inf).astype(np.float32))
+
+    ev = ItemShardedTopK.from_full_tables(torch.from_numpy(U), torch.from_numpy(I), torch.from_numpy(pop), rank, world,
+                                          score_fn=score, merge_fn=merge_double)
+    assert ev.hot_items == 0                       # a caller's own score_fn opts in
+    ev.hot_items, ev.sweep_seed_fn, ev.kth_fn, ev.prune = 12, sweep_seed, kth, "order"
+    users = torch.arange(nU, dtype=torch.int32)
+    blocks = [users[0:24], users[24:48]]
+    got = list(ev.topk_blocks(blocks, K, 1, (ip, ix), sharded=True))
+    ok = True
+    for b, (idx, val) in enumerate(got):
+        u = blocks[b].numpy()
+        bip = np.zeros(len(u) + 1, np.int64)
+        bip[1:] = np.cumsum([len(rows[x]) for x in u])
+        bix = np.concatenate([rows[x] for x in u])
+        ridx, rval = c_oracle.score_topk(U, I, u, K, 1, pop, bip, bix, order=1)
+        lo, hi = ev.user_slice(len(u))
+        finite = np.isfinite(rval[lo:hi])
+        ok = ok and idx.shape[0] == hi - lo and bool(np.array_equal(idx.numpy()[finite], ridx[lo:hi][finite]) and np.array_equal(val.numpy()[finite], rval[lo:hi][finite]))
+    per_block = ev.n_collectives / len(blocks)
+    # a new popularity vector: the hot set is rebuilt (one more all-reduce of the rows), results follow
+    pop2 = pop[::-1].copy()
+    ev.set_popularity(torch.from_numpy(pop2))
+    (idx, val), = list(ev.topk_blocks([blocks[0]], K, 1, None, sharded=True))
+    ridx, rval = c_oracle.score_topk(U, I, blocks[0].numpy(), K, 1, pop2, order=1)
+    lo, hi = ev.user_slice(24)
+    ok2 = bool(np.array_equal(idx.numpy(), ridx[lo:hi]) and np.array_equal(val.numpy(), rval[lo:hi]))
+    q.put((rank, ok, ok2, per_block, ev.n_epoch_collectives, seen["kept"] / max(1, seen["slots"]), ev.I_shard.shape[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_replicated_hot_items_gloo(world):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_worker_hot, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] for r in res), res
+    assert all(r[3] == 2 for r in res), res            # the seed all-gather and the exchange of the lists
+    assert all(r[4] == 2 for r in res), res            # the hot rows: once per popularity / weight version
+    assert all(r[5] < 0.5 for r in res if r[6] > 0), res   # the seed kept most of the cold pairs out of the lists
+    if world == 3:
+        assert res[2][6] == 0                          # a rank without items follows the same collectives
