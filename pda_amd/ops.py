@@ -230,6 +230,9 @@ def huge_splits(n_users: int, n_items_local: int) -> int:
     config 2 / config 1 (313 / 407 tiles) x 5 splits 0.37 / 0.39 ms (0.46 / 0.50)."""
     if n_users < HUGE_SPLIT_MIN_USERS:
         return 0
+    forced = os.environ.get("PDA_HUGE_SPLITS")          # A/B measurements only
+    if forced:
+        return int(forced)
     utiles = -(-n_users // 1024)
     tiles = -(-n_items_local // 64)
     smax = max(1, min(64, tiles // HUGE_MIN_TILES_PER_SPLIT))

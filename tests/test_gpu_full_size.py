@@ -79,7 +79,7 @@ def test_full_size_c3(dev, monkeypatch):
     # ---- 16 384 users: the three sweep modes return identical keys; the exact fp32-MFMA kernel agrees on a 2 048-user subset
     users = torch.arange(500_000, 500_000 + 16384, dtype=torch.int32, device=dev)
     out = {}
-    for name, prune, exp in (("natural", False, {"generation": 4, "geometry": "many"}), ("order", "order", {"generation": 4, "geometry": "lds", "early_stop": False}),
+    for name, prune, exp in (("natural", False, {"generation": 4, "geometry": "many"}), ("order", "order", {"generation": 4, "geometry": "huge", "early_stop": False}),
                              ("stop", True, {"generation": 4, "early_stop": True})):
         out[name], st = run(ops, W, hist, users, POP, prune, exp)
         if name == "stop":
@@ -127,10 +127,12 @@ def test_full_size_c3(dev, monkeypatch):
         raw[prune], _ = run(ops, W, hist, huge, RAW, prune, exp)
         assert_lists_match_oracle(raw[prune], *oracle[0], head=0)
     assert torch.equal(raw[None], raw[False])
-    # 98 304 users (the regrouped early-terminating sweep starts here; the dense sweep fills the chip with TWO item splits of the huge
-    # geometry: ops.huge_splits), again unforced; 53 248 users: five splits
+    # 98 304 users (the regrouped early-terminating sweep starts here; the dense sweep fills the chip with EIGHT item splits of the huge
+    # geometry -- three rounds of 256 workgroups behind one shared warm-up: ops.huge_splits), again unforced; 53 248 users: nine splits (two
+    # rounds); 16 384 users: sixteen; a 2 048-user block keeps the 256-user geometry
     mid = huge[:98304].contiguous()
-    assert ops.huge_splits(98304, W.n_items) == 2 and ops.huge_splits(53248, W.n_items) == 4 and ops.huge_splits(16384, W.n_items) == 0
+    assert ops.huge_splits(98304, W.n_items) == 8 and ops.huge_splits(53248, W.n_items) == 9 and ops.huge_splits(16384, W.n_items) == 16
+    assert ops.huge_splits(2048, W.n_items) == 0 and ops.huge_splits(262144, W.n_items) == 1
     for prune, exp in (("order", {"generation": 4, "geometry": "huge"}), (True, {"generation": 4, "early_stop": True})):
         k98, _ = run(ops, W, hist, mid, POP, prune, exp)
         assert torch.equal(k98, k262["order"][:98304]), prune

@@ -112,6 +112,12 @@ def test_sweep_kernel_and_geometry_selection(monkeypatch):
     assert ops.few_candidates_hint(P, "order", 98304, 128) == 4           # (the 256-user geometry would need a second round of workgroups)
     assert ops.few_candidates_hint(P, "order", 65536, 128) == 0           # one round of 256 workgroups: the 256-user geometry
     assert ops.few_candidates_hint(P, "order", 262144, 256) == 0
+    # ... and with the split count the library itself picks (score_topk_keys with n_splits left to it): the huge geometry from 4 096 users on,
+    # item splits by rounds of 256 workgroups (one shared warm-up: splits are cheap)
+    assert [ops.huge_splits(u, 200000) for u in (2048, 8192, 32768, 65536, 98304, 163840, 196608, 262144)] == [0, 32, 8, 4, 8, 3, 4, 1]
+    assert ops.huge_splits(50000, 20000) == 5 and ops.huge_splits(47890, 26047) == 5 and ops.huge_splits(262144, 25000) == 1
+    assert ops.few_candidates_hint(P, "order", 65536, 128, 200000, 4) == 128 and ops.few_candidates_hint(P, "order", 65536, 128, 200000, 2) == 0
+    assert ops.few_candidates_hint(P, "order", 50000, 64, 20000, 5) == 128
     assert ops.few_candidates_hint(P, True, 262144, 128) == 0             # early-terminating: a warm-up and a sort
     assert ops.few_candidates_hint(P, False, 50000, 64) == 8              # natural order
     assert ops.few_candidates_hint(R, "order", 262144, 128) == 8          # raw head by norm

@@ -20,7 +20,7 @@ for f in sorted(glob.glob(root + "/**/*_kernel_trace.csv", recursive=True))[:1]:
         print("derived: launch = %.4g shader cycles -> effective clock %.2f GHz (this trace's duration)" % (cyc, cyc / us / 1e3))
         print("derived: matrix-pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (cycles x 256 CUs x 4 SIMDs) = %.1f %%"
               % (100.0 * tot["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024)))
-        print("derived: MFMA instructions per launch = %.4g (32 busy cycles each: v_mfma_f32_32x32x16_bf16)" % (tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 32))
+        print("derived: MFMA work per launch = %.4g x 32 768 flop (busy cycles / 32: a v_mfma_f32_32x32x16_bf16 is 32 busy cycles, a v_mfma_f32_16x16x32_bf16 16 -- twice as many instructions)" % (tot["SQ_VALU_MFMA_BUSY_CYCLES"] / 32))
     if "FETCH_SIZE" in tot:
         print("derived: HBM traffic per launch = %.1f MB read (FETCH_SIZE KiB x 2: gfx950 correction for wide coalesced reads), %.1f MB written"
               % (tot["FETCH_SIZE"] * 1024 * 2 / 1e6, tot.get("WRITE_SIZE", 0) * 1024 / 1e6))
