@@ -257,6 +257,8 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
         dt_n, k_ms_n, _ = timed_pass(False)
         natural = {"value": Bu * steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / steps * 1e3, "kernel_ms": k_ms_n}
     dt, k_ms, st_d = timed_pass("order" if use_order else False)
+    if os.environ.get("PDA_BENCH_DUMP") and user_groups is None:      # (N > 1: the replicated-hot-items path of pda_amd.dist)
+        torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_dense_w%d_r%d.pt" % (world_all, rank)))
     if use_order and "tiles_scored" in st_d:
         # (generation 4 counts whole 64-item tiles and whole 128-user tiles: >= the 32-item count)
         assert int(st_d["tiles_scored"][0]) >= st_d["tiles_dense"], "the dense sweep must score every tile"
@@ -966,6 +968,11 @@ def main():
                                     "all-to-all of the partial top-K lists per step, result sharded by user slice; the groups split the users "
                                     "of a step" % (ev["layout"]["user_groups"], ev["layout"]["item_shards"])) if world > 1 else "single GPU",
                        "layout": ev["layout"],
+                       "item_shard_path": (("popularity head, from three item shards on: 256 replicated hot rows, a rank's 1 / R of the users warmed up on "
+                                            "them, their K-th values all-gathered as the seed, cold shards swept from empty lists (pda_amd.dist._topk_blocks_hot: "
+                                            "2 collectives per block)") if ev["layout"]["item_shards"] >= 3 else
+                                           "two item shards: every rank warms up its users itself; early-terminating sweeps exchange a seed (<= 3 collectives per block)")
+                                          if (world > 1 and ev["layout"]["item_shards"] > 1) else None,
                        "train_nnz": W.n_train,
                        "arithmetic": ("fp32 tables and fp32 results, bit-identical to the exact fp32-MFMA kernel; bf16 MFMA only as a "
                                       "pre-filter with a rigorous error bound, every returned score recomputed in fp32") if ev["table_dtype"] == "f32" else

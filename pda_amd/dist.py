@@ -129,6 +129,11 @@ class ItemShardedTopK:
         # hot_items = how many of the globally most popular rows live on every rank (0 = off); sweep_seed_fn / kth_fn default to
         # ops.sweep_from_seed / ops.kth_value when score_fn is ops.score_topk_keys (tests inject doubles)
         self.hot_items = 256 if score_fn is _ops_score_fn() else 0
+        # from how many item shards on: at two shards a rank's own warm-up costs about what the hot pass and the remaps do (config 3, 65 536
+        # users x 100 000 items per rank: 1.24 ms plain, 1.27 - 1.38 ms with hot items; eight shards: 1.85 vs 1.25 - 1.40).  PDA_HOT_ITEMS_MIN_SHARDS
+        # overrides (the same on every rank; tests run two ranks through the path)
+        import os
+        self.hot_min_shards = int(os.environ.get("PDA_HOT_ITEMS_MIN_SHARDS", "3"))
         self.sweep_seed_fn = self.kth_fn = None
         self.n_epoch_collectives = 0  # collectives per weight / popularity version (the hot rows), not per user block
         self._hot = None
@@ -282,9 +287,10 @@ class ItemShardedTopK:
     # K-th values are all-gathered (4 bytes per user) as every user's seed, and each rank sweeps its cold shard from EMPTY lists against
     # the seed (ops.sweep_from_seed: pda_score_topk4_phase_*, phase 4).  The all-to-all of the lists follows as before; the owner of
     # a user slice merges the R cold lists and its hot list.  Two collectives per block.  Exact: a pair of the final top K reaches the
-    # K-th value of any K items, so it is a hot pair or a cold pair at or above the seed.
+    # K-th value of any K items, so it is a hot pair or a cold pair at or above the seed.  Dense sweeps and early-terminating ones (the
+    # product default for this head: the cold sweep then stops where a one-GPU sweep would -- its seed is that sweep's warm-up value).
     def _hot_applies(self, K, head, hist, users, sharded) -> bool:
-        if not (self.hot_items and self.world > 1 and sharded and head == 1 and self.prune == "order"):
+        if not (self.hot_items and self.world >= max(2, self.hot_min_shards) and sharded and head == 1 and self.prune in ("order", True, None)):
             return False
         if getattr(self, "_pop_full", None) is None or users.numel() % self.world != 0:
             return False
@@ -385,7 +391,7 @@ class ItemShardedTopK:
         _, kth = self._hot_fns()
         lo, hi = self.user_slice(users.numel())
         mine = users[lo:hi].contiguous()
-        keys = self.score_fn(self.U, st["hot_I"], mine, K, head, st["hot_pop"], h_hot, 0, 1, prune=self.prune)      # [1, Bu / R, K], sorted
+        keys = self.score_fn(self.U, st["hot_I"], mine, K, head, st["hot_pop"], h_hot, 0, 1, prune="order")        # [1, Bu / R, K], sorted
         seed = kth(keys, K - 1)                                                                                    # float32 [Bu / R]
         return self.remap_keys(keys[0], st["hot_gid"]), seed
 
@@ -406,7 +412,7 @@ class ItemShardedTopK:
         sweep, _ = self._hot_fns()
         if st["I_cold"].shape[0] == 0:
             return torch.zeros((users.numel(), K), dtype=torch.int64, device=users.device)
-        keys = sweep(self.U, st["I_cold"], users, K, head, st["pop_cold"], h_cold, 0, seed)
+        keys = sweep(self.U, st["I_cold"], users, K, head, st["pop_cold"], h_cold, 0, seed, prune=(True if self.prune is None else self.prune))
         keys = keys[0] if keys.shape[0] == 1 else self.merge_fn(keys, users, None, want="keys")     # (the item splits of the sweep)
         return self.remap_keys(keys, st["cold_gid"])
 
@@ -440,7 +446,8 @@ class ItemShardedTopK:
             for users in blocks:
                 yield self.topk_sharded(users, K, head, hist) if sharded else self.topk(users, K, head, hist)
             return
-        if self.hot_items and self.world > 1 and sharded and head == 1 and self.prune == "order":
+        if self.hot_items and self.world >= max(2, self.hot_min_shards) and sharded and head == 1 and self.prune in ("order", True, None):
+            # (dense AND early-terminating sweeps of the popularity head: the hot rows' K-th value is the seed a one-GPU warm-up would find)
             yield from self._topk_blocks_hot(blocks, K, head, hist)
             return
         # (a rank without items follows the same order of collectives as the others: same pipeline, neutral values)

@@ -409,7 +409,7 @@ def _worker_hot(rank, world, port, q):
     def score(U_, I_, users, K_, head, pop_, hist, off, n_splits, prune=None):
         return score_double(U_, I_, users, K_, head, pop_, hist, off, n_splits)
 
-    def sweep_seed(U_, I_, users, K_, head, pop_, hist, off, seed):
+    def sweep_seed(U_, I_, users, K_, head, pop_, hist, off, seed, prune=None):
         keys = score_double(U_, I_, users, K_, head, pop_, hist, off, 1).numpy()[0].copy()
         v, i = _unpack(keys)
         with np.errstate(invalid="ignore"):
@@ -428,7 +428,7 @@ def _worker_hot(rank, world, port, q):
     ev = ItemShardedTopK.from_full_tables(torch.from_numpy(U), torch.from_numpy(I), torch.from_numpy(pop), rank, world,
                                           score_fn=score, merge_fn=merge_double)
     assert ev.hot_items == 0                       # a caller's own score_fn opts in
-    ev.hot_items, ev.sweep_seed_fn, ev.kth_fn, ev.prune = 12, sweep_seed, kth, "order"
+    ev.hot_items, ev.sweep_seed_fn, ev.kth_fn, ev.prune, ev.hot_min_shards = 12, sweep_seed, kth, "order", 2
     users = torch.arange(nU, dtype=torch.int32)
     blocks = [users[0:24], users[24:48]]
     got = list(ev.topk_blocks(blocks, K, 1, (ip, ix), sharded=True))

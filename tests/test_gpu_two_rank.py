@@ -24,8 +24,9 @@ def _run(cmd, env):
 
 
 def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
+    # (PDA_HOT_ITEMS_MIN_SHARDS=2: the replicated-hot-items path of pda_amd.dist, by default taken from three item shards on)
     env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               PDA_BENCH_DUMP=str(tmp_path))
+               PDA_BENCH_DUMP=str(tmp_path), PDA_HOT_ITEMS_MIN_SHARDS="2")
     one = _run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-train", "--no-cpu-baseline",
                 "--eval-block", "2048"], env)
     two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
@@ -39,6 +40,10 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
     b = torch.cat([torch.load(os.path.join(tmp_path, "topk_w2_r%d.pt" % r)) for r in range(2)])
     assert a.shape == b.shape == (2048, 50)
     assert torch.equal(a, b)
+    # ... and of the DENSE headline pass, which for N > 1 goes through the replicated-hot-items path (pda_amd.dist._topk_blocks_hot)
+    da = torch.load(os.path.join(tmp_path, "topk_dense_w1_r0.pt"))
+    db = torch.cat([torch.load(os.path.join(tmp_path, "topk_dense_w2_r%d.pt" % r)) for r in range(2)])
+    assert torch.equal(da, db) and torch.equal(da, a)
     # four ranks = 2 user groups x 2 item shards (pda_amd.dist.grid_layout, the default from four GPUs on): rank order = user order
     four = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                  "--master-port", "29519", "bench.py", "--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1",
@@ -47,6 +52,8 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
                                                                  "items_per_rank": 1504}
     c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w4_r%d.pt" % r)) for r in range(4)])
     assert torch.equal(a, c)
+    dc = torch.cat([torch.load(os.path.join(tmp_path, "topk_dense_w4_r%d.pt" % r)) for r in range(4)])
+    assert torch.equal(da, dc)
 
 
 def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
@@ -67,6 +74,9 @@ def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
     # BASELINE config 4 literally (item shards only) is timed beside the default layout
     iso = eight["item_sharded_only"]
     assert iso["value"] > 0 and iso["layout"]["user_groups"] == 1 and iso["layout"]["item_shards"] == 8 and iso["early_terminating_sweep"]["value"] > 0
+    assert "two item shards" in eight["config"]["item_shard_path"]
     a = torch.load(os.path.join(tmp_path, "topk_w1_r0.pt"))
     c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w8_r%d.pt" % r)) for r in range(8)])
     assert a.shape == c.shape and torch.equal(a, c) and one["n_gpus"] == 1
+    dc = torch.cat([torch.load(os.path.join(tmp_path, "topk_dense_w8_r%d.pt" % r)) for r in range(8)])
+    assert torch.equal(torch.load(os.path.join(tmp_path, "topk_dense_w1_r0.pt")), dc)

@@ -2,13 +2,14 @@
 GPU: hot pass of this rank's 1 / R of the users on the 256 replicated rows + K-th values, cold sweep of the whole block against the
 rank's shard (without its hot rows) from empty lists against the seed, split merge, id remap.  The two collectives (4 bytes per user
 all-gathered; the all-to-all of the lists, which the pipeline hides under the next block) are not in it.
-usage: hot_items.py [R=8] [users per step=262144]"""
+usage: hot_items.py [R=8] [users per step=262144] [order|stop]"""
 import sys, torch
 sys.path.insert(0, '.')
 from pda_amd import ops, synthetic
 from pda_amd.dist import ItemShardedTopK, shard_range
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 Bu = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+MODE = True if (len(sys.argv) > 3 and sys.argv[3] == "stop") else "order"      # "stop": the early-terminating sweep (the product default)
 dev = torch.device("cuda")
 W = synthetic.make_workload("c3", dev)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
@@ -37,9 +38,9 @@ def med(f, n=7):
     return sorted(ts)[len(ts) // 2]
 # the seed of ALL users (what the all-gather delivers), and the one-GPU step it is compared with
 seed = ops.kth_value(ops.score_topk_keys(W.U, hot_I, users, K, 1, hot_pop, h_hot, 0, 1, prune="order"), K - 1)
-one = med(lambda: ops.score_topk_keys(W.U, W.I, users, K, 1, pop, hist, prune="order"))
+one = med(lambda: ops.score_topk_keys(W.U, W.I, users, K, 1, pop, hist, prune=MODE))
 ref = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, K, 1, pop, hist, prune="order"), want="keys")
-print("# config 3, %d users per step, %d item shards, %d replicated hot rows; one MI355X, median of 7; ms" % (Bu, R, H))
+print("# config 3, %d users per step, %d item shards, %d replicated hot rows, %s sweep; one MI355X, median of 7; ms" % (Bu, R, H, "early-terminating" if MODE is True else "dense"))
 print("# one GPU (whole catalogue, one call): %.3f ms" % one)
 lists = [ItemShardedTopK.remap_keys(ops.score_topk_keys(W.U, hot_I, users, K, 1, hot_pop, h_hot, 0, 1, prune="order")[0], hot_gid)]
 worst = 0.0
@@ -57,10 +58,10 @@ for r in range(R):
         k = ops.score_topk_keys(W.U, hot_I, slice_u, K, 1, hot_pop, h_hot, 0, 1, prune="order")
         return ItemShardedTopK.remap_keys(k[0], hot_gid), ops.kth_value(k, K - 1)
     def cold_pass():
-        k = ops.sweep_from_seed(W.U, I_cold, users, K, 1, pop_cold, h_cold, 0, seed, prune="order")
+        k = ops.sweep_from_seed(W.U, I_cold, users, K, 1, pop_cold, h_cold, 0, seed, prune=MODE)
         return ItemShardedTopK.remap_keys(k[0] if k.shape[0] == 1 else ops.topk_merge(k, want="keys"), cold_gid)
     def sweep_only():
-        return ops.sweep_from_seed(W.U, I_cold, users, K, 1, pop_cold, h_cold, 0, seed, prune="order")
+        return ops.sweep_from_seed(W.U, I_cold, users, K, 1, pop_cold, h_cold, 0, seed, prune=MODE)
     th, tc, ts = med(hot_pass), med(cold_pass), med(sweep_only)
     worst = max(worst, th + tc)
     lists.append(cold_pass())
