@@ -315,11 +315,15 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
                        "VALU threshold test (no test k-step), sorted hand-over from the warm-up (pda_v5_sweep.h, tools/gen_v6_loop_asm.py)",
                "huge32": "huge, first form of the loop: v_mfma_f32_32x32x16_bf16 (tools/gen_v5_loop_asm.py)",
                "huge2": "huge, two 512-user workgroups per CU (256-register waves)"}.get(geo_name, "")
-        if W.d == 256:
+        if W.d == 256 and huge:
+            geo = ("huge at d = 256: 512 users per workgroup (128 users per wave: 8 blocks x 8 k-steps fill the 256 AGPRs), one workgroup per CU, "
+                   "transposed product on v_mfma_f32_16x16x32_bf16, VALU threshold test (Loop6<256, 8>, pda_v5_sweep.h)")
+        elif W.d == 256:
             geo = "256 users per workgroup, lists in the workspace, 8 + 2 + 2 waves (Geo4<256, 0>)"
         bf_s = "true" if td_name == "bf16" else "false"
         if huge:
-            ktemplate = "sweep5_kernel<%d, %s, %s, %d>" % (W.d, bf_s, "false" if geo_name == "huge32" else "true", 128 if geo_name == "huge2" else 256)
+            ktemplate = "sweep5_kernel<%d, %s, %s, %d>" % (W.d, bf_s, "false" if (geo_name == "huge32" and W.d != 256) else "true",
+                                                          128 if (geo_name == "huge2" or W.d == 256) else 256)
         elif gen == "v4":
             ktemplate = "sweep4_kernel<%d, %d, %s, %s, %d>" % (W.d, 1 if head else 0, bf_s, "true" if ident.get("early_stop") else "false",
                                                              {"lds": 0, "hbm": 1, "wide": 2, "many": 3}.get(geo_name, 0))

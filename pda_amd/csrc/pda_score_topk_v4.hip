@@ -128,14 +128,11 @@ Prep4Layout prep4_layout(int n, int d) {
     L.sufR = L.sufB + al((size_t)L.n_tiles * 4);
     L.rows = L.sufR + al((size_t)L.n_tiles * 4);
     L.total = L.rows + (size_t)L.n_tiles * tile_bytes(d);
-    // d <= 128: the image of the huge geometry -- rows scaled by the popularity, bf16, 16-byte chunks XOR-swizzled, 32-item half-tiles of
+    // the image of the huge geometry -- rows scaled by the popularity, bf16, 16-byte chunks XOR-swizzled, 32-item half-tiles of
     // 64 d bytes -- and (pmax, nmax) per half-tile
     L.rows5 = al(L.total);
-    L.meta5 = L.rows5;
-    if (d <= 128) {
-        L.meta5 = L.rows5 + al((size_t)L.n_tiles * 2 * 64 * (size_t)d);
-        L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 16);          // (pmax, nmax, 0, 0) per half-tile: one 16-byte LDS-DMA lane
-    }
+    L.meta5 = L.rows5 + al((size_t)L.n_tiles * 2 * 64 * (size_t)d);
+    L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 16);              // (pmax, nmax, 0, 0) per half-tile: one 16-byte LDS-DMA lane
     return L;
 }
 
@@ -167,7 +164,7 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
         *reinterpret_cast<u32x4*>(rp + 16 * e) = hq;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ss += a[k] * a[k] + b[k] * b[k];
-        if constexpr (D <= 128) {
+        {
             // the huge geometry's image: chunk e of row pos & 31 of half-tile pos >> 5, scaled by the popularity (NaN: a zero row -- such an
             // item never ranks), at the swizzled place the MFMA waves read it from (pda_v5_sweep.h)
             const float pv = pop ? ((popv == popv) ? popv : 0.f) : 1.0f;
@@ -183,7 +180,7 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
     } else {
         const u32x4 z = {0u, 0u, 0u, 0u};
         *reinterpret_cast<u32x4*>(rp + 16 * e) = z;
-        if constexpr (D <= 128) {
+        {
             const int r5 = pos & 31;
             const int sw = D >= 128 ? (r5 & 15) : ((r5 >> 1) & 7);
             *reinterpret_cast<u32x4*>(rows5 + (size_t)(pos >> 5) * (64 * D) + r5 * (2 * D) + ((e ^ sw) << 4)) = z;
@@ -193,7 +190,7 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
     for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (e == 0) {
         const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
-        if constexpr (D <= 128) {
+        {
             if (pos < n) {                                   // (pmax, nmax) of the half-tile: maxima of non-negative floats = maxima of their bit patterns
                 const float pv = pop ? ((popv == popv) ? popv : 0.f) : 1.0f;
                 atomicMax(&meta5[4 * (pos >> 5)], __float_as_int(pop ? pv : 0.f));
@@ -319,7 +316,7 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     if (order && hipMemsetAsync(hdr + 2, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;          // header word 2 := 1: a visiting order was given
     if (pop && hipMemsetAsync(hdr + 1, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;            // header word 1 := 1: the test operands carry 1/pop pieces
     const int n_pad = L.n_tiles * 64;
-    if (d <= 128 && hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 16, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    if (hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 16, s) != hipSuccess) return PDA_ERR_LAUNCH;
     unsigned char* r5 = pb + L.rows5;
     int* m5 = reinterpret_cast<int*>(pb + L.meta5);
 #define PDA_P4(DD)                                                                                                              \
@@ -2144,6 +2141,10 @@ int launch4_sweep(const Args4& g, hipStream_t stream, int geometry) {
         if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
             if (geometry == 3) return launch_sweep4<D, HEAD, BF, 3>(g, stream);
         }
+        if constexpr (D == 256 && HEAD == PDA_HEAD_POP) {
+            // d = 256 (config 5): the huge geometry as ONE 512-user workgroup per CU -- 128 users per wave fill the 256 AGPRs
+            if (geometry >= 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, 128>(g, stream);
+        }
         return launch_sweep4<D, HEAD, BF, 0>(g, stream);
     }
     return PDA_OK;
@@ -2175,7 +2176,7 @@ static Ws4 ws4_layout(int n_users_blk, int d, int n_splits) {
     // the huge geometry (d <= 128): the user block as bf16 MFMA operands (whole 1 024-user workgroups) and the users' padded norms
     w.ufrag = al(w.total);
     w.unorm = w.ufrag;
-    if (d <= 128) {
+    {
         const size_t n_pad = ((size_t)n_users_blk + kUT5 - 1) / kUT5 * kUT5;
         w.unorm = w.ufrag + al(n_pad * 2 * (size_t)d);
         w.total = w.unorm + al(n_pad * 4);
@@ -2251,7 +2252,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     // (the prep is the caller's, built by pda_item_prep4_* with the SAME pop_shard it passes here for the popularity head: ops.item_prep4
     // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
-    g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop && d <= 128) ? 1 : 0;
+    g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop) ? 1 : 0;
     g.lists_empty = from_empty ? 1 : 0;
     // one call over several item splits: ONE exact warm-up per user instead of one per split (warm_tiles_of; PDA_SWEEP_WARM_PER_SPLIT)
     if (phase == 3 && n_splits > 1 && seed == nullptr && !warm_per_split && L.n_tiles > n_splits * warm_tiles) {

@@ -46,6 +46,9 @@ __device__ unsigned pda_v5_log[1 << 18];      // debug build: [0] = entries used
 constexpr int kRing5 = 192;           // candidate ring entries per wave (u64 each); a push needs 64 free
 
 __host__ __device__ constexpr int half_bytes5(int d) { return 64 * d; }       // 32 rows of 2 d bytes, 16-byte chunks XOR-swizzled
+// an LDS slot: the half-tile's rows, then its meta entry; slots start at multiples of 256 (512 at d = 256: the loop forms fragment addresses by
+// XOR with k << 6, which reaches bit 8 from k = 4 on)
+__host__ __device__ constexpr int slot_bytes5(int d) { return 64 * d + (d == 256 ? 512 : 256); }
 template <int D>
 __device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((row >> 1) & 7); }
 
@@ -91,13 +94,14 @@ __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U,
 // measured (profiles/round4_huge_variants.txt): the pipe is 82 % busy then, but at 1.86 GHz: twice the LDS reads and LDS-DMA per MFMA
 // cost more clock than the overlap buys (8.38 vs 8.18 ms).  UPW = 256 is the product; 128 stays selectable (PDA_SWEEP_HUGE_2WG).
 template <int D, bool BF, bool S16, int UPW>
-__global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g) {
+__global__ void __launch_bounds__(256, (UPW == 128 && D <= 128) ? 2 : 1) sweep5_kernel(Args4 g) {
     [[maybe_unused]] constexpr int HB = half_bytes5(D);
-    static_assert(Loop5<D>::kSlotBytes == Loop6<D, 16>::kSlotBytes && Loop5<D>::kSlotBytes == Loop6<D, 8>::kSlotBytes, "one LDS image for all loops");
+    static_assert(slot_bytes5(D) == Loop6<D, 8>::kSlotBytes, "one LDS image for all loops");
     static_assert(UPW == 256 || (S16 && UPW == 128), "users per wave");
+    static_assert(D <= 128 || (S16 && UPW == 128), "d = 256: 128 users per wave (8 blocks x 8 k-steps = 256 AGPRs), one 512-user workgroup per CU");
     // NK k-steps per product, NU user blocks of UBW users per wave (S16: 16 x 16 x 32 MFMAs -- blocks of 16; else 32 x 32 x 16 -- 8 of 32)
     constexpr int NK = S16 ? D / 32 : D / 16, UBW = S16 ? 16 : 32, NU = UPW / UBW;
-    constexpr int SS = Loop5<D>::kSlotBytes, UT = 4 * UPW, CAPL = kCap4, RB4 = row_bytes(D);
+    constexpr int SS = slot_bytes5(D), UT = 4 * UPW, CAPL = kCap4, RB4 = row_bytes(D);
     constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
     constexpr float kEps5 = BF ? 2.01171875e-3f : 4.0234375e-3f;         // 2^-9 x 1.03 (only the scaled items are rounded)  |  2^-8 x 1.03
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -125,7 +129,7 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
     // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted -- unless the warm-up sorted them: warm_final; 40 .. 71: no row touched)
     if (tid < 72) sync[tid] = (tid < 8 || tid >= 40 || warm_final || starts_empty) ? 0u : 0xFFFFFFFFu;
     // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, one 1 024-user workgroup per CU; 6: the same, two 512-user workgroups; 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
-    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((!S16 ? 5u : UPW == 256 ? 4u : 6u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
+    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((!S16 ? 5u : (UPW == 256 || D == 256) ? 4u : 6u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the counts and K-th values of the warm-up's lists -> LDS (all waves); without a hand-over buffer the lists themselves -> the workspace
     if (starts_empty) {
         for (int rr = tid; rr < UT; rr += 256) {
@@ -236,10 +240,11 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
                 const float c_sd = (g.seed != nullptr && valid) ? g.seed[rb] : -INFINITY;
                 const float c_tau = taul[row0 + (valid ? row : 0)];
                 f32x4 uu[8], ii[8];
-                const size_t ub = (size_t)uid * D + q * 8, ib = (size_t)(valid ? loc : 0) * D + q * 8;
+                // d <= 128: lane q holds chunks LPC cq + q (interleaved: a cache line per candidate and load); d = 256: its 32 consecutive elements
+                const size_t ub = (size_t)uid * D + q * (LPC == 8 ? 32 : 8), ib = (size_t)(valid ? loc : 0) * D + q * (LPC == 8 ? 32 : 8);
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const int off = 8 * LPC * (c >> 1) + 4 * (c & 1);
+                    const int off = LPC == 8 ? 4 * c : 8 * LPC * (c >> 1) + 4 * (c & 1);
                     uu[c] = pda_load4<BF>(g.U, ub + off);
                     ii[c] = pda_load4<BF>(g.I, ib + off);
                 }
@@ -257,8 +262,39 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
                     }
                     return acc;
                 };
-                float o = 0.f;
-                if constexpr (LPC == 4) {
+                float o = 0.f, o_other = 0.f;
+                if constexpr (LPC == 8) {
+                    // d = 256: chunk x = 4 q + cc of the row feeds chain x & 1, the chunks of a chain in ascending order: the two chains
+                    // travel from lane to lane (sweep4_kernel's rows that are not interleaved)
+                    float c0 = 0.f, c1 = 0.f, o0 = 0.f, o1 = 0.f;
+#pragma unroll
+                    for (int ph = 0; ph < LPC; ++ph) {
+                        o0 = c0;
+                        o1 = c1;
+#pragma unroll
+                        for (int cc = 0; cc < 4; ++cc) {
+#pragma unroll
+                            for (int sidx = 0; sidx < 4; ++sidx) {
+                                if (cc & 1) {
+                                    o1 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o1);
+                                    o1 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o1);
+                                } else {
+                                    o0 = __builtin_fmaf(uu[2 * cc][sidx], ii[2 * cc][sidx], o0);
+                                    o0 = __builtin_fmaf(uu[2 * cc + 1][sidx], ii[2 * cc + 1][sidx], o0);
+                                }
+                            }
+                        }
+                        if (ph < LPC - 1) {
+                            const float r0 = __shfl_up(o0, 1, 64), r1 = __shfl_up(o1, 1, 64);
+                            if (q == ph + 1) {
+                                c0 = r0;
+                                c1 = r1;
+                            }
+                        }
+                    }
+                    o = o1;
+                    o_other = o0;
+                } else if constexpr (LPC == 4) {
                     const bool hi = q >= 2;
                     auto swap2 = [](float x) __attribute__((always_inline)) -> float {
                         return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
@@ -276,7 +312,7 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
 #pragma unroll
                     for (int cq = 0; cq < 4; ++cq) o = fma8(o, cq);
                 }
-                const float o0 = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(o), 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
+                const float o0 = LPC == 8 ? o_other : __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(o), 0xB1, 0xF, 0xF, true));            // quad_perm [1,0,3,2]
                 float sc = o0 + o;                                  // meaningful on the candidate's last lane
                 sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pv;
                 const float tt = (valid && q == LPC - 1) ? sc : -INFINITY;
@@ -370,7 +406,7 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
 
         unsigned h = 0, issued = 0, n_entries = 0;
         bool hend_ok = true;
-        if ((ring_lds & 255u) != 0u) { if (lane == 0) g.stats[0] = 6u; hend_ok = false; }      // (the slots must start at multiples of 256)
+        if ((ring_lds & (D == 256 ? 511u : 255u)) != 0u) { if (lane == 0) g.stats[0] = 6u; hend_ok = false; }      // (the slots must start at multiples of 256 / 512)
         for (unsigned guard = 0; hend_ok && guard < 2u * hend + 8u; ++guard) {
             ++n_entries;
             float thr[NU];
@@ -499,8 +535,9 @@ __global__ void __launch_bounds__(256, UPW == 128 ? 2 : 1) sweep5_kernel(Args4 g
 template <int D, bool BF, bool S16, int UPW>
 int launch_sweep5(const Args4& g, hipStream_t stream) {
     constexpr int UT = 4 * UPW;
-    constexpr size_t lds = (size_t)kNSlot5 * Loop5<D>::kSlotBytes + (size_t)UT * 8 + 4 * kRing5 * 8 + 80 * 4 + 64;
-    static_assert(UPW == 256 || 2 * lds <= 160 * 1024, "two workgroups per CU");
+    constexpr size_t lds = (size_t)kNSlot5 * slot_bytes5(D) + (size_t)UT * 8 + 4 * kRing5 * 8 + 80 * 4 + 64;
+    static_assert(UPW == 256 || D == 256 || 2 * lds <= 160 * 1024, "two workgroups per CU");
+    static_assert(lds <= 160 * 1024, "LDS per workgroup");
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep5_kernel<D, BF, S16, UPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

@@ -221,7 +221,7 @@ HUGE_SPLIT_MIN_USERS = 4096     # below: the 256-user geometry
 HUGE_MIN_TILES_PER_SPLIT = 32   # 64-item tiles: a workgroup's prologue (1 024 thresholds, 256 AGPRs per wave) wants a sweep behind it
 
 
-def huge_splits(n_users: int, n_items_local: int) -> int:
+def huge_splits(n_users: int, n_items_local: int, d: int = 128) -> int:
     """Item splits with which the huge geometry runs a block of n_users (one workgroup = 1 024 users x one split), or 0 when it should
     not (then the 256-user / wide geometry serves the call).  The time of a launch follows rounds of 256 workgroups x tiles per split:
     cost(S) = ceil(user tiles x S / 256) x (fixed cost of a workgroup + 1 / S), plus a little per split (the merge, the empty splits'
@@ -233,7 +233,7 @@ def huge_splits(n_users: int, n_items_local: int) -> int:
     forced = os.environ.get("PDA_HUGE_SPLITS")          # A/B measurements only
     if forced:
         return int(forced)
-    utiles = -(-n_users // 1024)
+    utiles = -(-n_users // (512 if d == 256 else 1024))        # (d = 256: 512-user workgroups -- 128 users per wave fill the AGPRs)
     tiles = -(-n_items_local // 64)
     smax = max(1, min(64, tiles // HUGE_MIN_TILES_PER_SPLIT))
     best, best_cost = 1, None
@@ -252,8 +252,8 @@ def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0, n_items_
     forced = os.environ.get("PDA_SCORE_LISTS", "")
     if forced in ("lds", "hbm", "wide", "many", "huge", "huge32", "huge2"):
         return {"lds": 0, "hbm": 2, "wide": 4, "many": 8, "huge": 128, "huge32": 128 | 256, "huge2": 128 | 512}[forced]
-    if head == HEAD_POP and prune == "order" and d in (64, 128) and n_items_local > 0 and n_splits > 0 \
-            and n_splits == huge_splits(n_users, n_items_local):
+    if head == HEAD_POP and prune == "order" and d in (64, 128, 256) and n_items_local > 0 and n_splits > 0 \
+            and n_splits == huge_splits(n_users, n_items_local, d):
         return 128          # (the caller splits the catalogue as huge_splits says: score_topk_keys with n_splits left to the library)
     if head == HEAD_POP and prune == "order" and n_users >= HUGE_MIN_USERS and d in (64, 128):
         return 128          # PDA_SWEEP_HUGE: 1 024-user workgroups of four 512-register waves, eight MFMAs per LDS read, no test k-step
@@ -466,8 +466,8 @@ def sweep_from_seed(U, I_shard, users, K, head, pop_shard, hist, item_offset, se
     prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
     if n_splits <= 0:
         n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
-        if head == HEAD_POP and prune == "order" and d in (64, 128) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
-            n_splits = huge_splits(nu, nloc) or n_splits
+        if head == HEAD_POP and prune == "order" and d in (64, 128, 256) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
+            n_splits = huge_splits(nu, nloc, d) or n_splits
     out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
     ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
     es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits)
@@ -574,8 +574,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
         if n_splits_auto and out_given is None:
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
-            if head == HEAD_POP and prune == "order" and d in (64, 128) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
-                n_splits = huge_splits(nu, nloc) or n_splits          # the huge geometry on a block that does not fill the chip by itself
+            if head == HEAD_POP and prune == "order" and d in (64, 128, 256) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
+                n_splits = huge_splits(nu, nloc, d) or n_splits          # the huge geometry on a block that does not fill the chip by itself
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
         es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)

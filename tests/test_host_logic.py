@@ -118,6 +118,9 @@ def test_sweep_kernel_and_geometry_selection(monkeypatch):
     assert ops.huge_splits(50000, 20000) == 5 and ops.huge_splits(47890, 26047) == 5 and ops.huge_splits(262144, 25000) == 1
     assert ops.few_candidates_hint(P, "order", 65536, 128, 200000, 4) == 128 and ops.few_candidates_hint(P, "order", 65536, 128, 200000, 2) == 0
     assert ops.few_candidates_hint(P, "order", 50000, 64, 20000, 5) == 128
+    # d = 256 (config 5): 512-user workgroups
+    assert ops.huge_splits(262144, 250000, 256) == 1 and ops.huge_splits(65536, 250000, 256) == 2
+    assert ops.few_candidates_hint(P, "order", 262144, 256, 250000, 1) == 128 and ops.few_candidates_hint(P, True, 262144, 256, 250000, 1) == 0
     assert ops.few_candidates_hint(P, True, 262144, 128) == 0             # early-terminating: a warm-up and a sort
     assert ops.few_candidates_hint(P, False, 50000, 64) == 8              # natural order
     assert ops.few_candidates_hint(R, "order", 262144, 128) == 8          # raw head by norm

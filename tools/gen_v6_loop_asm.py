@@ -47,6 +47,11 @@ def gen(D, UB):
     # two quads (one per half-tile parity) holding ct in all four registers: the C operand of a chain's first MFMA | ... | meta pairs
     # (pmax, nmax)[2] | address temporaries[2]
     CTQ0, VFLAG, VPUB, VRD, VSB, VFB, VOFF0, VGOFF0, VZERO, VRDB, META0, ATMP0 = (MISC0 + x for x in (0, 8, 9, 10, 11, 12, 13, 14, 16, 17, 18, 22))
+    if D == 256:
+        # d = 256 (bf16 tables of config 5): UB = 8 user blocks of 16 x NK = 8 k-steps fill the 256 AGPRs; ONE 512-user workgroup per CU (512
+        # registers per wave), four LDS-DMA pieces per wave and half-tile: their lane offsets live above the accumulators
+        assert UB == 8
+        VGOFF0 = 128
     assert MISC0 + 24 <= M0T and M0T + UB <= THR0 and THR0 + UB <= FRAG0 and FRAG0 + 8 * NSETK <= ACC0
 
     def acc(u, ib):
@@ -57,7 +62,9 @@ def gen(D, UB):
         return "v%d" % (ACC0 + 4 * (2 * u + ib) + r)
 
     HB = 32 * 2 * D                      # one half-tile: 32 rows of 2 D bytes, 16-byte chunks XOR-swizzled (no padding)
-    SS = HB + 256                        # LDS slot: the rows, then the half-tile's meta entry (pmax, nmax, 0, 0); a multiple of 256
+    # LDS slot: the rows, then the half-tile's meta entry (pmax, nmax, 0, 0).  Slots start at multiples of 256 -- of 512 at d = 256: the
+    # fragment addresses are formed by XOR with k << 6 (frag_read), which reaches bit 8 from k = 4 on
+    SS = HB + (512 if D == 256 else 256)
     PW = HB // 1024 // 4                 # LDS-DMA pieces per wave and half-tile (2 at d = 128, 1 at d = 64)
     OPS = 0 if "nodma" in VARIANT else PW + 1   # vector-memory operations per half-tile, ALL of them LDS-DMA (in order among themselves)
     G = UB // GU
@@ -352,7 +359,7 @@ def emit(D, UB):
     out = []
     out.append("template <>")
     out.append("struct Loop6<%d, %d> {" % (D, UB))
-    out.append("    static constexpr int kSlotBytes = %d, kPfd = %d;" % (64 * D + 256, PFD))
+    out.append("    static constexpr int kSlotBytes = %d, kPfd = %d;" % (64 * D + (512 if D == 256 else 256), PFD))
     out.append("    // h: the local half-tile to run next (in: where to (re)start; out: the half-tile in progress when the statement left).")
     out.append("    // issued: half-tiles whose pieces this wave has issued.  reason: 0 = the sweep is over, 1 = half-tile h - 2 raised a flag in some")
     out.append("    // wave of the workgroup (all four leave together; h - 1 has not been looked at).")
@@ -370,7 +377,8 @@ def emit(D, UB):
     ins += ['"{v%d}"(thr[%d])' % (THR0 + u, u) for u in range(UB)]
     out.append("            : " + ", ".join(ins))
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % r for r in range(80, 100)] + \
-           ['"v%d"' % r for r in range(LO, 16 * UB) if not THR0 <= r < THR0 + UB] + ['"a%d"' % r for r in range(4 * UB * (D // 32))]
+           ['"v%d"' % r for r in range(LO, 16 * UB) if not THR0 <= r < THR0 + UB] + ['"a%d"' % r for r in range(4 * UB * (D // 32))] + \
+           (['"v%d"' % r for r in range(128, 132)] if D == 256 else [])
     out.append("            : " + ", ".join(clob) + ");")
     out.append("#endif")
     out.append("    }")
@@ -385,6 +393,7 @@ def main():
     for UB in (16, 8):
         for D in (64, 128):
             print(emit(D, UB))
+    print(emit(256, 8))
 
 
 if __name__ == "__main__":
