@@ -25,16 +25,19 @@ def _case(rng, nU, nI, d, skew):
     return U, I, pop, ip, np.concatenate(hist).astype(np.int32)
 
 
-@pytest.mark.parametrize("d,nU,nI,K,R,H,mode", [(64, 1100, 9000, 50, 4, 256, "order"), (128, 700, 5000, 20, 8, 128, "order"),
-                                               (128, 2300, 12000, 50, 2, 256, "order"), (64, 900, 7000, 50, 3, 256, True),
-                                               (256, 300, 4000, 50, 2, 64, "order")])
-def test_emulated_item_shards_with_replicated_hot_items(dev, monkeypatch, d, nU, nI, K, R, H, mode):
+@pytest.mark.parametrize("d,nU,nI,K,R,H,mode,bf", [(64, 1100, 9000, 50, 4, 256, "order", False), (128, 700, 5000, 20, 8, 128, "order", False),
+                                                  (128, 2300, 12000, 50, 2, 256, "order", False), (64, 900, 7000, 50, 3, 256, True, False),
+                                                  (256, 300, 4000, 50, 2, 64, "order", False), (256, 1200, 6000, 50, 4, 256, "order", True),
+                                                  (128, 800, 5000, 50, 3, 256, True, True)])
+def test_emulated_item_shards_with_replicated_hot_items(dev, monkeypatch, d, nU, nI, K, R, H, mode, bf):
     from pda_amd import ops
     from pda_amd.dist import ItemShardedTopK, shard_range
     monkeypatch.setenv("PDA_CHECK_SWEEP_ERRORS", "1")
     rng = np.random.default_rng(d + R)
     U, I, pop, ip, ix = _case(rng, nU, nI, d, skew=1.0)
     Ut, It, popt = (torch.from_numpy(x).to(dev) for x in (U, I, pop))
+    if bf:                                             # config 5's table type: both tables bf16
+        Ut, It = Ut.to(torch.bfloat16), It.to(torch.bfloat16)
     hist = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
     users = torch.arange(nU, dtype=torch.int32, device=dev)
     want = ops.topk_merge(ops.score_topk_keys(Ut, It, users, K, 1, popt, hist, prune=mode), want="keys")

@@ -724,7 +724,9 @@ def test_shared_warm_up_equals_one_warm_up_per_split(dev, monkeypatch, mode, n_s
     if not impl.startswith("k4") or impl in ("k4nat", "k4many"):
         pytest.skip("generation 4 in visiting order")
     rng = np.random.default_rng(100 * n_splits + (1 if mode is True else 0))
-    for d, nU, nI, K in ((64, 1300, 9000, 50), (128, 517, 6100, 20)):
+    for d, nU, nI, K in ((64, 1300, 9000, 50), (128, 517, 6100, 20), (256, 700, 5000, 50)):
+        if d == 256 and n_splits > 8:
+            continue
         U, I, pop, hist = make_case(rng, nU, nI, d)
         I[100:140] = I[60:100]                       # exact ties between item rows
         pop[100:140] = pop[60:100]
