@@ -218,10 +218,12 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        Such a sweep is bound by its rescoring waves (cycle counters: 98 % busy at four per 256 users).  Identical keys. */
 #define PDA_SWEEP_MANY_CANDIDATES 8
 /*        bit 7 = PDA_SWEEP_HUGE, the geometry hint for the dense sweep of the popularity head in visiting order on VERY large user
- *        blocks (d <= 128; a prep built with the popularity the call passes): 1 024 users per workgroup, four waves of 512
+ *        blocks (a prep built with the popularity the call passes): 1 024 users per workgroup, four waves of 512
  *        registers, 256 users each -- the users' bf16 rows in AGPRs, every item fragment read from the LDS feeds EIGHT MFMAs, the
  *        product transposed so that the threshold test is a per-lane compare (no test k-step), the item image pre-scaled by the
- *        popularity (pda_v5_sweep.h).  Identical keys.  Dense sweeps only (with bit 0 set: ignored); other heads: the wide geometry. */
+ *        popularity (pda_v5_sweep.h).  d = 256: 512 users per workgroup, 128 per wave (bits 8 and 9 are ignored there).  Smaller
+ *        blocks fill the chip with item splits (pda_amd.ops.huge_splits chooses them; one shared warm-up, bit 10).  Identical keys.
+ *        Dense sweeps only (with bit 0 set: ignored); other heads: the wide geometry. */
 #define PDA_SWEEP_HUGE 128
 /*        bit 8 = PDA_SWEEP_HUGE_32X32, with bit 7: the first form of that loop, on v_mfma_f32_32x32x16_bf16 (eight user blocks of 32
  *        per wave) instead of v_mfma_f32_16x16x32_bf16 (sixteen of 16: half the accumulator registers moved per MAC, which on this

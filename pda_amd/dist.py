@@ -12,6 +12,11 @@ Early-terminating sweeps add the seed exchange (ops.seeded_begin / seeded_counts
 per user and, from four shards on, ONE all-reduce SUM of 28 bytes per user -- both depend on the block's warm-up only and are
 issued for block b + 1 on a second side stream under the sweep of block b (`topk_blocks`): at most three collectives per block.
 
+From three item shards on, sweeps of the popularity head replicate the 256 globally most popular rows on every rank and take them out
+of the shards (round 4, `_topk_blocks_hot`): a rank warms up only its 1 / R of the users on them, ONE all-gather of 4 bytes per user turns
+their K-th values into every rank's seed, and the cold shards are swept from empty lists (ops.sweep_from_seed) -- two collectives per
+block, and no rank pays an exact warm-up for all users any more.
+
 `score_fn` / `merge_fn` default to the HIP entry points; tests inject doubles to exercise the
 orchestration under gloo on CPU (there is no CPU product path).
 """
