@@ -174,6 +174,7 @@ def bench_reference_block_protocol(args, dev, workload):
             "device_only": {"users_per_s": Bu * nb / dk, "ms_per_block": dk / nb * 1e3, "roofline_frac": fl / (dk / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS},
             "nnz_per_block": int(np.mean([len(mk[0]) for _, mk in blocks])),
             "caller_pop_gather_ms": caller_ms,
+            "library_ms_per_block": dt / nb * 1e3 - caller_ms,          # do_recommendation itself: conversions, COO -> CSR, sweep, merge, copy back
             "note": "DatasetApi_Model.do_recommendation called like MF/train_new_api.py:792: Python lists in, COO mask triple, int32 ndarray "
                     "out, blocking; product-default sweep (early-terminating); device_only = the same blocks with ids and CSR already in HBM; "
                     "caller_pop_gather_ms = testing_popularity[batch_item] of the reference's loop (:788), part of ms_per_block, not of this library"}
