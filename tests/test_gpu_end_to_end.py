@@ -100,6 +100,18 @@ def test_training_reduces_the_loss_and_beats_random_ranking(dev, toy, tmp_path):
     assert topk.shape == (len(bu), 50) and topk.dtype == np.int32
     agree = (topk == ridx[:len(bu)]).mean()
     assert agree > 0.99
+    # the next evaluation epoch hands over the SAME mask array: its CSR is taken from the device cache, the result is the same; a caller
+    # that refills the array in place (here: the first user's first train item swapped for another one) gets a fresh conversion
+    cached = model._mask_cache[id(index)][2]
+    again = model.do_recommendation(sess, bu, list(range(d.n_items)), "condition", pos_pop=pop_last, sparse_cliked_matrix=mask)
+    assert np.array_equal(again, topk) and model._mask_cache[id(index)][2] is cached
+    row0 = np.nonzero(index[:, 0] == index[0, 0])[0]
+    freed = int(index[0, 1])
+    index[0, 1] = next(i for i in range(d.n_items) if i not in set(index[row0, 1].tolist()) and i not in set(topk[index[0, 0]].tolist()))
+    changed = model.do_recommendation(sess, bu, list(range(d.n_items)), "condition", pos_pop=pop_last, sparse_cliked_matrix=mask)
+    assert model._mask_cache[id(index)][2] is not cached
+    assert np.array_equal(changed[1:], topk[1:]) or index[0, 0] != 0          # only the first user's mask changed
+    index[0, 1] = freed
     with pytest.raises(NotImplementedError):
         model.do_recommendation(sess, bu, None, "bogus")
     # dense compatibility surface
