@@ -382,8 +382,11 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(MergeArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = a.R * a.K, K = a.K;
-    uint64_t* keys = reinterpret_cast<uint64_t*>(smem) + (size_t)wave * (n + PDA_MAX_K);
+    // per wave: the R lists | the merged list | the lists' lengths (lists behind a shared warm-up are all but empty: they are skipped)
+    const size_t per_wave = (size_t)(n + PDA_MAX_K) * 8 + (((size_t)a.R * 4 + 7) & ~(size_t)7);
+    uint64_t* keys = reinterpret_cast<uint64_t*>(smem + (size_t)wave * per_wave);
     uint64_t* outl = keys + n;
+    int* lens = reinterpret_cast<int*>(outl + PDA_MAX_K);
     const int waves_total = gridDim.x * 4;
     for (int u = blockIdx.x * 4 + wave; u < a.n_users_blk; u += waves_total) {
         pda_wave_sync();
@@ -396,7 +399,16 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(MergeArgs a) {
         // the largest K-th key of any list bounds the answer from below: K keys of that list are at least as large, so a smaller
         // key has rank >= K and needs no search (32 full lists: 50 + a few survivors of 1 600 keys)
         uint64_t floor_key = 0ull;
-        for (int r = lane; r < a.R; r += 64) floor_key = max(floor_key, keys[r * K + K - 1]);
+        for (int r = lane; r < a.R; r += 64) {
+            floor_key = max(floor_key, keys[r * K + K - 1]);
+            int lo = 0, hi = K;                      // the list's length: its first empty slot (sorted, zeros behind the keys)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (keys[r * K + mid] != 0ull) lo = mid + 1; else hi = mid;
+            }
+            lens[r] = lo;
+        }
+        pda_wave_sync();
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) floor_key = max(floor_key, (uint64_t)__shfl_xor((unsigned long long)floor_key, o, 64));
         for (int e = lane; e < n; e += 64) {
@@ -407,7 +419,7 @@ __global__ void __launch_bounds__(256) topk_merge_kernel(MergeArgs a) {
             for (int r2 = 0; r2 < a.R; ++r2) {
                 if (r2 == r) continue;
                 const uint64_t* l = keys + r2 * K;
-                int lo = 0, hi = K;  // first position whose key is <= mine (descending list)
+                int lo = 0, hi = lens[r2];  // first position whose key is <= mine (descending list)
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
                     if (l[mid] > key) lo = mid + 1; else hi = mid;
@@ -514,7 +526,7 @@ extern "C" int pda_topk_merge(const uint64_t* in_keys, int R, int n_users_blk, i
     if (!in_keys || R < 1 || n_users_blk <= 0 || K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
     if (!out_keys && !out_idx) return PDA_ERR_ARG;
     if (hist_indptr && (!hist_indices || (hist_row_mode == PDA_HIST_BY_USER_ID && !users))) return PDA_ERR_ARG;
-    const size_t smem = 4 * ((size_t)R * K + PDA_MAX_K) * sizeof(uint64_t);
+    const size_t smem = 4 * (((size_t)R * K + PDA_MAX_K) * sizeof(uint64_t) + (((size_t)R * 4 + 7) & ~(size_t)7));
     if (smem > 160 * 1024) return PDA_ERR_UNSUPPORTED;
     static int attr_set = 0;
     if (!attr_set) {
