@@ -981,10 +981,10 @@ def main():
                                     "all-to-all of the partial top-K lists per step, result sharded by user slice; the groups split the users "
                                     "of a step" % (ev["layout"]["user_groups"], ev["layout"]["item_shards"])) if world > 1 else "single GPU",
                        "layout": ev["layout"],
-                       "item_shard_path": (("popularity head, from three item shards on: 256 replicated hot rows, a rank's 1 / R of the users warmed up on "
-                                            "them, their K-th values all-gathered as the seed, cold shards swept from empty lists (pda_amd.dist._topk_blocks_hot: "
-                                            "2 collectives per block)") if ev["layout"]["item_shards"] >= 3 else
-                                           "two item shards: every rank warms up its users itself; early-terminating sweeps exchange a seed (<= 3 collectives per block)")
+                       "item_shard_path": (("popularity head: 256 replicated hot rows, a rank's 1 / R of the users warmed up on them, their K-th values "
+                                            "all-gathered as the seed, cold shards swept from empty lists (pda_amd.dist._topk_blocks_hot: 2 collectives per block)")
+                                           if (ev["layout"]["item_shards"] >= 3 or ev["layout"]["users_per_rank_and_step"] >= 131072) else
+                                           "two item shards, small blocks: every rank warms up its users itself; early-terminating sweeps exchange a seed (<= 3 collectives per block)")
                                           if (world > 1 and ev["layout"]["item_shards"] > 1) else None,
                        "train_nnz": W.n_train,
                        "arithmetic": ("fp32 tables and fp32 results, bit-identical to the exact fp32-MFMA kernel; bf16 MFMA only as a "

@@ -139,6 +139,9 @@ class ItemShardedTopK:
         # overrides (the same on every rank; tests run two ranks through the path)
         import os
         self.hot_min_shards = int(os.environ.get("PDA_HOT_ITEMS_MIN_SHARDS", "3"))
+        # ... and at two shards from this many users per block on (half a warm-up saved per rank: 262 144 users x 100 000 items 4.45 vs 4.80 ms,
+        # 131 072 users 2.3 - 2.5 vs 2.53 ms; profiles/round4_hot_items.txt)
+        self.hot_min_users_two_shards = 131072
         self.sweep_seed_fn = self.kth_fn = None
         self.n_epoch_collectives = 0  # collectives per weight / popularity version (the hot rows), not per user block
         self._hot = None
@@ -295,7 +298,9 @@ class ItemShardedTopK:
     # K-th value of any K items, so it is a hot pair or a cold pair at or above the seed.  Dense sweeps and early-terminating ones (the
     # product default for this head: the cold sweep then stops where a one-GPU sweep would -- its seed is that sweep's warm-up value).
     def _hot_applies(self, K, head, hist, users, sharded) -> bool:
-        if not (self.hot_items and self.world >= max(2, self.hot_min_shards) and sharded and head == 1 and self.prune in ("order", True, None)):
+        if not (self.hot_items and self.world >= 2 and sharded and head == 1 and self.prune in ("order", True, None)):
+            return False
+        if self.world < self.hot_min_shards and users.numel() < self.hot_min_users_two_shards:
             return False
         if getattr(self, "_pop_full", None) is None or users.numel() % self.world != 0:
             return False
@@ -451,8 +456,15 @@ class ItemShardedTopK:
             for users in blocks:
                 yield self.topk_sharded(users, K, head, hist) if sharded else self.topk(users, K, head, hist)
             return
-        if self.hot_items and self.world >= max(2, self.hot_min_shards) and sharded and head == 1 and self.prune in ("order", True, None):
-            # (dense AND early-terminating sweeps of the popularity head: the hot rows' K-th value is the seed a one-GPU warm-up would find)
+        # dense AND early-terminating sweeps of the popularity head through the replicated hot items (the hot rows' K-th value is the seed a
+        # one-GPU warm-up would find); the first block decides for the stream of blocks (a rank-invariant decision: block sizes are)
+        import itertools
+        it = iter(blocks)
+        first = next(it, None)
+        if first is None:
+            return
+        blocks = itertools.chain([first], it)
+        if self._hot_applies(K, head, hist, first, sharded):
             yield from self._topk_blocks_hot(blocks, K, head, hist)
             return
         # (a rank without items follows the same order of collectives as the others: same pipeline, neutral values)
