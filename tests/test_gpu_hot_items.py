@@ -95,3 +95,27 @@ def test_sweep_from_seed_without_a_bound_is_the_plain_sweep(dev, monkeypatch):
         for mode in ("order", True):
             got = ops.topk_merge(ops.sweep_from_seed(Ut, It, users, K, 1, popt, hist, 0, seed, n_splits=splits, prune=mode), want="keys")
             assert torch.equal(got, want), (d, mode, int((got != want).sum()))
+
+
+def test_remap_key_items_matches_the_torch_expression(dev):
+    """pda_topk_remap_items (in place, one launch) against ItemShardedTopK.remap_keys' torch expression on the CPU: scores of both signs,
+    empty slots (key 0 stays 0), local ids at both ends of the table."""
+    from pda_amd import ops
+    from pda_amd.dist import ItemShardedTopK
+    rng = np.random.default_rng(9)
+    n_gid = 1000
+    gid = np.sort(rng.choice(5_000_000, n_gid, replace=False)).astype(np.int32)
+    val = rng.standard_normal((64, 50)).astype(np.float32) * 3
+    loc = rng.integers(0, n_gid, (64, 50)).astype(np.int64)
+    loc[0, :2] = (0, n_gid - 1)
+    hi = val.view(np.uint32).astype(np.uint64)
+    ordb = np.where(hi & np.uint64(0x80000000), (~hi) & np.uint64(0xFFFFFFFF), hi | np.uint64(0x80000000))
+    keys = ((ordb << np.uint64(32)) | (np.uint64(0xFFFFFFFF) - loc.astype(np.uint64))).view(np.int64)
+    keys[3, 40:] = 0
+    keys[7] = 0
+    want = ItemShardedTopK.remap_keys(torch.from_numpy(keys.copy()), torch.from_numpy(gid))
+    got = ops.remap_key_items(torch.from_numpy(keys.copy()).to(dev), torch.from_numpy(gid).to(dev)).cpu()
+    assert torch.equal(got, want)
+    idx, v = ops.unpack_keys(got[:3])
+    assert np.array_equal(idx[0, :2], gid[[0, n_gid - 1]]) and np.array_equal(v, val[:3])
+    assert int((got[7] != 0).sum()) == 0 and int((got[3, 40:] != 0).sum()) == 0
