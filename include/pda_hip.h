@@ -313,6 +313,29 @@ int pda_score_topk4_phase_bf16(const uint16_t* U, const uint16_t* I_shard, const
                                int early_stop, int n_splits, int phase, int warm_tiles, const float* seed, uint64_t* out_keys,
                                void* workspace, void* stream);
 
+/* The funnel (round 5; pda_score_funnel.hip, pda_v7_funnel.h): score + mask + top-K for the RAW head -- the ranking the reference evaluates
+ * in every epoch and the only one of --train normal (MF/train_new_api.py:597-598,1139-1141,1160-1165) -- on large user blocks.  Same packed keys
+ * as every other generation, ONE list per user (out_keys [n_users_blk, K]; the item splits are merged inside).  A running exact list takes
+ * K ln(n / n0) insertions per user in any order that does not sort by score, each an exact rescoring with a gathered item row; the funnel sweeps
+ * growing parts of the catalogue against FIXED per-user thresholds on the huge geometry's machine mapping, writes the bf16 bounds of what beats
+ * them to per-lane lists, tightens the thresholds between the parts from the r-th largest lower bound seen, and rescores only the final K + the
+ * pairs inside the bound's band exactly.  Rows whose estimate was too bold (probability ~1e-6 per launch) or whose lists overflowed are served by
+ * generation 4's exact lists inside the same call.
+ *   prep       pda_item_prep4_f32 / _bf16 WITHOUT popularity, with a visiting order that is a RANDOM permutation of the shard (the thresholds'
+ *              ranks assume that the items seen so far are a uniform sample; any order gives exact results, a sorted one more fallbacks)
+ *   hist_*     optional; hist_row_mode must be PDA_HIST_BY_USER_ID (the fallback re-blocks the failed rows)
+ *   head       PDA_HEAD_RAW (PDA_ERR_UNSUPPORTED otherwise: the popularity head in visiting order is the huge geometry's)
+ *   d          64 / 128;  K <= 54;  4 096 <= n_items_local <= 2^26
+ *   workspace  pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d) bytes; +0 error word, +4 pairs rescored exactly, +16 kernel identity
+ * Reference counterpart: MF/model_api.py:62 (the raw ratings) + tf.nn.top_k(..., 50) behind the -inf mask, MF/train_new_api.py:594-612. */
+size_t pda_score_topk7_workspace_bytes(int n_users_blk, int n_items_local, int d);
+int pda_score_topk7_f32(const float* U, const float* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset,
+                        int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
+                        uint64_t* out_keys, void* workspace, void* stream);
+int pda_score_topk7_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset,
+                         int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
+                         uint64_t* out_keys, void* workspace, void* stream);
+
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0
  *   out_keys u64 [n_users_blk, K] or NULL;  out_idx i32 / out_val f32 [n_users_blk, K] or NULL.

@@ -77,6 +77,9 @@ SIGNATURES = {
     "pda_topk_seed_pick": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pda_score_topk4_phase_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_score_topk4_phase_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pda_score_topk7_workspace_bytes": (_sz, [_i, _i, _i]),
+    "pda_score_topk7_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "pda_score_topk7_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pda_topk_merge": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "pda_bpr_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "pda_triplet_plan_bytes": (_sz, [_i]),

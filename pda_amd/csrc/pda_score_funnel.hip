@@ -1,0 +1,329 @@
+// The funnel (round 5): score + mask + top-K for sweeps that meet hundreds of list insertions per user (raw head, natural order) on the huge
+// geometry's machine mapping -- pda_v7_funnel.h.  A translation unit of its own (pda_score_topk_v4.hip takes minutes to build).
+#include "pda_v4_shared.h"
+#include <cstdlib>
+
+namespace {
+#include "pda_v7_funnel.h"
+}  // namespace
+
+#include <cmath>
+#include <vector>
+
+namespace {
+
+// ---- tunables (pda_debug_funnel_tune: measurements only) ------------------------------------------------------------------------
+double g_fail_p = 1e-6;        // a launch's threshold lies above the row's final K-th value with at most this probability (then: the exact fallback)
+int g_growth = 4;              // every launch sees this many times the items seen before it (2 from a sixth of the catalogue on)
+int g_cap_e = 64;              // entries per (user, quarter) list and launch
+int g_first_tiles = 4;         // the first launch: 256 items against -inf
+constexpr int kFallbackSplits = 8;
+
+struct Stage7 {
+    int lo, hi;                // global 64-item tiles [lo, hi)
+    int rank_next;             // the threshold of the next launch: this rank among the lower bounds seen (0: none follows)
+};
+
+// P(Gamma(r, 1) <= x) = 1 - exp(-x) sum_{i < r} x^i / i!
+double gamma_cdf7(int r, double x) {
+    double term = 1.0, sum = 1.0;
+    for (int i = 1; i < r; ++i) {
+        term *= x / i;
+        sum += term;
+    }
+    return 1.0 - std::exp(-x) * sum;
+}
+// The items are visited in a random order, so the first m are a uniform sample of the n: the number of items ABOVE the r-th largest of the sample
+// is ~ Gamma(r) n / m.  The threshold is safe when at least K items of the catalogue reach it: the smallest r with P(Gamma(r) < K m / n) <= p.
+int rank_for7(int K, double m, double n, double p) {
+    if (m >= n) return K;
+    const double x = (double)K * m / n;
+    for (int r = 2; r < K; ++r)
+        if (gamma_cdf7(r, x) <= p) return r;
+    return K;
+}
+std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
+    std::vector<Stage7> st;
+    int lo = 0, hi = std::min(n_tiles, std::max(1, g_first_tiles));
+    for (;;) {
+        // (a last part of less than half a step joins the one before it)
+        if (n_tiles - hi < (hi - lo) / 2) hi = n_tiles;
+        Stage7 s7{lo, hi, 0};
+        if (hi < n_tiles) s7.rank_next = rank_for7(K, std::min((double)hi * 64.0, (double)n_items), (double)n_items, g_fail_p);
+        st.push_back(s7);
+        if (hi >= n_tiles) break;
+        lo = hi;
+        // the parts grow by g_growth, and by 2 from a sixth of the catalogue on: what a launch writes per list is ~ rank x (growth - 1) + the
+        // pairs inside the bound's band, and the lists of the last, longest launches are the ones that fill
+        const int gr = (long long)hi * 6 >= n_tiles ? 2 : std::max(2, g_growth);
+        hi = (int)std::min<long long>((long long)n_tiles, (long long)hi * gr);
+    }
+    return st;
+}
+
+// item splits of the emitting launches: the huge geometry's rule (ops.huge_splits; rounds of 256 workgroups x tiles per split)
+int funnel_splits7(int n_users, int n_items_local, int d) {
+    const int ut = d == 256 ? 512 : 1024;
+    const int utiles = (n_users + ut - 1) / ut;
+    const int tiles = (n_items_local + 63) / 64;
+    const int smax = std::max(1, std::min(64, tiles / 32));
+    int best = 1;
+    double best_cost = -1.0;
+    for (int s = 1; s <= smax; ++s) {
+        const double cost = (double)((utiles * s + 255) / 256) * (0.02 + 1.0 / s) + 0.004 * s * ((double)n_users / 262144.0);
+        if (best_cost < 0.0 || cost < best_cost - 1e-9) {
+            best = s;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
+struct Ws7 {
+    size_t ufrag, unorm, uerr, eu, ecnt, elist, thr, tk, tmax, ncand, flags, cand, qpool, qcnt, bloom, fail_list, fail_count, users2, fb_keys, fb_ws, total;
+    int n_splits, cap_e, cap_q;
+};
+Ws7 ws7_layout(int n, int n_items_local, int d) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    Ws7 w{};
+    w.n_splits = funnel_splits7(n, n_items_local, d);
+    w.cap_e = g_cap_e;
+    // slots of a (row, quarter, split) list of the pool: what a launch adds per quarter shrinks with the splits; the first launch (everything above
+    // -inf: 256 items over 4 quarters and S splits) must fit
+    w.cap_q = w.n_splits == 1 ? 64 : w.n_splits == 2 ? 40 : w.n_splits <= 4 ? 28 : 24;
+    const int ut = d == 256 ? 512 : 1024, nu = ut / 64;
+    const size_t utiles = ((size_t)n + ut - 1) / ut, n_pad = utiles * ut, wgs = utiles * (size_t)w.n_splits;
+    size_t b = 256;
+    w.ufrag = b;
+    b = al(b + n_pad * 2 * (size_t)d);
+    w.unorm = b;
+    b = al(b + n_pad * 4);
+    w.uerr = b;
+    b = al(b + n_pad * 4);
+    w.eu = b;
+    b = al(b + utiles * 4 * 8);
+    w.ecnt = b;
+    b = al(b + wgs * 4 * nu * 64 * 4);
+    w.elist = b;
+    b = al(b + wgs * 4 * (size_t)w.cap_e * (64 * nu * 48));
+    w.thr = b;
+    b = al(b + (size_t)n * 4);
+    w.tk = b;
+    b = al(b + (size_t)n * 4);
+    w.tmax = b;
+    b = al(b + (size_t)n * 4);
+    w.ncand = b;
+    b = al(b + (size_t)n * 4);
+    w.flags = b;
+    b = al(b + (size_t)n * 4);
+    w.cand = b;
+    b = al(b + (size_t)n * kCand7 * 16);
+    w.qpool = b;
+    b = al(b + (size_t)n * 4 * w.n_splits * w.cap_q * 16);
+    w.qcnt = b;
+    b = al(b + (size_t)n * 4 * w.n_splits * 4);
+    w.bloom = b;
+    b = al(b + (size_t)n * 128);
+    w.fail_list = b;
+    b = al(b + (size_t)n * 4);
+    w.fail_count = b;
+    b = al(b + 256);
+    w.users2 = b;
+    b = al(b + (size_t)n * 4);
+    w.fb_keys = b;
+    b = al(b + (size_t)kFallbackSplits * n * PDA_MAX_K * 8);
+    w.fb_ws = b;
+    b = al(b + pda_score_topk4_workspace_bytes(n, n_items_local, d, kFallbackSplits));
+    w.total = b;
+    return w;
+}
+
+__global__ void __launch_bounds__(256) init7_kernel(Rows7 r, int n, int* fail_count) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *fail_count = 0;
+    if (i >= n) return;
+    r.thr[i] = -INFINITY;
+    r.tk[i] = -INFINITY;
+    r.tmax[i] = -INFINITY;
+    r.ncand[i] = 0;
+    r.flags[i] = 0u;
+}
+
+template <int D, bool BF>
+int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int32_t* users, int n, int item_offset, int n_items_local, const int64_t* hist_indptr,
+                 const int32_t* hist_indices, int hist_row_mode, int K, uint64_t* out_keys, void* workspace, hipStream_t s) {
+    constexpr int UPW = D == 256 ? 128 : 256, UT = 4 * UPW;
+    const Ws7 W = ws7_layout(n, n_items_local, D);
+    const Prep4Layout L = prep4_layout(n_items_local, D);
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    if (hipMemsetAsync(workspace, 0, 256, s) != hipSuccess) return PDA_ERR_LAUNCH;
+    Rows7 R{reinterpret_cast<float*>(wsb + W.thr), reinterpret_cast<float*>(wsb + W.tk), reinterpret_cast<float*>(wsb + W.tmax), reinterpret_cast<int*>(wsb + W.ncand),
+            reinterpret_cast<uint64_t*>(wsb + W.qpool), reinterpret_cast<unsigned*>(wsb + W.qcnt), W.cap_q, reinterpret_cast<uint64_t*>(wsb + W.cand),
+            reinterpret_cast<unsigned*>(wsb + W.flags)};
+    int* fail_count = reinterpret_cast<int*>(wsb + W.fail_count);
+    hipLaunchKernelGGL(init7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, R, n, fail_count);
+    PDA_CHECK_LAUNCH();
+    const int n_pad = (n + UT - 1) / UT * UT;
+    hipLaunchKernelGGL((uprep5_kernel<D, BF, true, UPW>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, s, U, users, n, n_pad, wsb + W.ufrag,
+                       reinterpret_cast<float*>(wsb + W.unorm), reinterpret_cast<float*>(wsb + W.uerr));
+    PDA_CHECK_LAUNCH();
+    uint32_t* bloom = nullptr;
+    if (hist_indptr != nullptr) {
+        bloom = reinterpret_cast<uint32_t*>(wsb + W.bloom);
+        hipLaunchKernelGGL(hist_bloom7_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, s, users, hist_indptr, hist_indices, hist_row_mode, n,
+                           reinterpret_cast<const int*>(pb + L.pos_of), item_offset, n_items_local, bloom);
+        PDA_CHECK_LAUNCH();
+    }
+    Args7 e{pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), wsb + W.ufrag, reinterpret_cast<const float*>(wsb + W.unorm), reinterpret_cast<const float*>(wsb + W.uerr), R.thr,
+            wsb + W.elist,
+            reinterpret_cast<unsigned*>(wsb + W.ecnt), reinterpret_cast<float*>(wsb + W.eu), reinterpret_cast<unsigned*>(workspace), n, W.n_splits, L.n_tiles, 0, 0, W.cap_e,
+            nullptr};
+    Sel7 q{e, R, pb + L.rows, users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, U, I_shard, out_keys,
+           reinterpret_cast<int*>(wsb + W.fail_list), fail_count};
+    const std::vector<Stage7> stages = schedule7(L.n_tiles, n_items_local, K);
+    for (const Stage7& st : stages) {
+        e.tile_lo = st.lo;
+        e.tile_hi = st.hi;
+        const int rc = launch_sweep7<D, BF, UPW>(e, s);
+        if (rc != PDA_OK) return rc;
+        q.e = e;
+        q.rank_next = st.rank_next;
+        hipLaunchKernelGGL((expand7_kernel<D>), dim3((unsigned)(((size_t)(n + UT - 1) / UT) * W.n_splits * (UPW / 16))), dim3(256), 0, s, q);
+        PDA_CHECK_LAUNCH();
+        {
+            const int nsl = (4 * W.n_splits * W.cap_q + 63) / 64;          // 64-slot groups of a row's (quarter, split) lists
+            const dim3 gr((unsigned)((n + 3) / 4));
+            if (nsl <= 4) hipLaunchKernelGGL((threshold7_kernel<D, 4>), gr, dim3(256), 0, s, q);
+            else if (nsl <= 7) hipLaunchKernelGGL((threshold7_kernel<D, 7>), gr, dim3(256), 0, s, q);
+            else if (nsl <= 12) hipLaunchKernelGGL((threshold7_kernel<D, 12>), gr, dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((threshold7_kernel<D, 0>), gr, dim3(256), 0, s, q);
+            PDA_CHECK_LAUNCH();
+        }
+    }
+    hipLaunchKernelGGL((resolve7_kernel<D, BF>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, q);
+    PDA_CHECK_LAUNCH();
+    // ---- the exact fallback: generation 4's many-candidates geometry on the failed rows (a device-side count: nothing runs when nobody failed)
+    int32_t* users2 = reinterpret_cast<int32_t*>(wsb + W.users2);
+    hipLaunchKernelGGL(fail_users7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, users, q.fail_list, fail_count, n, users2);
+    PDA_CHECK_LAUNCH();
+    uint64_t* fb_keys = reinterpret_cast<uint64_t*>(wsb + W.fb_keys);
+    const int rc = pda_v4_run_score4_dev(U, I_shard, BF, prep, nullptr, users2, n, fail_count, item_offset, n_items_local, D, hist_indptr, hist_indices, hist_row_mode, K,
+                                         PDA_HEAD_RAW, PDA_SWEEP_MANY_CANDIDATES, kFallbackSplits, fb_keys, wsb + W.fb_ws, s);
+    if (rc != PDA_OK) return rc;
+    hipLaunchKernelGGL(fail_merge7_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb_keys, kFallbackSplits, n, K, q.fail_list, fail_count, out_keys, reinterpret_cast<unsigned*>(workspace));
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+int run_funnel(const void* U, const void* I_shard, bool bf16, const void* prep, const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+               const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head, uint64_t* out_keys, void* workspace, hipStream_t s) {
+    if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
+    if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
+    if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
+    if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
+    if (head != PDA_HEAD_RAW) return PDA_ERR_UNSUPPORTED;                          // (the popularity head in visiting order: generation 4 / the huge geometry)
+    if (hist_indptr && hist_row_mode != PDA_HIST_BY_USER_ID) return PDA_ERR_UNSUPPORTED;   // (the fallback re-blocks the failed rows: a history by user id follows them)
+    if (K > 54) return PDA_ERR_UNSUPPORTED;                                        // (the fallback is generation 4)
+    if ((uint64_t)n_items_local > (1ull << 26) || n_items_local < 64 * 64) return PDA_ERR_UNSUPPORTED;
+    switch (d) {
+#define PDA_F7(DD) case DD: return bf16 ? run_funnel_t<DD, true>(U, I_shard, prep, users, n_users_blk, item_offset, n_items_local, hist_indptr, hist_indices, hist_row_mode, K, out_keys, workspace, s) \
+                                         : run_funnel_t<DD, false>(U, I_shard, prep, users, n_users_blk, item_offset, n_items_local, hist_indptr, hist_indices, hist_row_mode, K, out_keys, workspace, s);
+        PDA_F7(64) PDA_F7(128)
+#undef PDA_F7
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t pda_score_topk7_workspace_bytes(int n_users_blk, int n_items_local, int d) {
+    if (n_users_blk <= 0 || n_items_local <= 0 || (d != 64 && d != 128)) return 0;
+    return ws7_layout(n_users_blk, n_items_local, d).total;
+}
+extern "C" int pda_score_topk7_f32(const float* U, const float* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
+                                   const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head, uint64_t* out_keys, void* workspace,
+                                   void* stream) {
+    return run_funnel(U, I_shard, false, prep, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices, hist_row_mode, K, head, out_keys, workspace,
+                      reinterpret_cast<hipStream_t>(stream));
+}
+extern "C" int pda_score_topk7_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset, int n_items_local,
+                                    int d, const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head, uint64_t* out_keys,
+                                    void* workspace, void* stream) {
+    return run_funnel(U, I_shard, true, prep, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices, hist_row_mode, K, head, out_keys, workspace,
+                      reinterpret_cast<hipStream_t>(stream));
+}
+// measurements only: failure probability target, growth factor, list capacity, first tiles (0 / negative: keep)
+extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int first_tiles) {
+    if (fail_p > 0.0) g_fail_p = fail_p;
+    if (growth >= 2) g_growth = growth;
+    if (cap_e > 0) g_cap_e = cap_e;
+    if (first_tiles > 0) g_first_tiles = first_tiles;
+    return PDA_OK;
+}
+// the workspace of a funnel: offs[0..9] = thr, tk, tmax, ncand, flags, cand, fail_list, fail_count, ecnt, elist; returns (n_splits << 16) | cap_e
+extern "C" int pda_debug_funnel_layout(int n_users_blk, int n_items_local, int d, size_t* offs) {
+    const Ws7 w = ws7_layout(n_users_blk, n_items_local, d);
+    const size_t o[10] = {w.thr, w.tk, w.tmax, w.ncand, w.flags, w.cand, w.fail_list, w.fail_count, w.ecnt, w.elist};
+    for (int i = 0; i < 10; ++i) offs[i] = o[i];
+    return (w.n_splits << 16) | w.cap_e;
+}
+// the launches of a funnel: out[3 i .. 3 i + 2] = (first tile, end tile, rank of the next threshold); returns their number
+extern "C" int pda_debug_funnel_schedule(int n_items_local, int K, int* out, int max_stages) {
+    const std::vector<Stage7> st = schedule7((n_items_local + 63) / 64, n_items_local, K);
+    for (size_t i = 0; i < st.size() && (int)i < max_stages; ++i) {
+        out[3 * i] = st[i].lo;
+        out[3 * i + 1] = st[i].hi;
+        out[3 * i + 2] = st[i].rank_next;
+    }
+    return (int)st.size();
+}
+
+// ---- debug / measurement entry of the funnel's emitting sweep (tools/time_emit.py): one launch against the caller's thresholds ----------
+// workspace: [256 B counters | user image | norms | eu per wave | cursors | lists]; offs[0..4] = byte offsets of (unorm, eu, cursors, lists, end)
+extern "C" size_t pda_debug_emit_layout(int n_users_blk, int d, int n_splits, int cap_e, size_t* offs) {
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int ut = d == 256 ? 512 : 1024, nu = ut / 64;
+    const size_t utiles = ((size_t)n_users_blk + ut - 1) / ut, n_pad = utiles * ut;
+    size_t b = 256;
+    b = al(b + n_pad * 2 * (size_t)d);
+    offs[0] = b;
+    b = al(b + n_pad * 4);
+    offs[1] = b;
+    b = al(b + utiles * 4 * 8);
+    offs[2] = b;
+    b = al(b + utiles * (size_t)n_splits * 4 * nu * 64 * 4);
+    offs[3] = b;
+    b = al(b + utiles * (size_t)n_splits * 4 * (size_t)cap_e * (64 * nu * 48) + (1 << 18));
+    offs[4] = b;                               // (the rows' residual norms sit behind everything)
+    return al(b + n_pad * 4);
+}
+extern "C" int pda_debug_emit_sweep(const void* U, int bf16, const int32_t* users, int n_users_blk, const void* prep, int n_items_local, int d, const float* thr,
+                                    int tile_lo, int tile_hi, int n_splits, int cap_e, void* workspace, void* stream) {
+    if (!U || !users || !prep || !thr || !workspace || n_users_blk <= 0 || n_splits <= 0 || cap_e <= 0) return PDA_ERR_ARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    size_t offs[5];
+    pda_debug_emit_layout(n_users_blk, d, n_splits, cap_e, offs);
+    const Prep4Layout L = prep4_layout(n_items_local, d);
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(prep);
+    unsigned char* wsb = reinterpret_cast<unsigned char*>(workspace);
+    Args7 g{pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), wsb + 256, reinterpret_cast<const float*>(wsb + offs[0]),
+            reinterpret_cast<const float*>(wsb + offs[4]), thr, wsb + offs[3],
+            reinterpret_cast<unsigned*>(wsb + offs[2]), reinterpret_cast<float*>(wsb + offs[1]), reinterpret_cast<unsigned*>(wsb), n_users_blk, n_splits, L.n_tiles,
+            tile_lo, tile_hi, cap_e, nullptr};
+#define PDA_E7(DD, BFV, UPWV)                                                                                                                      \
+    {                                                                                                                                              \
+        constexpr int UT = 4 * UPWV;                                                                                                               \
+        const int n_pad = (n_users_blk + UT - 1) / UT * UT;                                                                                        \
+        hipLaunchKernelGGL((uprep5_kernel<DD, BFV, true, UPWV>), dim3((unsigned)(((size_t)n_pad * (DD / 8) + 255) / 256)), dim3(256), 0, s, U, users, n_users_blk, n_pad, \
+                           wsb + 256, reinterpret_cast<float*>(wsb + offs[0]), reinterpret_cast<float*>(wsb + offs[4]));                           \
+        PDA_CHECK_LAUNCH();                                                                                                                        \
+        return launch_sweep7<DD, BFV, UPWV>(g, s);                                                                                                 \
+    }
+    if (d == 64) { if (bf16) PDA_E7(64, true, 256) else PDA_E7(64, false, 256) }
+    if (d == 128) { if (bf16) PDA_E7(128, true, 256) else PDA_E7(128, false, 256) }
+    if (d == 256) { if (bf16) PDA_E7(256, true, 128) else PDA_E7(256, false, 128) }
+#undef PDA_E7
+    return PDA_ERR_UNSUPPORTED;
+}
+

@@ -32,7 +32,7 @@
 //     masked at the candidate stage for all of them (binary search in the caller's id-sorted history by the rescoring wave).
 //
 // Error bound of the filter, folded test, tie handling: pda_score_topk_v3.hip (unchanged).
-#include "pda_topk_common.h"
+#include "pda_v4_shared.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -65,8 +65,6 @@ __device__ unsigned long long pda_prof4[24];
 #endif
 constexpr unsigned kSpinMax = 1u << 26;   // every spin is bounded: a protocol error sets stats[0] and leaves instead of hanging the GPU
 
-__host__ __device__ constexpr int row_bytes(int d) { return 2 * d + 48; }
-__host__ __device__ constexpr int tile_bytes(int d) { return 64 * row_bytes(d); }
 
 struct Args4 {
     const void* U;               // f32 or bf16 [n_users_total, d]
@@ -106,6 +104,8 @@ struct Args4 {
     int warm_shared;             // n_splits > 1, one call: ONE warm-up per user on tiles 0 .. warm_tiles - 1 of the whole visiting order, handed to
                                  // split 0; the other splits start empty and prune against its K-th value (seed); see warm_tiles_of
     float* seed_out;             // [n_users_blk] or NULL: warm4_kernel leaves a lower bound of every row's K-th value here (the shared warm-up's seed)
+    const int* n_users_dev;      // or NULL: a device-side count of the rows that exist (the funnel's exact fallback: the block is sized for the worst
+                                 // case, workgroups whose user tile lies beyond the count leave at once; rows beyond it inside a tile score the padding user)
     int lists_empty;             // phase 4: no warm-up ran on this catalogue -- every split starts with empty lists and sweeps ALL its tiles against
                                  // the caller's seed (the warm-up ran elsewhere: on replicated hot items, pda_amd.dist)
 };
@@ -113,28 +113,6 @@ struct Args4 {
 // ---------------------------------------------------------------------------------------------------------------------
 // prep: padded rows in visiting order
 // ---------------------------------------------------------------------------------------------------------------------
-struct Prep4Layout {
-    size_t hdr, pos_of, sufA, sufB, sufR, rows, rows5, meta5, total;
-    int n_tiles;
-};
-Prep4Layout prep4_layout(int n, int d) {
-    Prep4Layout L{};
-    L.n_tiles = (n + 63) / 64;
-    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    L.hdr = 0;                                  // +0 int: "order is not a permutation"; +4 int: prep was built with a popularity; +8 int: with an order
-    L.pos_of = 256;
-    L.sufA = L.pos_of + al((size_t)n * 4);
-    L.sufB = L.sufA + al((size_t)L.n_tiles * 4);
-    L.sufR = L.sufB + al((size_t)L.n_tiles * 4);
-    L.rows = L.sufR + al((size_t)L.n_tiles * 4);
-    L.total = L.rows + (size_t)L.n_tiles * tile_bytes(d);
-    // the image of the huge geometry -- rows scaled by the popularity, bf16, 16-byte chunks XOR-swizzled, 32-item half-tiles of
-    // 64 d bytes -- and (pmax, nmax) per half-tile
-    L.rows5 = al(L.total);
-    L.meta5 = L.rows5 + al((size_t)L.n_tiles * 2 * 64 * (size_t)d);
-    L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 16);              // (pmax, nmax, 0, 0) per half-tile: one 16-byte LDS-DMA lane
-    return L;
-}
 
 // one row per D/8 threads.  pos >= n: a null item (zero vector, constant slot -3e38: never a candidate, pop NaN)
 template <int D, bool BF>
@@ -145,7 +123,7 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
     const int pos = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
     if (pos >= n_pad) return;
     unsigned char* rp = rows + (size_t)pos * RB;
-    float ss = 0.f, popv = 1.0f;
+    float ss = 0.f, popv = 1.0f, rs = 0.f;
     int src = -1;
     if (pos < n) {
         src = pos;
@@ -173,6 +151,12 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
             for (int k = 0; k < 4; ++k) { as[k] *= pv; bs[k] *= pv; }
             u32x4 hs, ls;
             split8(as, bs, hs, ls);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                    // the rounding residual of the image row (exact differences): ||i' - bf16(i')||^2
+                const float r0 = as[k] - __uint_as_float((k & 1) ? (hs[k >> 1] & 0xFFFF0000u) : (hs[k >> 1] << 16));
+                const float r1 = bs[k] - __uint_as_float((k & 1) ? (hs[2 + (k >> 1)] & 0xFFFF0000u) : (hs[2 + (k >> 1)] << 16));
+                rs += r0 * r0 + r1 * r1;
+            }
             const int r5 = pos & 31;
             const int sw = D >= 128 ? (r5 & 15) : ((r5 >> 1) & 7);
             *reinterpret_cast<u32x4*>(rows5 + (size_t)(pos >> 5) * (64 * D) + r5 * (2 * D) + ((e ^ sw) << 4)) = hs;
@@ -187,14 +171,16 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
         }
     }
 #pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    for (int o = TPR / 2; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); rs += __shfl_xor(rs, o, 64); }
     if (e == 0) {
         const float v = sqrtf(ss) * 1.0009765625f * 1.0001f;
+        const float rv = sqrtf(rs) * 1.0009765625f * 1.0001f;       // padded ||i' - bf16(i')||: the funnel's bound uses the ACTUAL rounding residuals (pda_v7_funnel.h)
         {
             if (pos < n) {                                   // (pmax, nmax) of the half-tile: maxima of non-negative floats = maxima of their bit patterns
                 const float pv = pop ? ((popv == popv) ? popv : 0.f) : 1.0f;
                 atomicMax(&meta5[4 * (pos >> 5)], __float_as_int(pop ? pv : 0.f));
                 atomicMax(&meta5[4 * (pos >> 5) + 1], __float_as_int(pv * v * 1.000001f));
+                atomicMax(&meta5[4 * (pos >> 5) + 2], __float_as_int(rv));
             }
         }
         // the B side of the extra k-step (see pda_score_topk_v2.hip:item_prep_kernel): k 0..7 pieces of (1/pop)' rounded
@@ -225,7 +211,7 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
         tail[0] = pos < n ? __float_as_uint(pop ? popv : 1.0f) : 0x7FC00000u;     // null item: NaN (no comparison is ever true)
         tail[1] = (uint32_t)(pos < n ? src : 0);
         tail[2] = __float_as_uint(pos < n ? v : 0.f);
-        tail[3] = 0;
+        tail[3] = pos < n ? __float_as_uint(rv) : 0u;                 // (the residual norm of the row's huge-geometry image)
         *reinterpret_cast<u32x4*>(rp + 2 * D + 32) = tail;
     }
 }
@@ -271,39 +257,6 @@ __global__ void __launch_bounds__(1024) suffix_max4_kernel(float* __restrict__ t
     }
 }
 
-// Train items at the candidate stage: a candidate that passes the exact threshold must not be a train item of its user -- a
-// binary search in the user's id-sorted history, i.e. six to seven DEPENDENT loads from a 200 MB array: 5 of the 6.5 us of a
-// rescoring pass of 16 candidates (cycle counters, natural-order sweep).  A 1024-bit Bloom filter per block row (two hashes;
-// 50 train items: 0.9 % false positives) is read with the candidate's rows instead; only a hit pays for the search.
-__device__ __forceinline__ unsigned bloom_h1(int item) { return ((unsigned)item * 0x9E3779B1u) >> 22; }
-__device__ __forceinline__ unsigned bloom_h2(int item) { return ((unsigned)item * 0x85EBCA6Bu + 0x27D4EB2Fu) >> 22; }
-// 32 rows per workgroup, eight lanes per row: each lane hashes every eighth train item into the row's 32 words in LDS.
-// skip_if_ordered: sweeps of the popularity head in visiting order meet next to no candidates -- the filters would cost more
-// than they save (prep header word 2 = "an order was given"; the sweep reads the same word).
-__global__ void __launch_bounds__(256) hist_bloom4_kernel(const int32_t* __restrict__ users, const int64_t* __restrict__ indptr,
-                                                          const int32_t* __restrict__ indices, int hist_row_mode, int n_users_blk,
-                                                          uint32_t* __restrict__ bloom, const int* __restrict__ prep_hdr, int skip_if_ordered) {
-    if (skip_if_ordered && prep_hdr[2] != 0) return;
-    __shared__ uint32_t w[32 * 32];
-    const int tid = threadIdx.x, r = tid >> 3, sub = tid & 7;
-    for (int q = tid; q < 32 * 32; q += 256) w[q] = 0u;
-    __syncthreads();
-    const int u = (int)blockIdx.x * 32 + r;
-    if (u < n_users_blk) {
-        const int64_t hr = hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)users[u] : (int64_t)u;
-        const int64_t b = indptr[hr], e = indptr[hr + 1];
-        for (int64_t i = b + sub; i < e; i += 8) {
-            const int item = indices[i];
-            const unsigned h1 = bloom_h1(item), h2 = bloom_h2(item);
-            atomicOr(&w[r * 32 + (h1 >> 5)], 1u << (h1 & 31u));
-            atomicOr(&w[r * 32 + (h2 >> 5)], 1u << (h2 & 31u));
-        }
-    }
-    __syncthreads();
-    const size_t base = (size_t)blockIdx.x * 32 * 32;
-    for (int q = tid; q < 32 * 32; q += 256)
-        if ((int)blockIdx.x * 32 + (q >> 5) < n_users_blk) bloom[base + q] = w[q];
-}
 
 int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
     if (d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
@@ -355,10 +308,6 @@ __device__ __forceinline__ f32x16 zero16v() {
     return z;
 }
 
-// the tiles of split s: s, s + S, s + 2 S, ...
-__device__ __forceinline__ int split_tiles(int n_tiles, int split, int n_splits) {
-    return split < n_tiles ? (n_tiles - split + n_splits - 1) / n_splits : 0;
-}
 // how many of split s's first tiles the warm-up has scored: warm_tiles of its own -- or, behind a shared warm-up (tiles 0 .. warm_tiles - 1
 // of the whole order), those of them that are the split's: s, s + S, ... below warm_tiles
 __device__ __forceinline__ int warm_tiles_of(const Args4& g, int split) {
@@ -472,6 +421,7 @@ __global__ void __launch_bounds__(kThreads) warm_mask4_kernel(Args4 g, uint32_t*
     __shared__ unsigned hmask[kUserTile * 2 * kWarmTiles];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    if (g.n_users_dev != nullptr && utile * kUserTile >= *g.n_users_dev) return;
     const int nwarm = min(g.warm_tiles, split_tiles(g.n_tiles, split, g.n_splits));
     for (int q = tid; q < kUserTile * 2 * kWarmTiles; q += kThreads) hmask[q] = 0u;
     __syncthreads();
@@ -505,6 +455,7 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    if (g.n_users_dev != nullptr && utile * kUserTile >= *g.n_users_dev) return;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int nwarm = min(g.warm_tiles, nt);
@@ -900,7 +851,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     constexpr int CAPL = G::CAP;                       // list slots per user row
     constexpr int RINGL = G::RING;                     // entries per candidate ring
     constexpr int NM = D / 16;
-    constexpr float kEps = BF ? 6.103515625e-5f : 3.9453125e-3f;   // 2^-14  |  2^-8 * 1.01
+    constexpr float kEps = BF ? 6.103515625e-5f : 7.890625e-3f;   // 2^-14  |  2^-7 * 1.01 (pda_score_topk_v3.hip: the unit roundoff of bf16 is 2^-8)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tiles = smem;                                                             // NSLOT x BB
     uint64_t* lists = GL ? g.lists_ws + (size_t)blockIdx.x * UT * CAPL                      // [UT][CAPL] exact keys
@@ -922,6 +873,7 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int split = blockIdx.x % g.n_splits, utile = blockIdx.x / g.n_splits;
+    if (g.n_users_dev != nullptr && utile * UT >= *g.n_users_dev) return;
     const int K = g.K;
     const int nt = split_tiles(g.n_tiles, split, g.n_splits);
     const int wt = warm_tiles_of(g, split);                        // the split's tiles the warm-up has scored
@@ -2194,7 +2146,7 @@ extern "C" size_t pda_score_topk4_workspace_bytes(int n_users_blk, int n_items_l
 int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users,
                int n_users_blk, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
                int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s,
-               int phase = 3, const float* seed = nullptr, int warm_tiles = 0) {
+               int phase = 3, const float* seed = nullptr, int warm_tiles = 0, const int* n_users_dev = nullptr) {
     if (!U || !I_shard || !prep || !users || !out_keys || !workspace) return PDA_ERR_ARG;
     if (n_users_blk <= 0 || n_items_local <= 0 || item_offset < 0) return PDA_ERR_ARG;
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
@@ -2254,6 +2206,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
     g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop) ? 1 : 0;
     g.lists_empty = from_empty ? 1 : 0;
+    g.n_users_dev = n_users_dev;
     // one call over several item splits: ONE exact warm-up per user instead of one per split (warm_tiles_of; PDA_SWEEP_WARM_PER_SPLIT)
     if (phase == 3 && n_splits > 1 && seed == nullptr && !warm_per_split && L.n_tiles > n_splits * warm_tiles) {
         g.warm_shared = 1;
@@ -2415,6 +2368,14 @@ __global__ void __launch_bounds__(256) seed_pick_kernel(const float* __restrict_
 
 }  // namespace
 
+// the funnel's exact fallback (pda_score_funnel.hip): generation 4 on a block whose size is a device-side count
+int pda_v4_run_score4_dev(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users, int n_users_blk,
+                          const int* n_users_dev, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
+                          int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s) {
+    return run_score4(U, I_shard, bf16, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices, hist_row_mode, K, head,
+                      early_stop, n_splits, out_keys, workspace, s, 3, nullptr, 0, n_users_dev);
+}
+
 extern "C" int pda_topk_seed_bounds(const uint64_t* keys, int n_splits, int n_users_blk, int K, int m, float* bounds, void* stream) {
     if (!keys || !bounds || n_splits < 1 || n_users_blk < 1 || K < 1 || m < 1 || m > K) return PDA_ERR_ARG;
     hipLaunchKernelGGL(seed_bounds_kernel, dim3((unsigned)((n_users_blk + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), keys,
@@ -2439,6 +2400,7 @@ extern "C" int pda_topk_seed_pick(const float* bounds, const int32_t* counts, in
 }
 
 #ifdef PDA_V5_LOG
+
 extern "C" int pda_debug_v5_log(unsigned* out, int n_words, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pda_v5_log), (size_t)n_words * 4) != hipSuccess) return PDA_ERR_LAUNCH;
     if (reset) { unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(pda_v5_log), &z, 4) != hipSuccess) return PDA_ERR_LAUNCH; }

@@ -34,8 +34,6 @@
 #include "pda_v6_loop_asm.h"           // the same loop on v_mfma_f32_16x16x32_bf16 (S16 below; tools/gen_v6_loop_asm.py)
 #endif
 
-constexpr int kUT5 = 1024;            // users per workgroup
-constexpr int kNSlot5 = 8;            // half-tile slots in the LDS (pda_v5_loop_asm.h: NSLOT), Loop5<D>::kSlotBytes each: the rows, then the meta entry
 #ifdef PDA_V5_LOG
 __device__ unsigned pda_v5_log[1 << 18];      // debug build: [0] = entries used; then (block << 8 | wave, kind, a, b) per event
 #define V5LOG(kind, a, b) do { if (lane == 0) { const unsigned i_ = atomicAdd(&pda_v5_log[0], 1u); if (i_ < (1u << 16) - 1u) { \
@@ -45,48 +43,7 @@ __device__ unsigned pda_v5_log[1 << 18];      // debug build: [0] = entries used
 #endif
 constexpr int kRing5 = 192;           // candidate ring entries per wave (u64 each); a push needs 64 free
 
-__host__ __device__ constexpr int half_bytes5(int d) { return 64 * d; }       // 32 rows of 2 d bytes, 16-byte chunks XOR-swizzled
-// an LDS slot: the half-tile's rows, then its meta entry; slots start at multiples of 256 (512 at d = 256: the loop forms fragment addresses by
-// XOR with k << 6, which reaches bit 8 from k = 4 on)
-__host__ __device__ constexpr int slot_bytes5(int d) { return 64 * d + (d == 256 ? 512 : 256); }
-template <int D>
-__device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((row >> 1) & 7); }
 
-// ---- the user image: the block's rows as bf16 MFMA operands, in the order the waves load them into their AGPRs ------------------
-// fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes; lane l holds user 32 u + (l & 31), elements 16 k + 8 (l >> 5) .. + 7
-// S16 (the 16 x 16 x 32 loop): fragment (wg, w, u, k) is 16 users x 32 elements; lane l holds user 16 u + (l & 15), elements 32 k + 8 (l >> 4) .. + 7
-template <int D, bool BF, bool S16, int UPW>
-__global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U, const int32_t* __restrict__ users, int n_users_blk, int n_pad,
-                                                     unsigned char* __restrict__ ufrag, float* __restrict__ unorm) {
-    constexpr int TPR = D / 8;
-    const int gid = blockIdx.x * 256 + threadIdx.x;
-    const int rb = gid / TPR, c = gid % TPR;
-    if (rb >= n_pad) return;
-    f32x4 x = {0.f, 0.f, 0.f, 0.f}, y = x;
-    if (rb < n_users_blk) {
-        const int uid = users[rb];
-        x = pda_load4<BF>(U, (size_t)uid * D + 8 * c);
-        y = pda_load4<BF>(U, (size_t)uid * D + 8 * c + 4);
-    }
-    u32x4 hq, lq;
-    split8(x, y, hq, lq);
-    float ss = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
-#pragma unroll
-    for (int o = TPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if constexpr (S16) {
-        constexpr int NK = D / 32, NU = UPW / 16;                        // (wgw: the wave's index among all waves of the launch)
-        const int wgw = rb / UPW, u = (rb >> 4) & (NU - 1), j = rb & 15, k = c >> 2, g4 = c & 3;
-        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * NU + u) * NK + k) * 64 + (j + 16 * g4)) * 16) = hq;
-    } else {
-        constexpr int NK = D / 16;
-        static_assert(S16 || UPW == 256, "the 32 x 32 x 16 loop: 256 users per wave");
-        const int wgw = rb >> 8, u = (rb >> 5) & 7, j = rb & 31, k = c >> 1, hh = c & 1;
-        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 8 + u) * NK + k) * 64 + (j + 32 * hh)) * 16) = hq;
-    }
-    if (c == 0) unorm[rb] = sqrtf(ss) * 1.0009765625f * 1.0001f;          // padded ||u|| (as generation 4's nu_row)
-}
 
 // UPW users per wave: 256 -- one 1 024-user workgroup per CU, 512 registers per wave -- or (S16) 128: 512-user workgroups, TWO per CU, 256
 // registers per wave.  With one wave per SIMD nothing overlaps the wave's own VALU tests, LDS reads and scalar work with its MFMAs (PMC, UPW
@@ -103,7 +60,7 @@ __global__ void __launch_bounds__(256, (UPW == 128 && D <= 128) ? 2 : 1) sweep5_
     constexpr int NK = S16 ? D / 32 : D / 16, UBW = S16 ? 16 : 32, NU = UPW / UBW;
     constexpr int SS = slot_bytes5(D), UT = 4 * UPW, CAPL = kCap4, RB4 = row_bytes(D);
     constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
-    constexpr float kEps5 = BF ? 2.01171875e-3f : 4.0234375e-3f;         // 2^-9 x 1.03 (only the scaled items are rounded)  |  2^-8 x 1.03
+    constexpr float kEps5 = BF ? 4.0234375e-3f : 8.046875e-3f;           // 2^-8 x 1.03 (only the scaled items are rounded: one unit roundoff of bf16)  |  2^-7 x 1.03 (both sides)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* tiles = smem;                                         // kNSlot5 x SS (at LDS address 0: the loop XORs fragment offsets into slot addresses)
     int* cntl = reinterpret_cast<int*>(smem + kNSlot5 * SS);            // [UT]

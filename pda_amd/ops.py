@@ -563,6 +563,8 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
         if cnt is not None:
             seed_sum(cnt)
         return seeded_finish(c)
+    if n_splits_auto and out_given is None and impl == "v2" and funnel_applies(d, K, nu, nloc, head, prune, hist):
+        return score_topk_funnel(U, I_shard, users, K, hist, item_offset, stats)
     if n_splits <= 0:
         n_splits = lib.pda_score_topk_auto_splits(nu, nloc)
     if out is None:
@@ -629,7 +631,67 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     return out
 
 
-GEOMETRY_NAMES = {0: "lds", 1: "hbm", 2: "wide", 3: "many", 4: "huge", 5: "huge32", 6: "huge2"}
+# ---- the funnel (pda_score_topk7_*): the raw head on large user blocks ------------------------------------------------------------
+# Measured (config 3, same box): 262 144 users 22.3 vs 29.7 ms for generation 4's many-candidates geometry, 65 536 users 6.4 vs 7.3 ms; config 2 (50 000 users
+# x 20 000 items, d = 64) 3.3 vs 2.1 ms -- a funnel is ~25 launches whose per-row work does not shrink with the catalogue.
+FUNNEL_MIN_USERS = 32768
+FUNNEL_MIN_ITEMS = 65536
+_FUNNEL_ORDER = {}               # (n, device) -> a fixed pseudo-random permutation (the object is what the prep cache keys on)
+
+
+def funnel_order(I_shard: torch.Tensor) -> torch.Tensor:
+    """The visiting order of a funnel: a RANDOM permutation of the shard (seeded by its size: reproducible).  The ranks of the funnel's
+    thresholds assume that the items seen so far are a uniform sample of the catalogue; results are exact for any order."""
+    key = (I_shard.shape[0], str(I_shard.device))
+    o = _FUNNEL_ORDER.get(key)
+    if o is None:
+        g = torch.Generator(device="cpu").manual_seed(0x5EED + I_shard.shape[0])
+        o = torch.randperm(I_shard.shape[0], generator=g).to(torch.int32).to(I_shard.device)
+        _FUNNEL_ORDER[key] = o
+    return o
+
+
+def funnel_applies(d: int, K: int, nu: int, nloc: int, head: int, prune, hist: Optional[HistoryCSR]) -> bool:
+    """Does score_topk_keys serve this call with the funnel?  (PDA_SCORE_FUNNEL=0 | 1 forces it off / on wherever it can run.)"""
+    can = head == HEAD_RAW and d in (64, 128) and K <= TOPK_K_V4 and 4096 <= nloc <= (1 << 26) and prune is not True \
+        and (hist is None or hist.mode == HIST_BY_USER_ID)
+    forced = os.environ.get("PDA_SCORE_FUNNEL", "")
+    if forced == "0" or not can:
+        return False
+    if forced == "1":
+        return True
+    return nu >= FUNNEL_MIN_USERS and nloc >= FUNNEL_MIN_ITEMS and not os.environ.get("PDA_SCORE_KERNEL") and not os.environ.get("PDA_SCORE_LISTS")
+
+
+def score_topk_funnel(U, I_shard, users, K=50, hist: Optional[HistoryCSR] = None, item_offset=0, stats: Optional[dict] = None) -> torch.Tensor:
+    """pda_score_topk7_f32 / _bf16: the raw head through the funnel -> packed keys int64 [1, Bu, K] (the item splits are merged inside)."""
+    lib = _lib.load()
+    bf = I_shard.dtype == torch.bfloat16
+    U = _need(U, torch.bfloat16 if bf else torch.float32, "U")
+    I_shard = _need(I_shard, torch.bfloat16 if bf else torch.float32, "I_shard")
+    users = _need(users, torch.int32, "users")
+    nu, nloc, d = users.numel(), I_shard.shape[0], I_shard.shape[1]
+    if hist is not None and hist.indices.numel() == 0:
+        hist = None
+    prep = item_prep4(I_shard, None, funnel_order(I_shard))
+    out = torch.empty((1, nu, K), dtype=torch.int64, device=U.device)
+    nbytes = lib.pda_score_topk7_workspace_bytes(nu, nloc, d)
+    if nbytes == 0:
+        raise ValueError("the funnel: embed dim 64 / 128")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=U.device)
+    fn = lib.pda_score_topk7_bf16 if bf else lib.pda_score_topk7_f32
+    check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(users), nu, item_offset, nloc, d, ptr(hist.indptr) if hist else None,
+             ptr(hist.indices) if hist else None, hist.mode if hist else 0, K, HEAD_RAW, ptr(out), ptr(ws), stream_ptr()), "pda_score_topk7")
+    if stats is not None:
+        stats["pairs_rescored"] = ws[4:8].view(torch.int32)
+        stats["kernel_id"] = ws[16:20].view(torch.int32)
+        stats["error"] = ws[0:4].view(torch.int32)
+        stats["fallback_rows"] = ws[24:28].view(torch.int32)      # rows served by the exact fallback (generation 4) inside the call
+        stats["workspace"] = ws                                   # (tools/check_funnel.py reads the rows' state out of it)
+    return out
+
+
+GEOMETRY_NAMES = {0: "lds", 1: "hbm", 2: "wide", 3: "many", 4: "huge", 5: "huge32", 6: "huge2", 7: "funnel"}
 
 
 def kernel_identity(word) -> dict:

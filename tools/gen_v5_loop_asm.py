@@ -309,7 +309,7 @@ def emit(D):
     out.append("        asm volatile(")
     for l in L:
         out.append('            "%s\\n\\t"' % l)
-    out.append('            : [h] "+s"(h), [issued] "+s"(issued), [reason] "=&s"(reason), [m0save] "=&s"(m0save)')
+    out.append('            : [h] "+&s"(h), [issued] "+&s"(issued), [reason] "=&s"(reason), [m0save] "=&s"(m0save)')
     ins = ['[hend] "s"(hend)', '[ring] "s"(ring)', '[flags] "s"(flags)', '[w1024] "s"(w1024)', '[t0] "s"(t0)', '[nsplit] "s"(nsplit)',
            '[imglo] "s"(imglo)', '[imghi] "s"(imghi)', '[metalo] "s"(metalo)', '[metahi] "s"(metahi)', '[eu] "s"(eu)', '[ufrag] "s"(ufrag)', '[lane16] "v"(lane16)']
     ins += ['[thr%d] "v"(thr[%d])' % (u, u) for u in range(8)]
