@@ -45,7 +45,7 @@ def parse():
     p.add_argument("--table-dtype", default="auto", choices=["auto", "f32", "bf16"],
                    help="embedding table type (auto: bf16 for c5shard -- BASELINE config 5 --, f32 otherwise)")
     p.add_argument("--user-groups", type=int, default=0,
-                   help="N > 1: user groups of the 2-D layout (0 = pda_amd.dist.default_user_groups: world / 2 from four GPUs on, i.e. item shards of 2); "
+                   help="N > 1: user groups of the 2-D layout (0 = pda_amd.dist.default_user_groups: 1 = item shards only, BASELINE config 4's layout); "
                         "inside a group the catalogue is item-sharded, the groups split the users of a block")
     p.add_argument("--no-per-config", action="store_true", help="skip the per_config block (C1, C2: evaluation and training beside the headline)")
     p.add_argument("--eval-block", type=int, default=262144, help="users per step (the default of the product's --eval_block)")
@@ -903,15 +903,17 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)  # backend "nccl" IS RCCL on ROCm
     ev = bench_eval(args, rank, world, dev)
-    # BASELINE config 4 literally -- the catalogue item-sharded over ALL ranks, one list exchange among them -- beside the default
-    # layout (user groups x item shards), whenever the two differ
-    ev_items = None
-    if world >= 4 and ev["layout"]["user_groups"] != 1 and not args.headline_only:
-        e2 = bench_eval(args, rank, world, dev, light=True, user_groups=1)
-        ev_items = {"value": e2["users_per_s"], "unit": "users/s", "ms_per_step": e2["ms_per_step"], "layout": e2["layout"],
-                    "early_terminating_sweep": e2["ordered"],
-                    "note": "--user-groups 1: every rank scores ALL users of a step against its 1/N of the catalogue (the north_star's layout); "
-                            "every rank pays the exact warm-up and the list hand-over for all users, which is why the default splits users first"}
+    # `value` is BASELINE config 4's layout: the catalogue item-sharded over ALL ranks, one list exchange among them.  Beside it, from four
+    # ranks on: the two-dimensional layout of rounds 2 - 4 (user groups x item shards of 2)
+    ev_grid = None
+    from pda_amd.dist import grid_user_groups
+    if world >= 4 and ev["layout"]["user_groups"] == 1 and grid_user_groups(world) != 1 and not args.headline_only:
+        e2 = bench_eval(args, rank, world, dev, light=True, user_groups=grid_user_groups(world))
+        ev_grid = {"value": e2["users_per_s"], "unit": "users/s", "ms_per_step": e2["ms_per_step"], "layout": e2["layout"],
+                   "early_terminating_sweep": e2["ordered"],
+                   "note": "--user-groups %d: groups of two item shards, the groups split the users of a step and never talk (pda_amd.dist.grid_layout); "
+                           "predicted 6.9 x one GPU at eight ranks from per-rank steps against 6.1 - 6.9 x for item shards only (DESIGN.md section 4)"
+                           % grid_user_groups(world)}
         del e2
         torch.cuda.empty_cache()
     sharded_train = bench_train_sharded(args, rank, world, dev) if (world > 1 and args.train_sharded) else None
@@ -995,7 +997,7 @@ def main():
                                      ("bf16 tables; scores = the fp32 fmaf chain on the widened values (exact products), bit-identical to the exact "
                                       "kernel on the widened tables; the bf16 MFMA pass is a pre-filter with a rigorous error bound")},
             "roofline": ev["roofline"], "cpu_baseline": cpu, "dense_natural_order": ev["natural"],
-            "ordered_sweep": ev["ordered"], "raw_head": ev["raw_head"], "item_sharded_only": ev_items, "prep": ev["prep"], "per_config": per_config,
+            "ordered_sweep": ev["ordered"], "raw_head": ev["raw_head"], "user_groups_grid": ev_grid, "prep": ev["prep"], "per_config": per_config,
             "eval_block_2048": block2048,
             "train": train_pack[0] if train_pack else ({"item_parallel_sgd": sharded_train} if sharded_train else None),
         }

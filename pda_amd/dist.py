@@ -52,15 +52,20 @@ def grid_layout(rank: int, world: int, user_groups: int):
 
 
 def default_user_groups(world: int) -> int:
-    """world / 2 user groups from four GPUs on: item shards of 2 (the north_star's item-parallel evaluation inside each
-    group) x as many user groups as are left.  Measured per rank for one 262 144-user step of config 3 on one MI355X
-    (dense sweep; the exchange overlaps): 8 item shards 2.71 ms, 2 groups x 4 shards 2.30, 4 x 2 1.99, against 13.6 ms on one
-    GPU -- every rank pays the exact warm-up and the list hand-over for ITS users whatever its share of the items, so users
-    are the cheaper dimension to split.  PDA_USER_GROUPS overrides (1 = item shards only)."""
+    """1: the catalogue item-sharded over ALL ranks of the job, one list exchange among them -- BASELINE config 4's layout, and since the
+    replicated hot items (round 4: `_topk_blocks_hot`) predicted at 6.1 - 6.9 x one GPU at eight ranks from per-rank steps (DESIGN.md section 4;
+    unmeasured on eight GPUs).  PDA_USER_GROUPS overrides (grid_user_groups(world) = the two-dimensional layout of rounds 2 - 4)."""
     import os
     forced = os.environ.get("PDA_USER_GROUPS")
     if forced:
         return int(forced)
+    return 1
+
+
+def grid_user_groups(world: int) -> int:
+    """world / 2 user groups from four GPUs on: item shards of 2 x as many user groups as are left (grid_layout) -- the layout bench.py
+    times BESIDE the default one.  Measured per rank for one 262 144-user step of config 3 on one MI355X (round 4, dense sweep, the exchange
+    overlaps): 4 x 2 1.24 ms, 2 x 4 1.41 ms, item shards only 1.25 - 1.40 ms, against 8.55 ms on one GPU."""
     return world // 2 if (world >= 4 and world % 2 == 0) else 1
 
 
@@ -307,7 +312,15 @@ class ItemShardedTopK:
         if hist is not None and getattr(hist, "mode", 1) != 1:          # block-row histories: the caller's rows, not user ids
             return False
         fns = self._hot_fns()
-        return fns is not None and self._pop_full.numel() >= 4 * self.hot_items
+        if fns is None or self._pop_full.numel() < 4 * self.hot_items:
+            return False
+        if self.sweep_seed_fn is not None and self.kth_fn is not None:
+            return True                                         # (a caller's own functions: its business)
+        # (the library's hot pass, its K-th values and the sweep from a seed are generation 4's: d 64 / 128 / 256, K <= 54 -- the same on every
+        # rank, so that other shapes fall back to topk_sharded everywhere at once)
+        from . import ops
+        d = int(self.U.shape[1])
+        return d in (64, 128, 256) and K <= ops.TOPK_K_V4
 
     def _hot_fns(self):
         if self.sweep_seed_fn is not None and self.kth_fn is not None:
@@ -579,6 +592,9 @@ class ItemShardedTopK:
         take (a size the ranks cannot split evenly, a block-row history) drains the pipeline and goes through topk_sharded."""
         cuda = self._side is not None
         main = torch.cuda.current_stream() if cuda else None
+        # (a rank-local failure -- a negative popularity in this rank's slice -- must not leave the others waiting in the first collective:
+        # checked on every rank and shared, once per set_popularity epoch, as the seeded path does)
+        self._validate_once(head)
 
         def hand_over(p):
             res, done = p

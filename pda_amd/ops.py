@@ -63,7 +63,12 @@ class HistoryCSR:
         idx = torch.from_numpy(np.ascontiguousarray(np.asarray(index, dtype=np.int64).reshape(-1, 2))).to(device, non_blocking=True)
         if idx.shape[0] == 0:
             return HistoryCSR(torch.zeros(n_rows + 1, dtype=torch.int64, device=device), torch.zeros(0, dtype=torch.int32, device=device), by_user=False)
+        # (rows beyond n_rows or negative entries are a malformed mask: an error, as np.add.at / the reference's sparse tensor raise -- one min / max on
+        # the device, checked behind the sort)
+        bad = (idx[:, 0] < 0) | (idx[:, 0] >= n_rows) | (idx[:, 1] < 0)
         key = torch.sort((idx[:, 0] << 32) | idx[:, 1]).values
+        if bool(bad.any()):
+            raise IndexError("mask triple: row index outside [0, %d) or a negative item id" % n_rows)
         items = (key & 0xFFFFFFFF).to(torch.int32)
         indptr = torch.zeros(n_rows + 1, dtype=torch.int64, device=device)
         torch.cumsum(torch.bincount(key >> 32, minlength=n_rows)[:n_rows], 0, out=indptr[1:])

@@ -13,7 +13,7 @@ from oracle import c_oracle
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
-ENV = ("PDA_SCORE_IMPL", "PDA_SCORE_KERNEL", "PDA_SCORE_LISTS", "PDA_SCORE_PRUNE", "PDA_WARM_TILES", "PDA_SEED_ROUNDS")
+ENV = ("PDA_SCORE_IMPL", "PDA_SCORE_KERNEL", "PDA_SCORE_LISTS", "PDA_SCORE_PRUNE", "PDA_WARM_TILES", "PDA_SEED_ROUNDS", "PDA_SCORE_FUNNEL")
 
 
 @pytest.fixture(autouse=True)
@@ -107,8 +107,7 @@ def test_full_size_c3(dev, monkeypatch):
 
     # ---- the operating point of bench.py's headline: a 262 144-user block, NO PDA_* variable set -- the library's own choice of
     # kernel and geometry, asserted: the dense sweep of the popularity head in visiting order runs the huge geometry
-    # (sweep5_kernel<128, false>; the wide one, sweep4_kernel<128, 1, false, false, 2>, from 65 537 users on), the raw head and the
-    # natural-order sweeps the many-candidates geometry (<.., 3>).
+    # (sweep5_kernel<128, false, true, 256>), the natural-order sweep of that head the many-candidates geometry (<.., 3>), the raw head the funnel.
     # (a) the first 256 lists equal the oracle's on config 3's real history, both heads; (b) the users shared with the
     # 131 072-user block carry the same keys.
     huge = torch.arange(200_000, 200_000 + 262144, dtype=torch.int32, device=dev)
@@ -122,11 +121,20 @@ def test_full_size_c3(dev, monkeypatch):
         assert_lists_match_oracle(k262[prune], *oracle[1], head=1)
         if prune == "order":
             assert int(st["tiles_scored"][0]) >= st["tiles_dense"]          # the dense sweep scored every tile
+    # the raw head: the funnel (round 5: sweep7_kernel + expand7 / threshold7 / resolve7, pda_v7_funnel.h) from 32 768 users on, whatever the
+    # sweep mode asked for (it visits the catalogue in its own random order); generation 4's many-candidates geometry when switched off.
+    # Bit-exact scores and lists against the oracle, and against each other; next to no row may have needed the in-call exact fallback.
     raw = {}
-    for prune, exp in ((None, {"generation": 4, "geometry": "many", "head": 0, "early_stop": False}), (False, {"generation": 4, "geometry": "many", "head": 0})):
-        raw[prune], _ = run(ops, W, hist, huge, RAW, prune, exp)
+    for prune, exp in ((None, {"generation": 4, "geometry": "funnel", "head": 0, "d": 128, "bf16": False}), (False, {"generation": 4, "geometry": "funnel", "head": 0})):
+        raw[prune], st = run(ops, W, hist, huge, RAW, prune, exp)
         assert_lists_match_oracle(raw[prune], *oracle[0], head=0)
+        assert int(st["fallback_rows"][0]) <= 262144 // 1000, int(st["fallback_rows"][0])
+        assert 50 <= float(st["pairs_rescored"][0]) / 262144 <= 100          # exact rescorings per user: K + the pairs inside the bound's band
     assert torch.equal(raw[None], raw[False])
+    monkeypatch.setenv("PDA_SCORE_FUNNEL", "0")
+    raw_g4, _ = run(ops, W, hist, huge, RAW, None, {"generation": 4, "geometry": "many", "head": 0, "early_stop": False})
+    monkeypatch.delenv("PDA_SCORE_FUNNEL")
+    assert torch.equal(raw_g4, raw[None])
     # 98 304 users (the regrouped early-terminating sweep starts here; the dense sweep fills the chip with EIGHT item splits of the huge
     # geometry -- three rounds of 256 workgroups behind one shared warm-up: ops.huge_splits), again unforced; 53 248 users: nine splits (two
     # rounds); 16 384 users: sixteen; a 2 048-user block keeps the 256-user geometry
@@ -138,8 +146,10 @@ def test_full_size_c3(dev, monkeypatch):
         assert torch.equal(k98, k262["order"][:98304]), prune
     k53, _ = run(ops, W, hist, huge[:53248].contiguous(), POP, "order", {"generation": 4, "geometry": "huge"})
     assert torch.equal(k53, k262["order"][:53248])
-    k98r, _ = run(ops, W, hist, mid, RAW, None, {"generation": 4, "geometry": "many", "head": 0})
+    k98r, _ = run(ops, W, hist, mid, RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})       # (eight item splits)
     assert torch.equal(k98r, raw[None][:98304])
+    k20r, _ = run(ops, W, hist, huge[:20000].contiguous(), RAW, None, {"generation": 4, "geometry": "many", "head": 0})       # (below 32 768 users: generation 4)
+    assert torch.equal(k20r, raw[None][:20000])
 
     # ---- every other geometry forced on the same 262 144-user block: identical keys
     monkeypatch.setenv("PDA_SCORE_KERNEL", "v4")
@@ -191,7 +201,10 @@ def test_full_size_c5_shard_bf16(dev, monkeypatch):
     # ---- the block bench.py --workload c5shard times (262 144 users), no PDA_* variable set: generation 4, d = 256, bf16 tables
     huge = torch.arange(300_000, 300_000 + 262144, dtype=torch.int32, device=dev)
     for prune, es in (("order", False), (True, True)):
-        k262, st = run(ops, W, hist, huge, POP, prune, {"generation": 4, "d": 256, "bf16": True, "early_stop": es, "head": 1})
+        exp = {"generation": 4, "d": 256, "bf16": True, "early_stop": es, "head": 1}
+        if not es:
+            exp["geometry"] = "huge"              # the dense sweep of config 5's tables: sweep5_kernel<256, true, true, 128>
+        k262, st = run(ops, W, hist, huge, POP, prune, exp)
         assert torch.equal(k262[:8192], ref), prune
         assert_lists_match_oracle(k262, ridx, rval, sc, head=1)
         if not es:

@@ -44,12 +44,14 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
     da = torch.load(os.path.join(tmp_path, "topk_dense_w1_r0.pt"))
     db = torch.cat([torch.load(os.path.join(tmp_path, "topk_dense_w2_r%d.pt" % r)) for r in range(2)])
     assert torch.equal(da, db) and torch.equal(da, a)
-    # four ranks = 2 user groups x 2 item shards (pda_amd.dist.grid_layout, the default from four GPUs on): rank order = user order
+    # four ranks = four item shards (the default since round 5: BASELINE config 4's layout; replicated hot items from three shards on): rank order = user order
     four = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
                  "--master-port", "29519", "bench.py", "--gpus", "4", "--workload", "tiny", "--steps", "2", "--warmup", "1",
                  "--eval-block", "2048"], env)
-    assert four["n_gpus"] == 4 and four["config"]["layout"] == {"user_groups": 2, "item_shards": 2, "users_per_rank_and_step": 1024,
-                                                                 "items_per_rank": 1504}
+    assert four["n_gpus"] == 4 and four["config"]["layout"] == {"user_groups": 1, "item_shards": 4, "users_per_rank_and_step": 2048,
+                                                                 "items_per_rank": 768}
+    grid = four["user_groups_grid"]                                  # ... and beside it the two-dimensional layout: 2 user groups x 2 item shards
+    assert grid["value"] > 0 and grid["layout"] == {"user_groups": 2, "item_shards": 2, "users_per_rank_and_step": 1024, "items_per_rank": 1504}
     c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w4_r%d.pt" % r)) for r in range(4)])
     assert torch.equal(a, c)
     dc = torch.cat([torch.load(os.path.join(tmp_path, "topk_dense_w4_r%d.pt" % r)) for r in range(4)])
@@ -57,9 +59,9 @@ def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):
 
 
 def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
-    """What the driver's scaling run launches at N = 8, on one GPU over gloo: the default layout (4 user groups x 2 item
-    shards), seeded early-terminating sweeps inside each item group, the all-to-all of the partial lists -- and the
-    union of the ranks' lists equals the single-rank lists."""
+    """What the driver's scaling run launches at N = 8, on one GPU over gloo: the default layout -- eight item shards (BASELINE
+    config 4), the replicated hot items, the all-to-all of the partial lists -- and the union of the ranks' lists equals the
+    single-rank lists; the two-dimensional layout (4 user groups x 2 item shards) is timed beside it."""
     env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
                PDA_BENCH_DUMP=str(tmp_path))
     one = _run([sys.executable, "bench.py", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-train", "--no-cpu-baseline",
@@ -69,12 +71,11 @@ def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
                   "--eval-block", "2048"], env)
     assert eight["n_gpus"] == 8 and eight["value"] > 0 and eight["scaling"] == "strong"
     lay = eight["config"]["layout"]
-    assert lay["user_groups"] == 4 and lay["item_shards"] == 2 and lay["users_per_rank_and_step"] == 512
-    assert eight["ordered_sweep"]["value"] > 0                      # the seeded early-terminating pass ran on every rank
-    # BASELINE config 4 literally (item shards only) is timed beside the default layout
-    iso = eight["item_sharded_only"]
-    assert iso["value"] > 0 and iso["layout"]["user_groups"] == 1 and iso["layout"]["item_shards"] == 8 and iso["early_terminating_sweep"]["value"] > 0
-    assert "two item shards" in eight["config"]["item_shard_path"]
+    assert lay["user_groups"] == 1 and lay["item_shards"] == 8 and lay["users_per_rank_and_step"] == 2048
+    assert eight["ordered_sweep"]["value"] > 0                      # the early-terminating pass ran on every rank
+    grid = eight["user_groups_grid"]
+    assert grid["value"] > 0 and grid["layout"]["user_groups"] == 4 and grid["layout"]["item_shards"] == 2 and grid["early_terminating_sweep"]["value"] > 0
+    assert "replicated hot rows" in eight["config"]["item_shard_path"]
     a = torch.load(os.path.join(tmp_path, "topk_w1_r0.pt"))
     c = torch.cat([torch.load(os.path.join(tmp_path, "topk_w8_r%d.pt" % r)) for r in range(8)])
     assert a.shape == c.shape and torch.equal(a, c) and one["n_gpus"] == 1
