@@ -313,6 +313,43 @@ int pda_score_topk4_phase_bf16(const uint16_t* U, const uint16_t* I_shard, const
                                int early_stop, int n_splits, int phase, int warm_tiles, const float* seed, uint64_t* out_keys,
                                void* workspace, void* stream);
 
+/* WHICH entry point serves a call, with which item splits, geometry hint, visiting order and workspace: the library's own policy (round 5;
+ * before, a caller had to re-implement ~80 lines of pda_amd/ops.py).  Results never depend on the plan -- every path returns the same packed
+ * keys -- only the time does.  A caller:
+ *     pda_score_plan p;  pda_score_topk_plan(n_users_blk, n_items_local, d, K, head, PDA_SWEEP_MODE_DEFAULT, 0, hist_row_mode, &p);
+ *     build the item prep p.path wants with the visiting order p.order (pda_item_prep4_* for PDA_PATH_GEN4 / PDA_PATH_FUNNEL), allocate
+ *     p.workspace_bytes and keys of p.keys_rows x K, call the entry point of p.path with p.n_splits and p.early_stop, merge the splits
+ *     (pda_topk_merge) when p.n_splits > 1.
+ * Reference precedent for "one native call does the job": util/cython/include/arg_topk.h:29-45. */
+#define PDA_SWEEP_MODE_DEFAULT (-1)        /* the library's default for the head */
+#define PDA_SWEEP_MODE_NATURAL 0           /* every tile, natural item order */
+#define PDA_SWEEP_MODE_EARLY_STOP 1        /* visiting order + exact early termination */
+#define PDA_SWEEP_MODE_VISITING_ORDER 2    /* every tile, in visiting order (thresholds rise early) */
+#define PDA_PATH_EXACT_F32 1               /* pda_score_topk_f32 */
+#define PDA_PATH_GEN3 2                    /* pda_score_topk_prepped_f32 / pda_score_topk_bf16 */
+#define PDA_PATH_GEN3_ORDERED 3            /* pda_score_topk_ordered_f32 / _bf16 */
+#define PDA_PATH_GEN4 4                    /* pda_score_topk4_f32 / _bf16 */
+#define PDA_PATH_FUNNEL 7                  /* pda_score_topk7_f32 / _bf16 */
+#define PDA_ORDER_NATURAL 0
+#define PDA_ORDER_BY_POPULARITY 1          /* most popular first (stable) */
+#define PDA_ORDER_BY_NORM 2                /* largest ||i|| first (stable) */
+#define PDA_ORDER_RANDOM 3                 /* any fixed random permutation */
+typedef struct pda_score_plan {
+    int path;                 /* PDA_PATH_* */
+    int sweep_mode;           /* PDA_SWEEP_MODE_* the call will run (the default resolved) */
+    int n_splits;             /* item splits = leading dimension of out_keys */
+    int early_stop;           /* the early_stop argument of pda_score_topk4_* / pda_score_topk_ordered_*: sweep mode bit | geometry hint */
+    int order;                /* PDA_ORDER_*: the visiting order the item prep is built with */
+    int prep_with_pop;        /* the item prep is built WITH the popularity vector */
+    size_t workspace_bytes;
+    size_t keys_rows;         /* n_splits x n_users_blk rows of K keys */
+} pda_score_plan;
+/* hist_row_mode: PDA_HIST_BY_BLOCK_ROW / PDA_HIST_BY_USER_ID, or -1 for a call without a train-item mask */
+int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, int K, int head, int sweep_mode, int table_bf16, int hist_row_mode,
+                        pda_score_plan* plan);
+/* item splits of the huge geometry for a block (0: the block is too small for it) -- the rule behind PDA_PATH_GEN4 plans of dense sweeps */
+int pda_score_topk_huge_splits(int n_users_blk, int n_items_local, int d);
+
 /* The funnel (round 5; pda_score_funnel.hip, pda_v7_funnel.h): score + mask + top-K for the RAW head -- the ranking the reference evaluates
  * in every epoch and the only one of --train normal (MF/train_new_api.py:597-598,1139-1141,1160-1165) -- on large user blocks.  Same packed keys
  * as every other generation, ONE list per user (out_keys [n_users_blk, K]; the item splits are merged inside).  A running exact list takes

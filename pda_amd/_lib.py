@@ -25,6 +25,12 @@ TOPK_CAP = 60
 
 _vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
 
+class ScorePlan(C.Structure):
+    """struct pda_score_plan of include/pda_hip.h (pda_score_topk_plan)."""
+    _fields_ = [("path", _i), ("sweep_mode", _i), ("n_splits", _i), ("early_stop", _i), ("order", _i), ("prep_with_pop", _i),
+                ("workspace_bytes", _sz), ("keys_rows", _sz)]
+
+
 class SampleJob(C.Structure):
     """struct pda_sample_job of include/pda_hip.h (arguments of pda_sample_triplets_dev, for pda_bpr_step_sample_f32)."""
     _fields_ = [("users", _vp), ("gen_users", _i), ("user_pool", _vp), ("n_pool", _i), ("B", _i),
@@ -77,6 +83,8 @@ SIGNATURES = {
     "pda_topk_seed_pick": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "pda_score_topk4_phase_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "pda_score_topk4_phase_bf16": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "pda_score_topk_plan": (_i, [_i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "pda_score_topk_huge_splits": (_i, [_i, _i, _i]),
     "pda_score_topk7_workspace_bytes": (_sz, [_i, _i, _i]),
     "pda_score_topk7_f32": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "pda_score_topk7_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),

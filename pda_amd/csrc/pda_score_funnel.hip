@@ -279,6 +279,74 @@ extern "C" int pda_debug_funnel_schedule(int n_items_local, int K, int* out, int
     return (int)st.size();
 }
 
+
+// ---- which kernel serves a call: the policy behind the C ABI (round 5; rounds 2 - 4 kept it in pda_amd/ops.py, where a C caller could not reach it).
+// Results never depend on it (every path returns the same packed keys); the choices are by measurement.
+extern "C" int pda_score_topk_huge_splits(int n_users_blk, int n_items_local, int d) {
+    // item splits with which the huge geometry runs a block (one workgroup = 1 024 users x one split; d = 256: 512), or 0 when it should not: rounds of
+    // 256 workgroups x (a workgroup's fixed cost + its share of the catalogue) + a little per split; the smallest S at the minimum
+    if (n_users_blk < 4096 || n_items_local <= 0) return 0;
+    const int ut = d == 256 ? 512 : 1024;
+    const int utiles = (n_users_blk + ut - 1) / ut;
+    const int s = funnel_splits7(n_users_blk, n_items_local, d);
+    return utiles * s >= 128 ? s : 0;
+}
+extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, int K, int head, int sweep_mode, int table_bf16, int hist_row_mode,
+                                   pda_score_plan* plan) {
+    if (!plan || n_users_blk <= 0 || n_items_local <= 0 || K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
+    if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
+    if (sweep_mode < PDA_SWEEP_MODE_DEFAULT || sweep_mode > PDA_SWEEP_MODE_VISITING_ORDER) return PDA_ERR_ARG;
+    pda_score_plan p{};
+    const bool dv = d == 64 || d == 128 || d == 256;
+    // the sweep mode the library would choose itself: early-terminating for the popularity head; the raw head: dense in visiting order (by norm)
+    // at d <= 128, natural order at d = 256
+    if (sweep_mode == PDA_SWEEP_MODE_DEFAULT)
+        sweep_mode = head == PDA_HEAD_POP ? PDA_SWEEP_MODE_EARLY_STOP : ((d == 64 || d == 128) ? PDA_SWEEP_MODE_VISITING_ORDER : PDA_SWEEP_MODE_NATURAL);
+    p.sweep_mode = sweep_mode;
+    const bool early = sweep_mode == PDA_SWEEP_MODE_EARLY_STOP, ordered = sweep_mode != PDA_SWEEP_MODE_NATURAL;
+    if (!dv || K > PDA_TOPK_CAP - 4) {
+        if (table_bf16) return PDA_ERR_UNSUPPORTED;
+        p.path = PDA_PATH_EXACT_F32;                             // pda_score_topk_f32: the exact fp32-MFMA kernel
+        p.n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
+        p.order = PDA_ORDER_NATURAL;
+    } else if (head == PDA_HEAD_RAW && (d == 64 || d == 128) && K <= 54 && n_items_local >= 65536 && (uint64_t)n_items_local <= (1ull << 26) &&
+               n_users_blk >= 32768 && !early && (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID)) {
+        p.path = PDA_PATH_FUNNEL;                                // pda_score_topk7_*
+        p.n_splits = 1;                                          // (ONE list per user comes back: the item splits are merged inside)
+        p.order = PDA_ORDER_RANDOM;
+        p.workspace_bytes = pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d);
+    } else if (K <= 54 && (uint64_t)n_items_local <= (1ull << 26) && !(d == 256 && (head == PDA_HEAD_RAW || !ordered))) {
+        p.path = PDA_PATH_GEN4;                                  // pda_score_topk4_*
+        p.order = !ordered ? PDA_ORDER_NATURAL : (head == PDA_HEAD_POP ? PDA_ORDER_BY_POPULARITY : PDA_ORDER_BY_NORM);
+        p.prep_with_pop = head == PDA_HEAD_POP ? 1 : 0;
+        p.n_splits = pda_score_topk4_auto_splits(n_users_blk, n_items_local, d);
+        int hint = 0;
+        const int hs = (head == PDA_HEAD_POP && sweep_mode == PDA_SWEEP_MODE_VISITING_ORDER) ? pda_score_topk_huge_splits(n_users_blk, n_items_local, d) : 0;
+        if (hs > 0) {
+            p.n_splits = hs;
+            hint = PDA_SWEEP_HUGE;                               // the huge geometry, the catalogue split so that the block fills the chip
+        } else if (head == PDA_HEAD_POP && sweep_mode == PDA_SWEEP_MODE_VISITING_ORDER && n_users_blk >= 196609 && d <= 128) {
+            hint = PDA_SWEEP_HUGE;
+        } else if (head == PDA_HEAD_POP && sweep_mode == PDA_SWEEP_MODE_VISITING_ORDER && n_users_blk >= 65537 && d <= 128) {
+            hint = PDA_SWEEP_WIDE;
+        } else if (d <= 128 && !early && (head == PDA_HEAD_RAW || !ordered)) {
+            hint = PDA_SWEEP_MANY_CANDIDATES;                    // hundreds of list insertions per user
+        }
+        p.early_stop = (early ? 1 : 0) | hint;
+        p.workspace_bytes = pda_score_topk4_workspace_bytes(n_users_blk, n_items_local, d, p.n_splits);
+    } else {
+        p.path = ordered ? PDA_PATH_GEN3_ORDERED : PDA_PATH_GEN3;    // pda_score_topk_ordered_* | pda_score_topk_prepped_f32 / _bf16
+        p.order = !ordered ? PDA_ORDER_NATURAL : (head == PDA_HEAD_POP ? PDA_ORDER_BY_POPULARITY : PDA_ORDER_BY_NORM);
+        p.prep_with_pop = head == PDA_HEAD_POP && ordered ? 1 : 0;
+        p.n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
+        p.early_stop = early ? 1 : 0;
+        p.workspace_bytes = pda_score_topk_workspace_bytes(n_users_blk);
+    }
+    p.keys_rows = (size_t)p.n_splits * (size_t)n_users_blk;
+    *plan = p;
+    return PDA_OK;
+}
+
 // ---- debug / measurement entry of the funnel's emitting sweep (tools/time_emit.py): one launch against the caller's thresholds ----------
 // workspace: [256 B counters | user image | norms | eu per wave | cursors | lists]; offs[0..4] = byte offsets of (unorm, eu, cursors, lists, end)
 extern "C" size_t pda_debug_emit_layout(int n_users_blk, int d, int n_splits, int cap_e, size_t* offs) {

@@ -233,21 +233,26 @@ def huge_splits(n_users: int, n_items_local: int, d: int = 128) -> int:
     output rows); the smallest S at the minimum wins.  Measured, config 3, with the shared warm-up (profiles/round4_shared_warm.txt): 8 192 users x 32 splits 0.47 ms
     (256-user geometry 0.58), 16 384 x 16 0.72 (1.01), 32 768 x 8 1.21 (1.82), 65 536 x 4 2.30 (wide 3.1), 131 072 x 2 4.27 (5.6);
     config 2 / config 1 (313 / 407 tiles) x 5 splits 0.37 / 0.39 ms (0.46 / 0.50)."""
-    if n_users < HUGE_SPLIT_MIN_USERS:
-        return 0
     forced = os.environ.get("PDA_HUGE_SPLITS")          # A/B measurements only
-    if forced:
+    if forced and n_users >= HUGE_SPLIT_MIN_USERS:
         return int(forced)
-    utiles = -(-n_users // (512 if d == 256 else 1024))        # (d = 256: 512-user workgroups -- 128 users per wave fill the AGPRs)
-    tiles = -(-n_items_local // 64)
-    smax = max(1, min(64, tiles // HUGE_MIN_TILES_PER_SPLIT))
-    best, best_cost = 1, None
-    for s in range(1, smax + 1):
-        # rounds x (a workgroup's fixed cost + its share of the catalogue) + the empty splits' output rows and the merge
-        cost = -(-utiles * s // 256) * (0.02 + 1.0 / s) + 0.004 * s * (n_users / 262144.0)
-        if best_cost is None or cost < best_cost - 1e-9:
-            best, best_cost = s, cost
-    return best if utiles * best >= HUGE_MIN_WORKGROUPS else 0
+    return _lib.load().pda_score_topk_huge_splits(n_users, n_items_local, d)      # (the rule lives in the library since round 5: pda_score_topk_plan)
+
+
+SWEEP_MODE = {None: -1, False: 0, True: 1, "order": 2}
+PATH_NAMES = {1: "v1", 2: "v3", 3: "v3", 4: "v4", 7: "funnel"}
+
+
+def score_plan(n_users: int, n_items_local: int, d: int, K: int = 50, head: int = HEAD_POP, prune=None, bf16: bool = False,
+               hist: Optional["HistoryCSR"] = None) -> dict:
+    """pda_score_topk_plan: which entry point, item splits, geometry hint, visiting order and workspace the LIBRARY chooses for a call
+    (prune: None = its default for the head, False = natural order, True = early-terminating, "order" = dense in visiting order)."""
+    p = _lib.ScorePlan()
+    check(_lib.load().pda_score_topk_plan(n_users, n_items_local, d, K, head, SWEEP_MODE[prune], int(bool(bf16)),
+                                          -1 if hist is None else hist.mode, C.byref(p)), "pda_score_topk_plan")
+    return {"path": p.path, "kernel": PATH_NAMES[p.path], "sweep_mode": {0: False, 1: True, 2: "order"}[p.sweep_mode], "n_splits": p.n_splits,
+            "early_stop": p.early_stop, "order": p.order, "prep_with_pop": bool(p.prep_with_pop), "workspace_bytes": int(p.workspace_bytes),
+            "keys_rows": int(p.keys_rows)}
 
 
 def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0, n_items_local: int = 0, n_splits: int = 0) -> int:
@@ -579,13 +584,24 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
     if impl == "v2" and score_kernel(d, K, nloc, prune, head) == "v4":
         order = visiting_order(I_shard, pop_shard if head == HEAD_POP else None) if prune else None
         prep = item_prep4(I_shard, pop_shard if head == HEAD_POP else None, order)
-        if n_splits_auto and out_given is None:
+        forced_env = any(os.environ.get(k) for k in ("PDA_SCORE_LISTS", "PDA_SCORE_KERNEL", "PDA_HUGE_SPLITS"))
+        plan = None
+        if n_splits_auto and out_given is None and not forced_env and not (head == HEAD_POP and pop_shard is None):
+            # the library's own plan (pda_score_topk_plan): item splits and geometry hint
+            plan = score_plan(nu, nloc, d, K, head, prune, bf, hist)
+            if plan["kernel"] != "v4":
+                plan = None
+        if plan is not None:
+            n_splits = plan["n_splits"]
+            out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
+        elif n_splits_auto and out_given is None:
             n_splits = lib.pda_score_topk4_auto_splits(nu, nloc, d)
             if head == HEAD_POP and prune == "order" and d in (64, 128, 256) and not os.environ.get("PDA_SCORE_LISTS") and pop_shard is not None:
                 n_splits = huge_splits(nu, nloc, d) or n_splits          # the huge geometry on a block that does not fill the chip by itself
             out = torch.empty((n_splits, nu, K), dtype=torch.int64, device=U.device)
         ws = torch.empty(lib.pda_score_topk4_workspace_bytes(nu, nloc, d, n_splits), dtype=torch.uint8, device=U.device)
-        es = (1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits) | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
+        hint = plan["early_stop"] if plan is not None else ((1 if prune is True else 0) | few_candidates_hint(head, prune, nu, d, nloc, n_splits))
+        es = hint | ((min(4, max(0, int(warm_tiles))) & 7) << 4)
         if os.environ.get("PDA_WARM_PER_SPLIT"):      # A/B measurements and cross-checks: every item split warms up on its own tiles (before round 4)
             es |= SWEEP_WARM_PER_SPLIT
         fn = lib.pda_score_topk4_bf16 if bf else lib.pda_score_topk4_f32

@@ -209,3 +209,33 @@ def test_full_size_c5_shard_bf16(dev, monkeypatch):
         assert_lists_match_oracle(k262, ridx, rval, sc, head=1)
         if not es:
             assert int(st["tiles_scored"][0]) >= st["tiles_dense"]
+
+
+
+def test_a_c_caller_reaches_the_headline_kernel_through_the_plan(dev):
+    """ctypes only -- no pda_amd.ops: what INTEGRATION.md section 2 tells a maintainer of the reference to write.  pda_score_topk_plan decides (item splits,
+    geometry hint, visiting order, workspace); the prep, the call and the merge follow it; at 262 144 users of config 3 the identity word says
+    sweep5_kernel (the huge geometry) ran, and the lists equal the ones pda_amd.ops returns."""
+    import ctypes as C
+    from pda_amd import _lib, ops, synthetic
+    lib = _lib.load()
+    W = synthetic.make_workload("c3", dev)
+    nu, nI, d, K = 262144, W.n_items, W.d, 50
+    users = torch.arange(200_000, 200_000 + nu, dtype=torch.int32, device=dev)
+    p = _lib.ScorePlan()
+    assert lib.pda_score_topk_plan(nu, nI, d, K, _lib.HEAD_POP, 2, 0, _lib.HIST_BY_USER_ID, C.byref(p)) == 0          # 2 = PDA_SWEEP_MODE_VISITING_ORDER: the dense headline sweep
+    assert (p.path, p.n_splits, p.early_stop, p.order, p.prep_with_pop) == (4, 1, 128, 1, 1)
+    order = torch.argsort(W.pop_last.abs(), descending=True, stable=True).to(torch.int32)                                # PDA_ORDER_BY_POPULARITY
+    prep = torch.empty(lib.pda_item_prep4_bytes(nI, d), dtype=torch.uint8, device=dev)
+    ptr, sp = _lib.ptr, _lib.stream_ptr
+    assert lib.pda_item_prep4_f32(ptr(W.I), ptr(W.pop_last), ptr(order), nI, d, ptr(prep), sp()) == 0
+    ws = torch.empty(p.workspace_bytes, dtype=torch.uint8, device=dev)
+    keys = torch.empty((p.keys_rows, K), dtype=torch.int64, device=dev)
+    assert lib.pda_score_topk4_f32(ptr(W.U), ptr(W.I), ptr(prep), ptr(W.pop_last), ptr(users), nu, 0, nI, d, ptr(W.hist_indptr), ptr(W.hist_indices),
+                                   _lib.HIST_BY_USER_ID, K, _lib.HEAD_POP, p.early_stop, p.n_splits, ptr(keys), ptr(ws), sp()) == 0
+    torch.cuda.synchronize()
+    ident = ops.kernel_identity(ws[16:20].view(torch.int32)[0])
+    assert ident["generation"] == 4 and ident["geometry"] == "huge" and ident["d"] == 128 and int(ws[0:4].view(torch.int32)[0]) == 0, ident
+    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+    ref = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, K, ops.HEAD_POP, W.pop_last, hist, prune="order"), want="keys")
+    assert torch.equal(keys.view(nu, K), ref)

@@ -588,6 +588,26 @@ def test_negative_popularity_is_rejected(dev):
         ops.score_topk_keys(U, I, torch.arange(8, dtype=torch.int32, device=dev), 5, 1, pop)
 
 
+@pytest.mark.parametrize("d", [64, 128])
+def test_nan_popularity_items_never_rank(dev, d, impl):
+    """The reference's BPRMF-A search lets NaN popularities reach set_testing_popularity (its mask is computed from the already-powered values,
+    MF/train_new_api.py:969-970).  Defined here as: an item whose popularity is NaN has a NaN head, no comparison with it holds, it is NEVER
+    recommended -- every kernel path returns the lists of the catalogue without those items (tf.nn.top_k itself gives no usable order for NaN)."""
+    from pda_amd import ops
+    rng = np.random.default_rng(77 + d)
+    nU, nI, K = 260, 3000, 50
+    U, I, pop, hist = make_case(rng, nU, nI, d)
+    nan_items = np.unique(np.concatenate([rng.choice(nI, 40, replace=False), np.argsort(-pop)[:3]]))      # (some of the most popular ones among them)
+    pop_nan = pop.copy()
+    pop_nan[nan_items] = np.nan
+    users = np.arange(nU, dtype=np.int32)
+    with np.errstate(invalid="ignore"):
+        idx, val, _ = run_gpu(dev, U, I, users, K, 1, pop_nan, hist, by_user=True)
+    assert not np.isin(idx, nan_items).any() and np.isfinite(val).all()
+    masked = [np.union1d(h, nan_items).astype(np.int32) for h in hist]           # the oracle: the same items masked instead
+    check_against_oracle(idx, val, U, I, users, K, 1, pop, masked, exact=False)
+
+
 class FakeCollectives:
     """all_reduce among R threads of this process, one per emulated item shard (what pda_amd.dist does over RCCL)."""
 

@@ -130,3 +130,43 @@ def test_sweep_kernel_and_geometry_selection(monkeypatch):
     assert ops.prune_default(P, 128) is True and ops.prune_default(R, 128) == "order" and ops.prune_default(R, 256) is False
     monkeypatch.setenv("PDA_SCORE_LISTS", "many")
     assert ops.few_candidates_hint(P, "order", 262144, 128) == 8
+
+
+def test_the_library_plans_what_the_python_rules_chose(monkeypatch):
+    """pda_score_topk_plan (the policy behind the C ABI since round 5) against the Python rules of rounds 2 - 4 on their table of cases: kernel
+    generation, sweep mode, item splits, geometry hint; and the raw head on large blocks goes to the funnel."""
+    from pda_amd import ops
+    for k in ("PDA_SCORE_KERNEL", "PDA_SCORE_LISTS", "PDA_SCORE_PRUNE", "PDA_HUGE_SPLITS", "PDA_SCORE_FUNNEL"):
+        monkeypatch.delenv(k, raising=False)
+    P, R = ops.HEAD_POP, ops.HEAD_RAW
+    lib = ops._lib.load()
+    cases = [(nu, nI, d, head, prune) for (nu, nI, d) in ((262144, 200000, 128), (196608, 200000, 128), (98304, 200000, 128), (65536, 200000, 128),
+                                                           (20000, 200000, 128), (2048, 200000, 128), (50000, 20000, 64), (47890, 26047, 64),
+                                                           (262144, 250000, 256), (8192, 250000, 256), (1000, 3000, 32), (262144, 25000, 128))
+             for head in (P, R) for prune in (None, False, True, "order")]
+    n_funnel = 0
+    for nu, nI, d, head, prune in cases:
+        plan = ops.score_plan(nu, nI, d, 50, head, prune)
+        pr = ops.prune_default(head, d) if prune is None else prune
+        assert plan["sweep_mode"] == pr, (nu, nI, d, head, prune, plan)
+        if ops.score_impl(d, 50, nI) == "v1":
+            assert plan["kernel"] == "v1"
+            continue
+        if ops.funnel_applies(d, 50, nu, nI, head, pr, None):
+            assert plan["kernel"] == "funnel" and plan["n_splits"] == 1 and plan["order"] == 3 and plan["workspace_bytes"] == lib.pda_score_topk7_workspace_bytes(nu, nI, d)
+            n_funnel += 1
+            continue
+        gen = ops.score_kernel(d, 50, nI, pr, head)
+        assert plan["kernel"] == gen, (nu, nI, d, head, prune, plan)
+        if gen != "v4":
+            continue
+        ns = lib.pda_score_topk4_auto_splits(nu, nI, d)
+        if head == P and pr == "order":
+            ns = ops.huge_splits(nu, nI, d) or ns
+        es = (1 if pr is True else 0) | ops.few_candidates_hint(head, pr, nu, d, nI, ns)
+        assert (plan["n_splits"], plan["early_stop"]) == (ns, es), (nu, nI, d, head, prune, plan, ns, es)
+        assert plan["workspace_bytes"] == lib.pda_score_topk4_workspace_bytes(nu, nI, d, ns) and plan["keys_rows"] == ns * nu
+        assert plan["order"] == (0 if pr is False else (1 if head == P else 2)) and plan["prep_with_pop"] == (head == P)
+    assert n_funnel >= 6                     # (262 144 / 196 608 / 98 304 / 65 536 users x 200 000 items, raw head, default / natural / dense modes)
+    # the huge geometry's item splits: the library's rule IS the old Python rule
+    assert [ops.huge_splits(u, 200000) for u in (2048, 8192, 32768, 65536, 98304, 163840, 196608, 262144)] == [0, 32, 8, 4, 8, 3, 4, 1]
