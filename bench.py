@@ -117,6 +117,32 @@ class TimedScore:
     def mean_ms(self):
         return sum(s.elapsed_time(e) for s, e in self.events) / max(1, len(self.events))
 
+    def spread(self):
+        """min / median / 90th percentile of the timed calls: one mean cannot tell a slow box from a regression."""
+        t = sorted(s.elapsed_time(e) for s, e in self.events)
+        if not t:
+            return None
+        return {"min": t[0], "median": t[len(t) // 2], "p90": t[min(len(t) - 1, int(0.9 * len(t)))], "max": t[-1], "calls": len(t)}
+
+
+def gpu_clocks():
+    """What the box reports about itself (rocm-smi), best effort: a lease that runs 7 % slower should be visible as such."""
+    import subprocess
+    out = {}
+    try:
+        txt = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True, timeout=20).stdout
+        for ln in txt.splitlines():
+            l = ln.lower()
+            if "gpu[0]" not in l:
+                continue
+            for key, tag in (("sclk", "sclk clock level"), ("mclk", "mclk clock level"), ("power_w", "socket graphics package power"), ("power_w", "average graphics package power"),
+                             ("temp_hotspot_c", "temperature (sensor junction)")):
+                if tag in l:
+                    out[key] = ln.split(":")[-1].strip()
+    except Exception as e:                       # noqa: BLE001 -- diagnostics only
+        out["error"] = str(e)[:80]
+    return out
+
 
 def bench_reference_block_protocol(args, dev, workload):
     """What a maintainer who keeps MF/train_new_api.py and swaps only the model wrapper sees (INTEGRATION.md route 2):
@@ -228,6 +254,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
     sink = []
 
     last = [None]
+    last_spread = [None]
 
     def run(bl, hd):
         # N > 1: the all-to-all exchange -- every rank merges and keeps the lists of its slice of the users
@@ -257,6 +284,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t[0])
+        last_spread[0] = timed.spread()
         return dt, (timed.mean_ms() if timed.events else dt / steps * 1e3), dict(timed.stats)
 
     # headline: a DENSE sweep -- every user x item pair is scored.  With the PDA head the catalogue is visited most
@@ -268,7 +296,10 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
     if use_order and not args.headline_only and not light:
         dt_n, k_ms_n, _ = timed_pass(False)
         natural = {"value": Bu * steps / dt_n, "unit": "users/s", "ms_per_step": dt_n / steps * 1e3, "kernel_ms": k_ms_n}
+    clocks_before = gpu_clocks() if (world_all == 1 and not light) else None
     dt, k_ms, st_d = timed_pass("order" if use_order else False)
+    headline_spread = last_spread[0]
+    clocks_after = gpu_clocks() if (world_all == 1 and not light) else None
     if os.environ.get("PDA_BENCH_DUMP") and user_groups is None:      # (N > 1: the replicated-hot-items path of pda_amd.dist)
         torch.save(last[0].cpu(), os.path.join(os.environ["PDA_BENCH_DUMP"], "topk_dense_w%d_r%d.pt" % (world_all, rank)))
     if use_order and "tiles_scored" in st_d:
@@ -291,15 +322,21 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
     raw = None
     if head == ops.HEAD_POP and v2 and not args.headline_only and not light and world_all == 1:
         rp = ops.prune_default(ops.HEAD_RAW, W.d)
-        dt_r, k_ms_r, _ = timed_pass(rp, ops.HEAD_RAW)
+        dt_r, k_ms_r, st_r = timed_pass(rp, ops.HEAD_RAW)
         fl_r = 2.0 * blocks[0].numel() * ev.I_shard.shape[0] * W.d
+        ident_r = ops.kernel_identity(st_r["kernel_id"][0]) if "kernel_id" in st_r else {"generation": 0}
+        funnel = ident_r.get("geometry") == "funnel"
         gen_r = ops.score_kernel(W.d, args.K, ev.I_shard.shape[0], rp, ops.HEAD_RAW)
-        raw = {"value": Bu * steps / dt_r, "unit": "users/s", "ms_per_step": dt_r / steps * 1e3, "kernel_ms": k_ms_r,
-               "roofline_frac": fl_r / (k_ms_r * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
-               "kernel": "%s<%d,RAW,%s>" % ("sweep4_kernel" if gen_r == "v4" else "score_topk_v3_kernel", W.d, td_name),
-               "sweep": {"order": "dense, items visited largest norm first", False: "dense, natural item order", True: "early-terminating"}[rp],
-               "note": "rec_type 'main_branch' (top_k(R + M), MF/train_new_api.py:597-598); bit-exact fp32 scores and lists vs the oracle "
-                       "(tests/test_gpu_score_topk.py); no popularity to order by: ~K ln(I / K) true list insertions per user"}
+        raw = {"value": Bu * steps / dt_r, "unit": "users/s", "ms_per_step": dt_r / steps * 1e3, "kernel_ms": k_ms_r, "kernel_ms_spread": last_spread[0],
+               "roofline_frac": fl_r / (k_ms_r * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, "kernel_identity": ident_r,
+               "kernel": ("the funnel: sweep7_kernel<%d,%s> (emitting sweeps, fixed thresholds) + expand7 / threshold7 (bound-keyed pools) + resolve7 (one exact rescoring)"
+                          % (W.d, td_name)) if funnel else "%s<%d,RAW,%s>" % ("sweep4_kernel" if gen_r == "v4" else "score_topk_v3_kernel", W.d, td_name),
+               "sweep": "growing parts of the catalogue in a random visiting order" if funnel else
+                        {"order": "dense, items visited largest norm first", False: "dense, natural item order", True: "early-terminating"}[rp],
+               "exact_rescorings_per_user": (float(st_r["pairs_rescored"][0]) / blocks[0].numel()) if "pairs_rescored" in st_r else None,
+               "rows_through_the_exact_fallback": int(st_r["fallback_rows"][0]) if "fallback_rows" in st_r else None,
+               "note": "rec_type 'main_branch' (top_k(R + M), MF/train_new_api.py:597-598): evaluated in EVERY epoch, the only head of --train normal; bit-exact fp32 "
+                       "scores and lists vs the oracle (tests/test_gpu_funnel.py, test_full_size_c3); the whole call is timed (every launch of the funnel)"}
     n_local = ev.I_shard.shape[0]
     Bu_rank = blocks[0].numel()                           # users this rank scores per step (its group's share)
     flops = 2.0 * Bu_rank * n_local * W.d
@@ -348,6 +385,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
                 "bound": "mfma", "achieved": alg_tf,
                 "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": alg_tf / PEAK_BF16_MFMA_TFLOPS,
                 "traffic": profile_traffic(kname, workload if (world_all == 1 and Bu == 262144) else "none"), "kernel_ms": k_ms,
+                "kernel_ms_spread": headline_spread, "box": {"before": clocks_before, "after": clocks_after},
                 # N = 1: HIP events around every score call on its launch stream; N > 1: the pipelined multi-rank path is not wrapped
                 # per call -- the figure is then WALL time per step (max over ranks), collectives included
                 "kernel_ms_source": "hip_events_per_call" if world_all == 1 else "wall_time_per_step_max_over_ranks",
@@ -525,7 +563,10 @@ def bench_train(args, dev, workload=None, quick=False):
         tcount[0] += 1
         lr_t = ops.adam_lr_t(lr, min(tcount[0], 1000))       # host scalar frozen in the graph: fine for timing
         ops.bpr_step(U, I, *batches[i % NB], regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=st[2], gI=st[5], loss_acc=loss)
-        ops.adam_dense_sweep2(U, st[0], st[1], st[2], I, st[3], st[4], st[5], lr_t)
+        bt = batches[i % NB]
+        ops.adam_mark_rows(bt[0], bt[1], bt[2], tbits[0], tbits[1])          # six streams: the gradient tables are read on the batch's rows only
+        ops.adam_dense_sweep3(U, st[0], st[1], st[2], tbits[0], I, st[3], st[4], st[5], tbits[1], lr_t)
+    tbits = ops.adam_touched_bitmaps(W.n_users, W.n_items, dev)
     out["adam_dense_reference_faithful"] = timed_graph(adam_body, max(256, args.train_steps // 4))
     sweep_bytes = 6 * (W.n_users + W.n_items) * W.d * 4
     r = out["adam_dense_reference_faithful"]
@@ -678,9 +719,10 @@ def bench_adam_big_tables(args, dev, workload):
     loss = torch.zeros(3, device=dev)
     z = torch.zeros_like
 
-    def run(lazy, steps, fast=False):
+    def run(lazy, steps, fast=False, six=True):
         U, I = W.U.float().clone(), W.I.float().clone()
         st = [z(U), z(U), z(U), z(I), z(I), z(I)]
+        tb = ops.adam_touched_bitmaps(W.n_users, W.n_items, dev)
         lz = ops.LazyAdamState(W.n_users, W.n_items, lr, dev, fast=fast) if lazy else None
         t = 0
 
@@ -693,6 +735,9 @@ def bench_adam_big_tables(args, dev, workload):
             ops.bpr_step(U, I, *b, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=st[2], gI=st[5], loss_acc=loss)
             if lazy:
                 ops.adam_lazy(1, lz, U, st[0], st[1], st[2], I, st[3], st[4], st[5], b[0], b[1], b[2], t)
+            elif six:
+                ops.adam_mark_rows(b[0], b[1], b[2], tb[0], tb[1])
+                ops.adam_dense_sweep3(U, st[0], st[1], st[2], tb[0], I, st[3], st[4], st[5], tb[1], ops.adam_lr_t(lr, t))
             else:
                 ops.adam_dense_sweep2(U, st[0], st[1], st[2], I, st[3], st[4], st[5], ops.adam_lr_t(lr, t))
         for _ in range(8):
@@ -714,6 +759,8 @@ def bench_adam_big_tables(args, dev, workload):
     sweep_bytes = 6 * (W.n_users + W.n_items) * W.d * 4
     out["dense_sweep"]["algorithmic_bytes_per_step"] = sweep_bytes
     out["dense_sweep"]["hbm_frac"] = sweep_bytes / (out["dense_sweep"]["us_per_step"] * 1e-6) / 1e9 / PEAK_HBM_GBS
+    out["dense_sweep"]["kernel"] = "adam_mark_rows_kernel + adam_dense_sweep3_kernel: six streams (x, m, v read and written; the gradient tables only on the batch's rows)"
+    out["dense_sweep_seven_streams"] = run(False, 24 if workload != "tiny" else 8, six=False)     # pda_adam_dense_sweep2_f32: reads the dense gradient tables too
     out["replay"] = run(True, 1536 if workload != "tiny" else 64)
     out["replay"]["note"] = ("pda_adam_lazy_f32: bit-identical tables after the sync (tests/test_gpu_bpr_step.py); three launches per step, "
                              "traffic = the batch rows")

@@ -503,6 +503,14 @@ int pda_adam_dense_sweep2_f32(float* var_a, float* m_a, float* v_a, float* g_a, 
                               float* v_b, float* g_b, size_t n_b, float lr_t, float beta1, float beta2, float eps,
                               void* stream);
 
+/* The same dense-decay step as SIX streams instead of seven (round 5): the gradient tables are zero on all but the batch's rows, so they are read
+ * (and cleared) only where a row's bit is set.  pda_adam_mark_rows sets the bits of a batch (users -> touched_u; pos, neg -> touched_i; bitmaps of
+ * ceil(rows / 32) words, zero before the first step); pda_adam_dense_sweep3_f32 sweeps both tables (d a power of two) and clears the bits behind
+ * itself.  Bit-identical tables to pda_adam_dense_sweep2_f32 (an untouched row computes with g = 0, operation for operation).  MF/model_api.py:83. */
+int pda_adam_mark_rows(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, uint32_t* touched_u, uint32_t* touched_i, void* stream);
+int pda_adam_dense_sweep3_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, uint32_t* touched_a, float* var_b, float* m_b, float* v_b,
+                              float* g_b, size_t rows_b, uint32_t* touched_b, int d, float lr_t, float beta1, float beta2, float eps, void* stream);
+
 /* Lazy/sparse Adam on the touched rows only (declared deviation).  rows i32 [n_rows]
  * must be unique; g is the dense accumulator (reset on the touched rows). */
 int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const int32_t* rows, int n_rows, int d, float lr_t,

@@ -518,6 +518,56 @@ __global__ void __launch_bounds__(256) adam_dense_sweep2_kernel(float* __restric
     }
 }
 
+
+// ---- the dense-decay sweep as SIX streams (round 5): a step's gradient is zero on all but the batch's rows, so the dense gradient tables need not
+// be read at all -- one bit per row says "touched by this step" (adam_mark_rows_kernel: the batch's users / positives / negatives), the sweep
+// reads and clears g only where it is set (and its bits behind itself).  Same arithmetic as adam_dense_sweep2_kernel, operation for operation
+// (an untouched row computes with g = 0): bit-identical tables.  4.3 -> 3.7 GB per step on config 3's tables.
+__global__ void __launch_bounds__(256) adam_mark_rows_kernel(const int32_t* __restrict__ users, const int32_t* __restrict__ pos, const int32_t* __restrict__ neg,
+                                                             int B, uint32_t* __restrict__ touched_u, uint32_t* __restrict__ touched_i) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B) return;
+    const int u = users[i], p = pos[i], n = neg[i];
+    atomicOr(&touched_u[u >> 5], 1u << (u & 31));
+    atomicOr(&touched_i[p >> 5], 1u << (p & 31));
+    atomicOr(&touched_i[n >> 5], 1u << (n & 31));
+}
+__global__ void __launch_bounds__(256) adam_dense_sweep3_kernel(float* __restrict__ var_a, float* __restrict__ m_a, float* __restrict__ v_a,
+                                                                float* __restrict__ g_a, size_t n4_a, int sh_a, const uint32_t* __restrict__ t_a,
+                                                                float* __restrict__ var_b, float* __restrict__ m_b, float* __restrict__ v_b,
+                                                                float* __restrict__ g_b, size_t n4_b, int sh_b, const uint32_t* __restrict__ t_b,
+                                                                unsigned blocks_a, float lr_t, float b1, float b2, float eps) {
+    const bool first = blockIdx.x < blocks_a;
+    float* var = first ? var_a : var_b;
+    float* m = first ? m_a : m_b;
+    float* v = first ? v_a : v_b;
+    float* g = first ? g_a : g_b;
+    const uint32_t* tb = first ? t_a : t_b;
+    const int sh = first ? sh_a : sh_b;                       // log2 of the row's 16-byte chunks
+    const size_t n4 = first ? n4_a : n4_b;
+    const size_t blk = first ? blockIdx.x : blockIdx.x - blocks_a, nblk = first ? blocks_a : gridDim.x - blocks_a;
+    const size_t stride = nblk * blockDim.x;
+    for (size_t i = blk * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const size_t row = i >> sh;
+        const bool touched = ((tb[row >> 5] >> (row & 31)) & 1u) != 0u;
+        f32x4 gg = {0.f, 0.f, 0.f, 0.f};
+        if (touched) gg = reinterpret_cast<f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+        f32x4 xx = reinterpret_cast<f32x4*>(var)[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mm[k] = b1 * mm[k] + (1.f - b1) * gg[k];
+            vv[k] = b2 * vv[k] + (1.f - b2) * gg[k] * gg[k];
+            xx[k] = xx[k] - lr_t * mm[k] / (sqrtf(vv[k]) + eps);
+        }
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+        reinterpret_cast<f32x4*>(var)[i] = xx;
+        if (touched) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+
 template <int D>
 __global__ void __launch_bounds__(256) adam_rows_kernel(float* var, float* m, float* v, float* g, const int32_t* rows,
                                                         int n_rows, float lr_t, float b1, float b2, float eps) {
@@ -973,6 +1023,36 @@ extern "C" int pda_adam_dense_sweep2_f32(float* var_a, float* m_a, float* v_a, f
     hipLaunchKernelGGL(adam_dense_sweep2_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), var_a,
                        m_a, v_a, g_a, n4a, var_b, m_b, v_b, g_b, n4b, blocks_a, lr_t, beta1, beta2, eps);
     PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+
+extern "C" int pda_adam_mark_rows(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, uint32_t* touched_u, uint32_t* touched_i, void* stream) {
+    if (!users || !pos || !neg || !touched_u || !touched_i || B <= 0) return PDA_ERR_ARG;
+    hipLaunchKernelGGL(adam_mark_rows_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), users, pos, neg, B, touched_u,
+                       touched_i);
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+extern "C" int pda_adam_dense_sweep3_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, uint32_t* touched_a, float* var_b, float* m_b,
+                                         float* v_b, float* g_b, size_t rows_b, uint32_t* touched_b, int d, float lr_t, float beta1, float beta2, float eps,
+                                         void* stream) {
+    if (!var_a || !m_a || !v_a || !g_a || !touched_a || !var_b || !m_b || !v_b || !g_b || !touched_b || rows_a == 0 || rows_b == 0) return PDA_ERR_ARG;
+    if (d < 4 || (d & (d - 1)) != 0) return PDA_ERR_UNSUPPORTED;                // (a row is a power of two of 16-byte chunks: element -> row by a shift)
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int sh = 0;
+    while ((4 << sh) < d) ++sh;
+    const size_t n4a = rows_a * (size_t)(d / 4), n4b = rows_b * (size_t)(d / 4), total = 256u * 8u;               // 8 blocks / CU in all, split by size
+    size_t ba = (size_t)((double)total * (double)n4a / (double)(n4a + n4b));
+    ba = ba < 1 ? 1 : (ba > total - 1 ? total - 1 : ba);
+    const size_t wa = (n4a + 255) / 256, wb = (n4b + 255) / 256;
+    const unsigned blocks_a = (unsigned)(wa < ba ? wa : ba), blocks_b = (unsigned)(wb < total - ba ? wb : total - ba);
+    hipLaunchKernelGGL(adam_dense_sweep3_kernel, dim3(blocks_a + blocks_b), dim3(256), 0, s, var_a, m_a, v_a, g_a, n4a, sh, touched_a, var_b, m_b, v_b, g_b, n4b, sh,
+                       touched_b, blocks_a, lr_t, beta1, beta2, eps);
+    PDA_CHECK_LAUNCH();
+    // the step's marks are spent
+    if (hipMemsetAsync(touched_a, 0, ((rows_a + 31) / 32) * 4, s) != hipSuccess || hipMemsetAsync(touched_b, 0, ((rows_b + 31) / 32) * 4, s) != hipSuccess)
+        return PDA_ERR_LAUNCH;
     return PDA_OK;
 }
 

@@ -171,7 +171,7 @@ class _MFBase:
             ops.refresh_rows_bf16(I, I16, pos)
             ops.refresh_rows_bf16(I, I16, neg)
         elif self.optimizer == "adam":
-            ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
+            self._dense_sweep(U, I, st, users, pos, neg, lr_t)
             ops.refresh_rows_bf16(U, U16)                      # dense decay moves every row
             ops.refresh_rows_bf16(I, I16)
         else:
@@ -231,11 +231,23 @@ class _MFBase:
         if lazy:
             ops.adam_lazy(1, self._lazy, U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], users, pos, neg, self._t)
         elif self.optimizer == "adam":
-            ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
+            self._dense_sweep(U, I, st, users, pos, neg, lr_t)
         else:
             ops.adam_rows(U, st["mU"], st["vU"], st["gU"], torch.unique(users).int(), lr_t)
             ops.adam_rows(I, st["mI"], st["vI"], st["gI"], torch.unique(torch.cat([pos, neg])).int(), lr_t)
         return self._loss
+
+    def _dense_sweep(self, U, I, st, users, pos, neg, lr_t):
+        """TF-1.14's dense-decay Adam step on both tables: six streams (the gradient tables are read only on the batch's rows: pda_adam_mark_rows +
+        pda_adam_dense_sweep3_f32) where the row length is a power of two, the seven-stream sweep otherwise.  Bit-identical."""
+        d = U.shape[1]
+        if d >= 4 and (d & (d - 1)) == 0:
+            if "tU" not in st:
+                st["tU"], st["tI"] = ops.adam_touched_bitmaps(U.shape[0], I.shape[0], U.device)
+            ops.adam_mark_rows(users, pos, neg, st["tU"], st["tI"])
+            ops.adam_dense_sweep3(U, st["mU"], st["vU"], st["gU"], st["tU"], I, st["mI"], st["vI"], st["gI"], st["tI"], lr_t)
+        else:
+            ops.adam_dense_sweep2(U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], lr_t)
 
     # ---- checkpoint (tf.train.Saver stand-in, MF/train_new_api.py:1014,1218-1228) ---------------------
     CKPT_FORMAT = "pda_amd/2"     # torch.save pickle of this dict -- NOT a tf.train.Saver checkpoint (see README)

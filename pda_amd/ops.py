@@ -975,6 +975,29 @@ def adam_dense_sweep2(var_a, m_a, v_a, g_a, var_b, m_b, v_b, g_b, lr_t: float, b
     mark_modified(var_b)
 
 
+def adam_touched_bitmaps(n_users: int, n_items: int, device):
+    """Zeroed "touched by this step" bitmaps for adam_mark_rows / adam_dense_sweep3 (one bit per table row)."""
+    return (torch.zeros((n_users + 31) // 32, dtype=torch.int32, device=device), torch.zeros((n_items + 31) // 32, dtype=torch.int32, device=device))
+
+
+def adam_mark_rows(users, pos, neg, touched_u, touched_i):
+    """pda_adam_mark_rows: the batch's rows into the bitmaps."""
+    check(_lib.load().pda_adam_mark_rows(ptr(_need(users, torch.int32, "users")), ptr(_need(pos, torch.int32, "pos")), ptr(_need(neg, torch.int32, "neg")),
+                                         users.numel(), ptr(touched_u), ptr(touched_i), stream_ptr()), "pda_adam_mark_rows")
+
+
+def adam_dense_sweep3(var_a, m_a, v_a, g_a, touched_a, var_b, m_b, v_b, g_b, touched_b, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
+    """pda_adam_dense_sweep3_f32: the dense-decay Adam sweep over both tables without reading the gradient tables outside the marked rows
+    (bit-identical to adam_dense_sweep2); clears the marks."""
+    lib = _lib.load()
+    for t in (var_a, m_a, v_a, g_a, var_b, m_b, v_b, g_b):
+        _need(t, torch.float32, "adam state")
+    check(lib.pda_adam_dense_sweep3_f32(ptr(var_a), ptr(m_a), ptr(v_a), ptr(g_a), var_a.shape[0], ptr(touched_a), ptr(var_b), ptr(m_b), ptr(v_b), ptr(g_b),
+                                        var_b.shape[0], ptr(touched_b), var_a.shape[1], lr_t, beta1, beta2, eps, stream_ptr()), "pda_adam_dense_sweep3_f32")
+    mark_modified(var_a)
+    mark_modified(var_b)
+
+
 def adam_dense_sweep(var, m, v, g, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS):
     lib = _lib.load()
     for t, n in ((var, "var"), (m, "m"), (v, "v"), (g, "g")):

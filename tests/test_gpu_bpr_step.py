@@ -986,3 +986,36 @@ def test_two_table_adam_sweep_equals_two_sweeps(dev):
         for x, y in zip(a + b, a2 + b2):
             assert torch.equal(x, y)
         assert float(a2[3].abs().max()) == 0.0 and float(b2[3].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_six_stream_adam_sweep_equals_the_seven_stream_sweep(dev, d):
+    """pda_adam_mark_rows + pda_adam_dense_sweep3_f32 (the gradient tables read and cleared on the batch's rows only) leave the tables, the moments and the
+    gradient accumulators of pda_adam_dense_sweep2_f32, bit for bit, over several steps with repeated rows; the marks are spent after every sweep."""
+    from pda_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(11 + d)
+    nU, nI, B = 3001, 1777, 512
+    def tables():
+        return [torch.randn(n, d, generator=g, device=dev) * s for n in (nU, nI) for s in (0.1, 0.01, 0.001)]        # var, m, v(>= 0 below) per table
+    a = tables()
+    a[2].abs_(); a[5].abs_()
+    b = [t.clone() for t in a]
+    gUa, gIa = torch.zeros(nU, d, device=dev), torch.zeros(nI, d, device=dev)
+    gUb, gIb = gUa.clone(), gIa.clone()
+    tu, ti = ops.adam_touched_bitmaps(nU, nI, dev)
+    for t in range(1, 5):
+        users = torch.randint(0, nU, (B,), generator=g, device=dev, dtype=torch.int32)
+        pos = torch.randint(0, 40, (B,), generator=g, device=dev, dtype=torch.int32)                # hot items: many repeats
+        neg = torch.randint(0, nI, (B,), generator=g, device=dev, dtype=torch.int32)
+        for gU, gI in ((gUa, gIa), (gUb, gIb)):
+            gU.index_add_(0, users.long(), torch.ones(B, d, device=dev) * 0.01 * t)
+            gI.index_add_(0, pos.long(), torch.ones(B, d, device=dev) * 0.02)
+            gI.index_add_(0, neg.long(), torch.ones(B, d, device=dev) * -0.03)
+        lr_t = ops.adam_lr_t(1e-3, t)
+        ops.adam_dense_sweep2(a[0], a[1], a[2], gUa, a[3], a[4], a[5], gIa, lr_t)
+        ops.adam_mark_rows(users, pos, neg, tu, ti)
+        assert int(tu.count_nonzero()) > 0
+        ops.adam_dense_sweep3(b[0], b[1], b[2], gUb, tu, b[3], b[4], b[5], gIb, ti, lr_t)
+        for x, y in zip(a + [gUa, gIa], b + [gUb, gIb]):
+            assert torch.equal(x, y)
+        assert int(tu.count_nonzero()) == 0 and int(ti.count_nonzero()) == 0 and float(gUb.abs().max()) == 0.0
