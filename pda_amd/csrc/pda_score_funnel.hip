@@ -16,12 +16,14 @@ namespace {
 double g_fail_p = 1e-6;        // a launch's threshold lies above the row's final K-th value with at most this probability (then: the exact fallback)
 int g_growth = 4;              // every launch sees this many times the items seen before it (2 from a sixth of the catalogue on)
 int g_cap_e = 64;              // entries per (user, quarter) list and launch
-int g_first_tiles = 4;         // the first launch: 256 items against -inf
+int g_first_tiles = 4;         // without a maxima launch: the first launch, 256 items against -inf
+int g_maxima = 1;              // the first launch keeps maxima only (rank-8 thresholds for free: no lists, no selection)
 constexpr int kFallbackSplits = 8;
 
 struct Stage7 {
     int lo, hi;                // global 64-item tiles [lo, hi)
     int rank_next;             // the threshold of the next launch: this rank among the lower bounds seen (0: none follows)
+    int maxima;                // 1: the first launch in maxima mode (sweep7_kernel<.., MAXM> + maxthr7_kernel: rank 8, nothing written per half-tile)
 };
 
 // P(Gamma(r, 1) <= x) = 1 - exp(-x) sum_{i < r} x^i / i!
@@ -45,10 +47,20 @@ int rank_for7(int K, double m, double n, double p) {
 std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
     std::vector<Stage7> st;
     int lo = 0, hi = std::min(n_tiles, std::max(1, g_first_tiles));
+    if (g_maxima) {
+        // the maxima launch: as many tiles as rank 8 carries (P(Gamma(8) < K m / n) <= p), at least two; the first emitting launch starts over at tile 0
+        int m2 = 2;
+        while (m2 * 2 <= n_tiles / 8 && gamma_cdf7(8, (double)K * (m2 * 2) * 64.0 / n_items) <= g_fail_p) m2 *= 2;
+        if (m2 * 3 / 2 <= n_tiles / 8 && gamma_cdf7(8, (double)K * (m2 * 3 / 2) * 64.0 / n_items) <= g_fail_p) m2 = m2 * 3 / 2;
+        if (gamma_cdf7(8, (double)K * m2 * 64.0 / n_items) <= g_fail_p && K >= 8) {
+            st.push_back(Stage7{0, m2, 8, 1});
+            hi = std::min(n_tiles, m2 * 2);                    // (rank 8 is a coarse estimate: the first emitting launch stays short)
+        }
+    }
     for (;;) {
         // (a last part of less than half a step joins the one before it)
         if (n_tiles - hi < (hi - lo) / 2) hi = n_tiles;
-        Stage7 s7{lo, hi, 0};
+        Stage7 s7{lo, hi, 0, 0};
         if (hi < n_tiles) s7.rank_next = rank_for7(K, std::min((double)hi * 64.0, (double)n_items), (double)n_items, g_fail_p);
         st.push_back(s7);
         if (hi >= n_tiles) break;
@@ -80,7 +92,7 @@ int funnel_splits7(int n_users, int n_items_local, int d) {
 }
 
 struct Ws7 {
-    size_t ufrag, unorm, uerr, eu, ecnt, elist, thr, tk, tmax, ncand, flags, cand, qpool, qcnt, bloom, fail_list, fail_count, users2, fb_keys, fb_ws, total;
+    size_t ufrag, unorm, uerr, eu, ecnt, mrun, elist, thr, tk, tmax, ncand, flags, cand, qpool, qcnt, bloom, fail_list, fail_count, users2, fb_keys, fb_ws, total;
     int n_splits, cap_e, cap_q;
 };
 Ws7 ws7_layout(int n, int n_items_local, int d) {
@@ -104,6 +116,8 @@ Ws7 ws7_layout(int n, int n_items_local, int d) {
     b = al(b + utiles * 4 * 8);
     w.ecnt = b;
     b = al(b + wgs * 4 * nu * 64 * 4);
+    w.mrun = b;
+    b = al(b + wgs * 4 * (size_t)(2 * nu + 1) * 64 * 4);
     w.elist = b;
     b = al(b + wgs * 4 * (size_t)w.cap_e * (64 * nu * 48));
     w.thr = b;
@@ -178,18 +192,27 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
     Args7 e{pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), wsb + W.ufrag, reinterpret_cast<const float*>(wsb + W.unorm), reinterpret_cast<const float*>(wsb + W.uerr), R.thr,
             wsb + W.elist,
             reinterpret_cast<unsigned*>(wsb + W.ecnt), reinterpret_cast<float*>(wsb + W.eu), reinterpret_cast<unsigned*>(workspace), n, W.n_splits, L.n_tiles, 0, 0, W.cap_e,
-            nullptr};
-    Sel7 q{e, R, pb + L.rows, users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, U, I_shard, out_keys,
+            reinterpret_cast<float*>(wsb + W.mrun), nullptr};
+    Sel7 q{e, R, pb + L.rows, users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, 0, U, I_shard, out_keys,
            reinterpret_cast<int*>(wsb + W.fail_list), fail_count};
     const std::vector<Stage7> stages = schedule7(L.n_tiles, n_items_local, K);
     for (const Stage7& st : stages) {
         e.tile_lo = st.lo;
         e.tile_hi = st.hi;
+        if (st.maxima) {
+            const int rc = launch_sweep7<D, BF, UPW, true>(e, s);
+            if (rc != PDA_OK) return rc;
+            q.e = e;
+            hipLaunchKernelGGL((maxthr7_kernel<D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q);
+            PDA_CHECK_LAUNCH();
+            continue;
+        }
         const int rc = launch_sweep7<D, BF, UPW>(e, s);
         if (rc != PDA_OK) return rc;
         q.e = e;
         q.rank_next = st.rank_next;
-        hipLaunchKernelGGL((expand7_kernel<D>), dim3((unsigned)(((size_t)(n + UT - 1) / UT) * W.n_splits * (UPW / 16))), dim3(256), 0, s, q);
+        q.first_launch = (st.lo == 0 && !stages[0].maxima) ? 1 : 0;
+        hipLaunchKernelGGL((expand7_kernel<D>), dim3((unsigned)(((size_t)(n + UT - 1) / UT) * W.n_splits * 64)), dim3(256), 0, s, q);
         PDA_CHECK_LAUNCH();
         {
             const int nsl = (4 * W.n_splits * W.cap_q + 63) / 64;          // 64-slot groups of a row's (quarter, split) lists
@@ -261,6 +284,11 @@ extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int f
     if (first_tiles > 0) g_first_tiles = first_tiles;
     return PDA_OK;
 }
+// measurements / tests only: the first launch in maxima mode (1, the default) or as an emitting launch against -inf (0)
+extern "C" int pda_debug_funnel_maxima(int on) {
+    g_maxima = on ? 1 : 0;
+    return PDA_OK;
+}
 // the workspace of a funnel: offs[0..9] = thr, tk, tmax, ncand, flags, cand, fail_list, fail_count, ecnt, elist; returns (n_splits << 16) | cap_e
 extern "C" int pda_debug_funnel_layout(int n_users_blk, int n_items_local, int d, size_t* offs) {
     const Ws7 w = ws7_layout(n_users_blk, n_items_local, d);
@@ -274,7 +302,7 @@ extern "C" int pda_debug_funnel_schedule(int n_items_local, int K, int* out, int
     for (size_t i = 0; i < st.size() && (int)i < max_stages; ++i) {
         out[3 * i] = st[i].lo;
         out[3 * i + 1] = st[i].hi;
-        out[3 * i + 2] = st[i].rank_next;
+        out[3 * i + 2] = st[i].maxima ? -8 : st[i].rank_next;
     }
     return (int)st.size();
 }
@@ -378,7 +406,7 @@ extern "C" int pda_debug_emit_sweep(const void* U, int bf16, const int32_t* user
     Args7 g{pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), wsb + 256, reinterpret_cast<const float*>(wsb + offs[0]),
             reinterpret_cast<const float*>(wsb + offs[4]), thr, wsb + offs[3],
             reinterpret_cast<unsigned*>(wsb + offs[2]), reinterpret_cast<float*>(wsb + offs[1]), reinterpret_cast<unsigned*>(wsb), n_users_blk, n_splits, L.n_tiles,
-            tile_lo, tile_hi, cap_e, nullptr};
+            tile_lo, tile_hi, cap_e, nullptr, nullptr};
 #define PDA_E7(DD, BFV, UPWV)                                                                                                                      \
     {                                                                                                                                              \
         constexpr int UT = 4 * UPWV;                                                                                                               \

@@ -33,6 +33,7 @@ struct Args7 {
     int n_users_blk, n_splits, n_tiles;
     int tile_lo, tile_hi;            // this launch scores the 64-item tiles [tile_lo, tile_hi) of the visiting order (every split: its own of them)
     int cap_e;                       // entries per list
+    float* mrun;                     // [workgroup][wave][(2 NU + 1) 64]: the first launch's maxima (Loop7M): the two largest per (user block, lane), the largest ct
     const int* n_users_dev;          // or NULL: the number of rows that exist (a device-side count; workgroups beyond it leave at once)
 };
 
@@ -45,7 +46,9 @@ __device__ __forceinline__ void stage_tiles7(int n_tiles, int sp, int S, int lo,
 }
 
 // one launch of the emitting sweep: d = 64 / 128: 1 024-user workgroups (UPW = 256); d = 256: 512-user workgroups (UPW = 128)
-template <int D, bool BF, int UPW>
+// MAXM: the funnel's first launch -- no thresholds yet and nothing written per half-tile: every lane keeps the two largest maxima of each of its user
+// blocks (Loop7M), maxthr7_kernel turns them into the first thresholds.
+template <int D, bool BF, int UPW, bool MAXM = false>
 __global__ void __launch_bounds__(256, 1) sweep7_kernel(Args7 g) {
     constexpr int NK = D / 32, NU = UPW / 16, UT = 4 * UPW, SS = slot_bytes5(D);
     static_assert(SS == Loop7<D, NU>::kSlotBytes, "one LDS image for all loops");
@@ -88,9 +91,16 @@ __global__ void __launch_bounds__(256, 1) sweep7_kernel(Args7 g) {
         g.eu_wave[2 * (utile * 4 + wave) + 1] = eu2;
     }
     if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | (7u << 8) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);     // kernel identity: geometry 7
+    [[maybe_unused]] float* mr = MAXM ? g.mrun + widx * ((2 * NU + 1) * 64) : nullptr;
     if (hend == 0u) {
+        if constexpr (MAXM) {
 #pragma unroll
-        for (int u = 0; u < NU; ++u) cnt[u * 64 + lane] = 0u;
+            for (int u = 0; u < 2 * NU; ++u) mr[u * 64 + lane] = -INFINITY;
+            mr[2 * NU * 64 + lane] = 0.f;
+        } else {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) cnt[u * 64 + lane] = 0u;
+        }
         return;
     }
     const unsigned ring_lds = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -103,8 +113,12 @@ __global__ void __launch_bounds__(256, 1) sweep7_kernel(Args7 g) {
     rsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)region);
     rsrc[3] = 0x00020000u;
     const size_t img = (size_t)g.rows5, meta = (size_t)g.meta5;
-    Loop7<D, NU>::run(0u, 0u, hend, ring_lds, 1024u * (unsigned)wave, (unsigned)(split + i0 * g.n_splits), (unsigned)g.n_splits, (unsigned)img, (unsigned)(img >> 32),
-                      (unsigned)meta, (unsigned)(meta >> 32), eu, eu2, my_ufrag, rsrc, cnt, thr, (unsigned)lane * 16u);
+    if constexpr (MAXM)
+        Loop7M<D, NU>::run(0u, 0u, hend, ring_lds, 1024u * (unsigned)wave, (unsigned)(split + i0 * g.n_splits), (unsigned)g.n_splits, (unsigned)img, (unsigned)(img >> 32),
+                           (unsigned)meta, (unsigned)(meta >> 32), eu, eu2, my_ufrag, mr, (unsigned)lane * 16u);
+    else
+        Loop7<D, NU>::run(0u, 0u, hend, ring_lds, 1024u * (unsigned)wave, (unsigned)(split + i0 * g.n_splits), (unsigned)g.n_splits, (unsigned)img, (unsigned)(img >> 32),
+                          (unsigned)meta, (unsigned)(meta >> 32), eu, eu2, my_ufrag, rsrc, cnt, thr, (unsigned)lane * 16u);
 #ifdef PDA_V7_DUMP_LDS      /* debugging: workgroup 0 leaves its LDS behind the lists (tools/dbg_emit.py) */
     __syncthreads();
     if (blockIdx.x == 0) {
@@ -138,6 +152,7 @@ struct Sel7 {
     const int32_t* hist_indices;
     const uint32_t* bloom;            // [rows][32] or NULL
     int hist_row_mode, item_offset, n_items_local, K;
+    int first_launch;                 // the launch ran against -inf (no maxima launch in front of it): expand7_kernel takes shortcuts, threshold7_kernel masks
     int rank_next;                    // the next launch's threshold: the rank_next-th largest lower bound (0: this was the last launch)
     // resolve7_kernel
     const void* U;
@@ -150,6 +165,40 @@ struct Sel7 {
 __device__ __forceinline__ float lowered7(float tq) {     // strictly below tq (ties must pass), +-1e30 for +-inf (as sweep5_kernel's thr_of)
     const float tf = (tq == INFINITY || tq == -INFINITY) ? tq : tq - fabsf(tq) * 1.52587890625e-5f - 1e-30f;
     return fminf(fmaxf(tf, -1.0e30f), 1.0e30f);
+}
+
+// The first thresholds, from the maxima of the first launch (sweep7_kernel<.., MAXM>).  A lane of the sweep kept, per user block, the two largest
+// of its half-tile maxima: of (row, quarter) -- a fixed quarter of the items, random like the visiting order -- the two best bounds seen among the
+// launch's m items.  T = the smallest over the four quarters of the quarter's SECOND largest lower bound: eight distinct items reach it, two per
+// quarter, and the items of the whole catalogue that reach it number at least (n / m) x Gamma(8) (four independent Gamma(2) classes): the bet of
+// rank_for7 with rank 8.  Lower bounds: a maximum is s~ + ct of its half-tile; minus twice the wave's largest ct (which half-tile is not kept).
+// One thread per row; the splits' maxima of a quarter are merged first.
+template <int D>
+__global__ void __launch_bounds__(256) maxthr7_kernel(Sel7 g) {
+    constexpr int UPW = D == 256 ? 128 : 256, UT = 4 * UPW, NU = UPW / 16, MR = (2 * NU + 1) * 64;
+    const int n_rows = g.e.n_users_dev != nullptr ? min(g.e.n_users_blk, *g.e.n_users_dev) : g.e.n_users_blk;
+    const int rb = blockIdx.x * 256 + threadIdx.x;
+    if (rb >= n_rows) return;
+    const int S = g.e.n_splits;
+    const int utile = rb / UT, w = (rb % UT) / UPW, u = (rb % UPW) >> 4, j = rb & 15;
+    float t = INFINITY;
+    for (int hh = 0; hh < 4; ++hh) {
+        float b1 = -INFINITY, b2 = -INFINITY;                    // the quarter's two largest lower bounds over the splits
+        for (int sp = 0; sp < S; ++sp) {
+            const float* mr = g.e.mrun + (((size_t)utile * S + sp) * 4 + w) * MR;
+            const float ctm = mr[2 * NU * 64 + j + 16 * hh];
+            for (int k = 0; k < 2; ++k) {
+                const float m = mr[(k * NU + u) * 64 + j + 16 * hh];
+                const float lb = m == -INFINITY ? -INFINITY : (m - ctm) - ctm - (fabsf(m) + ctm) * 4.8e-7f;
+                const float lo = fminf(b1, lb);
+                b1 = fmaxf(b1, lb);
+                b2 = fmaxf(b2, lo);
+            }
+        }
+        t = fminf(t, b2);
+    }
+    g.r.thr[rb] = lowered7(t);
+    g.r.tmax[rb] = t;
 }
 
 // The selection between two launches, in two kernels (one wave per row doing both was latency-bound: ~15 dependent round trips per row at five
@@ -198,37 +247,41 @@ template <int D>
 __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
     constexpr int UPW = D == 256 ? 128 : 256, UT = 4 * UPW, NU = UPW / 16, RB4 = row_bytes(D);
     constexpr unsigned ES = 64u * NU * 48u, LS = NU * 48u;
+    constexpr int EPW = 64 / NU;                                 // entries of a list per step of the wave
     const int lane = threadIdx.x & 63;
     const int n_rows = g.e.n_users_dev != nullptr ? min(g.e.n_users_blk, *g.e.n_users_dev) : g.e.n_users_blk;
     const int S = g.e.n_splits;
-    // wave id -> (user tile, split, sweep wave, user block)
+    // One wave per LANE of a sweep wave: that lane's NU lists (its user blocks: NU rows, one quarter) lie side by side in every entry slot -- NU x 48
+    // contiguous bytes -- so a wave reads EPW entry slots of NU lists per step, coalesced, and a list of 20 entries is 5 steps, not 20.
+    // wave id -> (user tile, split, sweep wave, sweep lane); lane -> (list = user block u, entry slot es)
     const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int u = wid % NU, w = (wid / NU) & 3, ws = wid / (4 * NU), sp = ws % S, utile = ws / S;
+    const int l = wid & 63, w = (wid >> 6) & 3, ws = wid >> 8, sp = ws % S, utile = ws / S;
     if (utile * UT >= n_rows) return;
-    const int j = lane & 15, hh = lane >> 4;
-    const int rb = utile * UT + w * UPW + 16 * u + j;
+    const int u = lane % NU, es = lane / NU;
+    const int hh = l >> 4;
+    const int rb = utile * UT + w * UPW + 16 * u + (l & 15);
     const bool row_ok = rb < n_rows;
     const int rbs = row_ok ? rb : 0;
-    const size_t qidx = ((size_t)rbs * 4 + hh) * S + sp;         // this lane's list of the row's pool
+    const size_t qidx = ((size_t)rbs * 4 + hh) * S + sp;         // this list's slots of the row's pool
     int i0, i1;
     stage_tiles7(g.e.n_tiles, sp, S, g.e.tile_lo, g.e.tile_hi, i0, i1);
     const unsigned hend = 2u * (unsigned)(i1 - i0);
     const size_t widx = ((size_t)utile * S + sp) * 4 + w;
-    unsigned c = (row_ok && hend > 0u) ? g.e.ecnt[widx * (NU * 64) + u * 64 + lane] / ES : 0u;
+    unsigned c = (row_ok && hend > 0u) ? g.e.ecnt[widx * (NU * 64) + u * 64 + l] / ES : 0u;
     if (c > (unsigned)g.e.cap_e) {
         c = (unsigned)g.e.cap_e;
-        atomicOr(&g.r.flags[rb], 1u);
+        if (es == 0) atomicOr(&g.r.flags[rb], 1u);
     }
     unsigned cmax = c;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) cmax = max(cmax, (unsigned)__shfl_xor((int)cmax, o, 64));
     if (cmax == 0u) {
-        if (row_ok) g.r.qcnt[qidx] = 0u;
+        if (row_ok && es == 0) g.r.qcnt[qidx] = 0u;
         return;
     }
     const float thr_used = fminf(fmaxf(g.r.thr[rbs], -1.0e30f), 1.0e30f);      // (as sweep7_kernel clamps it)
     const uint32_t t_old_o = pda_ordf(g.r.tmax[rbs] + 0.0f);                   // the (un-lowered) source of thr_used: -inf in the first launch
-    const bool first = g.e.tile_lo == 0;
+    const bool first = g.first_launch != 0;
     const float eu = g.e.eu_wave[2 * (utile * 4 + w)], eu2 = g.e.eu_wave[2 * (utile * 4 + w) + 1];      // what the launch formed ct with
     const float ua = (g.e.uerr[rbs] + g.e.unorm[rbs] * 6.103515625e-5f) * 1.001f, ub2 = g.e.unorm[rbs] * 1.00390625f * 1.001f;   // the ROW's own A, B
     const bool hist_on = g.hist_indptr != nullptr;
@@ -238,23 +291,25 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
         hb = g.hist_indptr[hr];
         he = g.hist_indptr[hr + 1];
     }
-    const unsigned char* lp = g.e.elist + widx * ((size_t)g.e.cap_e * ES) + (size_t)lane * LS + (size_t)u * 48;
+    const unsigned char* lp = g.e.elist + widx * ((size_t)g.e.cap_e * ES) + (size_t)l * LS + (size_t)u * 48;
     uint64_t* prow = g.r.qpool + qidx * (size_t)(2 * g.r.cap_q);
-    int cq = 0;                                                  // pairs this lane has found
+    int cq = 0;                                                  // pairs found in this list so far (the same in its EPW lanes)
     f32x4 na = {0.f, 0.f, 0.f, 0.f}, nb = na;
     unsigned nhd = 0xFFFFFFFFu;
-    if (0u < c) {
-        na = *reinterpret_cast<const f32x4*>(lp);
-        nb = *reinterpret_cast<const f32x4*>(lp + 16);
-        nhd = *reinterpret_cast<const unsigned*>(lp + 32);
+    if ((unsigned)es < c) {
+        const unsigned char* ep = lp + (size_t)es * ES;
+        na = *reinterpret_cast<const f32x4*>(ep);
+        nb = *reinterpret_cast<const f32x4*>(ep + 16);
+        nhd = *reinterpret_cast<const unsigned*>(ep + 32);
     }
-    for (unsigned e = 0; e < cmax; ++e) {
+    for (unsigned e0 = 0; e0 < cmax; e0 += EPW) {
+        const unsigned e = e0 + (unsigned)es;
         const f32x4 a = na, b = nb;
         const unsigned hd = nhd;
         bool have = e < c && hd < hend;                         // (the two half-tiles behind the end write entries too)
         nhd = 0xFFFFFFFFu;
-        if (e + 1 < c) {
-            const unsigned char* ep = lp + (size_t)(e + 1) * ES;
+        if (e + EPW < c) {
+            const unsigned char* ep = lp + (size_t)(e + EPW) * ES;
             na = *reinterpret_cast<const f32x4*>(ep);
             nb = *reinterpret_cast<const f32x4*>(ep + 16);
             nhd = *reinterpret_cast<const unsigned*>(ep + 32);
@@ -269,7 +324,7 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
             pp[r] = have && vv[r] > thr_used && pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3) < (unsigned)g.n_items_local;
             any_p = any_p || pp[r];
         }
-        if (!__any(any_p)) continue;
+        if (!__any(any_p)) continue;                            // (wave-uniform: the shuffles below are reached by all lanes or none)
         float4 mt = {0.f, 0.f, 0.f, 0.f};
         if (any_p) mt = *reinterpret_cast<const float4*>(g.e.meta5 + 4 * (size_t)(pos0 >> 5));
         // the tails: (popularity, local id, ||i||, ||i - i~||).  The first launch (everything above -inf: 256 items per row, of which a handful stay)
@@ -295,12 +350,15 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
             }
         }
         const float ct = __builtin_fmaf(eu2, mt.z, __builtin_fmaf(eu, mt.y, mt.x));
+        uint64_t bnds[8];
+        int np = 0;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
             const float bp = __builtin_fmaf(ua, tl[r][2], ub2 * tl[r][3]);
             const float st = vv[r] - ct, guard = (fabsf(vv[r]) + ct) * 4.8e-7f;           // (the roundings of the accumulator and of this subtraction)
             const uint32_t ubo = pda_ordf(st + bp + guard + 0.0f), lbo = pda_ordf(st - bp - guard + 0.0f);
+            bnds[r] = ((uint64_t)ubo << 32) | lbo;
             bool p = pp[r] && ubo >= t_old_o;                    // (below a threshold already used: dropped for good)
             if (hist_on && !first) {                             // train items never enter: a binary search behind the two Bloom bits
                 const bool look = p && (((bw1[r] >> (bloom7_h1(pos) & 31u)) & (bw2[r] >> (bloom7_h2(pos) & 31u)) & 1u) != 0u);
@@ -316,14 +374,31 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
                     }
                 }
             }
-            if (p) {
-                if (cq < g.r.cap_q)
-                    *reinterpret_cast<ulonglong2*>(prow + 2 * cq) = make_ulonglong2(((uint64_t)pda_ordf(vv[r] + 0.0f) << 32) | (uint64_t)pos, ((uint64_t)ubo << 32) | lbo);
-                ++cq;                                            // (past the list's slots: threshold7_kernel sees the count and flags the row)
+            pp[r] = p;
+            np += p ? 1 : 0;
+        }
+        // the list's slots: its EPW lanes (NU apart) one after the other
+        int before = 0, total = 0;
+#pragma unroll
+        for (int k = 0; k < EPW; ++k) {
+            const int o = __shfl(np, u + k * NU, 64);
+            before += k < es ? o : 0;
+            total += o;
+        }
+        int slot = cq + before;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            if (pp[r]) {
+                if (slot < g.r.cap_q) {
+                    const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
+                    *reinterpret_cast<ulonglong2*>(prow + 2 * slot) = make_ulonglong2(((uint64_t)pda_ordf(vv[r] + 0.0f) << 32) | (uint64_t)pos, bnds[r]);
+                }
+                ++slot;                                          // (past the list's slots: threshold7_kernel sees the count and flags the row)
             }
         }
+        cq += total;
     }
-    if (row_ok) g.r.qcnt[qidx] = (unsigned)cq;
+    if (row_ok && es == 0) g.r.qcnt[qidx] = (unsigned)cq;
 }
 
 template <int D, int NSL>
@@ -431,7 +506,7 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
         keep_o = pda_ordf(tk + 0.0f);
         if (lane == 0) g.r.tk[rb] = tk;
     }
-    const bool mask_here = g.e.tile_lo == 0 && g.hist_indptr != nullptr;       // (the first launch: expand7_kernel left the train items in)
+    const bool mask_here = g.first_launch != 0 && g.hist_indptr != nullptr;       // (a launch against -inf: expand7_kernel left the train items in)
     long long hb = 0, he = 0;
     if (mask_here) {
         const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)g.users[rb] : (int64_t)rb;
@@ -624,18 +699,18 @@ __global__ void __launch_bounds__(256) fail_merge7_kernel(const uint64_t* __rest
     }
 }
 
-template <int D, bool BF, int UPW>
+template <int D, bool BF, int UPW, bool MAXM = false>
 int launch_sweep7(const Args7& g, hipStream_t stream) {
     constexpr int UT = 4 * UPW;
     constexpr size_t lds = (size_t)kNSlot5 * slot_bytes5(D) + 64;
     static int attr_set = 0;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep7_kernel<D, BF, UPW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep7_kernel<D, BF, UPW, MAXM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PDA_ERR_LAUNCH;
         attr_set = 1;
     }
     const int utiles = (g.n_users_blk + UT - 1) / UT;
-    hipLaunchKernelGGL((sweep7_kernel<D, BF, UPW>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
+    hipLaunchKernelGGL((sweep7_kernel<D, BF, UPW, MAXM>), dim3((unsigned)(utiles * g.n_splits)), dim3(256), lds, stream, g);
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

@@ -45,7 +45,9 @@ ONLY_U = int(os.environ.get("V7_ONLY_U", "-1"))        # debugging: only this us
 SPLIT_EMIT = int(os.environ.get("V7_SPLIT", "0"))   # 1: the emission as two events in consecutive slots (the MFMA between them ignores exec)
 
 
-def gen(D, UB):
+def gen(D, UB, maxmode=False):
+    """maxmode: the loop of the funnel's FIRST launch -- nothing is written per half-tile; every lane keeps the two largest maxima of its user blocks
+    (run1 in the cursor registers, run2 in the threshold registers) and the wave the largest ct it formed; they are stored at the exit."""
     NK = D // 32
     if UB == 16:
         ACC0, FRAG0, THR0, M0T, CUR0, MISC0 = 128, 96, 80, 64, 40, 16
@@ -89,6 +91,7 @@ def gen(D, UB):
     metar = lambda p: "v%d" % (META0 + 4 * p + 2)
     metapair = lambda p: "v[%d:%d]" % (META0 + 4 * p, META0 + 4 * p + 3)
     vh, vrd, vsb, voff0, vzero, vrdb = ("v%d" % x for x in (VH, VRD, VSB, VOFF0, VZERO, VRDB))
+    vctmax = "v%d" % (MISC0 + 18)
     vgoff = lambda j: "v%d" % (VGOFF0 + j)
     atmp = lambda i: "v%d" % (ATMP0 + (i & 1))
 
@@ -151,7 +154,8 @@ def gen(D, UB):
         if p == 1:
             ev(p, A_SLOT, "valu", None, ["s_waitcnt vmcnt(0)", "s_barrier"])
         ev(p, A_SLOT + 1, "lds", ("meta", q), ["ds_read_b128 %s, %s offset:%d" % (metapair(q), vsb, HB)])
-        ev(p, S_VH, "valu", None, ["v_mov_b32 %s, %%[h]" % vh])
+        if not maxmode:
+            ev(p, S_VH, "valu", None, ["v_mov_b32 %s, %%[h]" % vh])
         n_rd = 0
         for k in range(NK):
             for ib in range(IB):
@@ -200,6 +204,8 @@ def gen(D, UB):
                       "s_mov_b64 exec, -1"]
                 if BRANCH:
                     em = ["v_cmp_gt_f32 vcc, %s, %s" % (mt(u), thr(u)), "s_cbranch_vccz 7f", "s_mov_b64 exec, vcc"] + em[1:] + ["7:"]
+                if maxmode:
+                    em = ["v_min_f32 %s, %s, %s" % (vh, cur(u), mt(u)), "v_max_f32 %s, %s, %s" % (cur(u), cur(u), mt(u)), "v_max_f32 %s, %s, %s" % (thr(u), thr(u), vh)]
                 if ONLY_U >= 0 and u != ONLY_U:
                     em = ["s_nop 0"]
                 EMITS[p].append(mx + [(e_lo, e_hi, em)])
@@ -233,7 +239,8 @@ def gen(D, UB):
         # ct = pmax + A nmax + B rmax (A, B: the wave's rounding-residual and norm maxima -- sweep7_kernel)
         ev(p, sq, "check", ("meta", q), ["v_fma_f32 %s, %%[eu], %s, %s" % (ctr(q, 0), metan(q), metap(q)),
                                          "v_fma_f32 %s, %%[eu2], %s, %s" % (ctr(q, 0), metar(q), ctr(q, 0))])
-        ev(p, sq + 1, "valu", None, ["v_mov_b32 %s, %s" % (ctr(q, r), ctr(q, 0)) for r in (1, 2, 3)])
+        ev(p, sq + 1, "valu", None, ["v_mov_b32 %s, %s" % (ctr(q, r), ctr(q, 0)) for r in (1, 2, 3)] +
+           (["v_max_f32 %s, %s, %s" % (vctmax, vctmax, ctr(q, 0))] if maxmode else []))
         s1 = spread(p, s0 + 1, s0 + 4, [["s_add_u32 s97, %[h], 2"] + slot_addr("s95", "s97")])
         x_odd = (p + PFD) & 1
         step = ["s_add_u32 s80, %%[h], %d" % (PFD + 1), "s_cmp_lt_u32 s80, %[hend]", "s_cselect_b32 s86, %s, 0" % ("s90" if x_odd else "%d" % HB),
@@ -306,8 +313,11 @@ def gen(D, UB):
     P += ["s_mul_i32 s90, %%[nsplit], %d" % (2 * HB), "s_sub_u32 s90, s90, %d" % HB, "s_lshl_b32 s91, %[nsplit], 5", "s_sub_u32 s91, s91, 16"]
     # the cursors: the lane's first entry of every user block (lane16 = 16 lane); the accumulators and maxima: -inf (what the first slots
     # of the entry half-tile test belongs to no half-tile)
-    P.append("v_mul_u32_u24 %s, %d, %%[lane16]" % (cur(0), LSTRIDE // 16))
-    P += ["v_mov_b32 %s, %s" % (cur(u), cur(0)) for u in range(1, UB)]
+    if maxmode:
+        P += ["v_mov_b32 %s, 0xff800000" % cur(u) for u in range(UB)] + ["v_mov_b32 %s, 0xff800000" % thr(u) for u in range(UB)] + ["v_mov_b32 %s, 0" % vctmax]
+    else:
+        P.append("v_mul_u32_u24 %s, %d, %%[lane16]" % (cur(0), LSTRIDE // 16))
+        P += ["v_mov_b32 %s, %s" % (cur(u), cur(0)) for u in range(1, UB)]
     P += ["v_mov_b32 v%d, 0xff800000" % r for r in range(ACC0, ACC0 + 8 * UB)]
     P += ["v_mov_b32 %s, 0xff800000" % mt(u) for u in range(UB)]
     P.append("v_mov_b32 %s, -1" % vh)
@@ -325,6 +335,8 @@ def gen(D, UB):
     P += ["ds_read_b128 %s, %s offset:%d" % (metapair(0), vsb, HB), "s_waitcnt lgkmcnt(0)", "v_fma_f32 %s, %%[eu], %s, %s" % (ctr(0, 0), metan(0), metap(0)),
           "v_fma_f32 %s, %%[eu2], %s, %s" % (ctr(0, 0), metar(0), ctr(0, 0))]
     P += ["v_mov_b32 %s, %s" % (ctr(0, r), ctr(0, 0)) for r in (1, 2, 3)] + ["v_mov_b32 %s, %s" % (ctr(1, r), ctr(0, 0)) for r in range(4)]
+    if maxmode:
+        P.append("v_max_f32 %s, %s, %s" % (vctmax, vctmax, ctr(0, 0)))
     P += ["v_mov_b32 %s, %s" % (metap(1), metap(0))]
     for i, (k, ib) in enumerate(AHEAD):
         P += frag_read(k, ib, i, vrdb)
@@ -338,6 +350,10 @@ def gen(D, UB):
     E = ["92:", "s_waitcnt vmcnt(0) lgkmcnt(0)", "s_nop 15", "s_nop 15", "s_nop 15", "s_nop 15", "s_mov_b64 exec, -1", "s_mov_b32 m0, %[m0save]",
          "v_lshrrev_b32 %s, 2, %%[lane16]" % atmp(0)]
     E += ["global_store_dword %s, %s, %%[cnt] offset:%d" % (atmp(0), cur(u), 256 * u) for u in range(UB)]
+    if maxmode:      # behind the largest maxima [user block][lane]: the second largest, then the wave's largest ct (every lane the same)
+        E += ["v_add_u32 %s, %d, %s" % (atmp(0), 256 * UB, atmp(0))]
+        E += ["global_store_dword %s, %s, %%[cnt] offset:%d" % (atmp(0), thr(u), 256 * u) for u in range(UB)]
+        E += ["v_add_u32 %s, %d, %s" % (atmp(0), 256 * UB, atmp(0)), "global_store_dword %s, %s, %%[cnt]" % (atmp(0), vctmax)]
     E += ["s_waitcnt vmcnt(0)"]
     if os.environ.get("V5_LOADS"):
         for p in range(2):
@@ -345,18 +361,21 @@ def gen(D, UB):
     return P + b2 + E, THR0, LO_CLOBBER, CUR0
 
 
-def emit(D, UB):
-    L, THR0, LO, CUR0 = gen(D, UB)
+def emit(D, UB, maxmode=False):
+    L, THR0, LO, CUR0 = gen(D, UB, maxmode)
     out = []
     out.append("template <>")
-    out.append("struct Loop7<%d, %d> {" % (D, UB))
+    out.append("struct %s<%d, %d> {" % ("Loop7M" if maxmode else "Loop7", D, UB))
     out.append("    static constexpr int kSlotBytes = %d, kPfd = %d, kEntry = %d, kLaneStride = %d, kEntryStride = %d;" %
                (64 * D + (512 if D == 256 else 256), PFD, ENTRY, UB * ENTRY, 64 * UB * ENTRY))
     out.append("    // h: the local half-tile to start at (even).  hend: half-tiles of the launch (even).  rsrc: the wave's list region as a raw buffer; cnt: its")
     out.append("    // count words [user block][lane] (the cursors: lane * kLaneStride + entries * kEntryStride).")
     out.append("    static __device__ __forceinline__ void run(unsigned h, unsigned issued, unsigned hend, unsigned ring, unsigned w1024, unsigned t0, unsigned nsplit,")
     out.append("                                               unsigned imglo, unsigned imghi, unsigned metalo, unsigned metahi, float eu, float eu2, const void* ufrag,")
-    out.append("                                               u32x4 rsrc, unsigned* cnt, const float (&thr)[%d], unsigned lane16) {" % UB)
+    if maxmode:
+        out.append("                                               float* cnt, unsigned lane16) {     // cnt: [2][user block][lane] the two largest maxima, then [lane] the largest ct")
+    else:
+        out.append("                                               u32x4 rsrc, unsigned* cnt, const float (&thr)[%d], unsigned lane16) {" % UB)
     out.append("#if defined(__HIP_DEVICE_COMPILE__)")
     out.append("        unsigned m0save;")
     out.append("        asm volatile(")
@@ -365,12 +384,13 @@ def emit(D, UB):
     out.append('            : [h] "+&s"(h), [issued] "+&s"(issued), [m0save] "=&s"(m0save)')
     ins = ['[hend] "s"(hend)', '[ring] "s"(ring)', '[w1024] "s"(w1024)', '[t0] "s"(t0)', '[nsplit] "s"(nsplit)',
            '[imglo] "s"(imglo)', '[imghi] "s"(imghi)', '[metalo] "s"(metalo)', '[metahi] "s"(metahi)', '[eu] "s"(eu)', '[eu2] "s"(eu2)', '[ufrag] "s"(ufrag)',
-           '[rsrc] "s"(rsrc)', '[cnt] "s"(cnt)', '[lane16] "v"(lane16)']
-    ins += ['"{v%d}"(thr[%d])' % (THR0 + u, u) for u in range(UB)]
+           '[cnt] "s"(cnt)', '[lane16] "v"(lane16)']
+    if not maxmode:
+        ins += ['[rsrc] "s"(rsrc)'] + ['"{v%d}"(thr[%d])' % (THR0 + u, u) for u in range(UB)]
     out.append("            : " + ", ".join(ins))
     hi = 16 * UB
     clob = ['"memory"', '"vcc"', '"scc"'] + ['"s%d"' % r for r in range(80, 100)] + \
-           ['"v%d"' % r for r in range(LO, hi) if not THR0 <= r < THR0 + UB] + ['"a%d"' % r for r in range(4 * UB * (D // 32))] + \
+           ['"v%d"' % r for r in range(LO, hi) if maxmode or not THR0 <= r < THR0 + UB] + ['"a%d"' % r for r in range(4 * UB * (D // 32))] + \
            (['"v%d"' % r for r in range(128, 148)] if D == 256 else [])
     out.append("            : " + ", ".join(clob) + ");")
     out.append("#endif")
@@ -383,9 +403,12 @@ def main():
     print("// GENERATED by tools/gen_v7_emit_loop_asm.py -- do not edit.")
     print("#pragma once")
     print("template <int D, int UB> struct Loop7;")
+    print("template <int D, int UB> struct Loop7M;")
     for D in (64, 128):
         print(emit(D, 16))
+        print(emit(D, 16, True))
     print(emit(256, 8))
+    print(emit(256, 8, True))
 
 
 if __name__ == "__main__":
