@@ -49,6 +49,13 @@ def tune(fail_p=0.0, growth=0, cap_e=0, first_tiles=0):
 DEFAULTS = dict(fail_p=1e-6, growth=4, cap_e=64, first_tiles=4)
 
 
+def maxima(on):
+    from pda_amd import _lib
+    L = _lib.load()
+    L.pda_debug_funnel_maxima.restype, L.pda_debug_funnel_maxima.argtypes = C.c_int, [C.c_int]
+    assert L.pda_debug_funnel_maxima(int(on)) == 0
+
+
 def make(rng, nU, nI, d, scale=0.1):
     U = (rng.standard_normal((nU, d)) * scale).astype(np.float32)
     I = (rng.standard_normal((nI, d)) * scale * (0.5 + rng.random((nI, 1)))).astype(np.float32)
@@ -104,6 +111,32 @@ def test_funnel_lost_bets_and_overflowing_lists_take_the_exact_fallback(dev, mon
         np.testing.assert_array_equal(val, rval)
     finally:
         tune(**DEFAULTS)
+
+
+def test_funnel_without_the_maxima_launch(dev, monkeypatch):
+    """The first launch as an emitting launch against -inf (256 items, every value written, the train items masked by threshold7_kernel) instead of the
+    maxima launch: the same lists."""
+    from pda_amd import ops
+    rng = np.random.default_rng(17)
+    nU, nI, nu, d, K = 2600, 7000, 2100, 64, 50
+    U, I = make(rng, nU, nI, d)
+    users = np.arange(nu, dtype=np.int32)
+    rows = [rng.choice(nI, rng.integers(0, 40), replace=False) for _ in range(nU)]
+    rows[3] = np.arange(0, 300)                                    # (a user whose train items fill the first launch's items and more)
+    ip, ix = csr(rows)
+    Ut, It = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev)
+    hist = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    ridx, rval = c_oracle.score_topk(U, I, users, K, 0, None, *csr([rows[u] for u in users]), order=1)
+    try:
+        maxima(False)
+        (idx, val), nfb = funnel(ops, Ut, It, torch.from_numpy(users).to(dev), K, hist, monkeypatch)
+        np.testing.assert_array_equal(idx, ridx)
+        np.testing.assert_array_equal(val, rval)
+    finally:
+        maxima(True)
+    (idx, val), _ = funnel(ops, Ut, It, torch.from_numpy(users).to(dev), K, hist, monkeypatch)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(val, rval)
 
 
 def test_funnel_ties_zero_rows_and_short_lists(dev, monkeypatch):
