@@ -193,7 +193,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
             wsb + W.elist,
             reinterpret_cast<unsigned*>(wsb + W.ecnt), reinterpret_cast<float*>(wsb + W.eu), reinterpret_cast<unsigned*>(workspace), n, W.n_splits, L.n_tiles, 0, 0, W.cap_e,
             reinterpret_cast<float*>(wsb + W.mrun), nullptr};
-    Sel7 q{e, R, pb + L.rows, users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, 0, U, I_shard, out_keys,
+    Sel7 q{e, R, reinterpret_cast<const u32x4*>(pb + L.pinfo), users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, 0, U, I_shard, out_keys,
            reinterpret_cast<int*>(wsb + W.fail_list), fail_count};
     const std::vector<Stage7> stages = schedule7(L.n_tiles, n_items_local, K);
     for (const Stage7& st : stages) {

@@ -118,7 +118,7 @@ struct Args4 {
 template <int D, bool BF>
 __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, const float* __restrict__ pop, const int* __restrict__ order,
                                                     int n, int n_pad, unsigned char* __restrict__ rows, int* __restrict__ pos_of,
-                                                    int* __restrict__ hdr, unsigned char* __restrict__ rows5, int* __restrict__ meta5) {
+                                                    int* __restrict__ hdr, unsigned char* __restrict__ rows5, int* __restrict__ meta5, u32x4* __restrict__ pinfo) {
     constexpr int TPR = D / 8, RB = row_bytes(D);
     const int pos = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
     if (pos >= n_pad) return;
@@ -213,6 +213,7 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
         tail[2] = __float_as_uint(pos < n ? v : 0.f);
         tail[3] = pos < n ? __float_as_uint(rv) : 0u;                 // (the residual norm of the row's huge-geometry image)
         *reinterpret_cast<u32x4*>(rp + 2 * D + 32) = tail;
+        pinfo[pos] = u32x4{tail[2], tail[3], tail[1], tail[0]};                 // (||i||, ||i' - i~'||, local id, popularity)
     }
 }
 
@@ -272,12 +273,13 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     if (hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 16, s) != hipSuccess) return PDA_ERR_LAUNCH;
     unsigned char* r5 = pb + L.rows5;
     int* m5 = reinterpret_cast<int*>(pb + L.meta5);
+    u32x4* pi5 = reinterpret_cast<u32x4*>(pb + L.pinfo);
 #define PDA_P4(DD)                                                                                                              \
     case DD: {                                                                                                                  \
         constexpr int RPB = 256 / (DD / 8);                                                                                     \
         const dim3 grid((unsigned)((n_pad + RPB - 1) / RPB));                                                                   \
-        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5); \
-        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5);    \
+        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5, pi5); \
+        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5, pi5);    \
         break;                                                                                                                  \
     }
     switch (d) { PDA_P4(64) PDA_P4(128) PDA_P4(256) }

@@ -16,7 +16,7 @@ __host__ __device__ constexpr int row_bytes(int d) { return 2 * d + 48; }
 __host__ __device__ constexpr int tile_bytes(int d) { return 64 * row_bytes(d); }
 
 struct Prep4Layout {
-    size_t hdr, pos_of, sufA, sufB, sufR, rows, rows5, meta5, total;
+    size_t hdr, pos_of, sufA, sufB, sufR, rows, rows5, meta5, pinfo, total;
     int n_tiles;
 };
 Prep4Layout prep4_layout(int n, int d) {
@@ -34,7 +34,10 @@ Prep4Layout prep4_layout(int n, int d) {
     // 64 d bytes -- and (pmax, nmax) per half-tile
     L.rows5 = al(L.total);
     L.meta5 = L.rows5 + al((size_t)L.n_tiles * 2 * 64 * (size_t)d);
-    L.total = L.meta5 + al((size_t)L.n_tiles * 2 * 16);              // (pmax, nmax, 0, 0) per half-tile: one 16-byte LDS-DMA lane
+    L.pinfo = L.meta5 + al((size_t)L.n_tiles * 2 * 16);              // (pmax, nmax, rmax, 0) per half-tile: one 16-byte LDS-DMA lane
+    // per visiting position, 16 bytes: (||i|| padded, ||i' - bf16(i')|| padded, local id, popularity) -- what the funnel's selection gathers per pair: a
+    // dense 3 MB array (L2 / MALL resident) instead of the tails of the 2 d + 48-byte rows
+    L.total = L.pinfo + al((size_t)L.n_tiles * 64 * 16);
     return L;
 }
 

@@ -146,7 +146,7 @@ struct Rows7 {
 struct Sel7 {
     Args7 e;
     Rows7 r;
-    const unsigned char* rows;        // generation 4's image (the tail of a row: popularity, local id, padded norm)
+    const u32x4* pinfo;               // per visiting position: (||i|| padded, ||i' - i~'|| padded, local id, popularity) -- the prep's dense 16-byte records
     const int32_t* users;
     const int64_t* hist_indptr;
     const int32_t* hist_indices;
@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(256) hist_bloom7_kernel(const int32_t* __restr
 
 template <int D>
 __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
-    constexpr int UPW = D == 256 ? 128 : 256, UT = 4 * UPW, NU = UPW / 16, RB4 = row_bytes(D);
+    constexpr int UPW = D == 256 ? 128 : 256, UT = 4 * UPW, NU = UPW / 16;
     constexpr unsigned ES = 64u * NU * 48u, LS = NU * 48u;
     constexpr int EPW = 64 / NU;                                 // entries of a list per step of the wave
     const int lane = threadIdx.x & 63;
@@ -327,15 +327,15 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
         if (!__any(any_p)) continue;                            // (wave-uniform: the shuffles below are reached by all lanes or none)
         float4 mt = {0.f, 0.f, 0.f, 0.f};
         if (any_p) mt = *reinterpret_cast<const float4*>(g.e.meta5 + 4 * (size_t)(pos0 >> 5));
-        // the tails: (popularity, local id, ||i||, ||i - i~||).  The first launch (everything above -inf: 256 items per row, of which a handful stay)
+        // the positions' records: (||i||, ||i - i~||, local id, popularity).  The first launch (everything above -inf: 256 items per row, of which a handful stay)
         // takes the half-tile's maxima instead (looser, as valid) and leaves the train-item check of what stays to threshold7_kernel: its
         // threshold may then be one of the row's train items -- a rank less on a rank that is chosen with margin (rank_for7).
         f32x4 tl[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
-            tl[r] = f32x4{0.f, 0.f, mt.y, mt.z};
-            if (pp[r] && !first) tl[r] = *reinterpret_cast<const f32x4*>(g.rows + (size_t)pos * RB4 + 2 * D + 32);
+            tl[r] = f32x4{mt.y, mt.z, 0.f, 0.f};
+            if (pp[r] && !first) tl[r] = __builtin_bit_cast(f32x4, g.pinfo[pos]);
         }
         // (the Bloom words by visiting position: with the tails, not behind them)
         uint32_t bw1[8], bw2[8];
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
-            const float bp = __builtin_fmaf(ua, tl[r][2], ub2 * tl[r][3]);
+            const float bp = __builtin_fmaf(ua, tl[r][0], ub2 * tl[r][1]);
             const float st = vv[r] - ct, guard = (fabsf(vv[r]) + ct) * 4.8e-7f;           // (the roundings of the accumulator and of this subtraction)
             const uint32_t ubo = pda_ordf(st + bp + guard + 0.0f), lbo = pda_ordf(st - bp - guard + 0.0f);
             bnds[r] = ((uint64_t)ubo << 32) | lbo;
@@ -364,7 +364,7 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
                 const bool look = p && (((bw1[r] >> (bloom7_h1(pos) & 31u)) & (bw2[r] >> (bloom7_h2(pos) & 31u)) & 1u) != 0u);
                 if (__any(look)) {
                     if (look) {
-                        const int item = g.item_offset + __float_as_int(tl[r][1]);
+                        const int item = g.item_offset + __float_as_int(tl[r][2]);
                         long long lo = hb, hi2 = he;
                         while (lo < hi2) {
                             const long long mid = (lo + hi2) >> 1;
@@ -519,7 +519,7 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
         if (!(live & (1u << k))) continue;
         bool p = bnd[k] != 0ull && (uint32_t)(bnd[k] >> 32) >= keep_o;
         if (mask_here && p) {
-            const int item = g.item_offset + *reinterpret_cast<const int*>(g.rows + (size_t)(unsigned)key[k] * row_bytes(D) + 2 * D + 36);
+            const int item = g.item_offset + (int)g.pinfo[(unsigned)key[k]][2];
             long long lo = hb, hi2 = he;
             while (lo < hi2) {
                 const long long mid = (lo + hi2) >> 1;
@@ -544,7 +544,7 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
 // on the fallback list instead.
 template <int D, bool BF>
 __global__ void __launch_bounds__(256) resolve7_kernel(Sel7 g) {
-    constexpr int RB4 = row_bytes(D), LPC = D / 32, CPP = 64 / LPC;
+    constexpr int LPC = D / 32, CPP = 64 / LPC;
     __shared__ uint64_t keys_s[4][kCand7];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n_rows = g.e.n_users_dev != nullptr ? min(g.e.n_users_blk, *g.e.n_users_dev) : g.e.n_users_blk;
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(256) resolve7_kernel(Sel7 g) {
     for (int base = 0; base < n; base += CPP) {
         const bool have = base + ci < n;
         const unsigned pos = have ? (unsigned)g.r.cand[((size_t)rb * kCand7 + base + ci) * 2] : 0u;
-        const int loc = *reinterpret_cast<const int*>(g.rows + (size_t)pos * RB4 + 2 * D + 36);
+        const int loc = (int)g.pinfo[pos][2];
         f32x4 ii[8];
         const size_t ib = (size_t)loc * D + q * (LPC == 8 ? 32 : 8);
 #pragma unroll
