@@ -356,26 +356,22 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
         # which kernel the timed launches ran: decoded from the identity word the sweep kernel itself wrote into the workspace
         ident = ops.kernel_identity(st_d["kernel_id"]) if "kernel_id" in st_d else {"generation": 0}
         geo_name = ident.get("geometry") if ident.get("generation") == 4 else None
-        huge = geo_name in ("huge", "huge32", "huge2")
+        huge = geo_name == "huge"
         kname = "sweep5_kernel" if huge else ("sweep4_kernel" if gen == "v4" else "score_topk_v3_kernel")
-        geo = {"lds": "256 users per workgroup, lists in LDS (Geo4<D, 0>)", "hbm": "lists in the workspace (Geo4<D, 1>)",
-               "wide": "wide: 512 users per workgroup (Geo4<D, 2>)", "many": "many candidates: 128 users per workgroup (Geo4<D, 3>)",
+        geo = {"lds": "256 users per workgroup, lists in LDS (Geo4<D, 0>)", "many": "many candidates: 128 users per workgroup (Geo4<D, 3>)",
                "huge": "huge: 1 024 users per workgroup, four 512-register waves, user rows in AGPRs, transposed product on v_mfma_f32_16x16x32_bf16, "
-                       "VALU threshold test (no test k-step), sorted hand-over from the warm-up (pda_v5_sweep.h, tools/gen_v6_loop_asm.py)",
-               "huge32": "huge, first form of the loop: v_mfma_f32_32x32x16_bf16 (tools/gen_v5_loop_asm.py)",
-               "huge2": "huge, two 512-user workgroups per CU (256-register waves)"}.get(geo_name, "")
+                       "VALU threshold test (no test k-step), sorted hand-over from the warm-up (pda_v5_sweep.h, tools/gen_v6_loop_asm.py)"}.get(geo_name, "")
         if W.d == 256 and huge:
             geo = ("huge at d = 256: 512 users per workgroup (128 users per wave: 8 blocks x 8 k-steps fill the 256 AGPRs), one workgroup per CU, "
                    "transposed product on v_mfma_f32_16x16x32_bf16, VALU threshold test (Loop6<256, 8>, pda_v5_sweep.h)")
         elif W.d == 256:
-            geo = "256 users per workgroup, lists in the workspace, 8 + 2 + 2 waves (Geo4<256, 0>)"
+            geo = "256 users per workgroup, lists in the workspace, 8 + 3 + 1 waves (Geo4<256, 0>)"
         bf_s = "true" if td_name == "bf16" else "false"
         if huge:
-            ktemplate = "sweep5_kernel<%d, %s, %s, %d>" % (W.d, bf_s, "false" if (geo_name == "huge32" and W.d != 256) else "true",
-                                                          128 if (geo_name == "huge2" or W.d == 256) else 256)
+            ktemplate = "sweep5_kernel<%d, %s, true, %d>" % (W.d, bf_s, 128 if W.d == 256 else 256)
         elif gen == "v4":
             ktemplate = "sweep4_kernel<%d, %d, %s, %s, %d>" % (W.d, 1 if head else 0, bf_s, "true" if ident.get("early_stop") else "false",
-                                                             {"lds": 0, "hbm": 1, "wide": 2, "many": 3}.get(geo_name, 0))
+                                                             {"lds": 0, "many": 3}.get(geo_name, 0))
         else:
             ktemplate = None
         ksteps_exec = (W.d / 16) if huge else (W.d / 16 + 1)       # the huge geometry has no folded test k-step

@@ -198,19 +198,14 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        (blocks of 98 304 users and more with one item split; internal: rows of out_keys stay the caller's block rows)
  * d in {64,128,256}; K <= 54; n_items_local <= 2^26.  out_keys doubles as the
  * hand-over buffer between the exact warm-up kernel and the sweep.  PDA_ERR_UNSUPPORTED: use the entry points above.
- * early_stop: bit 0 = exact early termination; bit 1 = PDA_SWEEP_FEW_CANDIDATES, a GEOMETRY HINT (results never depend on it):
- *        the caller expects next to no list insertions behind the warm-up -- the popularity head swept in visiting order --, so
- *        at d <= 128 the exact lists move from the LDS to the workspace, which pays for four tile slots and loaders that run
- *        ahead of the MFMA waves (with two slots the MFMA waves of the dense sweep spend a fifth of their time waiting for tiles).
- *        Candidate-heavy sweeps (natural order, raw head) are 2 x slower with it.
+ * early_stop: bit 0 = exact early termination; the other bits are GEOMETRY HINTS (results never depend on them).
  *        bits 4 .. 6 = PDA_SWEEP_WARM_TILES(n), n = 1 .. 4 (0 = 4): 64-item tiles per split scored by the exact warm-up kernel.
  *        An item shard of an R-rank job wants 4 / R: the R warm-ups cover R x 64 n items between them, and the warm-up is the
- *        per-rank cost that does not shrink with the shard. */
+ *        per-rank cost that does not shrink with the shard.
+ *        bit 1 = PDA_SWEEP_FEW_CANDIDATES and bit 2 = PDA_SWEEP_WIDE: accepted, select nothing.  (Rounds 3 and 4: the default geometry with
+ *        its lists in the workspace, and 512-user workgroups with 64 user rows per MFMA wave -- the huge geometry, bit 7, took over every
+ *        block they served and round 5 removed them; profiles/README.md keeps their measurements.) */
 #define PDA_SWEEP_FEW_CANDIDATES 2
-/*        bit 2 = PDA_SWEEP_WIDE, a second geometry hint for the same kind of sweep on LARGE user blocks (> 65 536 users, d <= 128):
- *        512 users per workgroup, 64 user rows per MFMA wave (two A operands per B read), lists in the workspace, four tile slots --
- *        half the LDS reads and half the tile traffic per MFMA, which on this power-limited part is clock.  Identical keys.
- *        Dense sweeps only: with bit 0 set the hint is ignored. */
 #define PDA_SWEEP_WIDE 4
 /*        bit 3 = PDA_SWEEP_MANY_CANDIDATES, the geometry hint for the opposite kind of sweep (d <= 128): hundreds of list
  *        insertions per user -- the raw head, the popularity head in natural item order.  128 users per workgroup: four MFMA
@@ -221,17 +216,13 @@ int pda_score_topk_ordered_bf16(const uint16_t* U, const uint16_t* I_shard, cons
  *        blocks (a prep built with the popularity the call passes): 1 024 users per workgroup, four waves of 512
  *        registers, 256 users each -- the users' bf16 rows in AGPRs, every item fragment read from the LDS feeds EIGHT MFMAs, the
  *        product transposed so that the threshold test is a per-lane compare (no test k-step), the item image pre-scaled by the
- *        popularity (pda_v5_sweep.h).  d = 256: 512 users per workgroup, 128 per wave (bits 8 and 9 are ignored there).  Smaller
+ *        popularity (pda_v5_sweep.h).  d = 256: 512 users per workgroup, 128 per wave.  Smaller
  *        blocks fill the chip with item splits (pda_amd.ops.huge_splits chooses them; one shared warm-up, bit 10).  Identical keys.
- *        Dense sweeps only (with bit 0 set: ignored); other heads: the wide geometry. */
+ *        Dense sweeps only (with bit 0 set: ignored); other heads, or a prep built without the popularity: the default geometry. */
 #define PDA_SWEEP_HUGE 128
-/*        bit 8 = PDA_SWEEP_HUGE_32X32, with bit 7: the first form of that loop, on v_mfma_f32_32x32x16_bf16 (eight user blocks of 32
- *        per wave) instead of v_mfma_f32_16x16x32_bf16 (sixteen of 16: half the accumulator registers moved per MAC, which on this
- *        power-limited part is clock).  Kept for A/B measurements.  Identical keys. */
+/*        bits 8 and 9 = PDA_SWEEP_HUGE_32X32, PDA_SWEEP_HUGE_2WG: accepted, select nothing.  (Round 4's A/B variants of the huge loop -- on
+ *        v_mfma_f32_32x32x16_bf16, 9.16 against 8.07 ms, and as two 512-user workgroups per CU, 8.38 ms -- removed in round 5.) */
 #define PDA_SWEEP_HUGE_32X32 256
-/*        bit 9 = PDA_SWEEP_HUGE_2WG, with bit 7: TWO 512-user workgroups per CU (eight waves of 256 registers, 128 users each: a SIMD's
- *        second wave has the matrix pipe while the first runs its VALU tests) instead of one 1 024-user workgroup.  Measured slower on
- *        large blocks (the pipe is busier, the clock lower: twice the LDS traffic per MFMA); kept for A/B measurements.  Identical keys. */
 #define PDA_SWEEP_HUGE_2WG 512
 /*        bit 10 = PDA_SWEEP_WARM_PER_SPLIT.  By default a one-call sweep (warm-up + sweep in one entry point) over n_splits > 1 item
  *        splits runs ONE exact warm-up per user -- on the first warm tiles of the whole visiting order, handed to split 0 -- and every

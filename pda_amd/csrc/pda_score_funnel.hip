@@ -355,8 +355,6 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
             hint = PDA_SWEEP_HUGE;                               // the huge geometry, the catalogue split so that the block fills the chip
         } else if (head == PDA_HEAD_POP && sweep_mode == PDA_SWEEP_MODE_VISITING_ORDER && n_users_blk >= 196609 && d <= 128) {
             hint = PDA_SWEEP_HUGE;
-        } else if (head == PDA_HEAD_POP && sweep_mode == PDA_SWEEP_MODE_VISITING_ORDER && n_users_blk >= 65537 && d <= 128) {
-            hint = PDA_SWEEP_WIDE;
         } else if (d <= 128 && !early && (head == PDA_HEAD_RAW || !ordered)) {
             hint = PDA_SWEEP_MANY_CANDIDATES;                    // hundreds of list insertions per user
         }

@@ -9,12 +9,13 @@
 //     drains their candidate rings, gathers the exact rows, runs the fp32 fmaf chains, appends, compacts, publishes the
 //     thresholds).  The MFMA waves never wait for a gather: the latency-bound half of the algorithm runs beside them on the
 //     same SIMDs.  Results do not depend on the timing: a stale threshold is a LOWER threshold (more candidates, never
-//     fewer), every candidate is rescored exactly, and the lists keep the exact best K.  Four geometries (Geo4<D, GM>, chosen by
+//     fewer), every candidate is rescored exactly, and the lists keep the exact best K.  Two geometries (Geo4<D, GM>, chosen by
 //     the caller's hint, identical keys): 8 MFMA x 32 rows + 4 loaders + 4 rescoring waves with the lists in the LDS (default,
-//     d <= 128); the same with the lists in the workspace and four tile slots (d = 256: 8 + 2 + 2; PDA_SWEEP_FEW_CANDIDATES);
-//     WIDE: 8 MFMA x 64 rows (two A operands per B read), 512 users per workgroup -- the dense sweep of large blocks, power-
-//     limited, wants the fewest LDS reads and DMA bytes per MFMA; MANY: 4 MFMA x 32 rows + 4 loaders + 8 rescoring waves, 128
-//     users per workgroup -- the raw head and natural order, hundreds of list insertions per user, are bound by rescoring;
+//     d <= 128; d = 256: 8 + 3 + 1, the lists in the workspace and four tile slots); MANY: 4 MFMA x 32 rows + 4 loaders + 8
+//     rescoring waves, 128 users per workgroup -- the raw head and natural order, hundreds of list insertions per user, are
+//     bound by rescoring.  (Rounds 3 and 4 also shipped a FEW_CANDIDATES geometry -- the default with its lists in the workspace --
+//     and a WIDE one -- 8 MFMA x 64 rows, 512 users per workgroup; the huge geometry, pda_v5_sweep.h, took over every block
+//     they served and round 5 removed them: profiles/README.md keeps their measurements.)
 //   * has no s_barrier in the loop (it would tie the rescoring waves to the tile cadence): the MFMA waves hand tiles to each
 //     other through one monotonic LDS counter -- "my share of tile i+1 has landed and I am done reading tile i" -- which
 //     orders both the RAW and the WAR side of the two tile buffers;
@@ -737,18 +738,8 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_LSLEEP
 #define PDA_V4_LSLEEP 1     // loaders: s_sleep between polls for a free slot
 #endif
-#ifndef PDA_V4_UA
-#define PDA_V4_UA 1       // d <= 128: A operands (32 user rows each) per MFMA wave and B read of the DEFAULT geometry.  (2 as a build
-                          // option was round 2's experiment; the 64-rows-per-wave mapping is the WIDE geometry, Geo4<D, 2>, now.)
-#endif
 #ifndef PDA_V4_GL
-#define PDA_V4_GL 2       // exact lists: 0 in LDS (needs PDA_V4_UA=1), 1 in HBM, 2 = in HBM for d = 256 and for PDA_V4_UA=2
-#endif
-#ifndef PDA_V4_WIDE_DOUBLE
-#define PDA_V4_WIDE_DOUBLE 1     // wide geometry, d = 128: two half-tiles per asm statement, accumulators tested inside it
-#endif
-#ifndef PDA_V4_WIDE_PREFETCH
-#define PDA_V4_WIDE_PREFETCH 1   // wide geometry, d = 128: the next block's first B fragments are read under this block's last MFMAs
+#define PDA_V4_GL 2       // exact lists: 0 in LDS, 1 in HBM, 2 = in HBM for d = 256
 #endif
 #ifndef PDA_V4_HANDOVER_WS
 #define PDA_V4_HANDOVER_WS 1   // one-call sweeps: warm-up lists handed over through the workspace with K .. kCap4 keys per row
@@ -762,9 +753,6 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_RING_MANY
 #define PDA_V4_RING_MANY 128   // candidate ring entries of the many-candidates geometry (256 / 512: no faster -- later thresholds, more candidates)
 #endif
-#ifndef PDA_V4_LWIDE
-#define PDA_V4_LWIDE 2         // wide geometry: loader waves (of the four waves beside the eight MFMA waves; the rest rescore)
-#endif
 #ifndef PDA_V4_L256
 #define PDA_V4_L256 3          // d = 256: loader waves (three: config-5 shard 27.78 -> 26.21 ms dense, 0.51 of the roof; 35 DMA pieces per 64-item block were
                               // too many for two) (of the four waves beside the eight MFMA waves; the rest rescore)
@@ -775,9 +763,6 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 #ifndef PDA_V4_NB256
 #define PDA_V4_NB256 2        // d = 256: half-tiles per block.  64-item blocks = two accumulator chains per wave: config-5 shard 30.65 -> 29.10 ms dense,
                               // 5.87 -> 5.39 ms early-terminating (one chain per wave, two waves per SIMD, left the matrix pipe waiting on dependent MFMAs)
-#endif
-#ifndef PDA_V4_NSLOT_WIDE
-#define PDA_V4_NSLOT_WIDE 12  // tile slots of the wide geometry (32-item blocks of 9.5 KiB; 8 -> 12: -1 %, same box)
 #endif
 #ifndef PDA_V4_NSLOT_MAX
 #define PDA_V4_NSLOT_MAX 5   // (timing experiments raise it: the votes of the early termination are then wrong)
@@ -791,29 +776,22 @@ __global__ void __launch_bounds__(kThreads, (D <= 128 ? 2 : 1)) warm4_kernel(Arg
 // any skew between the eight MFMA waves turns into waiting -- 22 % of their time in the dense sweep (cycle counters of the
 // profiling build).  Candidate-heavy sweeps (natural order, raw head: hundreds of list insertions per user) keep their lists in
 // the LDS: every insertion would be a round trip to L2.  The caller says which (pda_score_topk4_*: early_stop bit 1).
-// GM = 2 (d <= 128; round 3), the WIDE geometry: 64 user rows per MFMA wave (two A operands per B read), 512 users per workgroup,
-// lists in the workspace, four tile slots, 8 MFMA + 2 loader + 2 rescoring waves at <= 168 VGPRs.  Half the LDS reads AND half the
-// tile traffic per MFMA: on a power-limited chip that is clock (tools/ubench/mfma_struct D: 1 494 - 1 520 TFLOP/s executed against
-// 1 335 for the 256-user mapping, random data).  Only for large user blocks with few candidates (the caller's hint): 512-user
-// workgroups leave half the chip idle below 131 072 users, and every list insertion is a round trip to L2.
 template <int D, int GM = 0>
 struct Geo4 {
-    static constexpr bool WIDE = D <= 128 && GM == 2;
+    static_assert(GM == 0 || GM == 3, "geometries: 0 = default, 3 = many candidates");
     static constexpr bool MANY = D <= 128 && GM == 3;
     static constexpr int MW = MANY ? 4 : kMainWaves;                  // MFMA waves
-    static constexpr int UA = D <= 128 ? (WIDE ? 2 : (MANY ? 1 : PDA_V4_UA)) : 1;  // A operands per B read: 32 UA user rows per MFMA wave
+    static constexpr int UA = 1;                                      // A operands per B read: 32 UA user rows per MFMA wave
     // the exact lists in HBM (workspace) free the LDS for four tile slots (d = 256: 8.1 instead of 9.0 ms on a config-5 shard);
     // 512 users x 57 x 8 B would not fit the LDS anyway
-    static constexpr bool GL = (PDA_V4_GL == 2 ? (D > 128 || UA > 1) : PDA_V4_GL != 0) || GM == 1 || GM == 2;
+    static constexpr bool GL = PDA_V4_GL == 2 ? D > 128 : PDA_V4_GL != 0;
 #ifdef PDA_V4_NBX   /* timing experiment only (results are wrong): NBX half-tiles per block at d <= 128 */
     static constexpr int NB = D <= 128 ? PDA_V4_NBX : 1;
 #else
-    static constexpr int NB = (D <= 128 && UA == 1) ? 2 : (D > 128 ? PDA_V4_NB256 : 1);          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
-    // (wide: 64 rows x 64 items per block would hold 64 + 64 registers of A operands and accumulators -- the block statement and what
-    // lives across it do not fit 168 VGPRs: hipcc spilled the accumulators behind every block; 64 rows x 32 items do)
+    static constexpr int NB = D <= 128 ? 2 : PDA_V4_NB256;          // half-tiles (32 items) per block; accumulator chains per wave = NB UA
 #endif
-    static constexpr int LOADERS = (D <= 128 && UA == 1) ? 4 : (D > 128 ? PDA_V4_L256 : PDA_V4_LWIDE);
-    static constexpr int RESCORERS = MANY ? 8 : ((D <= 128 && UA == 1) ? 4 : (D > 128 ? 4 - PDA_V4_L256 : 4 - PDA_V4_LWIDE));
+    static constexpr int LOADERS = D <= 128 ? 4 : PDA_V4_L256;
+    static constexpr int RESCORERS = MANY ? 8 : (D <= 128 ? 4 : 4 - PDA_V4_L256);
     static constexpr int ROWS = 32 * UA;                 // user rows per MFMA wave
     // candidate rings: one per MFMA wave, or (MANY) two -- rows 0..15 and 16..31 of the wave -- each with a rescoring wave of its own
     static constexpr int NRINGS = MW > RESCORERS ? MW : RESCORERS;
@@ -827,9 +805,8 @@ struct Geo4 {
     static constexpr int BB = NB * HB;                   // one block = one ring slot
     static constexpr int NP = (BB + 1023) / 1024;        // 1 KiB DMA pieces per block; the last one may be half a piece (32 lanes)
     static constexpr int LASTL = (BB % 1024) ? (BB % 1024) / 16 : 64;
-    // (MANY: 128 users' lists leave the LDS room for four slots; WIDE: eight -- its MFMA waves want block b + 1 landed before they
-    // start block b, see the cross-block prefetch: with four slots they waited for tiles a quarter of their time)
-    static constexpr int NSLOT = WIDE ? PDA_V4_NSLOT_WIDE : (GL || MANY) ? PDA_V4_NSLOT : 2;
+    // (MANY: 128 users' lists leave the LDS room for four slots)
+    static constexpr int NSLOT = (GL || MANY) ? PDA_V4_NSLOT : 2;
     static constexpr size_t lds_tiles = NSLOT * (size_t)BB;
     // list slots per user row: a full list is compacted to its best K, i.e. every CAP - K insertions (half of what a candidate costs
     // its rescoring wave); 128 users leave the LDS room for 64
@@ -838,8 +815,7 @@ struct Geo4 {
     static constexpr int RING = MANY ? PDA_V4_RING_MANY : kRing4;      // entries per candidate ring (a push needs 64 free)
     static constexpr size_t lds_total = lds_tiles + lds_lists + (size_t)UT * 8 + kMainWaves * RING * 4 + 512;
     static_assert(NRINGS <= kMainWaves && RPW * MW == NRINGS && MPR * RESCORERS == NRINGS, "ring bookkeeping: eight words each");
-    static_assert(NSLOT >= 2 && (NSLOT <= PDA_V4_NSLOT_MAX || WIDE), "vote timing of the early termination (the wide geometry has no early-terminating instance)");
-    static_assert(GL || UA == 1, "512-user workgroups keep their lists in HBM");
+    static_assert(NSLOT >= 2 && NSLOT <= PDA_V4_NSLOT_MAX, "vote timing of the early termination");
 };
 
 // ES: exact early termination on (sufA / sufB non-NULL).  Two instantiations: the votes and the dead-wave path are a handful of
@@ -1507,109 +1483,11 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         sb_nx = g.sufB[tn];
     }
     constexpr int S = NB * NM, PF = S < PDA_V4_PF ? S : PDA_V4_PF;
-    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && (D <= 128 || PDA_V4_ASM256 != 0) && ((UA == 1 && NB == 2) || (UA == 2 && NB == 1 && G::WIDE));     // the block as one asm statement (below)
+    constexpr bool kAsmGeo = PDA_V4_ASM != 0 && (D <= 128 || PDA_V4_ASM256 != 0) && UA == 1 && NB == 2;     // the block as one asm statement (below)
     constexpr bool PFX = !kAsmGeo && NSLOT >= 3 && S % PF == 0;          // prefetch across the block boundary
     u32x4 bq[PF];
-    // wide geometry, d = 128, dense sweep: cross-block prefetch of the B fragments (pda_v4_block_asm.h, BlockAsm2P)
-    constexpr bool kPrefetchGeo = kAsmGeo && G::WIDE && D == 128 && !ES && PDA_V4_WIDE_PREFETCH != 0;
-    [[maybe_unused]] u32x4 tqa[3] = {}, tqb[3] = {};
-    [[maybe_unused]] bool swp = false;
-    if constexpr (kPrefetchGeo) {
-        if (n_blk > 0) {
-            ensure_landed(0);
-            BlockAsm2Pro<D>::run(tqa[0], tqa[1], tqa[2], lane_base_lds);
-        }
-    }
     int dead_from = 0x7FFFFFFF;                // first tile from which no row of this wave can be reached (early termination)
-    // ---- wide geometry, d = 128, dense sweep: TWO half-tiles per statement (BlockAsm2D).  36 MFMAs per wave and statement instead of
-    // 18: what a wave does between two statements has twice the time to hide under the other wave's MFMAs (the config-5 shard, whose
-    // statements are that long, keeps the pipe 79 % busy).  The accumulators stay inside the statement -- it hands back the OR of
-    // their bit patterns per half-tile and row set; a half-tile with a set sign bit (next to none in a dense sweep in visiting
-    // order) is scored again on its own (BlockAsm2) and goes through the usual test and push.
-    constexpr bool kDoubleGeo = kPrefetchGeo && PDA_V4_WIDE_DOUBLE != 0;
-    if constexpr (kDoubleGeo) {
-        static_assert(G::WAVES <= 12 && BlockAsm2D<D>::kAccBase + 32 <= 168, "BlockAsm2D keeps its accumulators in v136 .. v167: 168 VGPRs per wave");
-        for (int b = 0; b < n_blk; b += 2) {
-            const unsigned pr_tv = lds_ld(&s_tver[w]);
-            const int bn = b + 2 < n_blk ? b + 2 : b + 1;           // the block whose first fragments this statement reads ahead
-            ensure_landed(bn);
-            unsigned lnd[kLoaders];
-            const bool asked = b + 2 < n_blk && landed_c < (unsigned)min(b + 5, n_blk);
-            if (asked) {
-#pragma unroll
-                for (int z = 0; z < kLoaders; ++z) lnd[z] = lds_ld(&s_landed[z]);
-            } else {
-#pragma unroll
-                for (int z = 0; z < kLoaders; ++z) lnd[z] = 0xFFFFFFFFu;
-            }
-            const unsigned a0 = lane_base_lds + (unsigned)((b % NSLOT) * BB), a1 = lane_base_lds + (unsigned)(((b + 1) % NSLOT) * BB);
-            const unsigned an = lane_base_lds + (unsigned)((bn % NSLOT) * BB);
-            const unsigned api0 = a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32), api1 = a1 - 16u * (unsigned)h + (unsigned)(2 * D + 32);
-            unsigned mo00, mo01, mo10, mo11;
-            u32x2 pi0, pi1;
-            BlockAsm2D<D>::run(mo00, mo01, mo10, mo11, pi0, pi1, tqa[0], tqa[1], tqa[2], ah, aex, a0, a1, api0, api1, an);
-            if (asked) {
-                unsigned mn = 0xFFFFFFFFu;
-#pragma unroll
-                for (int z = 0; z < kLoaders; ++z) mn = min(mn, lnd[z]);
-                landed_c = mn;
-            }
-            const float pv0 = __uint_as_float(pi0[0]), pv1 = __uint_as_float(pi1[0]);
-            bool c0 = (int)(mo00 | mo01) < 0, c1 = (int)(mo10 | mo11) < 0;
-            if constexpr (HEAD == PDA_HEAD_POP) {
-                const float tm = fminf(thr_min[0], thr_min[UA - 1]);
-                c0 = c0 || pv0 > tm;
-                c1 = c1 || pv1 > tm;
-            }
-            const bool hit0 = __any(c0), hit1 = __any(c1);
-            if (__builtin_expect(hit0 || hit1, 0)) {
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    if (hh == 0 ? !hit0 : !hit1) continue;
-                    f32x16 accr[2];
-                    u32x2 pid;
-                    BlockAsm2<D>::run(accr[0], accr[1], pid, ah, aex, hh == 0 ? a0 : a1, hh == 0 ? api0 : api1);
-                    const float popv1 = __uint_as_float(pid[0]);
-                    const int locv1 = (int)pid[1];
-#pragma unroll
-                    for (int u = 0; u < UA; ++u) {
-                        uint32_t mo = 0;
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) mo |= (uint32_t)__float_as_int(accr[u][r]);
-                        bool clampy = false;
-                        if constexpr (HEAD == PDA_HEAD_POP) clampy = __any(popv1 > thr_min[u]);
-                        if (__any((int)mo < 0) || clampy) {
-                            uint32_t mcb = 0;
-                            if (__any((int)mo < 0)) {
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) mcb = __builtin_amdgcn_alignbit(mcb, (uint32_t)__float_as_int(accr[u][r]), 31);
-                            }
-                            if (clampy) {
-                                int hv = h;
-#if defined(__HIP_DEVICE_COMPILE__)
-                                asm volatile("" : "+v"(hv));
-#endif
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) mcb |= (popv1 > thr_of(r, hv, u)) ? (1u << (15 - r)) : 0u;
-                            }
-                            push_mask(mcb, locv1, u);
-                            PDA_CBAR();
-                            publish_tails();
-                        }
-                    }
-                }
-            }
-            PDA_CBAR();
-            lds_st(&s_released[w], (unsigned)(b + 2));
-            PDA_CBAR();
-            if (pr_tv != tver_seen) {
-                tver_seen = pr_tv;
-                refresh_thr();
-            }
-            ++n_done;                              // a 64-item tile is complete
-        }
-    }
-    for (int b = kDoubleGeo ? n_blk : 0; b < n_blk && !stopped; ++b) {
+    for (int b = 0; b < n_blk && !stopped; ++b) {
         const unsigned pr_tv = lds_ld(&s_tver[w]);      // read here, used at the end of the iteration
         // ---- early termination.  In front of the last block of tile i every wave votes "nothing at or behind tile i + kVL
         // can reach my rows" (candidates still in the ring can only raise thresholds) -- BEFORE it releases that block.  Once
@@ -1654,13 +1532,11 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         // With three slots the first B fragments of block b + 1 are read while the MFMAs of block b are still being issued: the
         // wave comes back from the accumulator test of block b with its operands in registers.
         const bool has_next = (PFX || kAsmGeo) && b + 1 < n_blk;
-        if constexpr (kPrefetchGeo) ensure_landed(b + 1 < n_blk ? b + 1 : b);      // (this block's statement reads the start of the next)
-        else if (b == 0 || !PFX) ensure_landed(b);       // (asm path: a poll only when the answer read under the previous block said "not yet")
+        if (b == 0 || !PFX) ensure_landed(b);       // (asm path: a poll only when the answer read under the previous block said "not yet")
         // "has block b + 1 landed?" is asked here and looked at half a block later, in front of the first read of block b + 1:
         // a synchronous poll costs an LDS round trip per block (440 cycles of a block's 1 600 on a busy LDS)
         unsigned lnd[kLoaders];
-        // (with the cross-block prefetch the answer is wanted a block earlier: "has block b + 2 landed?")
-        const bool asked = has_next && landed_c < (unsigned)min(b + (kPrefetchGeo ? 3 : 2), n_blk);
+        const bool asked = has_next && landed_c < (unsigned)min(b + 2, n_blk);
         if (asked) {
 #pragma unroll
             for (int z = 0; z < kLoaders; ++z) lnd[z] = lds_ld(&s_landed[z]);
@@ -1684,37 +1560,12 @@ __global__ void __launch_bounds__((64 * Geo4<D, GM>::WAVES)) sweep4_kernel(Args4
         if constexpr (kAsmBlock) {
             if (HEAD == PDA_HEAD_POP || !raw_on_pop_prep) {
                 const unsigned a0 = lane_base_lds + (unsigned)((b % NSLOT) * BB);
-                if constexpr (UA == 1) {
-                    u32x4 piq;
-                    BlockAsm<D>::run(acc[0][0], acc[0][1], piq, ah[0], aex[0], a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
-                    popv[0] = __uint_as_float(piq[0]);
-                    locv[0] = (int)piq[1];
-                    popv[NB - 1] = __uint_as_float(piq[2]);
-                    locv[NB - 1] = (int)piq[3];
-                } else if constexpr (kPrefetchGeo) {
-                    // The first three B fragments of block b + 1 are read under the last MFMAs of block b (the wave waits for that block
-                    // to have landed first): a wave comes back from its accumulator test with operands in registers.  (A block of
-                    // this geometry is 576 cycles of MFMAs per wave; what a wave does between two blocks -- drain, test, hand-over,
-                    // the first LDS round trip -- has to fit under the OTHER wave's 576 for the pipe to stay busy.)
-                    u32x2 pid;
-                    const unsigned an = lane_base_lds + (unsigned)(((b + 1 < n_blk ? b + 1 : b) % NSLOT) * BB);      // (last block: itself, unused)
-                    const unsigned api = a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32);
-#define PDA_BLK2P(PRE, NXT)                                                                                                            \
-    do {                                                                                                                               \
-        if (!swp) BlockAsm2P<D, PRE, NXT>::run(acc[0][0], acc[UA - 1][0], pid, tqa[0], tqa[1], tqa[2], tqb[0], tqb[1], tqb[2], ah, aex, a0, api, an); \
-        else BlockAsm2P<D, PRE, NXT>::run(acc[0][0], acc[UA - 1][0], pid, tqb[0], tqb[1], tqb[2], tqa[0], tqa[1], tqa[2], ah, aex, a0, api, an);      \
-    } while (0)
-                    PDA_BLK2P(true, true);
-#undef PDA_BLK2P
-                    swp = !swp;                            // (the triple that took the next block's fragments is that block's own)
-                    popv[0] = __uint_as_float(pid[0]);
-                    locv[0] = (int)pid[1];
-                } else {
-                    u32x2 pid;
-                    BlockAsm2<D>::run(acc[0][0], acc[UA - 1][0], pid, ah, aex, a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
-                    popv[0] = __uint_as_float(pid[0]);
-                    locv[0] = (int)pid[1];
-                }
+                u32x4 piq;
+                BlockAsm<D>::run(acc[0][0], acc[0][1], piq, ah[0], aex[0], a0, a0 - 16u * (unsigned)h + (unsigned)(2 * D + 32));
+                popv[0] = __uint_as_float(piq[0]);
+                locv[0] = (int)piq[1];
+                popv[NB - 1] = __uint_as_float(piq[2]);
+                locv[NB - 1] = (int)piq[3];
                 asm_done = true;
                 if (asked) {                      // the hand-over words were read in front of the block: an LDS round trip hidden
                     unsigned mn = 0xFFFFFFFFu;
@@ -2002,7 +1853,7 @@ __global__ void __launch_bounds__(1024) stop_scatter4_kernel(const int* __restri
 template <int D, int HEAD, bool BF, int GM>
 int launch_sweep4(const Args4& g, hipStream_t stream) {
     using G = Geo4<D, GM>;
-    constexpr bool kHasES = GM != 2;         // (the wide geometry is a dense sweep's: launch4 sends early-terminating sweeps elsewhere)
+    constexpr bool kHasES = true;
     static int attr_set = 0;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sweep4_kernel<D, HEAD, BF, false, GM>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2083,21 +1934,13 @@ int launch4(const Args4& g, int phase, hipStream_t stream, int geometry) {      
 template <int D, int HEAD, bool BF>
 int launch4_sweep(const Args4& g, hipStream_t stream, int geometry) {
     {
-        // (the geometry hints are honoured for the popularity head only: that is where they pay, and every instantiation costs build time)
-        if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2 && HEAD == PDA_HEAD_POP) {
-            // the huge geometry (pda_v5_sweep.h): dense sweeps of the popularity head on a prep built WITH that popularity
-            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, 256>(g, stream);
-            if (geometry == 6 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, 128>(g, stream);
-            if (geometry == 5 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, false, 256>(g, stream);
-            if ((geometry == 2 || geometry >= 4) && g.sufA == nullptr) return launch_sweep4<D, HEAD, BF, 2>(g, stream);       // (dense sweeps only)
-            if (geometry == 1) return launch_sweep4<D, HEAD, BF, 1>(g, stream);
+        // the huge geometry (pda_v5_sweep.h): dense sweeps of the popularity head on a prep built WITH that popularity -- 1 024-user workgroups,
+        // or (d = 256, config 5) 512-user ones: 128 users per wave fill the 256 AGPRs.  Anything else asked for with that hint: the default.
+        if constexpr (HEAD == PDA_HEAD_POP) {
+            if (geometry == 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, D == 256 ? 128 : 256>(g, stream);
         }
-        if constexpr (D <= 128 && PDA_V4_UA == 1 && PDA_V4_GL == 2) {
+        if constexpr (D <= 128) {
             if (geometry == 3) return launch_sweep4<D, HEAD, BF, 3>(g, stream);
-        }
-        if constexpr (D == 256 && HEAD == PDA_HEAD_POP) {
-            // d = 256 (config 5): the huge geometry as ONE 512-user workgroup per CU -- 128 users per wave fill the 256 AGPRs
-            if (geometry >= 4 && g.sufA == nullptr && g.prep_hdr_pop != 0) return launch_sweep5<D, BF, true, 128>(g, stream);
         }
         return launch_sweep4<D, HEAD, BF, 0>(g, stream);
     }
@@ -2154,9 +1997,11 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
     if (early_stop < 0 || (early_stop & ~0x7FF) != 0) return PDA_ERR_ARG;
     const bool warm_per_split = (early_stop & PDA_SWEEP_WARM_PER_SPLIT) != 0;
-    // geometry hints (Geo4<D, 1 | 2 | 3>): results do not depend on them, and every geometry takes any n_splits and any user count
-    // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks); the wide geometry only PAYS on large blocks
-    int geometry = (early_stop & PDA_SWEEP_HUGE) ? ((early_stop & PDA_SWEEP_HUGE_32X32) ? 5 : (early_stop & PDA_SWEEP_HUGE_2WG) ? 6 : 4) : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : (early_stop & PDA_SWEEP_WIDE) ? 2 : ((early_stop & PDA_SWEEP_FEW_CANDIDATES) ? 1 : 0);
+    // geometry hints (Geo4<D, 3>, sweep5_kernel): results do not depend on them, and every geometry takes any n_splits and any user count
+    // (tests/test_gpu_score_topk.py runs each with 1 / 2 / 3 / 8 splits and ragged blocks)
+    // (PDA_SWEEP_FEW_CANDIDATES, PDA_SWEEP_WIDE and the two PDA_SWEEP_HUGE_* sub-variants named geometries that round 5 removed -- each
+    // measured slower than the huge geometry wherever it applied, profiles/README.md; the bits stay valid and select nothing)
+    int geometry = (early_stop & PDA_SWEEP_HUGE) ? 4 : (early_stop & PDA_SWEEP_MANY_CANDIDATES) ? 3 : 0;
     if (warm_tiles == 0) warm_tiles = (early_stop >> 4) & 7;                       // PDA_SWEEP_WARM_TILES(n)
     early_stop &= 1;
     if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
@@ -2204,7 +2049,7 @@ int run_score4(const void* U, const void* I_shard, bool bf16, const void* prep, 
     g.ufrag = wsb + W.ufrag;
     g.unorm = reinterpret_cast<const float*>(wsb + W.unorm);
     // (the prep is the caller's, built by pda_item_prep4_* with the SAME pop_shard it passes here for the popularity head: ops.item_prep4
-    // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the wide one)
+    // keys its cache on it; a prep built without one carries an unscaled image and the huge geometry falls back to the default one)
     g.prep_hdr_pop = (head == PDA_HEAD_POP && pop_shard != nullptr) ? 1 : 0;
     g.warm_final = (geometry >= 4 && phase == 3 && g.handover != nullptr && g.prep_hdr_pop && !early_stop) ? 1 : 0;
     g.lists_empty = from_empty ? 1 : 0;

@@ -57,8 +57,8 @@ template <int D>
 __device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((row >> 1) & 7); }
 
 // ---- the user image: the block's rows as bf16 MFMA operands, in the order the waves load them into their AGPRs ------------------
-// fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes; lane l holds user 32 u + (l & 31), elements 16 k + 8 (l >> 5) .. + 7
-// S16 (the 16 x 16 x 32 loop): fragment (wg, w, u, k) is 16 users x 32 elements; lane l holds user 16 u + (l & 15), elements 32 k + 8 (l >> 4) .. + 7
+// fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes = 16 users x 32 elements; lane l holds user 16 u + (l & 15),
+// elements 32 k + 8 (l >> 4) .. + 7  (the B operand of v_mfma_f32_16x16x32_bf16; S16 = true keeps the kernels' round-4 names)
 template <int D, bool BF, bool S16, int UPW>
 __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U, const int32_t* __restrict__ users, int n_users_blk, int n_pad,
                                                      unsigned char* __restrict__ ufrag, float* __restrict__ unorm, float* __restrict__ uerr = nullptr) {
@@ -84,16 +84,10 @@ __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U,
     }
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); rs += __shfl_xor(rs, o, 64); }
-    if constexpr (S16) {
-        constexpr int NK = D / 32, NU = UPW / 16;                        // (wgw: the wave's index among all waves of the launch)
-        const int wgw = rb / UPW, u = (rb >> 4) & (NU - 1), j = rb & 15, k = c >> 2, g4 = c & 3;
-        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * NU + u) * NK + k) * 64 + (j + 16 * g4)) * 16) = hq;
-    } else {
-        constexpr int NK = D / 16;
-        static_assert(S16 || UPW == 256, "the 32 x 32 x 16 loop: 256 users per wave");
-        const int wgw = rb >> 8, u = (rb >> 5) & 7, j = rb & 31, k = c >> 1, hh = c & 1;
-        *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * 8 + u) * NK + k) * 64 + (j + 32 * hh)) * 16) = hq;
-    }
+    static_assert(S16, "the 32 x 32 x 16 image left with its loop (round 5)");
+    constexpr int NK = D / 32, NU = UPW / 16;                        // (wgw: the wave's index among all waves of the launch)
+    const int wgw = rb / UPW, u = (rb >> 4) & (NU - 1), j = rb & 15, k = c >> 2, g4 = c & 3;
+    *reinterpret_cast<u32x4*>(ufrag + ((((size_t)wgw * NU + u) * NK + k) * 64 + (j + 16 * g4)) * 16) = hq;
     if (c == 0) unorm[rb] = sqrtf(ss) * 1.0009765625f * 1.0001f;          // padded ||u|| (as generation 4's nu_row)
     if (c == 0 && uerr != nullptr) uerr[rb] = sqrtf(rs) * 1.0009765625f * 1.0001f;       // padded ||u - bf16(u)|| (the funnel's bound)
 }

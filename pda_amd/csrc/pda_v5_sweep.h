@@ -23,15 +23,10 @@
 // Everything else is generation 4's: warm4_kernel's exact lists (handed over through the workspace), the packed keys, the epilogue.
 // Popularity head, d = 64 / 128, dense sweeps (no early termination); selected by the caller's hint PDA_SWEEP_HUGE.
 #pragma once
-#ifdef PDA_V5_LOOP_HEADER          // a timing-only A/B build of the loop (tools/ab_huge.sh)
-#include PDA_V5_LOOP_HEADER
-#else
-#include "pda_v5_loop_asm.h"
-#endif
 #ifdef PDA_V6_LOOP_HEADER
 #include PDA_V6_LOOP_HEADER
 #else
-#include "pda_v6_loop_asm.h"           // the same loop on v_mfma_f32_16x16x32_bf16 (S16 below; tools/gen_v6_loop_asm.py)
+#include "pda_v6_loop_asm.h"           // the loop, on v_mfma_f32_16x16x32_bf16 (tools/gen_v6_loop_asm.py)
 #endif
 
 #ifdef PDA_V5_LOG
@@ -45,19 +40,19 @@ constexpr int kRing5 = 192;           // candidate ring entries per wave (u64 ea
 
 
 
-// UPW users per wave: 256 -- one 1 024-user workgroup per CU, 512 registers per wave -- or (S16) 128: 512-user workgroups, TWO per CU, 256
-// registers per wave.  With one wave per SIMD nothing overlaps the wave's own VALU tests, LDS reads and scalar work with its MFMAs (PMC, UPW
-// = 256: matrix pipe 77 % busy at 2.03 GHz, 87 % without the tests); two independent workgroups per CU give every SIMD a second wave --
-// measured (profiles/round4_huge_variants.txt): the pipe is 82 % busy then, but at 1.86 GHz: twice the LDS reads and LDS-DMA per MFMA
-// cost more clock than the overlap buys (8.38 vs 8.18 ms).  UPW = 256 is the product; 128 stays selectable (PDA_SWEEP_HUGE_2WG).
+// UPW users per wave: 256 -- one 1 024-user workgroup per CU, 512 registers per wave; d = 256: 128 (the rows of 128 users fill the 256 AGPRs).
+// With one wave per SIMD nothing overlaps the wave's own VALU tests, LDS reads and scalar work with its MFMAs (PMC: matrix pipe 77 % busy at
+// 2.03 GHz, 87 % without the tests).  Round 4 measured the two obvious alternatives and round 5 removed them (profiles/round4_huge_variants.txt,
+// profiles/README.md): two 512-user workgroups per CU at d <= 128 -- the pipe 82 % busy, but at 1.86 GHz: twice the LDS reads and LDS-DMA per
+// MFMA cost more clock than the overlap buys (8.38 vs 8.18 ms) -- and the loop on v_mfma_f32_32x32x16_bf16 (9.16 ms).
 template <int D, bool BF, bool S16, int UPW>
-__global__ void __launch_bounds__(256, (UPW == 128 && D <= 128) ? 2 : 1) sweep5_kernel(Args4 g) {
+__global__ void __launch_bounds__(256, 1) sweep5_kernel(Args4 g) {
     [[maybe_unused]] constexpr int HB = half_bytes5(D);
     static_assert(slot_bytes5(D) == Loop6<D, 8>::kSlotBytes, "one LDS image for all loops");
-    static_assert(UPW == 256 || (S16 && UPW == 128), "users per wave");
-    static_assert(D <= 128 || (S16 && UPW == 128), "d = 256: 128 users per wave (8 blocks x 8 k-steps = 256 AGPRs), one 512-user workgroup per CU");
-    // NK k-steps per product, NU user blocks of UBW users per wave (S16: 16 x 16 x 32 MFMAs -- blocks of 16; else 32 x 32 x 16 -- 8 of 32)
-    constexpr int NK = S16 ? D / 32 : D / 16, UBW = S16 ? 16 : 32, NU = UPW / UBW;
+    static_assert(S16, "the loop on v_mfma_f32_32x32x16_bf16 (round 4's first form: 9.16 against 8.07 ms, profiles/README.md) left with round 5; the parameter keeps the kernel's name");
+    static_assert((D <= 128 && UPW == 256) || (D == 256 && UPW == 128), "users per wave: 256, or (d = 256) 128 -- 8 blocks x 8 k-steps = 256 AGPRs, one 512-user workgroup per CU");
+    // NK k-steps per product, NU user blocks of UBW = 16 users per wave (16 x 16 x 32 MFMAs)
+    constexpr int NK = D / 32, UBW = 16, NU = UPW / UBW;
     constexpr int SS = slot_bytes5(D), UT = 4 * UPW, CAPL = kCap4, RB4 = row_bytes(D);
     constexpr int LPC = D / 32, CPP = 64 / LPC;                          // lanes per candidate, candidates per rescoring pass
     constexpr float kEps5 = BF ? 4.0234375e-3f : 8.046875e-3f;           // 2^-8 x 1.03 (only the scaled items are rounded: one unit roundoff of bf16)  |  2^-7 x 1.03 (both sides)
@@ -86,7 +81,7 @@ __global__ void __launch_bounds__(256, (UPW == 128 && D <= 128) ? 2 : 1) sweep5_
     // (words 0, 1: the shared flag words; 8 .. 39: every list comes in unsorted -- unless the warm-up sorted them: warm_final; 40 .. 71: no row touched)
     if (tid < 72) sync[tid] = (tid < 8 || tid >= 40 || warm_final || starts_empty) ? 0u : 0xFFFFFFFFu;
     // kernel identity (workspace + 16): generation 4 | geometry (4: the 16 x 16 x 32 loop, one 1 024-user workgroup per CU; 6: the same, two 512-user workgroups; 5: the 32 x 32 x 16 loop) << 8 | head << 13 | bf16 tables << 14 | d / 64
-    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | ((!S16 ? 5u : (UPW == 256 || D == 256) ? 4u : 6u) << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
+    if (tid == 0 && blockIdx.x == 0) g.stats[4] = (4u << 28) | (4u << 8) | (1u << 13) | ((BF ? 1u : 0u) << 14) | (unsigned)(D >> 6);
     // ---- the counts and K-th values of the warm-up's lists -> LDS (all waves); without a hand-over buffer the lists themselves -> the workspace
     if (starts_empty) {
         for (int rr = tid; rr < UT; rr += 256) {
@@ -298,46 +293,30 @@ __global__ void __launch_bounds__(256, (UPW == 128 && D <= 128) ? 2 : 1) sweep5_
             const float2 mt = *reinterpret_cast<const float2*>(g.meta5 + 4 * (size_t)(2u * T + (ft & 1u)));
             const float ct = __builtin_fmaf(eu, mt.y, mt.x);
             const unsigned char* tb = tiles + (ft & (kNSlot5 - 1)) * SS + j * (2 * D);
-            // accumulator register r of the lane <-> item of the half-tile (S16: r = 4 ib + register of chain ib)
+            // accumulator register r of the lane <-> item of the half-tile (r = 4 ib + register of chain ib)
             auto item_of = [&](int r) __attribute__((always_inline)) -> unsigned {
-                return S16 ? 16u * (r >> 2) + 4u * hh + (r & 3) : 8u * (r >> 2) + 4u * hh + (r & 3);
+                return 16u * (r >> 2) + 4u * hh + (r & 3);
             };
-            constexpr int NR = S16 ? 8 : 16;
-            u32x4 af[S16 ? 2 * NK : NK];
-            if constexpr (S16) {
+            constexpr int NR = 8;
+            u32x4 af[2 * NK];
 #pragma unroll
-                for (int ib = 0; ib < 2; ++ib)
+            for (int ib = 0; ib < 2; ++ib)
 #pragma unroll
-                    for (int k = 0; k < NK; ++k) af[ib * NK + k] = *reinterpret_cast<const u32x4*>(tb + ib * 16 * (2 * D) + (((4 * k + hh) ^ swz5<D>(j)) << 4));
-            } else {
-#pragma unroll
-                for (int k = 0; k < NK; ++k) af[k] = *reinterpret_cast<const u32x4*>(tb + (((2 * k + hh) ^ swz5<D>(j)) << 4));
-            }
+                for (int k = 0; k < NK; ++k) af[ib * NK + k] = *reinterpret_cast<const u32x4*>(tb + ib * 16 * (2 * D) + (((4 * k + hh) ^ swz5<D>(j)) << 4));
             for (int u = 0; u < NU; ++u) {
                 const float tl = thr_of(u);
                 const bool clampy = mt.x > tl;
                 uint32_t m = 0;
-                if constexpr (S16) {
 #pragma unroll
-                    for (int ib = 0; ib < 2; ++ib) {
-                        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int k = 0; k < NK; ++k) {
-                            const u32x4 bf = *reinterpret_cast<const u32x4*>(my_ufrag + (((size_t)u * NK + k) * 64 + lane) * 16);
-                            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ib * NK + k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) m |= (acc[r] + ct > tl) ? (1u << (4 * ib + r)) : 0u;
-                    }
-                } else {
-                    f32x16 acc = zero16v();
+                for (int ib = 0; ib < 2; ++ib) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < NK; ++k) {
                         const u32x4 bf = *reinterpret_cast<const u32x4*>(my_ufrag + (((size_t)u * NK + k) * 64 + lane) * 16);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[ib * NK + k]), __builtin_bit_cast(bf16x8, bf), acc, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) m |= (acc[r] + ct > tl) ? (1u << r) : 0u;
+                    for (int r = 0; r < 4; ++r) m |= (acc[r] + ct > tl) ? (1u << (4 * ib + r)) : 0u;
                 }
                 if (__any(clampy)) {
                     // (rare: a user whose threshold lies below a popularity of this half-tile -- a head pop x exp(s), s <= 0, may qualify)
@@ -370,19 +349,15 @@ __global__ void __launch_bounds__(256, (UPW == 128 && D <= 128) ? 2 : 1) sweep5_
 #pragma unroll
             for (int u = 0; u < NU; ++u) thr[u] = thr_of(u);
             unsigned reason = 0;
-            if constexpr (S16) {
-                // the wave's lowest threshold: the clamp test (a popularity of the half-tile above a user's threshold) is wave-uniform
-                float tmin = thr[0];
+            // the wave's lowest threshold: the clamp test (a popularity of the half-tile above a user's threshold) is wave-uniform
+            float tmin = thr[0];
 #pragma unroll
-                for (int u = 1; u < NU; ++u) tmin = fminf(tmin, thr[u]);
+            for (int u = 1; u < NU; ++u) tmin = fminf(tmin, thr[u]);
 #pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
-                tmin = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmin)));
-                Loop6<D, NU>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
+            for (int o = 32; o >= 1; o >>= 1) tmin = fminf(tmin, __shfl_xor(tmin, o, 64));
+            tmin = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(tmin)));
+            Loop6<D, NU>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
                               (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, tmin, my_ufrag, thr, lane16);
-            } else
-                Loop5<D>::run(h, issued, reason, hend, ring_lds, flags_lds, 1024u * (unsigned)wave, t0, (unsigned)g.n_splits,
-                              (unsigned)img, (unsigned)(img >> 32), (unsigned)meta, (unsigned)(meta >> 32), eu, my_ufrag, thr, lane16);
             V5LOG(reason, h, issued);
             if (reason == 0u) break;
             if (reason != 1u) { if (lane == 0) g.stats[0] = 5u; break; }

@@ -215,9 +215,6 @@ def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) ->
     return "v4"        # (natural order at d <= 128 too since the many-candidates geometry: C3 65 536 users 7.0 vs 8.8 ms)
 
 
-# The wide geometry pays as soon as the 256-user geometry needs a second round of workgroups (> 256 x 256 users): measured at config 3,
-# 98 304 users 5.22 vs 5.78 ms, 131 072 x 50 000 items 1.75 vs 1.84 ms; at 65 536 users (one round of 256 workgroups) 5.00 vs 3.55 ms.
-WIDE_MIN_USERS = 65537
 # The huge geometry (pda_v5_sweep.h) wants a workgroup of 1 024 users on every CU: a block of fewer than 256 x 1 024 users fills the chip
 # with ITEM SPLITS (huge_splits below) -- cheap since round 4's shared warm-up (one exact warm-up per user, not per split)
 HUGE_MIN_USERS = 196609         # (kept for callers that pass their own n_splits: from here on the hint is given whatever the split count)
@@ -256,28 +253,23 @@ def score_plan(n_users: int, n_items_local: int, d: int, K: int = 50, head: int 
 
 
 def few_candidates_hint(head: int, prune, n_users: int = 0, d: int = 0, n_items_local: int = 0, n_splits: int = 0) -> int:
-    """PDA_SWEEP_FEW_CANDIDATES for pda_score_topk4_*: the popularity head swept in visiting order meets next to no candidates
-    behind the warm-up (< 1 per user at config 3), so the kernel MAY keep its exact lists in the workspace and spend the LDS on
-    four tile slots (results identical either way; PDA_SCORE_LISTS=lds|hbm forces one for A/B measurements and tests)."""
+    """The geometry hint (PDA_SWEEP_HUGE | PDA_SWEEP_MANY_CANDIDATES | 0) for pda_score_topk4_* when the caller passes its own n_splits --
+    the rules of pda_score_topk_plan (results identical whatever the hint; PDA_SCORE_LISTS=lds|many|huge forces one for A/B measurements
+    and tests).  (The name is round 3's: PDA_SWEEP_FEW_CANDIDATES and PDA_SWEEP_WIDE named geometries that round 5 removed.)"""
     forced = os.environ.get("PDA_SCORE_LISTS", "")
-    if forced in ("lds", "hbm", "wide", "many", "huge", "huge32", "huge2"):
-        return {"lds": 0, "hbm": 2, "wide": 4, "many": 8, "huge": 128, "huge32": 128 | 256, "huge2": 128 | 512}[forced]
+    if forced in ("lds", "many", "huge"):
+        return {"lds": 0, "many": 8, "huge": 128}[forced]
     if head == HEAD_POP and prune == "order" and d in (64, 128, 256) and n_items_local > 0 and n_splits > 0 \
             and n_splits == huge_splits(n_users, n_items_local, d):
         return 128          # (the caller splits the catalogue as huge_splits says: score_topk_keys with n_splits left to the library)
     if head == HEAD_POP and prune == "order" and n_users >= HUGE_MIN_USERS and d in (64, 128):
         return 128          # PDA_SWEEP_HUGE: 1 024-user workgroups of four 512-register waves, eight MFMAs per LDS read, no test k-step
-    if head == HEAD_POP and prune == "order" and n_users >= WIDE_MIN_USERS and d in (64, 128):
-        return 4            # PDA_SWEEP_WIDE: the dense sweep of a large user block (512-user workgroups, half the LDS and tile traffic per MFMA)
     early = prune is True or (prune == 1 and prune != "order")
     if d in (64, 128) and not early and (head == HEAD_RAW or not prune):
         # PDA_SWEEP_MANY_CANDIDATES: hundreds of list insertions per user (raw head; popularity head in natural item order) -- 128
         # users per workgroup with eight rescoring waves.  Same box: C3 262 144 users raw 31.3 -> 28.1 ms, natural order 34.2 ->
         # 28.3 ms; C2 raw 3.39 -> 2.10 ms, natural 4.37 -> 2.39 ms.  (Early-terminating raw sweeps: 30.5 vs 37.8 ms, not hinted.)
         return 8
-    # Measured (round 3, config 3, 262 144 users, same box): dense sweep 12.58 vs 12.71 ms with the lists in the workspace (four
-    # tile slots), early-terminating sweep 1.18 vs 1.04 ms, C1 / C2 0.28 vs 0.25 ms: the hand-over of the warm-up lists and the
-    # final sort go through L2 instead of the LDS.  Not worth it: off unless forced.
     return 0
 
 
@@ -712,7 +704,7 @@ def score_topk_funnel(U, I_shard, users, K=50, hist: Optional[HistoryCSR] = None
     return out
 
 
-GEOMETRY_NAMES = {0: "lds", 1: "hbm", 2: "wide", 3: "many", 4: "huge", 5: "huge32", 6: "huge2", 7: "funnel"}
+GEOMETRY_NAMES = {0: "lds", 3: "many", 4: "huge", 7: "funnel"}          # (1, 2, 5, 6: the geometries round 5 removed)
 
 
 def kernel_identity(word) -> dict:

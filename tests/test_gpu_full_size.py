@@ -153,16 +153,10 @@ def test_full_size_c3(dev, monkeypatch):
 
     # ---- every other geometry forced on the same 262 144-user block: identical keys
     monkeypatch.setenv("PDA_SCORE_KERNEL", "v4")
-    for geo, cases in (("lds", ((POP, "order"),)), ("hbm", ((POP, "order"), (POP, True))), ("wide", ((POP, "order"), (POP, True))),
-                       ("many", ((POP, "order"), (RAW, "order"))), ("huge", ((POP, "order"),)), ("huge32", ((POP, "order"),)),
-                       ("huge2", ((POP, "order"),))):
+    for geo, cases in (("lds", ((POP, "order"), (POP, True))), ("many", ((POP, "order"), (RAW, "order"))), ("huge", ((POP, "order"),))):
         monkeypatch.setenv("PDA_SCORE_LISTS", geo)
         for head, prune in cases:
-            # (the wide geometry has no early-terminating instance: the library falls back to the default geometry there)
-            exp = {"generation": 4, "head": head}
-            if not (geo == "wide" and prune is True):
-                exp["geometry"] = geo
-            kg, _ = run(ops, W, hist, huge, head, prune, exp)
+            kg, _ = run(ops, W, hist, huge, head, prune, {"generation": 4, "head": head, "geometry": geo})
             assert torch.equal(kg, k262["order"] if head == POP else raw[None]), (geo, head, prune)
     torch.cuda.synchronize()
 

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-5  # north_star: "within 1e-5 fp32 on scores"
 
 
-@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop", "k4hbm", "k4wide", "k4many", "k4huge", "k4huge32", "k4huge2"])
+@pytest.fixture(autouse=True, params=["v1", "v2", "v2ord", "v2order_only", "k3", "k4nat", "k4ord", "k4stop", "k4many", "k4huge"])
 def impl(request, monkeypatch):
     """Every test runs against all scoring paths: v1 = exact fp32 MFMA; v2 / v2ord / v2order_only = the pre-filtered path
     (bf16 MFMA filter + exact rescoring) in natural order / visiting order with early termination / visiting order without
@@ -29,15 +29,12 @@ def impl(request, monkeypatch):
     # k4*: the generation-4 kernel (pda_score_topk_v4.hip) in its three sweep modes; the older generations are pinned to v3
     # (v2 where the library picks it) so that they stay covered now that v4 is the default
     monkeypatch.setenv("PDA_SCORE_PRUNE", {"v2ord": "1", "v2order_only": "order", "k3": "1", "k4ord": "order",
-                                           "k4stop": "1", "k4hbm": "1", "k4wide": "order", "k4huge": "order", "k4huge32": "order", "k4huge2": "order"}.get(request.param, "0"))
-    # k4hbm: generation 4 with its exact lists in the workspace and four tile slots at d <= 128 (PDA_SWEEP_FEW_CANDIDATES);
-    # k4wide: the wide geometry (PDA_SWEEP_WIDE: 512 users per workgroup, 64 user rows per MFMA wave), dense in visiting order;
+                                           "k4stop": "1", "k4huge": "order"}.get(request.param, "0"))
     # k4many: the many-candidates geometry (PDA_SWEEP_MANY_CANDIDATES: 128 users per workgroup, eight rescoring waves), natural order
     # k4huge: the huge geometry (PDA_SWEEP_HUGE, pda_v5_sweep.h: 1 024 users per workgroup, user rows in AGPRs, transposed product, no test
-    # k-step), dense in visiting order; popularity head (the raw head keeps the default geometry under the same hint); its loop on
-    # v_mfma_f32_16x16x32_bf16 (k4huge, the product), on v_mfma_f32_32x32x16_bf16 (k4huge32) and as two 512-user workgroups per CU (k4huge2)
-    monkeypatch.setenv("PDA_SCORE_LISTS", {"k4hbm": "hbm", "k4wide": "wide", "k4many": "many", "k4huge": "huge", "k4huge32": "huge32",
-                                           "k4huge2": "huge2"}.get(request.param, "lds"))
+    # k-step), dense in visiting order; popularity head (the raw head keeps the default geometry under the same hint).
+    # WHICH geometry a generation-4 call ran is asserted in run_gpu (the identity word the sweep kernel writes).
+    monkeypatch.setenv("PDA_SCORE_LISTS", {"k4many": "many", "k4huge": "huge"}.get(request.param, "lds"))
     if request.param == "k3":
         monkeypatch.setenv("PDA_SCORE_KERNEL", "v3")
     elif request.param.startswith("k4"):
@@ -73,10 +70,27 @@ def run_gpu(dev, U, I, users, K, head, pop, hist_rows, by_user, n_splits=0, item
         ip, ix = csr(hist_rows)
         h = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=by_user)
     ut = torch.from_numpy(users).to(dev)
-    keys = ops.score_topk_keys(torch.from_numpy(U).to(dev), Ish, ut, K, head, popsh, h, item_offset, n_splits)
+    st = {}
+    keys = ops.score_topk_keys(torch.from_numpy(U).to(dev), Ish, ut, K, head, popsh, h, item_offset, n_splits, stats=st)
     idx, val = ops.topk_merge(keys, ut, h)
     torch.cuda.synchronize()
+    assert_identity(st, U.shape[1], K, head)
     return idx.cpu().numpy(), val.cpu().numpy(), keys
+
+
+def assert_identity(st, d, K, head):
+    """The kernel the impl fixture asked for is the kernel that ran: generation 4's sweeps write (generation, geometry, head, d) into the
+    workspace.  (0 = every split ended inside its exact warm-up: no sweep kernel ran.)"""
+    from pda_amd import ops
+    if os.environ.get("PDA_SCORE_KERNEL") != "v4" or d not in (64, 128, 256) or K > 54 or "kernel_id" not in st:
+        return
+    assert int(st["error"][0]) == 0
+    ident = ops.kernel_identity(st["kernel_id"][0])
+    if ident["generation"] == 0:
+        return
+    lists, order_only = os.environ["PDA_SCORE_LISTS"], os.environ["PDA_SCORE_PRUNE"] == "order"
+    want = "huge" if (lists == "huge" and head == 1 and order_only) else "many" if (lists == "many" and d <= 128) else "lds"
+    assert ident["generation"] == 4 and ident["geometry"] == want and ident["head"] == head and ident["d"] == d, (ident, want)
 
 
 def check_against_oracle(idx, val, U, I, users, K, head, pop, hist_block_rows, exact):

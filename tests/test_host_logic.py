@@ -105,12 +105,10 @@ def test_sweep_kernel_and_geometry_selection(monkeypatch):
     assert ops.score_kernel(256, 50, 250000, False, P) == "v3"
     assert ops.score_kernel(256, 50, 250000, "order", R) == "v3"
     assert ops.score_kernel(32, 50, 1000, True, P) == "v3"
-    # geometry hints (bits of early_stop): 128 = huge, 4 = wide, 8 = many candidates, 0 = default
+    # geometry hints (bits of early_stop): 128 = huge, 8 = many candidates, 0 = default
     assert ops.few_candidates_hint(P, "order", 262144, 128) == 128        # the headline: dense sweep of a very large block (1 024-user workgroups)
-    assert ops.few_candidates_hint(P, "order", 196608, 128) == 4          # (below 192 x 1 024 + 1 users the wide geometry fills the chip better)
-    assert ops.few_candidates_hint(P, "order", 131072, 64) == 4
-    assert ops.few_candidates_hint(P, "order", 98304, 128) == 4           # (the 256-user geometry would need a second round of workgroups)
-    assert ops.few_candidates_hint(P, "order", 65536, 128) == 0           # one round of 256 workgroups: the 256-user geometry
+    assert ops.few_candidates_hint(P, "order", 196608, 128) == 0          # (a caller's own split count, fewer than 192 x 1 024 + 1 users: the default geometry;
+    assert ops.few_candidates_hint(P, "order", 65536, 128) == 0           #  rounds 3 / 4 had a wide geometry here)
     assert ops.few_candidates_hint(P, "order", 262144, 256) == 0
     # ... and with the split count the library itself picks (score_topk_keys with n_splits left to it): the huge geometry from 4 096 users on,
     # item splits by rounds of 256 workgroups (one shared warm-up: splits are cheap)

@@ -1,11 +1,11 @@
-"""The huge geometry against the wide one on a bench workload: time per block, loop entries, candidates (HIP events around the call).
-usage: time_huge.py [workload=c3] [users per block=262144] [geometries=wide,huge] [n_items override: the fixed cost of a call, 0 = none] [item splits, 0 = the library's choice]"""
+"""The huge geometry against another one (lds | many) on a bench workload: time per block, loop entries, candidates (HIP events around the call).
+usage: time_huge.py [workload=c3] [users per block=262144] [geometries=lds,huge] [n_items override: the fixed cost of a call, 0 = none] [item splits, 0 = the library's choice]"""
 import os, sys, torch
 sys.path.insert(0, '.')
 from pda_amd import ops, synthetic
 wl = sys.argv[1] if len(sys.argv) > 1 else 'c3'
 Bu = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
-geos = (sys.argv[3] if len(sys.argv) > 3 else "wide,huge").split(",")
+geos = (sys.argv[3] if len(sys.argv) > 3 else "lds,huge").split(",")
 dev = torch.device('cuda')
 W = synthetic.make_workload(wl, dev, n_items=(int(sys.argv[4]) or None) if len(sys.argv) > 4 else None)
 NS = int(sys.argv[5]) if len(sys.argv) > 5 else 0
