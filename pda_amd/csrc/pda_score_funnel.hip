@@ -18,6 +18,9 @@ int g_growth = 4;              // every launch sees this many times the items se
 int g_cap_e = 64;              // entries per (user, quarter) list and launch
 int g_first_tiles = 4;         // without a maxima launch: the first launch, 256 items against -inf
 int g_maxima = 1;              // the first launch keeps maxima only (rank-8 thresholds for free: no lists, no selection)
+int g_first_mult = 2;          // the first emitting launch behind a maxima launch over m tiles: tiles [0, g_first_mult x m)
+int g_late_den = 6;            // from 1 / g_late_den of the catalogue on the parts grow by g_late_growth_x10 / 10 instead of g_growth
+int g_late_growth_x10 = 20;
 constexpr int kFallbackSplits = 8;
 
 struct Stage7 {
@@ -54,7 +57,7 @@ std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
         if (m2 * 3 / 2 <= n_tiles / 8 && gamma_cdf7(8, (double)K * (m2 * 3 / 2) * 64.0 / n_items) <= g_fail_p) m2 = m2 * 3 / 2;
         if (gamma_cdf7(8, (double)K * m2 * 64.0 / n_items) <= g_fail_p && K >= 8) {
             st.push_back(Stage7{0, m2, 8, 1});
-            hi = std::min(n_tiles, m2 * 2);                    // (rank 8 is a coarse estimate: the first emitting launch stays short)
+            hi = std::min(n_tiles, m2 * std::max(1, g_first_mult));          // (rank 8 is a coarse estimate: the first emitting launch stays short)
         }
     }
     for (;;) {
@@ -67,8 +70,8 @@ std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
         lo = hi;
         // the parts grow by g_growth, and by 2 from a sixth of the catalogue on: what a launch writes per list is ~ rank x (growth - 1) + the
         // pairs inside the bound's band, and the lists of the last, longest launches are the ones that fill
-        const int gr = (long long)hi * 6 >= n_tiles ? 2 : std::max(2, g_growth);
-        hi = (int)std::min<long long>((long long)n_tiles, (long long)hi * gr);
+        const int gr10 = (long long)hi * g_late_den >= n_tiles ? std::max(11, g_late_growth_x10) : 10 * std::max(2, g_growth);
+        hi = (int)std::min<long long>((long long)n_tiles, ((long long)hi * gr10 + 9) / 10);
     }
     return st;
 }
@@ -282,6 +285,12 @@ extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int f
     if (growth >= 2) g_growth = growth;
     if (cap_e > 0) g_cap_e = cap_e;
     if (first_tiles > 0) g_first_tiles = first_tiles;
+    return PDA_OK;
+}
+extern "C" int pda_debug_funnel_tune2(int first_mult, int late_den, int late_growth_x10) {
+    if (first_mult > 0) g_first_mult = first_mult;
+    if (late_den > 0) g_late_den = late_den;
+    if (late_growth_x10 > 10) g_late_growth_x10 = late_growth_x10;
     return PDA_OK;
 }
 // measurements / tests only: the first launch in maxima mode (1, the default) or as an emitting launch against -inf (0)

@@ -315,56 +315,56 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
             nhd = *reinterpret_cast<const unsigned*>(ep + 32);
         }
         const unsigned pos0 = (unsigned)(sp + (i0 + (int)((have ? hd : 0u) >> 1)) * S) * 64u + (hd & 1u) * 32u + 4u * (unsigned)hh;
+        // which of the entry's eight values are above the launch's threshold: one, as a rule (the entry exists because one was) -- the values are
+        // worked on one at a time, the first two with their loads issued together (8 x the work for all eight was most of this kernel's issue time)
         float vv[8];
-        bool pp[8];
-        bool any_p = false;
+        unsigned m = 0u;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             vv[r] = r < 4 ? a[r & 3] : b[r & 3];
-            pp[r] = have && vv[r] > thr_used && pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3) < (unsigned)g.n_items_local;
-            any_p = any_p || pp[r];
+            const bool p = have && vv[r] > thr_used && pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3) < (unsigned)g.n_items_local;
+            m |= p ? 1u << r : 0u;
         }
-        if (!__any(any_p)) continue;                            // (wave-uniform: the shuffles below are reached by all lanes or none)
+        if (!__any(m != 0u)) continue;                          // (wave-uniform: the shuffles below are reached by all lanes or none)
         float4 mt = {0.f, 0.f, 0.f, 0.f};
-        if (any_p) mt = *reinterpret_cast<const float4*>(g.e.meta5 + 4 * (size_t)(pos0 >> 5));
-        // the positions' records: (||i||, ||i - i~||, local id, popularity).  The first launch (everything above -inf: 256 items per row, of which a handful stay)
-        // takes the half-tile's maxima instead (looser, as valid) and leaves the train-item check of what stays to threshold7_kernel: its
-        // threshold may then be one of the row's train items -- a rank less on a rank that is chosen with margin (rank_for7).
-        f32x4 tl[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
-            tl[r] = f32x4{mt.y, mt.z, 0.f, 0.f};
-            if (pp[r] && !first) tl[r] = __builtin_bit_cast(f32x4, g.pinfo[pos]);
-        }
-        // (the Bloom words by visiting position: with the tails, not behind them)
-        uint32_t bw1[8], bw2[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            bw1[r] = 0xFFFFFFFFu;
-            bw2[r] = 0xFFFFFFFFu;
-            if (hist_on && !first && g.bloom != nullptr && pp[r]) {
-                const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
-                bw1[r] = g.bloom[(size_t)rb * 32 + (bloom7_h1(pos) >> 5)];
-                bw2[r] = g.bloom[(size_t)rb * 32 + (bloom7_h2(pos) >> 5)];
-            }
-        }
+        if (m != 0u) mt = *reinterpret_cast<const float4*>(g.e.meta5 + 4 * (size_t)(pos0 >> 5));
         const float ct = __builtin_fmaf(eu2, mt.z, __builtin_fmaf(eu, mt.y, mt.x));
-        uint64_t bnds[8];
-        int np = 0;
+        auto value_of = [&](int r) __attribute__((always_inline)) -> float {
+            float v = vv[0];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
-            const float bp = __builtin_fmaf(ua, tl[r][0], ub2 * tl[r][1]);
-            const float st = vv[r] - ct, guard = (fabsf(vv[r]) + ct) * 4.8e-7f;           // (the roundings of the accumulator and of this subtraction)
+            for (int q = 1; q < 8; ++q) v = r == q ? vv[q] : v;
+            return v;
+        };
+        // one value of the lane: its position's record (||i||, ||i - i~||, local id, popularity) and the two Bloom words by visiting position travel
+        // together.  The first launch against -inf (no maxima launch: everything passes, 256 items per row of which a handful stay) takes the half-tile's
+        // maxima instead (looser, as valid) and leaves the train-item check of what stays to threshold7_kernel: its threshold may then be one of the
+        // row's train items -- a rank less on a rank that is chosen with margin (rank_for7).
+        struct Req { bool on; unsigned pos; float v; f32x4 tl; uint32_t bw1, bw2; };
+        auto request = [&](bool on, int r) __attribute__((always_inline)) -> Req {
+            Req q;
+            q.on = on;
+            q.pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
+            q.v = value_of(r);
+            q.tl = f32x4{mt.y, mt.z, 0.f, 0.f};
+            q.bw1 = 0xFFFFFFFFu;
+            q.bw2 = 0xFFFFFFFFu;
+            if (on && !first) q.tl = __builtin_bit_cast(f32x4, g.pinfo[q.pos]);
+            if (hist_on && !first && g.bloom != nullptr && on) {
+                q.bw1 = g.bloom[(size_t)rb * 32 + (bloom7_h1(q.pos) >> 5)];
+                q.bw2 = g.bloom[(size_t)rb * 32 + (bloom7_h2(q.pos) >> 5)];
+            }
+            return q;
+        };
+        auto finish = [&](const Req& q) __attribute__((always_inline)) {
+            const float bp = __builtin_fmaf(ua, q.tl[0], ub2 * q.tl[1]);
+            const float st = q.v - ct, guard = (fabsf(q.v) + ct) * 4.8e-7f;               // (the roundings of the accumulator and of this subtraction)
             const uint32_t ubo = pda_ordf(st + bp + guard + 0.0f), lbo = pda_ordf(st - bp - guard + 0.0f);
-            bnds[r] = ((uint64_t)ubo << 32) | lbo;
-            bool p = pp[r] && ubo >= t_old_o;                    // (below a threshold already used: dropped for good)
+            bool p = q.on && ubo >= t_old_o;                     // (below a threshold already used: dropped for good)
             if (hist_on && !first) {                             // train items never enter: a binary search behind the two Bloom bits
-                const bool look = p && (((bw1[r] >> (bloom7_h1(pos) & 31u)) & (bw2[r] >> (bloom7_h2(pos) & 31u)) & 1u) != 0u);
+                const bool look = p && (((q.bw1 >> (bloom7_h1(q.pos) & 31u)) & (q.bw2 >> (bloom7_h2(q.pos) & 31u)) & 1u) != 0u);
                 if (__any(look)) {
                     if (look) {
-                        const int item = g.item_offset + __float_as_int(tl[r][2]);
+                        const int item = g.item_offset + __float_as_int(q.tl[2]);
                         long long lo = hb, hi2 = he;
                         while (lo < hi2) {
                             const long long mid = (lo + hi2) >> 1;
@@ -374,29 +374,33 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
                     }
                 }
             }
-            pp[r] = p;
-            np += p ? 1 : 0;
-        }
-        // the list's slots: its EPW lanes (NU apart) one after the other
-        int before = 0, total = 0;
+            // the list's slots: its EPW lanes (NU apart) one after the other
+            const int np = p ? 1 : 0;
+            int before = 0, total = 0;
 #pragma unroll
-        for (int k = 0; k < EPW; ++k) {
-            const int o = __shfl(np, u + k * NU, 64);
-            before += k < es ? o : 0;
-            total += o;
-        }
-        int slot = cq + before;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (pp[r]) {
-                if (slot < g.r.cap_q) {
-                    const unsigned pos = pos0 + 16u * (unsigned)(r >> 2) + (unsigned)(r & 3);
-                    *reinterpret_cast<ulonglong2*>(prow + 2 * slot) = make_ulonglong2(((uint64_t)pda_ordf(vv[r] + 0.0f) << 32) | (uint64_t)pos, bnds[r]);
-                }
-                ++slot;                                          // (past the list's slots: threshold7_kernel sees the count and flags the row)
+            for (int k = 0; k < EPW; ++k) {
+                const int o = __shfl(np, u + k * NU, 64);
+                before += k < es ? o : 0;
+                total += o;
             }
+            const int slot = cq + before;                       // (past the list's slots: threshold7_kernel sees the count and flags the row)
+            if (p && slot < g.r.cap_q)
+                *reinterpret_cast<ulonglong2*>(prow + 2 * slot) = make_ulonglong2(((uint64_t)pda_ordf(q.v + 0.0f) << 32) | (uint64_t)q.pos, ((uint64_t)ubo << 32) | lbo);
+            cq += total;
+        };
+        const int r1 = __builtin_ctz(m | 0x100u);
+        const unsigned m1 = m & (m - 1u);
+        const int r2 = __builtin_ctz(m1 | 0x100u);
+        unsigned mr = m1 & (m1 - 1u);
+        const Req q1 = request(m != 0u, r1 & 7), q2 = request(m1 != 0u, r2 & 7);
+        finish(q1);
+        if (__any(m1 != 0u)) finish(q2);
+        while (__any(mr != 0u)) {                               // (three and more of the eight: one more round trip each)
+            const int r3 = __builtin_ctz(mr | 0x100u);
+            const Req q3 = request(mr != 0u, r3 & 7);
+            mr &= mr - 1u;
+            finish(q3);
         }
-        cq += total;
     }
     if (row_ok && es == 0) g.r.qcnt[qidx] = (unsigned)cq;
 }
@@ -475,10 +479,29 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
     unsigned live = 0u;
 #pragma unroll
     for (int k = 0; k < NKP; ++k) live |= __ballot(bnd[k] != 0ull) != 0ull ? 1u << k : 0u;
-    // the q-th largest ordered lower bound (q <= n): bitwise descent over ballots
-    auto qth = [&](int q) __attribute__((always_inline)) -> uint32_t {
-        uint32_t t = 0u;
-        for (int bit = 31; bit >= 0; --bit) {
+    // the q-th largest ordered lower bound (q <= n): bitwise descent over ballots -- from the highest bit in which the pool's bounds differ at all (they
+    // share sign, exponent and more: ~24 of the 32 steps are left) down to bit `low`.  low > 0 leaves the low bits of the result zero: a value BELOW the
+    // q-th largest (in the ordered domain clearing low bits lowers positive and negative floats alike), which q pairs reach all the same.
+    uint32_t omx = 0u, omn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NKP; ++k) {
+        const uint32_t lb = (uint32_t)bnd[k];
+        omx = max(omx, lb);
+        omn = min(omn, bnd[k] != 0ull ? lb : 0xFFFFFFFFu);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        omx = max(omx, (uint32_t)__shfl_xor((int)omx, o, 64));
+        omn = min(omn, (uint32_t)__shfl_xor((int)omn, o, 64));
+    }
+    omx = (uint32_t)__builtin_amdgcn_readfirstlane((int)omx);
+    omn = (uint32_t)__builtin_amdgcn_readfirstlane((int)omn);
+    auto qth = [&](int q, int low) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t diff = omx ^ omn;                          // (n >= q >= 1: the pool holds a real pair, omn <= omx)
+        if (diff == 0u) return omx;
+        const int top = 31 - __builtin_clz(diff);
+        uint32_t t = top >= 31 ? 0u : (omx & ~((2u << top) - 1u));        // the bits above `top`: common to every real bound
+        for (int bit = top; bit >= low; --bit) {
             const uint32_t trial = t | (1u << bit);
             int cnt = 0;
 #pragma unroll
@@ -493,7 +516,7 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
     uint32_t keep_o;
     if (!last) {
         const int q = min(g.rank_next, K);
-        const float tr = n >= q ? fmaxf(pda_unordf(qth(q)), t_old) : t_old;       // (too few pairs above the old threshold: it stays)
+        const float tr = n >= q ? fmaxf(pda_unordf(qth(q, 8)), t_old) : t_old;       // (too few pairs above the old threshold: it stays)
         keep_o = pda_ordf(tr + 0.0f);
         if (lane == 0) {
             g.r.thr[rb] = lowered7(tr);
@@ -501,7 +524,7 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
         }
     } else {
         float tk = -INFINITY;
-        if (n >= K) tk = pda_unordf(qth(K));
+        if (n >= K) tk = pda_unordf(qth(K, 0));
         failed = n < K || tk < t_old;                            // fewer than K pairs reach the thresholds that were used: a bet was lost
         keep_o = pda_ordf(tk + 0.0f);
         if (lane == 0) g.r.tk[rb] = tk;

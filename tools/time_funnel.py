@@ -10,8 +10,23 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 6
 users = torch.arange(Bu, dtype=torch.int32, device=dev)
 hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
 os.environ["PDA_SCORE_FUNNEL"] = "1"
+# measurements: FUNNEL_TUNE="fail_p,growth,cap_e,first_tiles"  FUNNEL_TUNE2="first_mult,late_den,late_growth_x10"
+import ctypes as C
+from pda_amd import _lib
+L = _lib.load()
+if os.environ.get("FUNNEL_TUNE"):
+    a = os.environ["FUNNEL_TUNE"].split(",")
+    L.pda_debug_funnel_tune.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int]
+    L.pda_debug_funnel_tune(float(a[0]), int(a[1]), int(a[2]), int(a[3]))
+if os.environ.get("FUNNEL_TUNE2"):
+    a = [int(x) for x in os.environ["FUNNEL_TUNE2"].split(",")]
+    L.pda_debug_funnel_tune2(a[0], a[1], a[2])
+out = (C.c_int * 96)()
+ns = L.pda_debug_funnel_schedule(W.n_items, 50, out, 32)
+print("schedule", [(out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i in range(ns)])
 st = {}
-ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_RAW, None, hist, stats=st)
+for _ in range(3):          # (the workspace of a call is allocated per call: the allocator's blocks exist after two)
+    ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_RAW, None, hist, stats=st)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
