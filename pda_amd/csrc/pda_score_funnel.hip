@@ -255,7 +255,7 @@ int run_funnel(const void* U, const void* I_shard, bool bf16, const void* prep, 
     switch (d) {
 #define PDA_F7(DD) case DD: return bf16 ? run_funnel_t<DD, true>(U, I_shard, prep, users, n_users_blk, item_offset, n_items_local, hist_indptr, hist_indices, hist_row_mode, K, out_keys, workspace, s) \
                                          : run_funnel_t<DD, false>(U, I_shard, prep, users, n_users_blk, item_offset, n_items_local, hist_indptr, hist_indices, hist_row_mode, K, out_keys, workspace, s);
-        PDA_F7(64) PDA_F7(128)
+        PDA_F7(64) PDA_F7(128) PDA_F7(256)
 #undef PDA_F7
         default: return PDA_ERR_UNSUPPORTED;
     }
@@ -264,7 +264,7 @@ int run_funnel(const void* U, const void* I_shard, bool bf16, const void* prep, 
 }  // namespace
 
 extern "C" size_t pda_score_topk7_workspace_bytes(int n_users_blk, int n_items_local, int d) {
-    if (n_users_blk <= 0 || n_items_local <= 0 || (d != 64 && d != 128)) return 0;
+    if (n_users_blk <= 0 || n_items_local <= 0 || (d != 64 && d != 128 && d != 256)) return 0;
     return ws7_layout(n_users_blk, n_items_local, d).total;
 }
 extern "C" int pda_score_topk7_f32(const float* U, const float* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset, int n_items_local, int d,
@@ -346,7 +346,7 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
         p.path = PDA_PATH_EXACT_F32;                             // pda_score_topk_f32: the exact fp32-MFMA kernel
         p.n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
         p.order = PDA_ORDER_NATURAL;
-    } else if (head == PDA_HEAD_RAW && (d == 64 || d == 128) && K <= 54 && n_items_local >= 65536 && (uint64_t)n_items_local <= (1ull << 26) &&
+    } else if (head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 65536 && (uint64_t)n_items_local <= (1ull << 26) &&
                n_users_blk >= 32768 && !early && (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID)) {
         p.path = PDA_PATH_FUNNEL;                                // pda_score_topk7_*
         p.n_splits = 1;                                          // (ONE list per user comes back: the item splits are merged inside)

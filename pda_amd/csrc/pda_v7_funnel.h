@@ -516,16 +516,23 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
     uint32_t keep_o;
     if (!last) {
         const int q = min(g.rank_next, K);
-        const float tr = n >= q ? fmaxf(pda_unordf(qth(q, 8)), t_old) : t_old;       // (too few pairs above the old threshold: it stays)
+        const float tr = n >= q ? fmaxf(pda_unordf(qth(q, 12)), t_old) : t_old;       // (too few pairs above the old threshold: it stays)
         keep_o = pda_ordf(tr + 0.0f);
         if (lane == 0) {
             g.r.thr[rb] = lowered7(tr);
             g.r.tmax[rb] = tr;
         }
     } else {
+        // tk: K pairs reach it (the descent's low bits cleared: a little below the K-th largest lower bound); the bets held iff K pairs reach the
+        // thresholds that were used -- counted exactly, not read off the truncated tk
         float tk = -INFINITY;
-        if (n >= K) tk = pda_unordf(qth(K, 0));
-        failed = n < K || tk < t_old;                            // fewer than K pairs reach the thresholds that were used: a bet was lost
+        if (n >= K) tk = pda_unordf(qth(K, 8));
+        const uint32_t t_old_o = pda_ordf(t_old + 0.0f);
+        int c_old = 0;
+#pragma unroll
+        for (int k = 0; k < NKP; ++k)
+            if (live & (1u << k)) c_old += __popcll(__ballot(bnd[k] != 0ull && (uint32_t)bnd[k] >= t_old_o));
+        failed = n < K || c_old < K;                             // fewer than K pairs reach the thresholds that were used: a bet was lost
         keep_o = pda_ordf(tk + 0.0f);
         if (lane == 0) g.r.tk[rb] = tk;
     }

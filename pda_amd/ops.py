@@ -666,7 +666,7 @@ def funnel_order(I_shard: torch.Tensor) -> torch.Tensor:
 
 def funnel_applies(d: int, K: int, nu: int, nloc: int, head: int, prune, hist: Optional[HistoryCSR]) -> bool:
     """Does score_topk_keys serve this call with the funnel?  (PDA_SCORE_FUNNEL=0 | 1 forces it off / on wherever it can run.)"""
-    can = head == HEAD_RAW and d in (64, 128) and K <= TOPK_K_V4 and 4096 <= nloc <= (1 << 26) and prune is not True \
+    can = head == HEAD_RAW and d in (64, 128, 256) and K <= TOPK_K_V4 and 4096 <= nloc <= (1 << 26) and prune is not True \
         and (hist is None or hist.mode == HIST_BY_USER_ID)
     forced = os.environ.get("PDA_SCORE_FUNNEL", "")
     if forced == "0" or not can:

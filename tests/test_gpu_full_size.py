@@ -203,6 +203,20 @@ def test_full_size_c5_shard_bf16(dev, monkeypatch):
         assert_lists_match_oracle(k262, ridx, rval, sc, head=1)
         if not es:
             assert int(st["tiles_scored"][0]) >= st["tiles_dense"]
+    # ---- the raw head (rec_type main_branch) of the same block: the funnel at d = 256 (sweep7_kernel<256, true, 128>), unforced; the 8 192-user
+    # block through generation 3 in natural order gives the same keys, and a 256-user sample equals the oracle
+    RAW = ops.HEAD_RAW
+    monkeypatch.setenv("PDA_SCORE_KERNEL", "v3")
+    r8k, _ = run(ops, W, hist, users, RAW, False, {})
+    monkeypatch.delenv("PDA_SCORE_KERNEL")
+    st = {}
+    r262 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, huge, 50, RAW, None, hist, stats=st), want="keys")
+    ident = ops.kernel_identity(st["kernel_id"][0])
+    assert ident["generation"] == 4 and ident["geometry"] == "funnel" and ident["d"] == 256 and ident["bf16"] and int(st["error"][0]) == 0, ident
+    assert int(st["fallback_rows"][0]) <= 262
+    assert torch.equal(r262[:8192], r8k)
+    ridx0, rval0, sc0 = oracle_sample_lists(W, users, 0)
+    assert_lists_match_oracle(r262, ridx0, rval0, sc0, head=0)
 
 
 

@@ -62,9 +62,11 @@ def make(rng, nU, nI, d, scale=0.1):
     return U, I
 
 
-@pytest.mark.parametrize("d,K,with_hist,bf16", [(128, 50, True, False), (64, 50, True, False), (128, 7, False, False), (64, 54, False, False), (128, 50, True, True)])
+@pytest.mark.parametrize("d,K,with_hist,bf16", [(128, 50, True, False), (64, 50, True, False), (128, 7, False, False), (64, 54, False, False), (128, 50, True, True),
+                                                   (256, 50, True, False), (256, 20, False, True)])
 def test_funnel_equals_the_oracle(dev, monkeypatch, d, K, with_hist, bf16):
-    """Ragged block (4 200 users: four 1 024-user tiles and a rest; 9 000 items: 140 tiles and a rest), random user ids, item splits."""
+    """Ragged block (4 200 users: four 1 024-user tiles and a rest -- eight 512-user tiles and a rest at d = 256; 9 000 items: 140 tiles and a rest),
+    random user ids, item splits."""
     from pda_amd import ops
     rng = np.random.default_rng(100 + d + K)
     nU, nI, nu = 5000, 9000, 4200

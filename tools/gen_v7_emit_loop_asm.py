@@ -235,7 +235,9 @@ def gen(D, UB, maxmode=False):
         s0 = 10
         if p == 1:
             ev(p, s0, "valu", None, ["s_cmp_gt_u32 %[h], %[hend]", "s_cbranch_scc1 92f"])
-        sq = slot_of(G - 1, 0, 1, GU - 1) + 2
+        # (behind the read of the meta entry at A_SLOT + 1: with one group of user blocks -- UB = 8 -- the slot below lies in front of it, and ct would
+        # be formed from the entry read two half-tiles ago)
+        sq = max(slot_of(G - 1, 0, 1, GU - 1) + 2, A_SLOT + 4)
         # ct = pmax + A nmax + B rmax (A, B: the wave's rounding-residual and norm maxima -- sweep7_kernel)
         ev(p, sq, "check", ("meta", q), ["v_fma_f32 %s, %%[eu], %s, %s" % (ctr(q, 0), metan(q), metap(q)),
                                          "v_fma_f32 %s, %%[eu2], %s, %s" % (ctr(q, 0), metar(q), ctr(q, 0))])

@@ -5,6 +5,7 @@ usage: time_emit.py check [d=128]                         small case against tor
        time_emit.py time [workload=c3] [users=262144]     thresholds at several sample ranks -> entries per user, ms, fraction of 2.5 PF
 """
 import ctypes as C
+import os
 import sys
 
 import numpy as np
@@ -89,6 +90,7 @@ def check(d):
         thr_c = thr.cpu()
         nt = PL["n_tiles"]
         bad = n_ent = n_exp = 0
+        examples = []
         for rb in list(range(0, n_users, 97)) + [n_users - 1]:
             utile, wave, u, j = rb // ut, (rb % ut) // (ut // 4), (rb % (ut // 4)) // 16, rb % 16
             e_a, e_b = np.float32(eu[2 * (utile * 4 + wave)]), np.float32(eu[2 * (utile * 4 + wave) + 1])
@@ -130,11 +132,15 @@ def check(d):
                                 for p, v in zip(ps, vals):
                                     if p not in got or abs(got[p] - v) > 2e-5:
                                         bad += 1
+                                        if len(examples) < 12:
+                                            examples.append(("row", rb, "tile", T, "half", half, "hh", hh, "pos", p, "got", got.get(p), "want", v, "ct", ct, "thr", t))
                             elif m < t - 1e-5 * abs(t):
                                 bad += sum(1 for p in ps if p in got)
         print("d=%d S=%d tiles [%d, %d) q=%.3f: %d entries read, %d expected groups, mismatches %d, stats error %d, kernel id %#x" %
               (d, S, lo, hi, q, n_ent, n_exp, bad, int(ws[0:4].view(torch.int32)[0]), int(ws[16:20].view(torch.int32)[0])))
-        assert bad == 0
+        for e in examples:
+            print("   ", e)
+        assert bad == 0 or os.environ.get("EMIT_CHECK_GO_ON")
 
 
 def time_(wl, Bu):
