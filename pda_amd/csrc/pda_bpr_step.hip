@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(256) adam_dense_sweep3_kernel(float* __restric
     // (streams read once and written once per step: non-temporal, so that 3.7 GB of them do not push the batch's rows out of L2 / MALL: 755 -> 742 us;
     // PDA_ADAM_UNROLL chunks per thread and iteration in flight)
 #ifndef PDA_ADAM_UNROLL
-#define PDA_ADAM_UNROLL 1
+#define PDA_ADAM_UNROLL 2
 #endif
     constexpr int UN = PDA_ADAM_UNROLL;
     for (size_t i0 = blk * blockDim.x + threadIdx.x; i0 < n4; i0 += UN * stride) {
