@@ -21,6 +21,8 @@ int g_maxima = 1;              // the first launch keeps maxima only (rank-8 thr
 int g_first_mult = 2;          // the first emitting launch behind a maxima launch over m tiles: tiles [0, g_first_mult x m)
 int g_late_den = 6;            // from 1 / g_late_den of the catalogue on the parts grow by g_late_growth_x10 / 10 instead of g_growth
 int g_late_growth_x10 = 20;
+int g_two_pass_items = 65536;  // catalogues below this (and of at least kTwoPassSplits x 32 tiles): TWO launches over the whole shard instead of growing parts (see schedule7)
+constexpr int kTwoPassSplits = 7;      // 8 maxima per item split: 56 distinct items reach the threshold (K <= 54)
 constexpr int kFallbackSplits = 8;
 
 struct Stage7 {
@@ -47,8 +49,18 @@ int rank_for7(int K, double m, double n, double p) {
         if (gamma_cdf7(r, x) <= p) return r;
     return K;
 }
+bool two_pass7(int n_tiles, int n_items) { return n_items < g_two_pass_items && n_tiles / 32 >= kTwoPassSplits; }
 std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
     std::vector<Stage7> st;
+    if (two_pass7(n_tiles, n_items)) {
+        // Small catalogues: the per-launch costs of the selection outweigh what growing parts save.  Two launches over the WHOLE shard: the maxima launch
+        // with >= 7 item splits -- the two largest per (row, quarter, split): 56 distinct items -- whose smallest second maximum is the threshold of ONE
+        // emitting launch (its rank in the row: ~150 - 200).  No bet on a sample: the threshold fails only where train items crowd a row's maxima, and
+        // the last selection finds that out like any lost bet (maxima = 2: maxthr7_kernel does not merge the splits).
+        st.push_back(Stage7{0, n_tiles, 8, 2});
+        st.push_back(Stage7{0, n_tiles, 0, 0});
+        return st;
+    }
     int lo = 0, hi = std::min(n_tiles, std::max(1, g_first_tiles));
     if (g_maxima) {
         // the maxima launch: as many tiles as rank 8 carries (P(Gamma(8) < K m / n) <= p), at least two; the first emitting launch starts over at tile 0
@@ -91,6 +103,7 @@ int funnel_splits7(int n_users, int n_items_local, int d) {
             best_cost = cost;
         }
     }
+    if (two_pass7(tiles, n_items_local)) best = std::max(best, kTwoPassSplits);
     return best;
 }
 
@@ -106,6 +119,7 @@ Ws7 ws7_layout(int n, int n_items_local, int d) {
     // slots of a (row, quarter, split) list of the pool: what a launch adds per quarter shrinks with the splits; the first launch (everything above
     // -inf: 256 items over 4 quarters and S splits) must fit
     w.cap_q = w.n_splits == 1 ? 64 : w.n_splits == 2 ? 40 : w.n_splits <= 4 ? 28 : 24;
+    if (two_pass7((n_items_local + 63) / 64, n_items_local)) w.cap_q = 48;      // (ONE emitting launch takes everything: 7 - 8 entries per list on average, 30 seen)
     const int ut = d == 256 ? 512 : 1024, nu = ut / 64;
     const size_t utiles = ((size_t)n + ut - 1) / ut, n_pad = utiles * ut, wgs = utiles * (size_t)w.n_splits;
     size_t b = 256;
@@ -206,6 +220,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
             const int rc = launch_sweep7<D, BF, UPW, true>(e, s);
             if (rc != PDA_OK) return rc;
             q.e = e;
+            q.first_launch = st.maxima == 2 ? 2 : 0;                // (2: the splits' maxima are not merged -- the two-pass schedule)
             hipLaunchKernelGGL((maxthr7_kernel<D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q);
             PDA_CHECK_LAUNCH();
             continue;
@@ -228,6 +243,8 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
         }
     }
     hipLaunchKernelGGL((resolve7_kernel<D, BF>), dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, q);
+    PDA_CHECK_LAUNCH();
+    hipLaunchKernelGGL(stat7_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, R, n, (const int*)nullptr, reinterpret_cast<unsigned*>(workspace));
     PDA_CHECK_LAUNCH();
     // ---- the exact fallback: generation 4's many-candidates geometry on the failed rows (a device-side count: nothing runs when nobody failed)
     int32_t* users2 = reinterpret_cast<int32_t*>(wsb + W.users2);

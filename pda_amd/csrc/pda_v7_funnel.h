@@ -181,12 +181,19 @@ __global__ void __launch_bounds__(256) maxthr7_kernel(Sel7 g) {
     if (rb >= n_rows) return;
     const int S = g.e.n_splits;
     const int utile = rb / UT, w = (rb % UT) / UPW, u = (rb % UPW) >> 4, j = rb & 15;
+    // g.first_launch == 2 (the two-pass schedule of small catalogues: every split saw its whole share of the shard): the splits are NOT merged -- the
+    // smallest second maximum over the 4 S (quarter, split) classes: 8 S distinct items reach it
+    const bool per_split = g.first_launch == 2;
     float t = INFINITY;
     for (int hh = 0; hh < 4; ++hh) {
         float b1 = -INFINITY, b2 = -INFINITY;                    // the quarter's two largest lower bounds over the splits
         for (int sp = 0; sp < S; ++sp) {
             const float* mr = g.e.mrun + (((size_t)utile * S + sp) * 4 + w) * MR;
             const float ctm = mr[2 * NU * 64 + j + 16 * hh];
+            if (per_split) {
+                b1 = -INFINITY;
+                b2 = -INFINITY;
+            }
             for (int k = 0; k < 2; ++k) {
                 const float m = mr[(k * NU + u) * 64 + j + 16 * hh];
                 const float lb = m == -INFINITY ? -INFINITY : (m - ctm) - ctm - (fabsf(m) + ctm) * 4.8e-7f;
@@ -194,8 +201,9 @@ __global__ void __launch_bounds__(256) maxthr7_kernel(Sel7 g) {
                 b1 = fmaxf(b1, lb);
                 b2 = fmaxf(b2, lo);
             }
+            if (per_split) t = fminf(t, b2);
         }
-        t = fminf(t, b2);
+        if (!per_split) t = fminf(t, b2);
     }
     g.r.thr[rb] = lowered7(t);
     g.r.tmax[rb] = t;
@@ -599,10 +607,23 @@ __global__ void __launch_bounds__(256) resolve7_kernel(Sel7 g) {
     const size_t ub = (size_t)uid * D + q * (LPC == 8 ? 32 : 8);
 #pragma unroll
     for (int c = 0; c < 8; ++c) uu[c] = pda_load4<BF>(g.U, ub + (LPC == 8 ? 4 * c : 8 * LPC * (c >> 1) + 4 * (c & 1)));
+    // the pool's items up front, a lane per candidate (two round trips for the whole row: visiting positions, then their local ids) -- a pass below
+    // then starts with its row loads: one round trip per pass instead of three dependent ones
+    constexpr int NKC0 = kCand7 / 64;
+    int locs[NKC0];
+#pragma unroll
+    for (int k = 0; k < NKC0; ++k) {
+        const int i = lane + 64 * k;
+        const unsigned pos = i < n ? (unsigned)g.r.cand[((size_t)rb * kCand7 + i) * 2] : 0u;
+        locs[k] = i < n ? (int)g.pinfo[pos][2] : 0;
+    }
     for (int base = 0; base < n; base += CPP) {
         const bool have = base + ci < n;
-        const unsigned pos = have ? (unsigned)g.r.cand[((size_t)rb * kCand7 + base + ci) * 2] : 0u;
-        const int loc = (int)g.pinfo[pos][2];
+        const int kk = base >> 6;                                // (wave-uniform: CPP divides 64)
+        int lsel = locs[0];
+#pragma unroll
+        for (int k = 1; k < NKC0; ++k) lsel = kk == k ? locs[k] : lsel;
+        const int loc = __shfl(lsel, (base & 63) + ci, 64);
         f32x4 ii[8];
         const size_t ib = (size_t)loc * D + q * (LPC == 8 ? 32 : 8);
 #pragma unroll
@@ -689,7 +710,23 @@ __global__ void __launch_bounds__(256) resolve7_kernel(Sel7 g) {
         n_valid += __popcll(__ballot(mine[k] != 0ull));
     }
     if (lane >= n_valid && lane < K) orow[lane] = 0ull;
-    if (lane == 0) atomicAdd(g.e.stats + 1, (unsigned)n);                       // pairs rescored exactly
+}
+// the statistic "pairs rescored exactly" (workspace + 4): the rows' final pool sizes summed -- one atomic per 1 024 rows.  (One per row, from
+// resolve7_kernel itself, serialised 262 144 atomics on one address: 3.3 ms of a 17.9 ms call.)
+__global__ void __launch_bounds__(1024) stat7_kernel(Rows7 r, int n, const int* __restrict__ n_users_dev, unsigned* __restrict__ stats) {
+    __shared__ unsigned part[16];
+    const int n_rows = n_users_dev != nullptr ? min(n, *n_users_dev) : n;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    unsigned v = (i < n_rows && r.flags[i] == 0u) ? (unsigned)r.ncand[i] : 0u;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += (unsigned)__shfl_xor((int)v, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (int k = 0; k < 16; ++k) t += part[k];
+        if (t != 0u) atomicAdd(stats + 1, t);
+    }
 }
 
 // ---- the exact fallback's plumbing: the failed rows' users as a block of their own (padded with the block's first user), and their merged

@@ -1,9 +1,4 @@
-python -m pytest tests/test_gpu_funnel.py -x -q 2>&1 | tail -5
-python -m pytest tests/test_gpu_full_size.py -x -q -k c5 2>&1 | tail -5
-python bench.py --workload c5shard --no-train --no-cpu-baseline --no-per-config > gpurun_out/r5i_c5.json 2> gpurun_out/r5i_c5.err
-python - <<'PY'
-import json
-d=json.loads(open("gpurun_out/r5i_c5.json").read().strip().splitlines()[-1])
-print(d["ms_per_step"], d["roofline"]["frac"])
-print({k:d["raw_head"][k] for k in d["raw_head"] if k in ("ms_per_step","roofline_frac","kernel_identity","exact_rescorings_per_user","rows_through_the_exact_fallback")})
-PY
+python tools/check_funnel.py small 2>&1 | grep -c "rows that differ 0"
+python tools/check_funnel.py c3 262144 2>&1 | tail -4
+bash tools/prof_funnel.sh c3 262144 r5l 2>&1 | grep "7_kernel"
+python tools/check_funnel.py c2 2>&1 | tail -3
