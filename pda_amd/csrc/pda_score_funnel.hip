@@ -118,7 +118,7 @@ Ws7 ws7_layout(int n, int n_items_local, int d) {
     w.cap_e = g_cap_e;
     // slots of a (row, quarter, split) list of the pool: what a launch adds per quarter shrinks with the splits; the first launch (everything above
     // -inf: 256 items over 4 quarters and S splits) must fit
-    w.cap_q = w.n_splits == 1 ? 64 : w.n_splits == 2 ? 40 : w.n_splits <= 4 ? 28 : 24;
+    w.cap_q = w.n_splits == 1 ? 64 : w.n_splits == 2 ? 40 : w.n_splits <= 4 ? 28 : 24;        // (one split: 48 slots overflowed on 33 of 262 144 rows at config 3)
     if (two_pass7((n_items_local + 63) / 64, n_items_local)) w.cap_q = 48;      // (ONE emitting launch takes everything: 7 - 8 entries per list on average, 30 seen)
     const int ut = d == 256 ? 512 : 1024, nu = ut / 64;
     const size_t utiles = ((size_t)n + ut - 1) / ut, n_pad = utiles * ut, wgs = utiles * (size_t)w.n_splits;
@@ -302,6 +302,13 @@ extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int f
     if (growth >= 2) g_growth = growth;
     if (cap_e > 0) g_cap_e = cap_e;
     if (first_tiles > 0) g_first_tiles = first_tiles;
+    return PDA_OK;
+}
+// (a narrow mapping of expand7_kernel -- 64 lists x one entry slot per wave, a quarter of the waves -- measured slower on every launch: 15.6 -> 16.0 ms with the
+// first two, 16.8 with all; removed)
+extern "C" int pda_debug_funnel_tune3(int reserved, int two_pass_items) {
+    (void)reserved;
+    if (two_pass_items >= 0) g_two_pass_items = two_pass_items;
     return PDA_OK;
 }
 extern "C" int pda_debug_funnel_tune2(int first_mult, int late_den, int late_growth_x10) {
