@@ -353,7 +353,7 @@ int pda_score_topk_huge_splits(int n_users_blk, int n_items_local, int d);
  *              ranks assume that the items seen so far are a uniform sample; any order gives exact results, a sorted one more fallbacks)
  *   hist_*     optional; hist_row_mode must be PDA_HIST_BY_USER_ID (the fallback re-blocks the failed rows)
  *   head       PDA_HEAD_RAW (PDA_ERR_UNSUPPORTED otherwise: the popularity head in visiting order is the huge geometry's)
- *   d          64 / 128;  K <= 54;  4 096 <= n_items_local <= 2^26
+ *   d          64 / 128 / 256 (d = 256: 512-user workgroups, as the huge geometry);  K <= 54;  4 096 <= n_items_local <= 2^26
  *   workspace  pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d) bytes; +0 error word, +4 pairs rescored exactly, +16 kernel identity
  * Reference counterpart: MF/model_api.py:62 (the raw ratings) + tf.nn.top_k(..., 50) behind the -inf mask, MF/train_new_api.py:594-612. */
 size_t pda_score_topk7_workspace_bytes(int n_users_blk, int n_items_local, int d);

@@ -103,7 +103,6 @@ int funnel_splits7(int n_users, int n_items_local, int d) {
             best_cost = cost;
         }
     }
-    if (two_pass7(tiles, n_items_local)) best = std::max(best, kTwoPassSplits);
     return best;
 }
 
@@ -115,6 +114,7 @@ Ws7 ws7_layout(int n, int n_items_local, int d) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     Ws7 w{};
     w.n_splits = funnel_splits7(n, n_items_local, d);
+    if (two_pass7((n_items_local + 63) / 64, n_items_local)) w.n_splits = std::max(w.n_splits, kTwoPassSplits);      // (the funnel's own launches only: pda_score_topk_huge_splits shares the rule above)
     w.cap_e = g_cap_e;
     // slots of a (row, quarter, split) list of the pool: what a launch adds per quarter shrinks with the splits; the first launch (everything above
     // -inf: 256 items over 4 quarters and S splits) must fit

@@ -1,8 +1,7 @@
 #!/usr/bin/env python
-"""Per CALL of the funnel: time, HBM traffic and matrix-pipe busy cycles of its kernels, from the CSVs of tools/pmc_funnel.sh (5 calls per run: 1 + 4)."""
+"""Per CALL of the funnel: time, HBM traffic and matrix-pipe busy cycles of its kernels, from the CSVs of tools/pmc_funnel.sh (calls per run: counted -- one uprep5_kernel launch per call)."""
 import csv, glob, sys, collections
 root = sys.argv[1]
-CALLS = 5.0
 KER = ("sweep7_kernel", "expand7_kernel", "threshold7_kernel", "maxthr7_kernel", "resolve7_kernel", "uprep5_kernel", "hist_bloom7_kernel", "sweep4_kernel", "warm4_kernel", "fail_")
 def name(k):
     for x in KER:
@@ -16,6 +15,7 @@ for f in sorted(glob.glob(root + "/stats/**/*_kernel_trace.csv", recursive=True)
         if n:
             dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
             cnt[n] += 1
+CALLS = float(max(1, cnt.get("uprep5_kernel", 1)))
 ctr = collections.defaultdict(lambda: collections.defaultdict(float))
 for f in sorted(glob.glob(root + "/p*/**/*_counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
