@@ -21,8 +21,6 @@ int g_maxima = 1;              // the first launch keeps maxima only (rank-8 thr
 int g_first_mult = 2;          // the first emitting launch behind a maxima launch over m tiles: tiles [0, g_first_mult x m)
 int g_late_den = 6;            // from 1 / g_late_den of the catalogue on the parts grow by g_late_growth_x10 / 10 instead of g_growth
 int g_late_growth_x10 = 20;
-int g_two_pass_items = 65536;  // catalogues below this (and of at least kTwoPassSplits x 32 tiles): TWO launches over the whole shard instead of growing parts (see schedule7)
-constexpr int kTwoPassSplits = 7;      // 8 maxima per item split: 56 distinct items reach the threshold (K <= 54)
 constexpr int kFallbackSplits = 8;
 
 struct Stage7 {
@@ -49,18 +47,8 @@ int rank_for7(int K, double m, double n, double p) {
         if (gamma_cdf7(r, x) <= p) return r;
     return K;
 }
-bool two_pass7(int n_tiles, int n_items) { return n_items < g_two_pass_items && n_tiles / 32 >= kTwoPassSplits; }
 std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
     std::vector<Stage7> st;
-    if (two_pass7(n_tiles, n_items)) {
-        // Small catalogues: the per-launch costs of the selection outweigh what growing parts save.  Two launches over the WHOLE shard: the maxima launch
-        // with >= 7 item splits -- the two largest per (row, quarter, split): 56 distinct items -- whose smallest second maximum is the threshold of ONE
-        // emitting launch (its rank in the row: ~150 - 200).  No bet on a sample: the threshold fails only where train items crowd a row's maxima, and
-        // the last selection finds that out like any lost bet (maxima = 2: maxthr7_kernel does not merge the splits).
-        st.push_back(Stage7{0, n_tiles, 8, 2});
-        st.push_back(Stage7{0, n_tiles, 0, 0});
-        return st;
-    }
     int lo = 0, hi = std::min(n_tiles, std::max(1, g_first_tiles));
     if (g_maxima) {
         // the maxima launch: as many tiles as rank 8 carries (P(Gamma(8) < K m / n) <= p), at least two; the first emitting launch starts over at tile 0
@@ -107,19 +95,17 @@ int funnel_splits7(int n_users, int n_items_local, int d) {
 }
 
 struct Ws7 {
-    size_t ufrag, unorm, uerr, eu, ecnt, mrun, elist, thr, tk, tmax, ncand, flags, cand, qpool, qcnt, bloom, fail_list, fail_count, users2, fb_keys, fb_ws, total;
+    size_t ufrag, unorm, uerr, eu, ecnt, mrun, elist, thr, tk, tmax, ncand, flags, cand, qpool, qcnt, bloom, fail_list, fail_count, users2, seed2, fb_keys, fb_ws, total;
     int n_splits, cap_e, cap_q;
 };
 Ws7 ws7_layout(int n, int n_items_local, int d) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     Ws7 w{};
     w.n_splits = funnel_splits7(n, n_items_local, d);
-    if (two_pass7((n_items_local + 63) / 64, n_items_local)) w.n_splits = std::max(w.n_splits, kTwoPassSplits);      // (the funnel's own launches only: pda_score_topk_huge_splits shares the rule above)
     w.cap_e = g_cap_e;
     // slots of a (row, quarter, split) list of the pool: what a launch adds per quarter shrinks with the splits; the first launch (everything above
     // -inf: 256 items over 4 quarters and S splits) must fit
     w.cap_q = w.n_splits == 1 ? 64 : w.n_splits == 2 ? 40 : w.n_splits <= 4 ? 28 : 24;        // (one split: 48 slots overflowed on 33 of 262 144 rows at config 3)
-    if (two_pass7((n_items_local + 63) / 64, n_items_local)) w.cap_q = 48;      // (ONE emitting launch takes everything: 7 - 8 entries per list on average, 30 seen)
     const int ut = d == 256 ? 512 : 1024, nu = ut / 64;
     const size_t utiles = ((size_t)n + ut - 1) / ut, n_pad = utiles * ut, wgs = utiles * (size_t)w.n_splits;
     size_t b = 256;
@@ -160,6 +146,8 @@ Ws7 ws7_layout(int n, int n_items_local, int d) {
     w.fail_count = b;
     b = al(b + 256);
     w.users2 = b;
+    b = al(b + (size_t)n * 4);
+    w.seed2 = b;
     b = al(b + (size_t)n * 4);
     w.fb_keys = b;
     b = al(b + (size_t)kFallbackSplits * n * PDA_MAX_K * 8);
@@ -220,7 +208,6 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
             const int rc = launch_sweep7<D, BF, UPW, true>(e, s);
             if (rc != PDA_OK) return rc;
             q.e = e;
-            q.first_launch = st.maxima == 2 ? 2 : 0;                // (2: the splits' maxima are not merged -- the two-pass schedule)
             hipLaunchKernelGGL((maxthr7_kernel<D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q);
             PDA_CHECK_LAUNCH();
             continue;
@@ -248,11 +235,12 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
     PDA_CHECK_LAUNCH();
     // ---- the exact fallback: generation 4's many-candidates geometry on the failed rows (a device-side count: nothing runs when nobody failed)
     int32_t* users2 = reinterpret_cast<int32_t*>(wsb + W.users2);
-    hipLaunchKernelGGL(fail_users7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, users, q.fail_list, fail_count, n, users2);
+    float* seed2 = reinterpret_cast<float*>(wsb + W.seed2);
+    hipLaunchKernelGGL(fail_users7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, users, q.fail_list, fail_count, n, R.tk, users2, seed2);
     PDA_CHECK_LAUNCH();
     uint64_t* fb_keys = reinterpret_cast<uint64_t*>(wsb + W.fb_keys);
     const int rc = pda_v4_run_score4_dev(U, I_shard, BF, prep, nullptr, users2, n, fail_count, item_offset, n_items_local, D, hist_indptr, hist_indices, hist_row_mode, K,
-                                         PDA_HEAD_RAW, PDA_SWEEP_MANY_CANDIDATES, kFallbackSplits, fb_keys, wsb + W.fb_ws, s);
+                                         PDA_HEAD_RAW, PDA_SWEEP_MANY_CANDIDATES, kFallbackSplits, seed2, fb_keys, wsb + W.fb_ws, s);
     if (rc != PDA_OK) return rc;
     hipLaunchKernelGGL(fail_merge7_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb_keys, kFallbackSplits, n, K, q.fail_list, fail_count, out_keys, reinterpret_cast<unsigned*>(workspace));
     PDA_CHECK_LAUNCH();
@@ -302,13 +290,6 @@ extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int f
     if (growth >= 2) g_growth = growth;
     if (cap_e > 0) g_cap_e = cap_e;
     if (first_tiles > 0) g_first_tiles = first_tiles;
-    return PDA_OK;
-}
-// (a narrow mapping of expand7_kernel -- 64 lists x one entry slot per wave, a quarter of the waves -- measured slower on every launch: 15.6 -> 16.0 ms with the
-// first two, 16.8 with all; removed)
-extern "C" int pda_debug_funnel_tune3(int reserved, int two_pass_items) {
-    (void)reserved;
-    if (two_pass_items >= 0) g_two_pass_items = two_pass_items;
     return PDA_OK;
 }
 extern "C" int pda_debug_funnel_tune2(int first_mult, int late_den, int late_growth_x10) {
@@ -370,8 +351,11 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
         p.path = PDA_PATH_EXACT_F32;                             // pda_score_topk_f32: the exact fp32-MFMA kernel
         p.n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
         p.order = PDA_ORDER_NATURAL;
-    } else if (head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 65536 && (uint64_t)n_items_local <= (1ull << 26) &&
-               n_users_blk >= 32768 && !early && (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID)) {
+    } else if (head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 16384 && (uint64_t)n_items_local <= (1ull << 26) &&
+               n_users_blk >= 1024 && (n_items_local >= 65536 || n_users_blk <= 16384) && !early &&
+               (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID)) {
+        // (tools/funnel_crossover.py: from ONE 1 024-user tile on the funnel beats generation 4's many-candidates geometry on catalogues of 65 536 items and
+        // more -- 2 048 users x 200 000 items 0.88 vs 1.85 ms --, on smaller ones up to 16 384 users; config 1 / 2 -- 48 000 users x 26 000 items -- keep generation 4)
         p.path = PDA_PATH_FUNNEL;                                // pda_score_topk7_*
         p.n_splits = 1;                                          // (ONE list per user comes back: the item splits are merged inside)
         p.order = PDA_ORDER_RANDOM;

@@ -8,7 +8,7 @@ using namespace pda_topk;
 // defined in pda_score_topk_v4.hip: generation 4 on a block whose size is a device-side count (the funnel's exact fallback)
 int pda_v4_run_score4_dev(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users, int n_users_blk,
                           const int* n_users_dev, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
-                          int hist_row_mode, int K, int head, int early_stop, int n_splits, uint64_t* out_keys, void* workspace, hipStream_t s);
+                          int hist_row_mode, int K, int head, int early_stop, int n_splits, const float* seed, uint64_t* out_keys, void* workspace, hipStream_t s);
 
 namespace {
 

@@ -181,19 +181,12 @@ __global__ void __launch_bounds__(256) maxthr7_kernel(Sel7 g) {
     if (rb >= n_rows) return;
     const int S = g.e.n_splits;
     const int utile = rb / UT, w = (rb % UT) / UPW, u = (rb % UPW) >> 4, j = rb & 15;
-    // g.first_launch == 2 (the two-pass schedule of small catalogues: every split saw its whole share of the shard): the splits are NOT merged -- the
-    // smallest second maximum over the 4 S (quarter, split) classes: 8 S distinct items reach it
-    const bool per_split = g.first_launch == 2;
     float t = INFINITY;
     for (int hh = 0; hh < 4; ++hh) {
         float b1 = -INFINITY, b2 = -INFINITY;                    // the quarter's two largest lower bounds over the splits
         for (int sp = 0; sp < S; ++sp) {
             const float* mr = g.e.mrun + (((size_t)utile * S + sp) * 4 + w) * MR;
             const float ctm = mr[2 * NU * 64 + j + 16 * hh];
-            if (per_split) {
-                b1 = -INFINITY;
-                b2 = -INFINITY;
-            }
             for (int k = 0; k < 2; ++k) {
                 const float m = mr[(k * NU + u) * 64 + j + 16 * hh];
                 const float lb = m == -INFINITY ? -INFINITY : (m - ctm) - ctm - (fabsf(m) + ctm) * 4.8e-7f;
@@ -201,9 +194,8 @@ __global__ void __launch_bounds__(256) maxthr7_kernel(Sel7 g) {
                 b1 = fmaxf(b1, lb);
                 b2 = fmaxf(b2, lo);
             }
-            if (per_split) t = fminf(t, b2);
         }
-        if (!per_split) t = fminf(t, b2);
+        t = fminf(t, b2);
     }
     g.r.thr[rb] = lowered7(t);
     g.r.tmax[rb] = t;
@@ -732,9 +724,20 @@ __global__ void __launch_bounds__(1024) stat7_kernel(Rows7 r, int n, const int* 
 // ---- the exact fallback's plumbing: the failed rows' users as a block of their own (padded with the block's first user), and their merged
 // lists back into the rows they belong to
 __global__ void __launch_bounds__(256) fail_users7_kernel(const int32_t* __restrict__ users, const int* __restrict__ fail_list, const int* __restrict__ fail_count,
-                                                          int n, int32_t* __restrict__ users2) {
+                                                          int n, const float* __restrict__ tk, int32_t* __restrict__ users2, float* __restrict__ seed2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n) users2[i] = i < *fail_count ? users[fail_list[i]] : users[0];
+    if (i >= n) return;
+    const bool real = i < *fail_count;
+    users2[i] = real ? users[fail_list[i]] : users[0];
+    // The seed of generation 4's sweep: the failed row's tk -- K unmasked items reach it whatever became of the bets (-inf: fewer than K pairs in its pool)
+    // -- so the fallback rescans the catalogue against an almost final threshold instead of building a list from nothing (d = 256: 45 -> ms per call with
+    // one failed row); the rows that pad the block: +1e30, nothing qualifies.
+    float sd = 1.0e30f;
+    if (real) {
+        const float t = tk[fail_list[i]];
+        sd = (t > -1.0e30f && t < 1.0e30f) ? lowered7(t) : -INFINITY;
+    }
+    seed2[i] = sd;
 }
 // one wave per failed row: the best K of its S sorted partial lists (K rounds of "the largest head"), written to the row it came from
 __global__ void __launch_bounds__(256) fail_merge7_kernel(const uint64_t* __restrict__ keys, int S, int n, int K, const int* __restrict__ fail_list,

@@ -647,8 +647,9 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
 # ---- the funnel (pda_score_topk7_*): the raw head on large user blocks ------------------------------------------------------------
 # Measured (config 3, same box): 262 144 users 22.3 vs 29.7 ms for generation 4's many-candidates geometry, 65 536 users 6.4 vs 7.3 ms; config 2 (50 000 users
 # x 20 000 items, d = 64) 3.3 vs 2.1 ms -- a funnel is ~25 launches whose per-row work does not shrink with the catalogue.
-FUNNEL_MIN_USERS = 32768
-FUNNEL_MIN_ITEMS = 65536
+FUNNEL_MIN_USERS = 1024          # one 1 024-user tile (tools/funnel_crossover.py: 2 048 users x 200 000 items 0.88 vs 1.85 ms for generation 4)
+FUNNEL_MIN_ITEMS = 16384
+FUNNEL_SMALL_ITEMS, FUNNEL_SMALL_MAX_USERS = 65536, 16384     # catalogues below 65 536 items: up to 16 384 users (config 1 / 2 keep generation 4)
 _FUNNEL_ORDER = {}               # (n, device) -> a fixed pseudo-random permutation (the object is what the prep cache keys on)
 
 
@@ -673,7 +674,8 @@ def funnel_applies(d: int, K: int, nu: int, nloc: int, head: int, prune, hist: O
         return False
     if forced == "1":
         return True
-    return nu >= FUNNEL_MIN_USERS and nloc >= FUNNEL_MIN_ITEMS and not os.environ.get("PDA_SCORE_KERNEL") and not os.environ.get("PDA_SCORE_LISTS")
+    return nu >= FUNNEL_MIN_USERS and nloc >= FUNNEL_MIN_ITEMS and (nloc >= FUNNEL_SMALL_ITEMS or nu <= FUNNEL_SMALL_MAX_USERS) \
+        and not os.environ.get("PDA_SCORE_KERNEL") and not os.environ.get("PDA_SCORE_LISTS")
 
 
 def score_topk_funnel(U, I_shard, users, K=50, hist: Optional[HistoryCSR] = None, item_offset=0, stats: Optional[dict] = None) -> torch.Tensor:

@@ -148,8 +148,12 @@ def test_full_size_c3(dev, monkeypatch):
     assert torch.equal(k53, k262["order"][:53248])
     k98r, _ = run(ops, W, hist, mid, RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})       # (eight item splits)
     assert torch.equal(k98r, raw[None][:98304])
-    k20r, _ = run(ops, W, hist, huge[:20000].contiguous(), RAW, None, {"generation": 4, "geometry": "many", "head": 0})       # (below 32 768 users: generation 4)
+    k20r, _ = run(ops, W, hist, huge[:20000].contiguous(), RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})
     assert torch.equal(k20r, raw[None][:20000])
+    k2r, _ = run(ops, W, hist, huge[:2048].contiguous(), RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})        # (the reference's own block size: 32 item splits)
+    assert torch.equal(k2r, raw[None][:2048])
+    k1r, _ = run(ops, W, hist, huge[:1000].contiguous(), RAW, None, {"generation": 4, "geometry": "many", "head": 0})          # (below one 1 024-user tile: generation 4)
+    assert torch.equal(k1r, raw[None][:1000])
 
     # ---- every other geometry forced on the same 262 144-user block: identical keys
     monkeypatch.setenv("PDA_SCORE_KERNEL", "v4")

@@ -21,9 +21,6 @@ if os.environ.get("FUNNEL_TUNE"):
 if os.environ.get("FUNNEL_TUNE2"):
     a = [int(x) for x in os.environ["FUNNEL_TUNE2"].split(",")]
     L.pda_debug_funnel_tune2(a[0], a[1], a[2])
-if os.environ.get("FUNNEL_TUNE3"):
-    a = [int(x) for x in os.environ["FUNNEL_TUNE3"].split(",")]
-    L.pda_debug_funnel_tune3(a[0], a[1])
 out = (C.c_int * 96)()
 ns = L.pda_debug_funnel_schedule(W.n_items, 50, out, 32)
 print("schedule", [(out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i in range(ns)])
