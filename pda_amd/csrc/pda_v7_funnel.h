@@ -424,11 +424,21 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
     uint64_t key[NKP], bnd[NKP];
     if constexpr (NSL > 0) {
         const int cap_q = g.r.cap_q, slots = nl * cap_q;
-        int lcn[NSL];
+        // Which slot a (lane, group) pair reads.  The lists fill from slot 0 and hold ~10 entries of their 64: with the lists INTERLEAVED -- 64 / nl lanes
+        // per list, group k = the k-th run of 64 / nl slots of every list -- the pairs sit in the first one or two groups and the others are dead (skipped by
+        // the descent and the keep pass: a third of this kernel's instructions); list after list (group = 64 consecutive slots) where nl does not divide 64.
+        const int lpl = 64 / nl;
+        const bool inter = nl * lpl == 64 && NSL * lpl >= cap_q;
+        int lcn[NSL], slot_t[NSL];
+        bool in_list[NSL];
 #pragma unroll
         for (int k = 0; k < NSL; ++k) {
             const int t = lane + 64 * k;
-            lcn[k] = t < slots ? (int)g.r.qcnt[(size_t)rb * nl + t / cap_q] : 0;
+            const int list = inter ? lane / lpl : t / cap_q, idx = inter ? lane % lpl + k * lpl : t % cap_q;
+            in_list[k] = inter ? idx < cap_q : t < slots;
+            slot_t[k] = list * cap_q + idx;
+            lcn[k] = (in_list[k] || inter) ? (int)g.r.qcnt[(size_t)rb * nl + list] : 0;
+            in_list[k] = in_list[k] && idx < lcn[k];
         }
 #pragma unroll
         for (int k = 0; k < NKK; ++k) {
@@ -439,10 +449,9 @@ __global__ void __launch_bounds__(256) threshold7_kernel(Sel7 g) {
         }
 #pragma unroll
         for (int k = 0; k < NSL; ++k) {
-            const int t = lane + 64 * k;
-            const bool real = t < slots && (t % cap_q) < lcn[k];
+            const bool real = in_list[k];
             over = over || lcn[k] > cap_q;
-            const ulonglong2 kv = real ? *reinterpret_cast<const ulonglong2*>(g.r.qpool + ((size_t)rb * slots + t) * 2) : make_ulonglong2(0ull, 0ull);
+            const ulonglong2 kv = real ? *reinterpret_cast<const ulonglong2*>(g.r.qpool + ((size_t)rb * slots + slot_t[k]) * 2) : make_ulonglong2(0ull, 0ull);
             key[NKK + k] = kv.x;
             bnd[NKK + k] = kv.y;                                 // (ordered bounds of real pairs are > 0)
             n += __popcll(__ballot(real));
