@@ -320,7 +320,7 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
     # the raw head ('main_branch'): the reference evaluates it in EVERY evaluation epoch before the two PDA passes
     # (MF/train_new_api.py:1139-1141, head at :597-598) and it is the only head of --train normal.  Product-default sweep mode.
     raw = None
-    if head == ops.HEAD_POP and v2 and not args.headline_only and not light and world_all == 1:
+    if head == ops.HEAD_POP and v2 and not args.headline_only and world_all == 1:
         rp = ops.prune_default(ops.HEAD_RAW, W.d)
         dt_r, k_ms_r, st_r = timed_pass(rp, ops.HEAD_RAW)
         fl_r = 2.0 * blocks[0].numel() * ev.I_shard.shape[0] * W.d
@@ -999,6 +999,8 @@ def main():
                      "eval": {"users_per_s": e["users_per_s"], "ms_per_step": e["ms_per_step"], "users_per_step": e["Bu"],
                               "roofline_frac": e["roofline"]["frac"], "kernel": e["roofline"]["kernel"], "kernel_ms": e["roofline"]["kernel_ms"],
                               "early_terminating_sweep": e["ordered"], "prep": e["prep"],
+                              "raw_head": None if e["raw_head"] is None else {k: e["raw_head"][k] for k in ("value", "unit", "ms_per_step", "kernel_ms", "roofline_frac", "kernel_identity",
+                                                                                                               "exact_rescorings_per_user", "rows_through_the_exact_fallback")},
                               "note": "a %d-item catalogue is %d tiles of 64: the fixed cost per user block (exact warm-up on the "
                                       "first 256 items, list hand-over, launch) is a visible share of the step" % (e["W"].n_items, -(-e["W"].n_items // 64))}}
             if not args.no_train:

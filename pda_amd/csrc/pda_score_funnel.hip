@@ -102,6 +102,8 @@ Ws7 ws7_layout(int n, int n_items_local, int d) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     Ws7 w{};
     w.n_splits = funnel_splits7(n, n_items_local, d);
+    // (a power of two: threshold7_kernel then reads a row's 4 S lists interleaved -- 12 sparse register groups at S = 5 cost it 2.6 ns per row, 0.9 at S = 1)
+    while (w.n_splits & (w.n_splits - 1)) w.n_splits &= w.n_splits - 1;
     w.cap_e = g_cap_e;
     // slots of a (row, quarter, split) list of the pool: what a launch adds per quarter shrinks with the splits; the first launch (everything above
     // -inf: 256 items over 4 quarters and S splits) must fit
@@ -352,10 +354,11 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
         p.n_splits = pda_score_topk_auto_splits(n_users_blk, n_items_local);
         p.order = PDA_ORDER_NATURAL;
     } else if (head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 16384 && (uint64_t)n_items_local <= (1ull << 26) &&
-               n_users_blk >= 1024 && (n_items_local >= 65536 || n_users_blk <= 16384) && !early &&
+               n_users_blk >= 1024 && (n_items_local >= 20000 || n_users_blk <= 16384) && !early &&
                (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID)) {
         // (tools/funnel_crossover.py: from ONE 1 024-user tile on the funnel beats generation 4's many-candidates geometry on catalogues of 65 536 items and
-        // more -- 2 048 users x 200 000 items 0.88 vs 1.85 ms --, on smaller ones up to 16 384 users; config 1 / 2 -- 48 000 users x 26 000 items -- keep generation 4)
+        // more -- 2 048 users x 200 000 items 0.88 vs 1.85 ms --, and on smaller ones too (config 2, 50 000 users x 20 000 items: 1.73 vs 2.13 ms; config 1: 1.58 vs
+        // 2.30) except the very smallest with many users (16 384 items x 65 536 users: 2.1 vs 1.9))
         p.path = PDA_PATH_FUNNEL;                                // pda_score_topk7_*
         p.n_splits = 1;                                          // (ONE list per user comes back: the item splits are merged inside)
         p.order = PDA_ORDER_RANDOM;

@@ -649,7 +649,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
 # x 20 000 items, d = 64) 3.3 vs 2.1 ms -- a funnel is ~25 launches whose per-row work does not shrink with the catalogue.
 FUNNEL_MIN_USERS = 1024          # one 1 024-user tile (tools/funnel_crossover.py: 2 048 users x 200 000 items 0.88 vs 1.85 ms for generation 4)
 FUNNEL_MIN_ITEMS = 16384
-FUNNEL_SMALL_ITEMS, FUNNEL_SMALL_MAX_USERS = 65536, 16384     # catalogues below 65 536 items: up to 16 384 users (config 1 / 2 keep generation 4)
+FUNNEL_SMALL_ITEMS, FUNNEL_SMALL_MAX_USERS = 20000, 16384     # catalogues below 20 000 items: up to 16 384 users (16 384 items x 65 536 users: 2.1 vs 1.9 ms for generation 4)
 _FUNNEL_ORDER = {}               # (n, device) -> a fixed pseudo-random permutation (the object is what the prep cache keys on)
 
 

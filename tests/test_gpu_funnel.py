@@ -87,6 +87,37 @@ def test_funnel_equals_the_oracle(dev, monkeypatch, d, K, with_hist, bf16):
     assert nfb <= nu // 100
 
 
+@pytest.mark.parametrize("wl", ["c1", "c2"])
+def test_configs_1_and_2_take_the_funnel_unforced(dev, wl):
+    """BASELINE configs 1 and 2 (47 890 x 26 047 and 50 000 x 20 000, d = 64; config 1's only model head is the raw one): NO PDA_* variable set, all users in one
+    block -- the library's plan sends the raw head to the funnel (identity word; four item splits), the keys equal generation 4's, and a 256-user sample equals
+    the oracle on the workload's real train rows."""
+    from pda_amd import ops, synthetic
+    W = synthetic.make_workload(wl, dev)
+    hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+    users = torch.arange(W.n_users, dtype=torch.int32, device=dev)
+    assert ops.score_plan(W.n_users, W.n_items, W.d, 50, ops.HEAD_RAW, None, hist=hist)["kernel"] == "funnel"
+    st = {}
+    keys = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_RAW, None, hist, stats=st), want="keys")
+    ident = ops.kernel_identity(st["kernel_id"][0])
+    assert ident["generation"] == 4 and ident["geometry"] == "funnel" and ident["d"] == 64 and int(st["error"][0]) == 0, ident
+    assert int(st["fallback_rows"][0]) <= W.n_users // 1000
+    import os
+    os.environ["PDA_SCORE_FUNNEL"] = "0"
+    try:
+        g4 = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, ops.HEAD_RAW, None, hist), want="keys")
+    finally:
+        del os.environ["PDA_SCORE_FUNNEL"]
+    assert torch.equal(keys, g4)
+    n = 256
+    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
+    bip, bix = csr([ix[ip[u]:ip[u + 1]] for u in range(n)])
+    ridx, rval = c_oracle.score_topk(W.U[:n].float().cpu().numpy(), W.I.float().cpu().numpy(), np.arange(n, dtype=np.int32), 50, 0, None, bip, bix, order=1)
+    idx, val = ops.unpack_keys(keys[:n])
+    np.testing.assert_array_equal(val, rval)
+    np.testing.assert_array_equal(idx, ridx)
+
+
 def test_funnel_lost_bets_and_overflowing_lists_take_the_exact_fallback(dev, monkeypatch):
     """Thresholds that are far too bold (every second bet lost) and lists of two entries: most rows end in generation 4's exact lists inside the
     same call -- and the result does not move."""
