@@ -87,6 +87,33 @@ def test_funnel_equals_the_oracle(dev, monkeypatch, d, K, with_hist, bf16):
     assert nfb <= nu // 100
 
 
+def test_funnel_on_item_shards_merges_to_the_oracle(dev, monkeypatch):
+    """Item-sharded evaluation (one shard per rank): the funnel on two ragged shards of the catalogue with GLOBAL item ids in the train rows (item_offset),
+    the two partial lists merged by pda_topk_merge -- the oracle's lists over the whole catalogue, bit for bit."""
+    from pda_amd import ops
+    rng = np.random.default_rng(77)
+    nU, nI, nu, d, K = 3000, 40000, 2500, 128, 50
+    U, I = make(rng, nU, nI, d)
+    users = rng.permutation(nU)[:nu].astype(np.int32)
+    rows = [rng.choice(nI, rng.integers(0, 70), replace=False) for _ in range(nU)]
+    ip, ix = csr(rows)
+    Ut, It = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev)
+    hist = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    ut = torch.from_numpy(users).to(dev)
+    monkeypatch.setenv("PDA_SCORE_FUNNEL", "1")
+    parts = []
+    for lo, hi in ((0, 17001), (17001, nI)):
+        st = {}
+        k = ops.score_topk_keys(Ut, It[lo:hi].contiguous(), ut, K, ops.HEAD_RAW, None, hist, item_offset=lo, stats=st)
+        assert ops.kernel_identity(st["kernel_id"][0])["geometry"] == "funnel" and int(st["error"][0]) == 0
+        parts.append(k)
+    idx, val = ops.unpack_keys(ops.topk_merge(torch.cat(parts, dim=0), want="keys"))
+    bip, bix = csr([rows[u] for u in users])
+    ridx, rval = c_oracle.score_topk(U[users], I, np.arange(nu, dtype=np.int32), K, 0, None, bip, bix, order=1)
+    np.testing.assert_array_equal(val, rval)
+    np.testing.assert_array_equal(idx, ridx)
+
+
 @pytest.mark.parametrize("wl", ["c1", "c2"])
 def test_configs_1_and_2_take_the_funnel_unforced(dev, wl):
     """BASELINE configs 1 and 2 (47 890 x 26 047 and 50 000 x 20 000, d = 64; config 1's only model head is the raw one): NO PDA_* variable set, all users in one
