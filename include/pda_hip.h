@@ -349,13 +349,18 @@ int pda_score_topk_huge_splits(int n_users_blk, int n_items_local, int d);
  * them to per-lane lists, tightens the thresholds between the parts from the r-th largest lower bound seen, and rescores only the final K + the
  * pairs inside the bound's band exactly.  Rows whose estimate was too bold (probability ~1e-6 per launch) or whose lists overflowed are served by
  * generation 4's exact lists inside the same call.
- *   prep       pda_item_prep4_f32 / _bf16 WITHOUT popularity, with a visiting order that is a RANDOM permutation of the shard (the thresholds'
- *              ranks assume that the items seen so far are a uniform sample; any order gives exact results, a sorted one more fallbacks)
+ *   prep       pda_item_prep7_f32 / _bf16 (below: pda_item_prep4_* without a popularity and with the half-tile image in FP16 -- the funnel's sweeps run
+ *              v_mfma_f32_16x16x32_f16: eleven significant bits instead of bf16's eight, the band of the rigorous bound 8 x narrower on fp32 tables), with a
+ *              visiting order that is a RANDOM permutation of the shard (the thresholds' ranks assume that the items seen so far are a uniform sample; any
+ *              order gives exact results, a sorted one more fallbacks).  A prep of pda_item_prep4_* is refused: error word 7, every row served by the
+ *              exact fallback.
  *   hist_*     optional; hist_row_mode must be PDA_HIST_BY_USER_ID (the fallback re-blocks the failed rows)
  *   head       PDA_HEAD_RAW (PDA_ERR_UNSUPPORTED otherwise: the popularity head in visiting order is the huge geometry's)
  *   d          64 / 128 / 256 (d = 256: 512-user workgroups, as the huge geometry);  K <= 54;  4 096 <= n_items_local <= 2^26
  *   workspace  pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d) bytes; +0 error word, +4 pairs rescored exactly, +16 kernel identity
  * Reference counterpart: MF/model_api.py:62 (the raw ratings) + tf.nn.top_k(..., 50) behind the -inf mask, MF/train_new_api.py:594-612. */
+int pda_item_prep7_f32(const float* I_shard, const int32_t* order, int n_items_local, int d, void* prep, void* stream);      /* pda_item_prep4_bytes(n, d) bytes */
+int pda_item_prep7_bf16(const uint16_t* I_shard, const int32_t* order, int n_items_local, int d, void* prep, void* stream);
 size_t pda_score_topk7_workspace_bytes(int n_users_blk, int n_items_local, int d);
 int pda_score_topk7_f32(const float* U, const float* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset,
                         int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pda_item_prep4_bytes": (_sz, [_i, _i]),
     "pda_item_prep4_f32": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     "pda_item_prep4_bf16": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "pda_item_prep7_f32": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "pda_item_prep7_bf16": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "pda_item_prep4_check": (_i, [_vp, _i, _i, _vp]),
     "pda_score_topk4_auto_splits": (_i, [_i, _i, _i]),
     "pda_score_topk4_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

@@ -186,7 +186,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
     hipLaunchKernelGGL(init7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, R, n, fail_count);
     PDA_CHECK_LAUNCH();
     const int n_pad = (n + UT - 1) / UT * UT;
-    hipLaunchKernelGGL((uprep5_kernel<D, BF, true, UPW>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, s, U, users, n, n_pad, wsb + W.ufrag,
+    hipLaunchKernelGGL((uprep5_kernel<D, BF, true, UPW, true>), dim3((unsigned)(((size_t)n_pad * (D / 8) + 255) / 256)), dim3(256), 0, s, U, users, n, n_pad, wsb + W.ufrag,
                        reinterpret_cast<float*>(wsb + W.unorm), reinterpret_cast<float*>(wsb + W.uerr));
     PDA_CHECK_LAUNCH();
     uint32_t* bloom = nullptr;
@@ -199,7 +199,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
     Args7 e{pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), wsb + W.ufrag, reinterpret_cast<const float*>(wsb + W.unorm), reinterpret_cast<const float*>(wsb + W.uerr), R.thr,
             wsb + W.elist,
             reinterpret_cast<unsigned*>(wsb + W.ecnt), reinterpret_cast<float*>(wsb + W.eu), reinterpret_cast<unsigned*>(workspace), n, W.n_splits, L.n_tiles, 0, 0, W.cap_e,
-            reinterpret_cast<float*>(wsb + W.mrun), nullptr};
+            reinterpret_cast<float*>(wsb + W.mrun), nullptr, reinterpret_cast<const int*>(pb + L.hdr)};
     Sel7 q{e, R, reinterpret_cast<const u32x4*>(pb + L.pinfo), users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, 0, U, I_shard, out_keys,
            reinterpret_cast<int*>(wsb + W.fail_list), fail_count};
     const std::vector<Stage7> stages = schedule7(L.n_tiles, n_items_local, K);
@@ -424,12 +424,12 @@ extern "C" int pda_debug_emit_sweep(const void* U, int bf16, const int32_t* user
     Args7 g{pb + L.rows5, reinterpret_cast<const float*>(pb + L.meta5), wsb + 256, reinterpret_cast<const float*>(wsb + offs[0]),
             reinterpret_cast<const float*>(wsb + offs[4]), thr, wsb + offs[3],
             reinterpret_cast<unsigned*>(wsb + offs[2]), reinterpret_cast<float*>(wsb + offs[1]), reinterpret_cast<unsigned*>(wsb), n_users_blk, n_splits, L.n_tiles,
-            tile_lo, tile_hi, cap_e, nullptr, nullptr};
+            tile_lo, tile_hi, cap_e, nullptr, nullptr, reinterpret_cast<const int*>(pb + L.hdr)};
 #define PDA_E7(DD, BFV, UPWV)                                                                                                                      \
     {                                                                                                                                              \
         constexpr int UT = 4 * UPWV;                                                                                                               \
         const int n_pad = (n_users_blk + UT - 1) / UT * UT;                                                                                        \
-        hipLaunchKernelGGL((uprep5_kernel<DD, BFV, true, UPWV>), dim3((unsigned)(((size_t)n_pad * (DD / 8) + 255) / 256)), dim3(256), 0, s, U, users, n_users_blk, n_pad, \
+        hipLaunchKernelGGL((uprep5_kernel<DD, BFV, true, UPWV, true>), dim3((unsigned)(((size_t)n_pad * (DD / 8) + 255) / 256)), dim3(256), 0, s, U, users, n_users_blk, n_pad, \
                            wsb + 256, reinterpret_cast<float*>(wsb + offs[0]), reinterpret_cast<float*>(wsb + offs[4]));                           \
         PDA_CHECK_LAUNCH();                                                                                                                        \
         return launch_sweep7<DD, BFV, UPWV>(g, s);                                                                                                 \

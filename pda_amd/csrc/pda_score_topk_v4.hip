@@ -119,7 +119,8 @@ struct Args4 {
 template <int D, bool BF>
 __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, const float* __restrict__ pop, const int* __restrict__ order,
                                                     int n, int n_pad, unsigned char* __restrict__ rows, int* __restrict__ pos_of,
-                                                    int* __restrict__ hdr, unsigned char* __restrict__ rows5, int* __restrict__ meta5, u32x4* __restrict__ pinfo) {
+                                                    int* __restrict__ hdr, unsigned char* __restrict__ rows5, int* __restrict__ meta5, u32x4* __restrict__ pinfo,
+                                                    int f16img) {
     constexpr int TPR = D / 8, RB = row_bytes(D);
     const int pos = blockIdx.x * (256 / TPR) + threadIdx.x / TPR, e = threadIdx.x % TPR;
     if (pos >= n_pad) return;
@@ -151,12 +152,16 @@ __global__ void __launch_bounds__(256) prep4_kernel(const void* __restrict__ I, 
 #pragma unroll
             for (int k = 0; k < 4; ++k) { as[k] *= pv; bs[k] *= pv; }
             u32x4 hs, ls;
-            split8(as, bs, hs, ls);
+            if (f16img) {                                    // the funnel's prep (pda_item_prep7_*): the image in fp16, its residuals accordingly
+                hs = pack_half8(as, bs, rs);
+            } else {
+                split8(as, bs, hs, ls);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {                    // the rounding residual of the image row (exact differences): ||i' - bf16(i')||^2
-                const float r0 = as[k] - __uint_as_float((k & 1) ? (hs[k >> 1] & 0xFFFF0000u) : (hs[k >> 1] << 16));
-                const float r1 = bs[k] - __uint_as_float((k & 1) ? (hs[2 + (k >> 1)] & 0xFFFF0000u) : (hs[2 + (k >> 1)] << 16));
-                rs += r0 * r0 + r1 * r1;
+                for (int k = 0; k < 4; ++k) {                // the rounding residual of the image row (exact differences): ||i' - bf16(i')||^2
+                    const float r0 = as[k] - __uint_as_float((k & 1) ? (hs[k >> 1] & 0xFFFF0000u) : (hs[k >> 1] << 16));
+                    const float r1 = bs[k] - __uint_as_float((k & 1) ? (hs[2 + (k >> 1)] & 0xFFFF0000u) : (hs[2 + (k >> 1)] << 16));
+                    rs += r0 * r0 + r1 * r1;
+                }
             }
             const int r5 = pos & 31;
             const int sw = D >= 128 ? (r5 & 15) : ((r5 >> 1) & 7);
@@ -260,7 +265,7 @@ __global__ void __launch_bounds__(1024) suffix_max4_kernel(float* __restrict__ t
 }
 
 
-int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s) {
+int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order, int n, int d, void* prep, hipStream_t s, int f16img = 0) {
     if (d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
     const Prep4Layout L = prep4_layout(n, d);
     unsigned char* pb = reinterpret_cast<unsigned char*>(prep);
@@ -270,6 +275,7 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     if (order && hipMemsetAsync(pos_of, 0xFF, (size_t)n * 4, s) != hipSuccess) return PDA_ERR_LAUNCH;
     if (order && hipMemsetAsync(hdr + 2, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;          // header word 2 := 1: a visiting order was given
     if (pop && hipMemsetAsync(hdr + 1, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;            // header word 1 := 1: the test operands carry 1/pop pieces
+    if (f16img && hipMemsetAsync(hdr + 3, 1, 1, s) != hipSuccess) return PDA_ERR_LAUNCH;         // header word 3 := 1: the half-tile image is fp16 (the funnel's)
     const int n_pad = L.n_tiles * 64;
     if (hipMemsetAsync(pb + L.meta5, 0, (size_t)L.n_tiles * 2 * 16, s) != hipSuccess) return PDA_ERR_LAUNCH;
     unsigned char* r5 = pb + L.rows5;
@@ -279,8 +285,8 @@ int run_prep4(const void* I_shard, bool bf16, const float* pop, const int* order
     case DD: {                                                                                                                  \
         constexpr int RPB = 256 / (DD / 8);                                                                                     \
         const dim3 grid((unsigned)((n_pad + RPB - 1) / RPB));                                                                   \
-        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5, pi5); \
-        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5, pi5);    \
+        if (bf16) hipLaunchKernelGGL((prep4_kernel<DD, true>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5, pi5, f16img); \
+        else hipLaunchKernelGGL((prep4_kernel<DD, false>), grid, dim3(256), 0, s, I_shard, pop, order, n, n_pad, pb + L.rows, pos_of, hdr, r5, m5, pi5, f16img);    \
         break;                                                                                                                  \
     }
     switch (d) { PDA_P4(64) PDA_P4(128) PDA_P4(256) }
@@ -2287,6 +2293,15 @@ extern "C" int pda_item_prep4_bf16(const uint16_t* I_shard, const float* pop_sha
                                    void* stream) {
     if (!I_shard || !prep || n_items_local <= 0) return PDA_ERR_ARG;
     return run_prep4(I_shard, true, pop_shard, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream));
+}
+// the funnel's prep (pda_score_topk7_*): as pda_item_prep4_* without a popularity, the half-tile image in fp16 (header word 3)
+extern "C" int pda_item_prep7_f32(const float* I_shard, const int32_t* order, int n_items_local, int d, void* prep, void* stream) {
+    if (!I_shard || !prep || !order || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_prep4(I_shard, false, nullptr, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream), 1);
+}
+extern "C" int pda_item_prep7_bf16(const uint16_t* I_shard, const int32_t* order, int n_items_local, int d, void* prep, void* stream) {
+    if (!I_shard || !prep || !order || n_items_local <= 0) return PDA_ERR_ARG;
+    return run_prep4(I_shard, true, nullptr, order, n_items_local, d, prep, reinterpret_cast<hipStream_t>(stream), 1);
 }
 extern "C" int pda_item_prep4_check(const void* prep, int n_items_local, int d, void* stream) {
     if (!prep || n_items_local <= 0) return PDA_ERR_ARG;

@@ -59,7 +59,23 @@ __device__ __forceinline__ int swz5(int row) { return D >= 128 ? (row & 15) : ((
 // ---- the user image: the block's rows as bf16 MFMA operands, in the order the waves load them into their AGPRs ------------------
 // fragment (workgroup wg, wave w, user block u, k-step k): 64 lanes x 16 bytes = 16 users x 32 elements; lane l holds user 16 u + (l & 15),
 // elements 32 k + 8 (l >> 4) .. + 7  (the B operand of v_mfma_f32_16x16x32_bf16; S16 = true keeps the kernels' round-4 names)
-template <int D, bool BF, bool S16, int UPW>
+// eight floats as fp16 (RNE, clamped to the largest finite half: the funnel's bound is formed from the ACTUAL residuals, so any rounding -- an underflow, a
+// clamp -- is accounted for), and the exact residuals' squared norm
+__device__ __forceinline__ u32x4 pack_half8(const f32x4& a, const f32x4& b, float& rs) {
+    u32x4 h;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float x0 = k < 2 ? a[2 * k] : b[2 * (k - 2)], x1 = k < 2 ? a[2 * k + 1] : b[2 * (k - 2) + 1];
+        const _Float16 h0 = (_Float16)fminf(fmaxf(x0, -65504.0f), 65504.0f), h1 = (_Float16)fminf(fmaxf(x1, -65504.0f), 65504.0f);
+        const float r0 = x0 - (float)h0, r1 = x1 - (float)h1;
+        rs += r0 * r0 + r1 * r1;
+        h[k] = (uint32_t)__builtin_bit_cast(unsigned short, h0) | ((uint32_t)__builtin_bit_cast(unsigned short, h1) << 16);
+    }
+    return h;
+}
+
+// F16: the image in fp16 for v_mfma_f32_16x16x32_f16 (the funnel: eleven significant bits instead of eight -- the rounding residuals, hence the bound's band, 8 x smaller)
+template <int D, bool BF, bool S16, int UPW, bool F16 = false>
 __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U, const int32_t* __restrict__ users, int n_users_blk, int n_pad,
                                                      unsigned char* __restrict__ ufrag, float* __restrict__ unorm, float* __restrict__ uerr = nullptr) {
     constexpr int TPR = D / 8;
@@ -73,14 +89,20 @@ __global__ void __launch_bounds__(256) uprep5_kernel(const void* __restrict__ U,
         y = pda_load4<BF>(U, (size_t)uid * D + 8 * c + 4);
     }
     u32x4 hq, lq;
-    split8(x, y, hq, lq);
     float ss = 0.f, rs = 0.f;
+    if constexpr (F16) {
+        hq = pack_half8(x, y, rs);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ss += x[k] * x[k] + y[k] * y[k];
-        const float r0 = x[k] - __uint_as_float((k & 1) ? (hq[k >> 1] & 0xFFFF0000u) : (hq[k >> 1] << 16));       // exact rounding residuals
-        const float r1 = y[k] - __uint_as_float((k & 1) ? (hq[2 + (k >> 1)] & 0xFFFF0000u) : (hq[2 + (k >> 1)] << 16));
-        rs += r0 * r0 + r1 * r1;
+        for (int k = 0; k < 4; ++k) ss += x[k] * x[k] + y[k] * y[k];
+    } else {
+        split8(x, y, hq, lq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            ss += x[k] * x[k] + y[k] * y[k];
+            const float r0 = x[k] - __uint_as_float((k & 1) ? (hq[k >> 1] & 0xFFFF0000u) : (hq[k >> 1] << 16));       // exact rounding residuals
+            const float r1 = y[k] - __uint_as_float((k & 1) ? (hq[2 + (k >> 1)] & 0xFFFF0000u) : (hq[2 + (k >> 1)] << 16));
+            rs += r0 * r0 + r1 * r1;
+        }
     }
 #pragma unroll
     for (int o = TPR / 2; o > 0; o >>= 1) { ss += __shfl_xor(ss, o, 64); rs += __shfl_xor(rs, o, 64); }

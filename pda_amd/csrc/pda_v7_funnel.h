@@ -24,7 +24,7 @@ struct Args7 {
     const float* meta5;              // (pmax, nmax, 0, 0) per half-tile
     const unsigned char* ufrag;      // the user block as MFMA operands (uprep5_kernel)
     const float* unorm;              // padded ||u|| per block row
-    const float* uerr;               // padded ||u - bf16(u)|| per block row
+    const float* uerr;               // padded ||u - fp16(u)|| per block row
     const float* thr;                // [n_users_blk] the thresholds of this launch (already lowered)
     unsigned char* elist;            // [workgroup][wave] list regions of cap_e entries per list
     unsigned* ecnt;                  // [workgroup][wave][user block][lane] cursors
@@ -35,6 +35,7 @@ struct Args7 {
     int cap_e;                       // entries per list
     float* mrun;                     // [workgroup][wave][(2 NU + 1) 64]: the first launch's maxima (Loop7M): the two largest per (user block, lane), the largest ct
     const int* n_users_dev;          // or NULL: the number of rows that exist (a device-side count; workgroups beyond it leave at once)
+    const int* prep_hdr;             // the prep's header: word 3 = 1 <=> its half-tile image is fp16 (pda_item_prep7_*)
 };
 
 // the local tiles [i0, i1) of split sp that lie in the global tile range [lo, hi)
@@ -61,7 +62,11 @@ __global__ void __launch_bounds__(256, 1) sweep7_kernel(Args7 g) {
     if (utile * UT >= n_rows) return;
     int i0, i1;
     stage_tiles7(g.n_tiles, split, g.n_splits, g.tile_lo, g.tile_hi, i0, i1);
-    const unsigned hend = 2u * (unsigned)(i1 - i0);
+    // (a prep whose image is bf16 -- pda_item_prep4_*: the products below would be of reinterpreted bits -- is refused: error word 7, nothing is scored, every row
+    // ends with an empty pool and is served by the exact fallback)
+    const bool prep_ok = g.prep_hdr[3] == 1;
+    if (!prep_ok && tid == 0 && blockIdx.x == 0) g.stats[0] = 7u;
+    const unsigned hend = prep_ok ? 2u * (unsigned)(i1 - i0) : 0u;
     const int row0 = wave * UPW, j = lane & 15;
     const size_t widx = (size_t)blockIdx.x * 4 + wave;
     unsigned* cnt = g.ecnt + widx * (NU * 64);

@@ -195,6 +195,33 @@ def item_prep4(I_shard: torch.Tensor, pop_shard: Optional[torch.Tensor], order: 
     return buf
 
 
+_PREP7_CACHE = {}
+
+
+def item_prep7(I_shard: torch.Tensor, order: torch.Tensor) -> torch.Tensor:
+    """pda_item_prep7_f32 / _bf16: the funnel's item prep (no popularity, the half-tile image in fp16), cached per (weight version, order object) beside
+    the generation-4 prep of the same table (an evaluation epoch alternates between the two heads)."""
+    lib = _lib.load()
+    n, d = I_shard.shape
+    hit = _PREP7_CACHE.get(id(I_shard))
+    buf = None
+    if hit is not None and hit[0]() is I_shard:
+        buf = hit[3]
+        if hit[1] == I_shard._version and hit[2] is order:
+            return buf
+    if buf is None:
+        buf = torch.empty(lib.pda_item_prep4_bytes(n, d), dtype=torch.uint8, device=I_shard.device)
+    order = _need(order, torch.int32, "order")
+    if order.numel() != n:
+        raise ValueError("order must have one entry per local item row")
+    fn = lib.pda_item_prep7_bf16 if I_shard.dtype == torch.bfloat16 else lib.pda_item_prep7_f32
+    check(fn(ptr(I_shard), ptr(order), n, d, ptr(buf), stream_ptr()), "pda_item_prep7")
+    for k in [k for k, v in _PREP7_CACHE.items() if v[0]() is None]:
+        del _PREP7_CACHE[k]
+    _PREP7_CACHE[id(I_shard)] = (weakref.ref(I_shard), I_shard._version, order, buf)
+    return buf
+
+
 def score_kernel(d: int, K: int, nloc: int, prune=None, head: int = HEAD_POP) -> str:
     """Which pre-filtered kernel generation serves a call.  All of them return the same keys; the choice is by measured
     speed (65 536 users per block).  Generation 4 (pda_score_topk_v4.hip: two MFMA waves per SIMD, loader and rescoring
@@ -688,7 +715,7 @@ def score_topk_funnel(U, I_shard, users, K=50, hist: Optional[HistoryCSR] = None
     nu, nloc, d = users.numel(), I_shard.shape[0], I_shard.shape[1]
     if hist is not None and hist.indices.numel() == 0:
         hist = None
-    prep = item_prep4(I_shard, None, funnel_order(I_shard))
+    prep = item_prep7(I_shard, funnel_order(I_shard))
     out = torch.empty((1, nu, K), dtype=torch.int64, device=U.device)
     nbytes = lib.pda_score_topk7_workspace_bytes(nu, nloc, d)
     if nbytes == 0:

@@ -87,6 +87,30 @@ def test_funnel_equals_the_oracle(dev, monkeypatch, d, K, with_hist, bf16):
     assert nfb <= nu // 100
 
 
+def test_funnel_refuses_a_prep_whose_image_is_bf16(dev):
+    """pda_score_topk7_* wants pda_item_prep7_* (fp16 image: its sweeps run v_mfma_f32_16x16x32_f16).  Handed a pda_item_prep4_* prep it must not form products of
+    reinterpreted bits: error word 7, nothing scored, every row through the exact fallback -- and the oracle's lists all the same."""
+    from pda_amd import _lib, ops
+    from pda_amd._lib import ptr, stream_ptr
+    rng = np.random.default_rng(5)
+    nU, nI, d, K = 1500, 9000, 128, 50
+    U, I = make(rng, nU, nI, d)
+    Ut, It = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev)
+    users = torch.arange(nU, dtype=torch.int32, device=dev)
+    lib = _lib.load()
+    prep = ops.item_prep4(It, None, ops.funnel_order(It))
+    ws = torch.zeros(lib.pda_score_topk7_workspace_bytes(nU, nI, d), dtype=torch.uint8, device=dev)
+    keys = torch.empty((nU, K), dtype=torch.int64, device=dev)
+    rc = lib.pda_score_topk7_f32(ptr(Ut), ptr(It), ptr(prep), ptr(users), nU, 0, nI, d, None, None, 0, K, ops.HEAD_RAW, ptr(keys), ptr(ws), stream_ptr())
+    torch.cuda.synchronize()
+    assert rc == 0
+    assert int(ws[0:4].view(torch.int32)[0]) == 7 and int(ws[24:28].view(torch.int32)[0]) == nU
+    idx, val = ops.unpack_keys(keys)
+    ridx, rval = c_oracle.score_topk(U, I, np.arange(nU, dtype=np.int32), K, 0, None, None, None, order=1)
+    np.testing.assert_array_equal(val, rval)
+    np.testing.assert_array_equal(idx, ridx)
+
+
 def test_funnel_on_item_shards_merges_to_the_oracle(dev, monkeypatch):
     """Item-sharded evaluation (one shard per rank): the funnel on two ragged shards of the catalogue with GLOBAL item ids in the train rows (item_offset),
     the two partial lists merged by pda_topk_merge -- the oracle's lists over the whole catalogue, bit for bit."""

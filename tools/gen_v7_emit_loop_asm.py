@@ -2,7 +2,7 @@
 """Generates pda_amd/csrc/pda_v7_emit_loop_asm.h: the EMITTING loop of the huge geometry (sweep7_kernel, pda_v7_funnel.h; round 5).
 
 Same machine mapping as tools/gen_v6_loop_asm.py (read its header first): four waves per workgroup, one per SIMD; a wave's bf16 user rows in
-AGPRs as B operands of v_mfma_f32_16x16x32_bf16; 32-item half-tiles DMA-ed into eight LDS slots by the MFMA waves themselves, one s_barrier per
+AGPRs as B operands of v_mfma_f32_16x16x32_f16 (FP16 here, not bf16: see pda_v7_funnel.h); 32-item half-tiles DMA-ed into eight LDS slots by the MFMA waves themselves, one s_barrier per
 half-tile; the product transposed, so that an accumulator lane holds 8 items of ONE user per half-tile (two chains of four registers).
 
 What differs: nothing leaves the loop.  Where the testing loop raises a flag (and all four waves leave, score the half-tile again and rescore its
@@ -279,7 +279,8 @@ def gen(D, UB, maxmode=False):
                             s, u = slot_of(g, k, ib, j), g * GU + j
                             if g == 0 and j == 0:
                                 wait_for(("frag", p, k, ib))
-                            out.append("v_mfma_f32_16x16x32_bf16 %s, %s, %s, %s" % (acc(u, ib), frag(k, ib), usr(u, k), ctq(p) if k == 0 else acc(u, ib)))
+                            # (fp16 operands: the funnel's image and user fragments are halves -- pda_item_prep7_*, uprep5_kernel<.., F16 = true>)
+                            out.append("v_mfma_f32_16x16x32_f16 %s, %s, %s, %s" % (acc(u, ib), frag(k, ib), usr(u, k), ctq(p) if k == 0 else acc(u, ib)))
                             for kind, tag, lines in order_events(EV[p].get(s, [])):
                                 if kind == "lds":
                                     out.extend(lines)

@@ -1,2 +1,1 @@
-python -m pytest tests/test_gpu_funnel.py -x -q 2>&1 | tail -4
-python -m pytest tests/test_gpu_two_rank.py -x -q 2>&1 | tail -3
+python tools/time_emit.py time c3 262144 2>&1 | grep "users,"

@@ -1,5 +1,5 @@
 """The funnel's emitting sweep (sweep7_kernel) alone, through the debug entry pda_debug_emit_sweep: what does the loop cost at a given rate of
-entries per user?  And (mode check) are the entries the ones torch finds with the same bf16 products?
+entries per user?  And (mode check) are the entries the ones torch finds with the same fp16 products?
 
 usage: time_emit.py check [d=128]                         small case against torch
        time_emit.py time [workload=c3] [users=262144]     thresholds at several sample ranks -> entries per user, ms, fraction of 2.5 PF
@@ -68,7 +68,7 @@ def check(d):
     I = (torch.randn(nI, d, generator=g) * 0.1 * (0.5 + torch.rand(nI, 1, generator=g))).to(dev)
     users = torch.randperm(nU, generator=g)[:n_users].to(torch.int32).to(dev)
     order = ops.visiting_order(I, None)
-    prep = ops.item_prep4(I, None, order)
+    prep = ops.item_prep7(I, order)
     PL = prep_layout(nI, d)
     ut = 512 if d == 256 else 1024
     nu = ut // 64
@@ -77,7 +77,7 @@ def check(d):
         cap = 64
         tot, offs = layout(n_users, d, S, cap)
         ws = torch.zeros(tot, dtype=torch.uint8, device=dev)
-        Ub, Ib = U[users.long()].bfloat16().float(), I.bfloat16().float()
+        Ub, Ib = U[users.long()].half().float(), I.half().float()
         s = Ub @ Ib[order.long()].T                        # [n_users, pos]
         thr = torch.quantile(s[:, :2000], q, dim=1).contiguous() if q > 0 else torch.full((n_users,), -float("inf"), device=dev)
         run(U, users, prep, nI, d, thr, lo, hi, S, cap, ws)
@@ -150,17 +150,17 @@ def time_(wl, Bu):
     Bu = min(Bu, W.n_users)
     users = torch.arange(Bu, dtype=torch.int32, device=dev)
     order = ops.visiting_order(W.I, None)
-    prep = ops.item_prep4(W.I, None, order)
+    prep = ops.item_prep7(W.I, order)
     cap, S = 64, 1
     tot, offs = layout(Bu, d, S, cap)
     print("workspace %.2f GB" % (tot / 1e9))
     ws = torch.zeros(tot, dtype=torch.uint8, device=dev)
     m = 8192
     samp = torch.randperm(W.n_items, device=dev)[:m]
-    Is = W.I[samp].bfloat16().float()
+    Is = W.I[samp].half().float()
     tops = []
     for s0 in range(0, Bu, 16384):
-        sc = W.U[s0:s0 + 16384].bfloat16().float() @ Is.T
+        sc = W.U[s0:s0 + 16384].half().float() @ Is.T
         tops.append(torch.topk(sc, 64, dim=1).values)
     tops = torch.cat(tops)                                # [Bu, 64] descending
     for rank in (-1, 1, 2, 4, 8, 16, 32, 64):
