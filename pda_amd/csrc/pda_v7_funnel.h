@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256, 1) sweep7_kernel(Args7 g) {
     else
         Loop7<D, NU>::run(0u, 0u, hend, ring_lds, 1024u * (unsigned)wave, (unsigned)(split + i0 * g.n_splits), (unsigned)g.n_splits, (unsigned)img, (unsigned)(img >> 32),
                           (unsigned)meta, (unsigned)(meta >> 32), eu, eu2, my_ufrag, rsrc, cnt, thr, (unsigned)lane * 16u);
-#ifdef PDA_V7_DUMP_LDS      /* debugging: workgroup 0 leaves its LDS behind the lists (tools/dbg_emit.py) */
+#ifdef PDA_V7_DUMP_LDS      /* debugging: workgroup 0 leaves its LDS behind the lists */
     __syncthreads();
     if (blockIdx.x == 0) {
         unsigned char* dst = g.elist + (size_t)gridDim.x * 4 * region;
