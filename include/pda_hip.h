@@ -354,7 +354,9 @@ int pda_score_topk_huge_splits(int n_users_blk, int n_items_local, int d);
  *              visiting order that is a RANDOM permutation of the shard (the thresholds' ranks assume that the items seen so far are a uniform sample; any
  *              order gives exact results, a sorted one more fallbacks).  A prep of pda_item_prep4_* is refused: error word 7, every row served by the
  *              exact fallback.
- *   hist_*     optional; hist_row_mode must be PDA_HIST_BY_USER_ID (the fallback re-blocks the failed rows)
+ *   hist_*     optional; PDA_HIST_BY_USER_ID (the exact fallback re-blocks the failed rows: its cost follows their number) or PDA_HIST_BY_BLOCK_ROW (the
+ *              reference's per-block COO mask: the rows keep their places and the fallback sweeps the WHOLE block again if a row failed -- pda_score_topk_plan
+ *              sends such calls here up to 16 384 users)
  *   head       PDA_HEAD_RAW (PDA_ERR_UNSUPPORTED otherwise: the popularity head in visiting order is the huge geometry's)
  *   d          64 / 128 / 256 (d = 256: 512-user workgroups, as the huge geometry);  K <= 54;  4 096 <= n_items_local <= 2^26
  *   workspace  pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d) bytes; +0 error word, +4 pairs rescored exactly, +16 kernel identity

@@ -238,13 +238,15 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
     // ---- the exact fallback: generation 4's many-candidates geometry on the failed rows (a device-side count: nothing runs when nobody failed)
     int32_t* users2 = reinterpret_cast<int32_t*>(wsb + W.users2);
     float* seed2 = reinterpret_cast<float*>(wsb + W.seed2);
-    hipLaunchKernelGGL(fail_users7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, users, q.fail_list, fail_count, n, R.tk, users2, seed2);
+    const int by_row = (hist_indptr != nullptr && hist_row_mode != PDA_HIST_BY_USER_ID) ? 1 : 0;
+    int* n_dev2 = fail_count + 1;
+    hipLaunchKernelGGL(fail_users7_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, users, q.fail_list, fail_count, n, R.tk, R.flags, by_row, users2, seed2, n_dev2);
     PDA_CHECK_LAUNCH();
     uint64_t* fb_keys = reinterpret_cast<uint64_t*>(wsb + W.fb_keys);
-    const int rc = pda_v4_run_score4_dev(U, I_shard, BF, prep, nullptr, users2, n, fail_count, item_offset, n_items_local, D, hist_indptr, hist_indices, hist_row_mode, K,
+    const int rc = pda_v4_run_score4_dev(U, I_shard, BF, prep, nullptr, users2, n, n_dev2, item_offset, n_items_local, D, hist_indptr, hist_indices, hist_row_mode, K,
                                          PDA_HEAD_RAW, PDA_SWEEP_MANY_CANDIDATES, kFallbackSplits, seed2, fb_keys, wsb + W.fb_ws, s);
     if (rc != PDA_OK) return rc;
-    hipLaunchKernelGGL(fail_merge7_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb_keys, kFallbackSplits, n, K, q.fail_list, fail_count, out_keys, reinterpret_cast<unsigned*>(workspace));
+    hipLaunchKernelGGL(fail_merge7_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb_keys, kFallbackSplits, n, K, q.fail_list, fail_count, by_row, out_keys, reinterpret_cast<unsigned*>(workspace));
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }
@@ -256,7 +258,7 @@ int run_funnel(const void* U, const void* I_shard, bool bf16, const void* prep, 
     if (K < 1 || K > PDA_MAX_K) return PDA_ERR_ARG;
     if (hist_indptr && !hist_indices) return PDA_ERR_ARG;
     if (head != PDA_HEAD_RAW) return PDA_ERR_UNSUPPORTED;                          // (the popularity head in visiting order: generation 4 / the huge geometry)
-    if (hist_indptr && hist_row_mode != PDA_HIST_BY_USER_ID) return PDA_ERR_UNSUPPORTED;   // (the fallback re-blocks the failed rows: a history by user id follows them)
+    if (hist_indptr && hist_row_mode != PDA_HIST_BY_USER_ID && hist_row_mode != PDA_HIST_BY_BLOCK_ROW) return PDA_ERR_ARG;
     if (K > 54) return PDA_ERR_UNSUPPORTED;                                        // (the fallback is generation 4)
     if ((uint64_t)n_items_local > (1ull << 26) || n_items_local < 64 * 64) return PDA_ERR_UNSUPPORTED;
     switch (d) {
@@ -355,7 +357,7 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
         p.order = PDA_ORDER_NATURAL;
     } else if (head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 16384 && (uint64_t)n_items_local <= (1ull << 26) &&
                n_users_blk >= 1024 && (n_items_local >= 20000 || n_users_blk <= 16384) && !early &&
-               (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID)) {
+               (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID || (hist_row_mode == PDA_HIST_BY_BLOCK_ROW && n_users_blk <= 16384))) {
         // (tools/funnel_crossover.py: from ONE 1 024-user tile on the funnel beats generation 4's many-candidates geometry on catalogues of 65 536 items and
         // more -- 2 048 users x 200 000 items 0.88 vs 1.85 ms --, and on smaller ones too (config 2, 50 000 users x 20 000 items: 1.73 vs 2.13 ms; config 1: 1.58 vs
         // 2.30) except the very smallest with many users (16 384 items x 65 536 users: 2.1 vs 1.9))

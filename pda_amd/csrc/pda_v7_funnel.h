@@ -738,34 +738,47 @@ __global__ void __launch_bounds__(1024) stat7_kernel(Rows7 r, int n, const int* 
 // ---- the exact fallback's plumbing: the failed rows' users as a block of their own (padded with the block's first user), and their merged
 // lists back into the rows they belong to
 __global__ void __launch_bounds__(256) fail_users7_kernel(const int32_t* __restrict__ users, const int* __restrict__ fail_list, const int* __restrict__ fail_count,
-                                                          int n, const float* __restrict__ tk, int32_t* __restrict__ users2, float* __restrict__ seed2) {
+                                                          int n, const float* __restrict__ tk, const unsigned* __restrict__ flags, int by_row,
+                                                          int32_t* __restrict__ users2, float* __restrict__ seed2, int* __restrict__ n_dev2) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) *n_dev2 = by_row ? (*fail_count > 0 ? n : 0) : *fail_count;
     if (i >= n) return;
-    const bool real = i < *fail_count;
-    users2[i] = real ? users[fail_list[i]] : users[0];
     // The seed of generation 4's sweep: the failed row's tk -- K unmasked items reach it whatever became of the bets (-inf: fewer than K pairs in its pool)
-    // -- so the fallback rescans the catalogue against an almost final threshold instead of building a list from nothing (d = 256: 45 -> ms per call with
-    // one failed row); the rows that pad the block: +1e30, nothing qualifies.
+    // -- so the fallback rescans the catalogue against an almost final threshold instead of building a list from nothing; rows that are only there to fill
+    // the block: +1e30, nothing qualifies.
+    //   by_row = 0 (history by user id): the failed rows are RE-BLOCKED -- row i of the fallback's block is row fail_list[i] -- and the block is as large as the count;
+    //   by_row = 1 (history by block row: the reference's per-block COO mask, MF/train_new_api.py:791): the rows keep their places (their mask rows with them); the
+    //   whole block is swept again iff anybody failed, the rows that did not fail against +1e30.
+    int src = i;
+    bool real;
+    if (by_row) {
+        real = flags[i] != 0u;
+    } else {
+        real = i < *fail_count;
+        src = real ? fail_list[i] : 0;
+    }
+    users2[i] = users[src];
     float sd = 1.0e30f;
     if (real) {
-        const float t = tk[fail_list[i]];
+        const float t = tk[src];
         sd = (t > -1.0e30f && t < 1.0e30f) ? lowered7(t) : -INFINITY;
     }
     seed2[i] = sd;
 }
 // one wave per failed row: the best K of its S sorted partial lists (K rounds of "the largest head"), written to the row it came from
 __global__ void __launch_bounds__(256) fail_merge7_kernel(const uint64_t* __restrict__ keys, int S, int n, int K, const int* __restrict__ fail_list,
-                                                          const int* __restrict__ fail_count, uint64_t* __restrict__ out_keys, unsigned* __restrict__ stats) {
+                                                          const int* __restrict__ fail_count, int by_row, uint64_t* __restrict__ out_keys, unsigned* __restrict__ stats) {
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[6] = (unsigned)*fail_count;      // workspace + 24: rows served by the exact fallback
     if (i >= min(n, *fail_count)) return;
     int cur = 0;                                                                  // lane s < S: the head of list s
     uint64_t* orow = out_keys + (size_t)fail_list[i] * K;
+    const size_t krow = by_row ? (size_t)fail_list[i] : (size_t)i;                // (by_row: the fallback's rows kept their places)
     for (int k = 0; k < K; ++k) {
         uint64_t h = 0ull;
         for (int s0 = 0; s0 < S; s0 += 64) {                                      // (S <= 64 in practice: one round)
             const int s = s0 + lane;
-            const uint64_t v = (s < S && cur < K) ? keys[((size_t)s * n + i) * K + cur] : 0ull;
+            const uint64_t v = (s < S && cur < K) ? keys[((size_t)s * n + krow) * K + cur] : 0ull;
             h = v > h ? v : h;
         }
         uint64_t best = h;

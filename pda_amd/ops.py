@@ -676,6 +676,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
 # x 20 000 items, d = 64) 3.3 vs 2.1 ms -- a funnel is ~25 launches whose per-row work does not shrink with the catalogue.
 FUNNEL_MIN_USERS = 1024          # one 1 024-user tile (tools/funnel_crossover.py: 2 048 users x 200 000 items 0.88 vs 1.85 ms for generation 4)
 FUNNEL_MIN_ITEMS = 16384
+FUNNEL_BLOCK_ROW_MAX_USERS = 16384        # a mask by BLOCK ROW (the reference's per-block COO triple): the exact fallback sweeps the whole block again if a row fails
 FUNNEL_SMALL_ITEMS, FUNNEL_SMALL_MAX_USERS = 20000, 16384     # catalogues below 20 000 items: up to 16 384 users (16 384 items x 65 536 users: 2.1 vs 1.9 ms for generation 4)
 _FUNNEL_ORDER = {}               # (n, device) -> a fixed pseudo-random permutation (the object is what the prep cache keys on)
 
@@ -695,7 +696,7 @@ def funnel_order(I_shard: torch.Tensor) -> torch.Tensor:
 def funnel_applies(d: int, K: int, nu: int, nloc: int, head: int, prune, hist: Optional[HistoryCSR]) -> bool:
     """Does score_topk_keys serve this call with the funnel?  (PDA_SCORE_FUNNEL=0 | 1 forces it off / on wherever it can run.)"""
     can = head == HEAD_RAW and d in (64, 128, 256) and K <= TOPK_K_V4 and 4096 <= nloc <= (1 << 26) and prune is not True \
-        and (hist is None or hist.mode == HIST_BY_USER_ID)
+        and (hist is None or hist.mode == HIST_BY_USER_ID or nu <= FUNNEL_BLOCK_ROW_MAX_USERS)
     forced = os.environ.get("PDA_SCORE_FUNNEL", "")
     if forced == "0" or not can:
         return False

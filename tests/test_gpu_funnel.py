@@ -87,6 +87,36 @@ def test_funnel_equals_the_oracle(dev, monkeypatch, d, K, with_hist, bf16):
     assert nfb <= nu // 100
 
 
+@pytest.mark.parametrize("force_failures", [False, True])
+def test_funnel_with_a_mask_by_block_row(dev, monkeypatch, force_failures):
+    """The reference's per-block mask (a COO triple whose rows are the block's rows, MF/train_new_api.py:736,791 -> HistoryCSR by_user=False): the funnel serves it;
+    rows that fail (forced here: bold bets, two-entry lists) are swept again IN PLACE by generation 4 -- the oracle's lists either way."""
+    from pda_amd import ops
+    rng = np.random.default_rng(31)
+    nU, nI, nu, d, K = 4000, 30000, 2048, 64, 50
+    U, I = make(rng, nU, nI, d)
+    users = rng.permutation(nU)[:nu].astype(np.int32)
+    rows = [rng.choice(nI, rng.integers(0, 90), replace=False) for _ in range(nu)]          # row r of the BLOCK
+    bip, bix = csr(rows)
+    hist = ops.HistoryCSR(torch.from_numpy(bip).to(dev), torch.from_numpy(bix).to(dev), by_user=False)
+    if force_failures:
+        tune(fail_p=0.5, cap_e=2)
+    try:
+        assert ops.score_plan(nu, nI, d, K, ops.HEAD_RAW, None, hist=hist)["kernel"] == "funnel"
+        st = {}
+        keys = ops.score_topk_keys(torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.from_numpy(users).to(dev), K, ops.HEAD_RAW, None, hist, stats=st)
+        ident = ops.kernel_identity(st["kernel_id"][0])
+        assert ident["geometry"] == "funnel" and int(st["error"][0]) == 0
+        nfb = int(st["fallback_rows"][0])
+    finally:
+        tune(**DEFAULTS)
+    assert (nfb > nu // 10) if force_failures else (nfb <= nu // 100)
+    idx, val = ops.unpack_keys(keys[0])
+    ridx, rval = c_oracle.score_topk(U[users], I, np.arange(nu, dtype=np.int32), K, 0, None, bip, bix, order=1)
+    np.testing.assert_array_equal(val, rval)
+    np.testing.assert_array_equal(idx, ridx)
+
+
 def test_funnel_refuses_a_prep_whose_image_is_bf16(dev):
     """pda_score_topk7_* wants pda_item_prep7_* (fp16 image: its sweeps run v_mfma_f32_16x16x32_f16).  Handed a pda_item_prep4_* prep it must not form products of
     reinterpreted bits: error word 7, nothing scored, every row through the exact fallback -- and the oracle's lists all the same."""
