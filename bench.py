@@ -203,8 +203,28 @@ def bench_reference_block_protocol(args, dev, workload):
         ops.recommend_topk(W.U, W.I, u, 50, ops.HEAD_POP, W.pop_last, h)
     torch.cuda.synchronize()
     dk = time.perf_counter() - t1
+    # the raw head ('main_branch': evaluated in every epoch, the only head of --train normal) through the same call: no popularity vector, the same COO masks
+    for users, mask in blocks[:2]:
+        m.do_recommendation(None, users, items, "main_branch", None, mask)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for users, mask in blocks[2:]:
+        out_r = m.do_recommendation(None, users, items, "main_branch", None, mask)
+    dt_raw = time.perf_counter() - t2
+    st_r = {}
+    ops.score_topk_keys(W.U, W.I, us[0], 50, ops.HEAD_RAW, None, hs[0], stats=st_r)
+    torch.cuda.synchronize()
+    t3 = time.perf_counter()
+    for u, h in zip(us, hs):
+        ops.recommend_topk(W.U, W.I, u, 50, ops.HEAD_RAW, None, h)
+    torch.cuda.synchronize()
+    dk_raw = time.perf_counter() - t3
+    raw_blk = {"ms_per_block": dt_raw / nb * 1e3, "users_per_s": Bu * nb / dt_raw, "device_only_ms_per_block": dk_raw / nb * 1e3,
+               "kernel_identity": ops.kernel_identity(st_r["kernel_id"][0]) if "kernel_id" in st_r else None,
+               "note": "rec_type 'main_branch' through do_recommendation, masks by block row (the COO triple): the funnel from one 1 024-user tile on"}
+    assert out_r.shape == (Bu, 50)
     fl = 2.0 * Bu * W.n_items * W.d
-    return {"users_per_s": Bu * nb / dt, "ms_per_block": dt / nb * 1e3, "blocks": nb, "users_per_block": Bu,
+    return {"users_per_s": Bu * nb / dt, "ms_per_block": dt / nb * 1e3, "blocks": nb, "users_per_block": Bu, "raw_head": raw_blk,
             "roofline_frac": fl / (dt / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
             "device_only": {"users_per_s": Bu * nb / dk, "ms_per_block": dk / nb * 1e3, "roofline_frac": fl / (dk / nb) / 1e12 / PEAK_BF16_MFMA_TFLOPS},
             "nnz_per_block": int(np.mean([len(mk[0]) for _, mk in blocks])),
