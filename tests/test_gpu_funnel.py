@@ -199,12 +199,13 @@ def test_configs_1_and_2_take_the_funnel_unforced(dev, wl):
     np.testing.assert_array_equal(idx, ridx)
 
 
-def test_funnel_lost_bets_and_overflowing_lists_take_the_exact_fallback(dev, monkeypatch):
+@pytest.mark.parametrize("d", [128, 256])
+def test_funnel_lost_bets_and_overflowing_lists_take_the_exact_fallback(dev, monkeypatch, d):
     """Thresholds that are far too bold (every second bet lost) and lists of two entries: most rows end in generation 4's exact lists inside the
-    same call -- and the result does not move."""
+    same call (seeded with the rows' tk; d = 256: generation 4's 256-user geometry) -- and the result does not move."""
     from pda_amd import ops
     rng = np.random.default_rng(7)
-    nU, nI, nu, d, K = 3000, 8000, 2500, 128, 50
+    nU, nI, nu, K = 3000, 8000, 2500, 50
     U, I = make(rng, nU, nI, d)
     users = np.arange(nu, dtype=np.int32)
     rows = [rng.choice(nI, rng.integers(0, 40), replace=False) for _ in range(nU)]
