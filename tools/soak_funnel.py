@@ -27,10 +27,13 @@ for c in range(n_cases):
     users = torch.randperm(nu + 50, generator=g)[:nu].to(torch.int32).to(dev)
     hist = None
     if ri(0, 2) > 0:
+        # (vectorised: 120 sorted draws per user, the first len kept -- a row may name an item twice, which the binary searches do not mind)
         lens = torch.randint(0, 120, (nu + 50,), generator=g)
         indptr = torch.zeros(nu + 51, dtype=torch.int64); indptr[1:] = torch.cumsum(lens, 0)
-        rows = [torch.sort(torch.randperm(nI, generator=g)[:int(l)]).values for l in lens]
-        idx = (torch.cat(rows) if len(rows) else torch.zeros(0, dtype=torch.int64)).to(torch.int32)
+        draws = torch.randint(0, nI, (nu + 50, 120), generator=g)
+        keep = torch.arange(120)[None, :] < lens[:, None]
+        draws = torch.where(keep, draws, torch.full_like(draws, nI + 1)).sort(dim=1).values
+        idx = draws[keep.sort(dim=1, descending=True).values].to(torch.int32)
         hist = ops.HistoryCSR(indptr.to(dev), idx.to(dev), by_user=True)
     lo = ri(0, nI // 3) if ri(0, 2) == 0 else 0
     Ish = I[lo:].contiguous()
