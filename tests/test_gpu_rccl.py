@@ -18,9 +18,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(cmd, env):
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
-    return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    """Runs bench.py; checks what the driver ingests (the last stdout line: compact JSON) and returns the FULL record (bench_extras)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        extras = os.path.join(td, "extras.json")
+        p = subprocess.run(cmd + ["--extras-path", extras], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len([ln for ln in lines if ln.startswith("{")]) == 1, p.stdout[-2000:]
+        line = json.loads(lines[-1])
+        assert len(lines[-1]) < 8192
+        full = json.load(open(extras))
+    assert line["value"] == full["value"] and line["n_gpus"] == full["n_gpus"] and line["config"]["layout"] == full["config"]["layout"]
+    return full
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs two GPUs (the pod has one; the driver's 8-GPU node runs it)")

@@ -16,11 +16,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(cmd, env):
-    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
-    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]
-    return json.loads(lines[0])
+    """Runs bench.py; checks what the driver ingests (the last stdout line: compact JSON) and returns the FULL record (bench_extras)."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        extras = os.path.join(td, "extras.json")
+        p = subprocess.run(cmd + ["--extras-path", extras], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len([ln for ln in lines if ln.startswith("{")]) == 1, p.stdout[-2000:]
+        line = json.loads(lines[-1])
+        assert len(lines[-1]) < 8192
+        full = json.load(open(extras))
+    assert line["value"] == full["value"] and line["n_gpus"] == full["n_gpus"] and line["config"]["layout"] == full["config"]["layout"]
+    return full
 
 
 def test_bench_two_ranks_on_one_gpu_matches_one_rank(tmp_path):

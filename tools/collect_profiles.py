@@ -27,5 +27,8 @@ open(os.path.join(dst, name + "_pmc.txt"), "w").write(
     "# mean counter value per dispatch of the kernel named below, summed over the 8 XCDs; FETCH_SIZE/WRITE_SIZE in KiB\n"
     "# (gfx950: FETCH_SIZE under-reports wide coalesced reads by 2x -- guides/MI355X_MICROARCH.md, HBM section)\n" + pm)
 line = open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1]
+ex = os.path.join(src, "bench_extras.json")
+if os.path.exists(ex):
+    open(os.path.join(dst, name + "_bench_extras.json"), "w").write(open(ex).read() + "\n")
 open(os.path.join(dst, name + "_bench.json"), "w").write(line + "\n")
 print(open(os.path.join(dst, name + "_pmc.txt")).read())
