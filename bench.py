@@ -584,7 +584,23 @@ def bench_train(args, dev, workload=None, quick=False):
         ops.adam_mark_rows(bt[0], bt[1], bt[2], tbits[0], tbits[1])          # six streams: the gradient tables are read on the batch's rows only
         ops.adam_dense_sweep3(U, st[0], st[1], st[2], tbits[0], I, st[3], st[4], st[5], tbits[1], lr_t)
     tbits = ops.adam_touched_bitmaps(W.n_users, W.n_items, dev)
-    out["adam_dense_reference_faithful"] = timed_graph(adam_body, max(256, args.train_steps // 4))
+    out["adam_dense_five_launches"] = timed_graph(adam_body, max(256, args.train_steps // 4))
+    out["adam_dense_five_launches"]["note"] = "round 5's step: pda_bpr_step_f32(DENSE_GRAD) + pda_adam_mark_rows + pda_adam_dense_sweep3_f32 (non-temporal streams) + two memsets"
+    # round 6: the step in two launches (row tags written by the step kernel, the sweep out of the Infinity Cache while the tables fit it)
+    U, I = W.U.clone(), W.I.clone()
+    st = [torch.zeros_like(t) for t in (U, U, U, I, I, I)]
+    tags = ops.adam_row_tags(W.n_users, W.n_items, dev)
+    tcount[0] = 0
+
+    def adam_step_body(i):
+        tcount[0] += 1
+        ops.adam_step(U, st[0], st[1], st[2], tags[0], I, st[3], st[4], st[5], tags[1], *batches[i % NB], regs=regs, reg_div=B, step=tcount[0],
+                      lr_t=ops.adam_lr_t(lr, min(tcount[0], 1000)), grouped=True, users_distinct=B <= W.n_users, loss_acc=loss)
+    out["adam_dense_reference_faithful"] = timed_graph(adam_step_body, max(256, args.train_steps // 4))
+    assert sync_int(ws.abs().sum()) == 0, "pda_adam_step_f32: a device-side wait gave up"
+    out["adam_dense_reference_faithful"]["note"] = ("pda_adam_step_f32, policy by working set: %s" %
+                                                    ("resident (plain accesses: the tables stay in the Infinity Cache)" if 3 * (W.n_users + W.n_items) * W.d * 4 <= (160 << 20) else
+                                                     "streaming (non-temporal)") + "; two launches: bpr_step_kernel (gradients + row tags) + adam_dense_sweep4_kernel")
     sweep_bytes = 6 * (W.n_users + W.n_items) * W.d * 4
     r = out["adam_dense_reference_faithful"]
     r["algorithmic_bytes_per_step"] = sweep_bytes

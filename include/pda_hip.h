@@ -509,6 +509,30 @@ int pda_adam_mark_rows(const int32_t* users, const int32_t* pos, const int32_t* 
 int pda_adam_dense_sweep3_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, uint32_t* touched_a, float* var_b, float* m_b, float* v_b,
                               float* g_b, size_t rows_b, uint32_t* touched_b, int d, float lr_t, float beta1, float beta2, float eps, void* stream);
 
+/* Round 6 -- one reference train step in TWO launches (MF/model_api.py:83,470-471: minimize() = the batch's gradients + TF-1.14 dense-decay Adam on
+ * every row of both tables; MF/train_new_api.py:1078-1090 runs it once per batch).
+ *   pda_adam_step_f32: the step kernel of pda_bpr_step_f32(PDA_UPD_DENSE_GRAD) sums the batch's gradients into gU / gI AND writes `step_tag` into
+ *     tagU[user] / tagI[pos], tagI[neg] (i32 [rows], zero before the first step; step_tag >= 1 and different from the previous call's -- the step
+ *     number); then pda_adam_dense_sweep4_f32's kernel sweeps both tables, reads gU / gI only where tag == step_tag and zeroes them there.
+ *     No bitmaps, no mark launch, no memsets (pda_adam_mark_rows + pda_adam_dense_sweep3_f32: five launches per step).
+ *     flags: PDA_UPD_ANY_ORDER | PDA_UPD_USERS_DISTINCT or 0.  loss_acc f32 [3] accumulates (loss, mf, reg) or NULL.
+ *     PRECONDITION (both functions): gU / gI are ZERO on every row whose tag differs from step_tag (true when they are only ever written by
+ *     this function: the sweep zeroes what the step wrote).  A caller that accumulates gradients of other rows must tag them, too.
+ *   cache_policy: PDA_ADAM_CACHE_AUTO = plain loads / stores while x, m, v of both tables (3 (rows_a + rows_b) d 4 bytes) fit
+ *     PDA_ADAM_RESIDENT_BYTES -- they then stay in the 256 MiB Infinity Cache from step to step (C1 / C2: 54 MB) --, non-temporal streams above
+ *     (C3: 1.8 GB); _RESIDENT / _STREAM force one.  Bit-identical tables either way, and to pda_adam_dense_sweep2_f32 / 3. */
+#define PDA_ADAM_CACHE_AUTO 0
+#define PDA_ADAM_CACHE_RESIDENT 1
+#define PDA_ADAM_CACHE_STREAM 2
+#define PDA_ADAM_RESIDENT_BYTES (160u << 20)
+int pda_adam_dense_sweep4_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, const int32_t* tag_a, float* var_b, float* m_b, float* v_b,
+                              float* g_b, size_t rows_b, const int32_t* tag_b, int d, int tag, float lr_t, float beta1, float beta2, float eps,
+                              int cache_policy, void* stream);
+int pda_adam_step_f32(float* U, float* mU, float* vU, float* gU, int32_t* tagU, size_t n_users, float* I, float* mI, float* vI, float* gI, int32_t* tagI,
+                      size_t n_items, const int32_t* users, const int32_t* pos, const int32_t* neg, const float* pos_pop, const float* neg_pop, int B,
+                      int d, float regs, float reg_div, int step_tag, float lr_t, float beta1, float beta2, float eps, int flags, int cache_policy,
+                      float* loss_acc, void* stream);
+
 /* Lazy/sparse Adam on the touched rows only (declared deviation).  rows i32 [n_rows]
  * must be unique; g is the dense accumulator (reset on the touched rows). */
 int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const int32_t* rows, int n_rows, int d, float lr_t,

@@ -41,6 +41,9 @@ struct StepArgs {
     const void* Ifwd;  // (pda_bpr_step_bf16: U / I are then the fp32 masters that take the update)
     int any_order;     // PDA_UPD_ANY_ORDER: equal positives are combined wherever they sit in the workgroup
     int users_distinct;  // PDA_UPD_USERS_DISTINCT: no user id occurs twice in the batch -- its row takes a plain store
+    int32_t* tag_u = nullptr;   // pda_adam_step_f32: "row touched by step `tag`" words (one int32 per table row) that replace the bitmaps +
+    int32_t* tag_i = nullptr;   // their memsets of pda_adam_mark_rows / pda_adam_dense_sweep3_f32: the step kernel itself leaves the tag
+    int tag = 0;
 };
 
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
@@ -157,9 +160,16 @@ __device__ __forceinline__ void bpr_step_body(const StepArgs& a, const int bid) 
             atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
             ptarget = a.gI + (size_t)p * D + 4 * e;
         } else if (a.mode == PDA_UPD_DENSE_GRAD) {
-            atomic_add4(a.gU + (size_t)u * D + 4 * e, due);
+            // (tagged step + distinct users: gU is zero off the rows the sweep clears behind itself, the row has one writer -- a plain store)
+            if (a.tag_u && a.users_distinct && !COH) *reinterpret_cast<f32x4*>(a.gU + (size_t)u * D + 4 * e) = due;
+            else atomic_add4(a.gU + (size_t)u * D + 4 * e, due);
             atomic_add4(a.gI + (size_t)n * D + 4 * e, dne);
             ptarget = a.gI + (size_t)p * D + 4 * e;
+            if (a.tag_u && e == 0) {            // same value from every writer of a row: plain stores
+                a.tag_u[u] = a.tag;
+                a.tag_i[p] = a.tag;
+                a.tag_i[n] = a.tag;
+            }
         }
         if (scatter) *reinterpret_cast<f32x4*>(s_dpe + g * D + 4 * e) = dpe;
         if (a.g_user) *reinterpret_cast<f32x4*>(a.g_user + (size_t)t * a.g_stride + 4 * e) = due;
@@ -584,6 +594,70 @@ __global__ void __launch_bounds__(256) adam_dense_sweep3_kernel(float* __restric
                 xx[q] = ld(var, i);
             }
         }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const size_t i = i0 + q * stride;
+            if (i >= n4) break;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                mm[q][k] = b1 * mm[q][k] + (1.f - b1) * gg[q][k];
+                vv[q][k] = b2 * vv[q][k] + (1.f - b2) * gg[q][k] * gg[q][k];
+                xx[q][k] = xx[q][k] - lr_t * mm[q][k] / (sqrtf(vv[q][k]) + eps);
+            }
+            st(m, i, mm[q]);
+            st(v, i, vv[q]);
+            st(var, i, xx[q]);
+            if (touched[q]) reinterpret_cast<f32x4*>(g)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// ---- round 6: the sweep keyed by per-row step TAGS instead of bitmaps (tag[row] == step  <=>  the step's batch touched the row; written by
+// the step kernel itself, never cleared: no mark launch, no memsets -- five launches per reference step become two), and the cache policy by
+// working set: NT = false reads and writes x, m, v with plain accesses, so tables that fit the 256 MiB Infinity Cache (C1 / C2: 54 MB)
+// are swept out of it instead of out of HBM; NT = true is adam_dense_sweep3_kernel's streaming policy for the big tables.  Same
+// arithmetic as adam_dense_sweep2_kernel / 3, operation for operation: bit-identical tables.
+template <bool NT, int UN>
+__global__ void __launch_bounds__(256) adam_dense_sweep4_kernel(float* __restrict__ var_a, float* __restrict__ m_a, float* __restrict__ v_a,
+                                                                float* __restrict__ g_a, size_t n4_a, const int32_t* __restrict__ t_a,
+                                                                float* __restrict__ var_b, float* __restrict__ m_b, float* __restrict__ v_b,
+                                                                float* __restrict__ g_b, size_t n4_b, const int32_t* __restrict__ t_b,
+                                                                int sh, int tag, unsigned blocks_a, float lr_t, float b1, float b2, float eps) {
+    const bool first = blockIdx.x < blocks_a;
+    float* var = first ? var_a : var_b;
+    float* m = first ? m_a : m_b;
+    float* v = first ? v_a : v_b;
+    float* g = first ? g_a : g_b;
+    const int32_t* tg = first ? t_a : t_b;
+    const size_t n4 = first ? n4_a : n4_b;
+    const size_t blk = first ? blockIdx.x : blockIdx.x - blocks_a, nblk = first ? blocks_a : gridDim.x - blocks_a;
+    const size_t stride = nblk * blockDim.x;
+    auto ld = [&](float* p, size_t i) __attribute__((always_inline)) -> f32x4 {
+        if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<f32x4*>(p) + i);
+        else return reinterpret_cast<f32x4*>(p)[i];
+    };
+    auto st = [&](float* p, size_t i, f32x4 x) __attribute__((always_inline)) {
+        if constexpr (NT) __builtin_nontemporal_store(x, reinterpret_cast<f32x4*>(p) + i);
+        else reinterpret_cast<f32x4*>(p)[i] = x;
+    };
+    for (size_t i0 = blk * blockDim.x + threadIdx.x; i0 < n4; i0 += UN * stride) {
+        f32x4 gg[UN], mm[UN], vv[UN], xx[UN];
+        bool touched[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const size_t i = i0 + q * stride;
+            const bool in = i < n4;
+            touched[q] = in && tg[i >> sh] == tag;
+            gg[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (in) {
+                mm[q] = ld(m, i);
+                vv[q] = ld(v, i);
+                xx[q] = ld(var, i);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q)
+            if (touched[q]) gg[q] = reinterpret_cast<f32x4*>(g)[i0 + q * stride];
 #pragma unroll
         for (int q = 0; q < UN; ++q) {
             const size_t i = i0 + q * stride;
@@ -1088,6 +1162,72 @@ extern "C" int pda_adam_dense_sweep3_f32(float* var_a, float* m_a, float* v_a, f
     if (hipMemsetAsync(touched_a, 0, ((rows_a + 31) / 32) * 4, s) != hipSuccess || hipMemsetAsync(touched_b, 0, ((rows_b + 31) / 32) * 4, s) != hipSuccess)
         return PDA_ERR_LAUNCH;
     return PDA_OK;
+}
+
+static int launch_sweep4(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, const int32_t* tag_a, float* var_b, float* m_b, float* v_b,
+                         float* g_b, size_t rows_b, const int32_t* tag_b, int d, int tag, float lr_t, float beta1, float beta2, float eps, int cache_policy,
+                         hipStream_t s) {
+    int sh = 0;
+    while ((4 << sh) < d) ++sh;
+    const size_t n4a = rows_a * (size_t)(d / 4), n4b = rows_b * (size_t)(d / 4);
+    // x, m, v of both tables, read and written: what has to stay in the Infinity Cache between two steps for the plain policy to pay
+    const size_t working_set = 3 * (n4a + n4b) * 16;
+    const bool nt = cache_policy == PDA_ADAM_CACHE_STREAM || (cache_policy == PDA_ADAM_CACHE_AUTO && working_set > PDA_ADAM_RESIDENT_BYTES);
+    // 7 workgroups per CU (the kernel's 71 registers: all resident at once), two chunks per thread, grid-stride.  Measured at C2 (1.1 M chunks, the
+    // sweep alone): 1 024 ... 4 608 workgroups x 1 / 2 chunks 15.4 - 17.1 us, four chunks per thread with every load in flight at once 18.3 us -- the
+    // sweep sits at ~6.7 TB/s of its algorithmic bytes whatever the geometry (profiles/round6_adam_small.txt).
+    const size_t total = 256u * 7u;
+    size_t ba = (size_t)((double)total * (double)n4a / (double)(n4a + n4b));
+    ba = ba < 1 ? 1 : (ba > total - 1 ? total - 1 : ba);
+    const size_t wa = (n4a + 255) / 256, wb = (n4b + 255) / 256;
+    const unsigned blocks_a = (unsigned)(wa < ba ? wa : ba), blocks_b = (unsigned)(wb < total - ba ? wb : total - ba);
+#define PDA_SWEEP4(NTV, UNV)                                                                                                                          \
+    hipLaunchKernelGGL((adam_dense_sweep4_kernel<NTV, UNV>), dim3(blocks_a + blocks_b), dim3(256), 0, s, var_a, m_a, v_a, g_a, n4a, tag_a, var_b, m_b, v_b, \
+                       g_b, n4b, tag_b, sh, tag, blocks_a, lr_t, beta1, beta2, eps)
+    if (nt) PDA_SWEEP4(true, 2);
+    else PDA_SWEEP4(false, 2);
+#undef PDA_SWEEP4
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
+extern "C" int pda_adam_dense_sweep4_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, const int32_t* tag_a, float* var_b, float* m_b,
+                                         float* v_b, float* g_b, size_t rows_b, const int32_t* tag_b, int d, int tag, float lr_t, float beta1, float beta2,
+                                         float eps, int cache_policy, void* stream) {
+    if (!var_a || !m_a || !v_a || !g_a || !tag_a || !var_b || !m_b || !v_b || !g_b || !tag_b || rows_a == 0 || rows_b == 0) return PDA_ERR_ARG;
+    if (d < 4 || (d & (d - 1)) != 0) return PDA_ERR_UNSUPPORTED;
+    if (cache_policy < PDA_ADAM_CACHE_AUTO || cache_policy > PDA_ADAM_CACHE_STREAM) return PDA_ERR_ARG;
+    return launch_sweep4(var_a, m_a, v_a, g_a, rows_a, tag_a, var_b, m_b, v_b, g_b, rows_b, tag_b, d, tag, lr_t, beta1, beta2, eps, cache_policy,
+                         reinterpret_cast<hipStream_t>(stream));
+}
+
+// One reference train step (MF/model_api.py:83 minimize = gradients + TF-1.14 dense-decay Adam) in TWO launches: the step kernel sums the batch's
+// gradients into gU / gI and tags the rows it touched, the sweep applies Adam to every row of both tables (g = 0 off the tagged rows) and zeroes
+// g behind itself.
+extern "C" int pda_adam_step_f32(float* U, float* mU, float* vU, float* gU, int32_t* tagU, size_t n_users, float* I, float* mI, float* vI, float* gI,
+                                 int32_t* tagI, size_t n_items, const int32_t* users, const int32_t* pos, const int32_t* neg, const float* pos_pop,
+                                 const float* neg_pop, int B, int d, float regs, float reg_div, int step_tag, float lr_t, float beta1, float beta2, float eps,
+                                 int flags, int cache_policy, float* loss_acc, void* stream) {
+    if (!U || !mU || !vU || !gU || !tagU || !I || !mI || !vI || !gI || !tagI || !users || !pos || !neg || B <= 0 || reg_div <= 0.f || n_users == 0 ||
+        n_items == 0 || step_tag <= 0)
+        return PDA_ERR_ARG;
+    if ((pos_pop == nullptr) != (neg_pop == nullptr)) return PDA_ERR_ARG;
+    if (flags & ~(PDA_UPD_ANY_ORDER | PDA_UPD_USERS_DISTINCT)) return PDA_ERR_ARG;
+    if (cache_policy < PDA_ADAM_CACHE_AUTO || cache_policy > PDA_ADAM_CACHE_STREAM) return PDA_ERR_ARG;
+    if (d != 32 && d != 64 && d != 128 && d != 256) return PDA_ERR_UNSUPPORTED;
+    StepArgs a{U, I, users, pos, neg, pos_pop, neg_pop, nullptr, nullptr, nullptr, gU, gI, loss_acc,
+               B, 1.0f / (float)B, regs / reg_div, 0.f, PDA_UPD_DENSE_GRAD, 0, d, U, I, (flags & PDA_UPD_ANY_ORDER) ? 1 : 0,
+               (flags & PDA_UPD_USERS_DISTINCT) ? 1 : 0, tagU, tagI, step_tag};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
+    switch (d) {
+        case 32: rc = launch_step<32>(a, s); break;
+        case 64: rc = launch_step<64>(a, s); break;
+        case 128: rc = launch_step<128>(a, s); break;
+        default: rc = launch_step<256>(a, s); break;
+    }
+    if (rc != PDA_OK) return rc;
+    return launch_sweep4(U, mU, vU, gU, n_users, tagU, I, mI, vI, gI, n_items, tagI, d, step_tag, lr_t, beta1, beta2, eps, cache_policy, s);
 }
 
 extern "C" int pda_adam_rows_f32(float* var, float* m, float* v, float* g, const int32_t* rows, int n_rows, int d,

@@ -224,6 +224,15 @@ class _MFBase:
         self._t += 1
         lr_t = ops.adam_lr_t(self.lr, self._t)
         lazy = self.optimizer == "adam" and self.adam_exact_lazy
+        d = U.shape[1]
+        if self.optimizer == "adam" and not lazy and d in (32, 64, 128, 256):
+            # the reference's step in two launches (round 6): gradients + row tags, then the tagged sweep (cache policy by working set)
+            if "tagU" not in st:
+                st["tagU"], st["tagI"] = ops.adam_row_tags(U.shape[0], I.shape[0], U.device)
+            ops.adam_step(U, st["mU"], st["vU"], st["gU"], st["tagU"], I, st["mI"], st["vI"], st["gI"], st["tagI"], users, pos, neg, pos_pop, neg_pop,
+                          regs=self.decay, reg_div=self.batch_size, step=self._t, lr_t=lr_t, loss_acc=self._loss,
+                          users_distinct=bool(getattr(self, "users_distinct", False)))
+            return self._loss
         if lazy:        # the batch rows up to step t - 1: the forward pass reads them
             ops.adam_lazy(0, self._lazy_state(), U, st["mU"], st["vU"], st["gU"], I, st["mI"], st["vI"], st["gI"], users, pos, neg, self._t)
         ops.bpr_step(U, I, users, pos, neg, pos_pop, neg_pop, regs=self.decay, reg_div=self.batch_size,

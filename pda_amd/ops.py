@@ -1004,6 +1004,8 @@ def adam_touched_bitmaps(n_users: int, n_items: int, device):
 
 def adam_mark_rows(users, pos, neg, touched_u, touched_i):
     """pda_adam_mark_rows: the batch's rows into the bitmaps."""
+    if pos.numel() != users.numel() or neg.numel() != users.numel():
+        raise ValueError("users/pos/neg must have the same length")
     check(_lib.load().pda_adam_mark_rows(ptr(_need(users, torch.int32, "users")), ptr(_need(pos, torch.int32, "pos")), ptr(_need(neg, torch.int32, "neg")),
                                          users.numel(), ptr(touched_u), ptr(touched_i), stream_ptr()), "pda_adam_mark_rows")
 
@@ -1016,6 +1018,53 @@ def adam_dense_sweep3(var_a, m_a, v_a, g_a, touched_a, var_b, m_b, v_b, g_b, tou
         _need(t, torch.float32, "adam state")
     check(lib.pda_adam_dense_sweep3_f32(ptr(var_a), ptr(m_a), ptr(v_a), ptr(g_a), var_a.shape[0], ptr(touched_a), ptr(var_b), ptr(m_b), ptr(v_b), ptr(g_b),
                                         var_b.shape[0], ptr(touched_b), var_a.shape[1], lr_t, beta1, beta2, eps, stream_ptr()), "pda_adam_dense_sweep3_f32")
+    mark_modified(var_a)
+    mark_modified(var_b)
+
+
+ADAM_CACHE_AUTO, ADAM_CACHE_RESIDENT, ADAM_CACHE_STREAM = 0, 1, 2
+
+
+def adam_row_tags(n_users: int, n_items: int, device):
+    """Zeroed per-row step tags for adam_step / adam_dense_sweep4 (i32 per table row; a row is 'touched by step t' iff its tag == t)."""
+    return torch.zeros(n_users, dtype=torch.int32, device=device), torch.zeros(n_items, dtype=torch.int32, device=device)
+
+
+def adam_step(U, mU, vU, gU, tagU, I, mI, vI, gI, tagI, users, pos, neg, pos_pop=None, neg_pop=None, *, regs: float, reg_div: float, step: int,
+              lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS, grouped: bool = False, users_distinct: bool = False,
+              cache_policy: int = ADAM_CACHE_AUTO, loss_acc: Optional[torch.Tensor] = None):
+    """pda_adam_step_f32: one reference train step (gradients of the batch + TF-1.14 dense-decay Adam over both tables) in two launches.
+    step >= 1 is the step number (the tag the touched rows get); gU / gI must be zero off the rows of the running step (they are, when only
+    this function writes them)."""
+    lib = _lib.load()
+    for t in (U, mU, vU, gU, I, mI, vI, gI):
+        _need(t, torch.float32, "adam state")
+    users, pos, neg = (_need(t, torch.int32, n) for t, n in ((users, "users"), (pos, "pos"), (neg, "neg")))
+    tagU, tagI = _need(tagU, torch.int32, "tagU"), _need(tagI, torch.int32, "tagI")
+    pos_pop = _need(pos_pop, torch.float32, "pos_pop", optional=True)
+    neg_pop = _need(neg_pop, torch.float32, "neg_pop", optional=True)
+    B, d = users.numel(), U.shape[1]
+    if pos.numel() != B or neg.numel() != B:
+        raise ValueError("users/pos/neg must have the same length")
+    if tagU.numel() != U.shape[0] or tagI.numel() != I.shape[0]:
+        raise ValueError("tagU / tagI hold one int32 per table row")
+    loss_acc = _need(loss_acc, torch.float32, "loss_acc", optional=True)
+    check(lib.pda_adam_step_f32(ptr(U), ptr(mU), ptr(vU), ptr(gU), ptr(tagU), U.shape[0], ptr(I), ptr(mI), ptr(vI), ptr(gI), ptr(tagI), I.shape[0],
+                                ptr(users), ptr(pos), ptr(neg), ptr(pos_pop), ptr(neg_pop), B, d, float(regs), float(reg_div), int(step), float(lr_t),
+                                beta1, beta2, eps, (0 if grouped else UPD_ANY_ORDER) | (UPD_USERS_DISTINCT if users_distinct else 0),
+                                int(cache_policy), ptr(loss_acc), stream_ptr()), "pda_adam_step_f32")
+    mark_modified(U, I)
+
+
+def adam_dense_sweep4(var_a, m_a, v_a, g_a, tag_a, var_b, m_b, v_b, g_b, tag_b, tag: int, lr_t: float, beta1=ADAM_BETA1, beta2=ADAM_BETA2, eps=ADAM_EPS,
+                      cache_policy: int = ADAM_CACHE_AUTO):
+    """pda_adam_dense_sweep4_f32: the sweep of adam_step alone (the gradients and the tags came from elsewhere)."""
+    lib = _lib.load()
+    for t in (var_a, m_a, v_a, g_a, var_b, m_b, v_b, g_b):
+        _need(t, torch.float32, "adam state")
+    check(lib.pda_adam_dense_sweep4_f32(ptr(var_a), ptr(m_a), ptr(v_a), ptr(g_a), var_a.shape[0], ptr(_need(tag_a, torch.int32, "tag_a")), ptr(var_b), ptr(m_b),
+                                        ptr(v_b), ptr(g_b), var_b.shape[0], ptr(_need(tag_b, torch.int32, "tag_b")), var_a.shape[1], int(tag), float(lr_t),
+                                        beta1, beta2, eps, int(cache_policy), stream_ptr()), "pda_adam_dense_sweep4_f32")
     mark_modified(var_a)
     mark_modified(var_b)
 

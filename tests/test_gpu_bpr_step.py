@@ -1019,3 +1019,74 @@ def test_six_stream_adam_sweep_equals_the_seven_stream_sweep(dev, d):
         for x, y in zip(a + [gUa, gIa], b + [gUb, gIb]):
             assert torch.equal(x, y)
         assert int(tu.count_nonzero()) == 0 and int(ti.count_nonzero()) == 0 and float(gUb.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+@pytest.mark.parametrize("policy", [0, 1, 2])
+def test_two_launch_adam_step_equals_the_step_plus_seven_stream_sweep(dev, d, policy):
+    """pda_adam_step_f32 (round 6: the step kernel tags the rows it touched, adam_dense_sweep4_kernel reads the gradient tables only there; resident
+    or streaming cache policy) leaves the tables, moments, accumulators and loss words of pda_bpr_step_f32(DENSE_GRAD) + pda_adam_dense_sweep2_f32
+    bit for bit, over several steps with hot items, with and without popularity, distinct users asserted (plain gU stores) or not."""
+    from pda_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(5 + d + policy)
+    nU, nI, B, regs, lr = 3001, 1777, 512, 1e-2, 1e-2
+    U0, I0 = torch.randn(nU, d, generator=g, device=dev) * 0.1, torch.randn(nI, d, generator=g, device=dev) * 0.1
+    z = torch.zeros_like
+    Ua, Ia, Ub, Ib = U0.clone(), I0.clone(), U0.clone(), I0.clone()
+    sa = [z(Ua), z(Ua), z(Ua), z(Ia), z(Ia), z(Ia)]          # mU vU gU mI vI gI
+    sb = [z(Ub), z(Ub), z(Ub), z(Ib), z(Ib), z(Ib)]
+    tagU, tagI = ops.adam_row_tags(nU, nI, dev)
+    for t in range(1, 7):
+        distinct = t % 2 == 0
+        users = (torch.randperm(nU, generator=g, device=dev)[:B] if distinct else torch.randint(0, nU, (B,), generator=g, device=dev)).to(torch.int32)
+        pos = torch.randint(0, 40 if t % 3 else nI, (B,), generator=g, device=dev, dtype=torch.int32)
+        neg = torch.randint(0, nI, (B,), generator=g, device=dev, dtype=torch.int32)
+        pp = torch.rand(B, generator=g, device=dev) if t > 2 else None
+        pn = torch.rand(B, generator=g, device=dev) if t > 2 else None
+        la, lb = torch.zeros(3, device=dev), torch.zeros(3, device=dev)
+        lr_t = ops.adam_lr_t(lr, t)
+        ops.bpr_step(Ua, Ia, users, pos, neg, pp, pn, regs=regs, reg_div=B, mode=ops.UPD_DENSE_GRAD, gU=sa[2], gI=sa[5], loss_acc=la)
+        ops.adam_dense_sweep2(Ua, sa[0], sa[1], sa[2], Ia, sa[3], sa[4], sa[5], lr_t)
+        ops.adam_step(Ub, sb[0], sb[1], sb[2], tagU, Ib, sb[3], sb[4], sb[5], tagI, users, pos, neg, pp, pn, regs=regs, reg_div=B, step=t, lr_t=lr_t,
+                      users_distinct=distinct, cache_policy=policy, loss_acc=lb)
+        # rows referenced once per batch: one gradient term, bit-identical; repeated rows are summed by atomics in either path, in an order that
+        # may differ between two launches: equal to rounding of that order
+        once_u = torch.bincount(users.long(), minlength=nU) <= 1
+        once_i = torch.bincount(torch.cat([pos, neg]).long(), minlength=nI) <= 1
+        for x, y, once in ((Ua, Ub, once_u), (sa[0], sb[0], once_u), (sa[1], sb[1], once_u), (Ia, Ib, once_i), (sa[3], sb[3], once_i), (sa[4], sb[4], once_i)):
+            assert torch.equal(x[once], y[once])
+            torch.testing.assert_close(x, y, atol=1e-6, rtol=1e-5)
+        assert float(sb[2].abs().max()) == 0.0 and float(sb[5].abs().max()) == 0.0
+        torch.testing.assert_close(la, lb, atol=1e-6, rtol=1e-5)
+        # keep the two paths in step so that rounding differences of the atomic order do not compound
+        for x, y in ((Ua, Ub), (sa[0], sb[0]), (sa[1], sb[1]), (Ia, Ib), (sa[3], sb[3]), (sa[4], sb[4])):
+            y.copy_(x)
+    assert int((tagU == 6).sum()) > 0 and int((tagI == 6).sum()) > 0
+
+
+def test_tagged_adam_sweep_equals_the_seven_stream_sweep_on_given_gradients(dev):
+    """pda_adam_dense_sweep4_f32 alone, gradients and tags from the caller: bit-identical to pda_adam_dense_sweep2_f32; a stale tag on a row whose
+    gradient is zero is harmless."""
+    from pda_amd import ops
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    nU, nI, d, B = 2000, 900, 64, 300
+    a = [torch.randn(n, d, generator=g, device=dev) * s for n in (nU, nI) for s in (0.1, 0.01, 0.001)]
+    a[2].abs_(); a[5].abs_()
+    b = [t.clone() for t in a]
+    gUa, gIa = torch.zeros(nU, d, device=dev), torch.zeros(nI, d, device=dev)
+    gUb, gIb = gUa.clone(), gIa.clone()
+    tu, ti = ops.adam_row_tags(nU, nI, dev)
+    tu[:50] = 3                                                     # stale tags of a "future" step on rows without gradient
+    for t in range(1, 5):
+        users = torch.randint(0, nU, (B,), generator=g, device=dev)
+        items = torch.randint(0, 60, (B,), generator=g, device=dev)
+        for gU, gI in ((gUa, gIa), (gUb, gIb)):
+            gU.index_add_(0, users, torch.ones(B, d, device=dev) * 0.01 * t)
+            gI.index_add_(0, items, torch.ones(B, d, device=dev) * -0.02)
+        tu[users] = t
+        ti[items] = t
+        lr_t = ops.adam_lr_t(1e-3, t)
+        ops.adam_dense_sweep2(a[0], a[1], a[2], gUa, a[3], a[4], a[5], gIa, lr_t)
+        ops.adam_dense_sweep4(b[0], b[1], b[2], gUb, tu, b[3], b[4], b[5], gIb, ti, t, lr_t, cache_policy=1 + (t & 1))
+        for x, y in zip(a + [gUa, gIa], b + [gUb, gIb]):
+            assert torch.equal(x, y)
