@@ -53,6 +53,7 @@ def parse():
     p.add_argument("--K", type=int, default=50)
     p.add_argument("--no-train", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-cli-epoch", action="store_true", help="skip per_config.c1.cli_epoch (the drop-in CLI on the Douban-shaped synthetic: ~15 s)")
     p.add_argument("--train-steps", type=int, default=2048)
     p.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU work for the baseline sample")
     p.add_argument("--extras-path", default=None, help="where the full record goes (default: bench_extras.json in the cwd)")
@@ -859,6 +860,30 @@ def bench_train_sharded(args, rank, world, dev):
             "note": "eager; one all_gather_into_tensor per step; strong scaling of one 2048-triplet step"}
 
 
+def cli_epoch(cpu_entry):
+    """python -m pda_amd.train_new_api on the Douban-shaped synthetic (tools/cli_epoch.py: three epochs, an evaluation after each): the
+    wall-clock the reference itself prints (`Epoch %d [%.1fs]`, MF/train_new_api.py:1110), sampler + 3 371 steps of the reference's optimiser
+    + the three evaluation heads -- the drop-in number."""
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    try:
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "cli_epoch.py"), "--epochs", "3"], capture_output=True, text=True, timeout=600, cwd=root)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode != 0 or not line:
+            return {"error": (p.stderr or p.stdout)[-400:]}
+        r = json.loads(line[-1])
+    except Exception as e:              # noqa: BLE001 -- a figure beside the headline must not take the line down
+        return {"error": repr(e)[:400]}
+    out = {k: r[k] for k in ("shape", "epoch_s", "train_epoch_s", "eval_epoch_s", "epoch_print_s", "steps_per_epoch", "us_per_step_through_the_cli", "main_wall_s") if k in r}
+    out["cli"] = "python -m pda_amd.train_new_api --train s_condition --test s_condition --batch_size 2048 --log_interval 1 (adam, device sampler)"
+    out["us_per_step_through_the_cli"] = r["train_epoch_s"] / r["steps_per_epoch"] * 1e6 if r.get("train_epoch_s") else None
+    tr = (cpu_entry or {}).get("train") if isinstance(cpu_entry, dict) else None
+    if tr and tr.get("value"):
+        out["cpu_restatement_epoch_s"] = r["steps_per_epoch"] * 2048 / tr["value"]
+        out["cpu_restatement_note"] = "steps_per_epoch x 2048 / cpu_baseline.train (torch-CPU restatement of the reference's train step on the C2 tables, dense-decay Adam, this box's host threads)"
+    return out
+
+
 def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
     """Reference op sequence on the host cores (torch CPU fp32), bounded sample.  kind = "port".  Protocol of BASELINE.md
     section 3: 3 warm-up blocks, median of up to 10 timed 2048-user blocks (fewer if the budget runs out).
@@ -1042,9 +1067,15 @@ def main():
                                       "first 256 items, list hand-over, launch) is a visible share of the step" % (e["W"].n_items, -(-e["W"].n_items // 64))}}
             if not args.no_train:
                 t = bench_train(args, dev, workload=wl, quick=True)[0]
-                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_exact_planned", "sgd_planned_one_launch", "sgd_fused_loop_one_launch", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful") if k in t}
+                entry["train"] = {k: t[k] for k in ("sgd_fused", "sgd_exact_planned", "sgd_planned_one_launch", "sgd_fused_loop_one_launch", "sgd_fused_batches_in_sampling_order", "adam_dense_reference_faithful", "adam_dense_five_launches") if k in t}
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(args, e, None, budget=6.0, full=False)
+            if wl == "c1" and not args.no_train and not args.no_cli_epoch:
+                entry["cli_epoch"] = cli_epoch(cpu)
+                if entry["cli_epoch"].get("train_epoch_s"):
+                    entry["cli_epoch_s"] = entry["cli_epoch"]["train_epoch_s"]
+                    ev_s = entry["cli_epoch"].get("eval_epoch_s") or []
+                    entry["cli_eval_s"] = min(ev_s[1:]) if len(ev_s) > 1 else (ev_s[0] if ev_s else None)
             per_config[wl] = entry
             del e
             torch.cuda.empty_cache()
