@@ -269,6 +269,11 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
     Bu = min(args.eval_block, W.n_users)
     n_blocks = args.warmup + steps
     starts = [(b * Bu) % max(1, W.n_users - Bu + 1) for b in range(n_blocks)]
+    if W.n_users > (1 << 23) + Bu:
+        # the whole user table of config 5: the timed blocks come from the TOP of the id range -- user ids above 2^23, i.e. row offsets uid * d * 2
+        # and CSR offsets indptr[uid] * 4 beyond 2^31 bytes in every gather of the timed region
+        top_blocks = max(1, (W.n_users - (1 << 23)) // Bu)
+        starts = [W.n_users - (1 + b % top_blocks) * Bu for b in range(n_blocks)]
     per_g = Bu // ugroups                               # this group's users of every step
     blocks = [torch.arange(s + gidx * per_g, s + (gidx + 1) * per_g if gidx < ugroups - 1 else s + Bu, dtype=torch.int32, device=dev) for s in starts]
     if world_all > 1:

@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDA_HIP_LIB") or os.path.join(_HERE, "csrc", "libpda_hip.so")   # PDA_HIP_LIB: an A/B build of the same library (tools/)
 
 # Constants mirrored from include/pda_hip.h
-ABI_VERSION = 1
+ABI_VERSION = 2
 HEAD_RAW, HEAD_POP = 0, 1
 HIST_BY_BLOCK_ROW, HIST_BY_USER_ID = 0, 1
 UPD_NONE, UPD_SGD_FUSED, UPD_DENSE_GRAD = 0, 1, 2

@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include "pda_hip.h"
+#include "pda_hip_experimental.h" // (includes pda_hip.h: the stable surface)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -23,8 +23,10 @@ CONFIGS = {
     "c2": (50_000, 20_000, 64, 150),
     "c3": (1_000_000, 200_000, 128, 50),
     # c5shard: ONE rank's share of config 5 (10 M users x 2 M items, d = 256, bf16 tables, item-sharded over 8 GPUs):
-    #     250 000 item rows; the user table is replicated, 1 M of its 10 M rows are enough for any number of timed blocks
-    "c5shard": (1_000_000, 250_000, 256, 50),
+    #     250 000 item rows against the WHOLE replicated user table (10 M rows: 5.1 GB of bf16) and its 600 M-entry history CSR (2.4 GB of item ids: byte offsets beyond 2^31; round 6; rounds 2 - 5
+    #     kept a 1 M-row replica, "c5shard1m": byte offsets of user rows and CSR entries never passed 2^31 there)
+    "c5shard": (10_000_000, 250_000, 256, 60),
+    "c5shard1m": (1_000_000, 250_000, 256, 50),
     "tiny": (4_000, 3_000, 64, 30),
 }
 
@@ -63,6 +65,8 @@ def make_workload(name: str = "c2", device="cuda", gamma: float = 0.22, n_slots:
 
     U = torch.randn(n_users, d, generator=gw, device=dev) * 0.1
     I = torch.randn(n_items, d, generator=gw, device=dev) * 0.1
+    if table_dtype != torch.float32:          # (at once: 10 M x 256 fp32 rows are 10 GB the caller never sees)
+        U, I = U.to(table_dtype), I.to(table_dtype)
 
     # history lengths: clipped log-normal with the requested mean (sigma 0.8)
     sigma = 0.8

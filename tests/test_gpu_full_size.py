@@ -33,8 +33,8 @@ def oracle_sample_lists(W, users_t, head, n=256):
     """c_oracle.score_topk (the fp32 fmaf chain of the kernels, order=1) on the first n of `users_t` against the WHOLE
     catalogue of workload W with the users' real train rows; bf16 tables are widened (that is how their scores are defined)."""
     sub = users_t[:n].cpu().numpy()
-    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
-    rows = [ix[ip[u]:ip[u + 1]] for u in sub]
+    lo_, hi_ = W.hist_indptr[users_t[:n].long()].cpu().numpy(), W.hist_indptr[users_t[:n].long() + 1].cpu().numpy()
+    rows = [W.hist_indices[int(a):int(b)].cpu().numpy() for a, b in zip(lo_, hi_)]      # (row by row: the CSR of config 5 has 500 M entries)
     bip, bix = csr(rows)
     Uw, Iw = W.U[users_t[:n].long()].float().cpu().numpy(), W.I.float().cpu().numpy()
     pop = W.pop_last.cpu().numpy() if head else None
@@ -166,8 +166,8 @@ def test_full_size_c3(dev, monkeypatch):
 
 
 def test_full_size_c5_shard_bf16(dev, monkeypatch):
-    """One rank's share of BASELINE config 5 at full size (250 000 item rows x d = 256, bf16 tables, 1M-user replica of the
-    user table, 50M-entry history CSR): the three sweep modes of both kernel generations return identical merged keys for
+    """One rank's share of BASELINE config 5 at full size (250 000 item rows x d = 256, bf16 tables, the WHOLE 10M-row user
+    table and its 600M-entry history CSR since round 6): the three sweep modes of both kernel generations return identical merged keys for
     8 192 users; a 256-user sample equals the oracle on the widened tables (popularity head: 1e-5 + near-tie rule); lists
     are sorted, in range and free of train items; then the 262 144-user block bench.py --workload c5shard times, unforced."""
     from pda_amd import ops, synthetic
@@ -190,10 +190,9 @@ def test_full_size_c5_shard_bf16(dev, monkeypatch):
         assert torch.equal(ref, v), k
     idx, val = ops.unpack_keys(ref)
     assert (np.diff(val, axis=1) <= 0).all() and (idx >= 0).all() and (idx < W.n_items).all()
-    ip, ix = W.hist_indptr.cpu().numpy(), W.hist_indices.cpu().numpy()
     for r in range(0, 8192, 512):
         u = 300_000 + r
-        assert not set(idx[r]) & set(ix[ip[u]:ip[u + 1]])
+        assert not set(idx[r]) & set(W.hist_indices[int(W.hist_indptr[u]):int(W.hist_indptr[u + 1])].cpu().numpy())
     ridx, rval, sc = oracle_sample_lists(W, users, 1)
     assert_lists_match_oracle(ref, ridx, rval, sc, head=1)
     # ---- the block bench.py --workload c5shard times (262 144 users), no PDA_* variable set: generation 4, d = 256, bf16 tables
@@ -221,6 +220,50 @@ def test_full_size_c5_shard_bf16(dev, monkeypatch):
     assert torch.equal(r262[:8192], r8k)
     ridx0, rval0, sc0 = oracle_sample_lists(W, users, 0)
     assert_lists_match_oracle(r262, ridx0, rval0, sc0, head=0)
+    # ---- round 6: the WHOLE user table of config 5 (10 M x 256 bf16 = 5.1 GB, a 600 M-entry history CSR with int64 row pointers).  A block from
+    # the top of the id range: every user-row gather (uid * 512 bytes) and every CSR read (indptr[uid] * 4 bytes) of these launches lies beyond 2^31
+    # bytes.  Both sweep modes of the popularity head and the funnel agree with the oracle on a sample, with generation 3 on 8 192 users, and the
+    # early-terminating keys equal the dense ones on all 262 144 rows.
+    assert W.n_users == 10_000_000 and W.hist_indices.numel() > 560_000_000 and W.hist_indptr.dtype == torch.int64
+    lo = 9_600_000
+    assert lo > (1 << 23) and lo * 256 * 2 > (1 << 31) and int(W.hist_indptr[lo]) * 4 > (1 << 31)
+    top = torch.arange(lo, lo + 262144, dtype=torch.int32, device=dev)
+    tidx, tval, tsc = oracle_sample_lists(W, top, 1)
+    tdense, _ = run(ops, W, hist, top, POP, "order", {"generation": 4, "d": 256, "bf16": True, "geometry": "huge", "head": 1})
+    tstop, _ = run(ops, W, hist, top, POP, True, {"generation": 4, "d": 256, "bf16": True, "early_stop": True, "head": 1})
+    assert torch.equal(tdense, tstop)
+    assert_lists_match_oracle(tdense, tidx, tval, tsc, head=1)
+    st = {}
+    traw = ops.topk_merge(ops.score_topk_keys(W.U, W.I, top, 50, RAW, None, hist, stats=st), want="keys")
+    ident = ops.kernel_identity(st["kernel_id"][0])
+    assert ident["geometry"] == "funnel" and ident["d"] == 256 and int(st["error"][0]) == 0, ident
+    tidx0, tval0, tsc0 = oracle_sample_lists(W, top, 0)
+    assert_lists_match_oracle(traw, tidx0, tval0, tsc0, head=0)
+    monkeypatch.setenv("PDA_SCORE_KERNEL", "v3")
+    t8k, _ = run(ops, W, hist, top[:8192].contiguous(), RAW, False, {})
+    monkeypatch.delenv("PDA_SCORE_KERNEL")
+    assert torch.equal(traw[:8192], t8k)
+    tidxs, _ = ops.unpack_keys(tdense[::4096])
+    ipt = W.hist_indptr[top[::4096].long()].cpu().numpy(), W.hist_indptr[top[::4096].long() + 1].cpu().numpy()
+    for r in range(tidxs.shape[0]):                               # train items never appear
+        row = W.hist_indices[int(ipt[0][r]):int(ipt[1][r])].cpu().numpy()
+        assert not set(tidxs[r]) & set(row)
+    # ... and one SGD step on rows up there: the bf16 step kernel against torch on the gathered rows (fp32 masters take the update)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    B = 2048
+    bu = (lo + torch.randperm(262144, generator=g, device=dev)[:B]).to(torch.int32)
+    bp = torch.randint(0, W.n_items, (B,), generator=g, device=dev, dtype=torch.int32)
+    bn = torch.randint(0, W.n_items, (B,), generator=g, device=dev, dtype=torch.int32)
+    gU, gP, gN = (torch.zeros(B, 256, device=dev) for _ in range(3))
+    loss = torch.zeros(3, device=dev)
+    ops.bpr_step_bf16(W.U, W.I, bu, bp, bn, None, None, regs=1e-2, reg_div=B, mode=ops.UPD_NONE, grads_out=(gU, gP, gN), loss_acc=loss)
+    ue, pe, ne = W.U[bu.long()].double(), W.I[bp.long()].double(), W.I[bn.long()].double()
+    x = (ue * pe).sum(1) - (ue * ne).sum(1)
+    sg = torch.sigmoid(x)
+    gg = (-(1.0 / B) * sg * (1 - sg) / (sg + 1e-10))[:, None]
+    torch.testing.assert_close(gU.double(), gg * (pe - ne) + 1e-2 / B * ue, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(gP.double(), gg * ue + 1e-2 / B * pe, atol=1e-6, rtol=1e-5)
+    torch.testing.assert_close(float(loss[1]), float(-(torch.log(sg + 1e-10)).mean()), atol=1e-5, rtol=1e-5)
 
 
 

@@ -89,3 +89,23 @@ def test_bench_eight_ranks_default_layout_on_one_gpu(tmp_path):
     assert a.shape == c.shape and torch.equal(a, c) and one["n_gpus"] == 1
     dc = torch.cat([torch.load(os.path.join(tmp_path, "topk_dense_w8_r%d.pt" % r)) for r in range(8)])
     assert torch.equal(torch.load(os.path.join(tmp_path, "topk_dense_w1_r0.pt")), dc)
+
+
+def test_config4_eight_item_shards_at_full_size_on_one_gpu(tmp_path):
+    """BASELINE config 4 (1M users x 200k items, d = 128, the catalogue item-sharded over EIGHT ranks: 25 000 items per rank, 262 144 users per
+    step, replicated hot items, the all-to-all of the partial lists) with the real kernels at full size -- eight processes on the ONE GPU of the
+    test box over gloo (RCCL needs eight devices: tests/test_gpu_rccl.py, the driver's scaling run).  The union of the ranks' lists of a step
+    equals the one-rank lists row for row, for the dense headline pass and for the early-terminating pass."""
+    env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PDA_BENCH_DUMP=str(tmp_path))
+    common = ["--workload", "c3", "--steps", "2", "--warmup", "1", "--no-train", "--no-cpu-baseline", "--no-per-config", "--eval-block", "262144"]
+    one = _run([sys.executable, "bench.py"] + common, env)
+    eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                  "--master-port", "29541", "bench.py", "--gpus", "8"] + common, env)
+    lay = eight["config"]["layout"]
+    assert lay == {"user_groups": 1, "item_shards": 8, "users_per_rank_and_step": 262144, "items_per_rank": 25000}, lay
+    assert "replicated hot rows" in eight["config"]["item_shard_path"] and one["config"]["layout"]["item_shards"] == 1
+    for name in ("topk_dense", "topk"):
+        a = torch.load(os.path.join(tmp_path, "%s_w1_r0.pt" % name))
+        b = torch.cat([torch.load(os.path.join(tmp_path, "%s_w8_r%d.pt" % (name, r))) for r in range(8)])
+        assert a.shape == b.shape == (262144, 50), (name, a.shape, b.shape)
+        assert torch.equal(a, b), name
