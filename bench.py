@@ -253,7 +253,16 @@ def bench_eval(args, rank, world, dev, workload=None, light=False, user_groups=N
     workload = workload or args.workload
     td_name, td = table_dtype_of(args, workload)
     steps = max(2, args.steps // 3) if light else args.steps
-    W = synthetic.make_workload(workload, dev, table_dtype=td)
+    if world > 1 and os.environ.get("PDA_BENCH_ONE_GPU") == "1":
+        # N processes on ONE GPU (the plumbing check of tests/test_gpu_two_rank.py): eight of them generating config 3 at the same time spend
+        # minutes in the GPU's time slicing (measured: still inside make_workload after 120 s; four ranks: 27 s for the whole run) -- one at a time
+        for r in range(world):
+            if r == rank:
+                W = synthetic.make_workload(workload, dev, table_dtype=td)
+                torch.cuda.synchronize()
+            dist.barrier()
+    else:
+        W = synthetic.make_workload(workload, dev, table_dtype=td)
     head = ops.HEAD_POP if args.head == "condition" else ops.HEAD_RAW
     timed = TimedScore()
     # N > 1: `ugroups` user groups x (world / ugroups) item shards (pda_amd.dist.grid_layout)
@@ -994,6 +1003,9 @@ def cpu_baseline(args, ev_res, train_pack, budget=None, full=True):
 
 def main():
     args = parse()
+    if os.environ.get("PDA_BENCH_WATCHDOG"):           # debugging aid: every thread's stack to stderr after N seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["PDA_BENCH_WATCHDOG"]), exit=True)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

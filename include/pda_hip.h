@@ -272,6 +272,7 @@ int pda_score_topk4_bf16(const uint16_t* U, const uint16_t* I_shard, const void*
 #define PDA_PATH_GEN3_ORDERED 3            /* pda_score_topk_ordered_f32 / _bf16 */
 #define PDA_PATH_GEN4 4                    /* pda_score_topk4_f32 / _bf16 */
 #define PDA_PATH_FUNNEL 7                  /* pda_score_topk7_f32 / _bf16 */
+#define PDA_FUNNEL_WORKSPACE_BUDGET ((size_t)24 << 30)   /* a block whose funnel workspace (~27 KB per user) would pass this is planned on PDA_PATH_GEN4 */
 #define PDA_ORDER_NATURAL 0
 #define PDA_ORDER_BY_POPULARITY 1          /* most popular first (stable) */
 #define PDA_ORDER_BY_NORM 2                /* largest ||i|| first (stable) */
@@ -318,6 +319,14 @@ int pda_score_topk7_f32(const float* U, const float* I_shard, const void* prep, 
 int pda_score_topk7_bf16(const uint16_t* U, const uint16_t* I_shard, const void* prep, const int32_t* users, int n_users_blk, int item_offset,
                          int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices, int hist_row_mode, int K, int head,
                          uint64_t* out_keys, void* workspace, void* stream);
+
+/* The ratings as a MATRIX: batch_ratings / condition_ratings (MF/model_api.py:62,113) as DatasetApi_Model.testing fetches them for the NeuRec
+ * evaluators' predict() protocol (MF/train_new_api.py:642-696; the reference imports that protocol and never calls it).  out f32 [n_users_blk, n_items]:
+ * out[r][j] = head(U[users[r]] . I[items[j]]) with pop[j] (f32 [n_items], required for PDA_HEAD_POP) -- items i32 [n_items] row ids of I, or NULL for
+ * rows 0 .. n_items - 1.  No mask, no top-K.  The same k-ordered fmaf chain as every top-K entry point: a value here equals the value a top-K call
+ * returns for the pair, bit for bit.  d in {32, 64, 128, 256}.  Not a hot path -- the top-K calls exist so that this matrix is never formed. */
+int pda_score_dense_f32(const float* U, const float* I, const float* pop, const int32_t* users, int n_users_blk, const int32_t* items, int n_items, int d,
+                        int head, float* out, void* stream);
 
 /* Merge R partial lists per user (R item splits of one GPU, or R ranks after the RCCL all-gather).
  *   in_keys  u64 [R, n_users_blk, K]  each list best-first, empty slots = 0

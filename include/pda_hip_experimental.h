@@ -130,7 +130,11 @@ int pda_group_triplets_by_pos(int32_t* users, int32_t* pos, int32_t* neg, float*
 /* The same dense-decay step as SIX streams instead of seven (round 5): the gradient tables are zero on all but the batch's rows, so they are read
  * (and cleared) only where a row's bit is set.  pda_adam_mark_rows sets the bits of a batch (users -> touched_u; pos, neg -> touched_i; bitmaps of
  * ceil(rows / 32) words, zero before the first step); pda_adam_dense_sweep3_f32 sweeps both tables (d a power of two) and clears the bits behind
- * itself.  Bit-identical tables to pda_adam_dense_sweep2_f32 (an untouched row computes with g = 0, operation for operation).  MF/model_api.py:83. */
+ * itself.  Bit-identical tables to pda_adam_dense_sweep2_f32 (an untouched row computes with g = 0, operation for operation).  MF/model_api.py:83.
+ * PRECONDITIONS: users / pos / neg hold B valid row ids each (the kernel does no bounds check: an id beyond the tables writes beyond the bitmaps);
+ * g_a / g_b are ZERO on every row whose bit is not set -- a caller that accumulates gradients for rows outside (users, pos, neg) (micro-batches,
+ * gradients reduced from other ranks) must mark those rows too, or use pda_adam_dense_sweep2_f32, which reads every row's gradient.
+ * Superseded for single-GPU training by pda_adam_step_f32 (pda_hip.h: row tags instead of bitmaps, two launches instead of five). */
 int pda_adam_mark_rows(const int32_t* users, const int32_t* pos, const int32_t* neg, int B, uint32_t* touched_u, uint32_t* touched_i, void* stream);
 int pda_adam_dense_sweep3_f32(float* var_a, float* m_a, float* v_a, float* g_a, size_t rows_a, uint32_t* touched_a, float* var_b, float* m_b, float* v_b,
                               float* g_b, size_t rows_b, uint32_t* touched_b, int d, float lr_t, float beta1, float beta2, float eps, void* stream);

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pda_adam_dense_sweep2_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _vp]),
     "pda_adam_mark_rows": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "pda_adam_dense_sweep3_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _f, _f, _f, _f, _vp]),
+    "pda_score_dense_f32": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "pda_adam_dense_sweep4_f32": (_i, [_vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _i, _i, _f, _f, _f, _f, _i, _vp]),
     "pda_adam_step_f32": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _i, _f, _f, _f, _f,
                                _i, _i, _vp, _vp]),

@@ -106,6 +106,70 @@ extern "C" int pda_topk_remap_items(uint64_t* keys, size_t n_keys, const int32_t
     return PDA_OK;
 }
 
+namespace {
+// ------------------------------------------------------------------------------------------------
+// Dense ratings: batch_ratings / condition_ratings as a matrix (MF/model_api.py:62,113 fetched by DatasetApi_Model.testing,
+// MF/train_new_api.py:642-669: the NeuRec evaluators' protocol -- the reference imports and never calls it).  Every score is the
+// k-ordered fmaf chain of the top-K kernels (oracle/pda_oracle.c:dot_chain), so out[r][j] equals the value a top-K call returns
+// for that pair bit for bit.  A 16-user x 64-item tile per workgroup, the users' rows in LDS; not a hot path: the point of the
+// top-K entry points is that this matrix is never formed.
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__global__ void __launch_bounds__(256) score_dense_kernel(const float* __restrict__ U, const float* __restrict__ I, const float* __restrict__ pop,
+                                                          const int32_t* __restrict__ users, int n_users_blk, const int32_t* __restrict__ items,
+                                                          int n_items, int head, float* __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float su[16][D + 4];
+    const int tid = threadIdx.x;
+    const int u0 = blockIdx.y * 16, j0 = blockIdx.x * 64;
+    for (int q = tid; q < 16 * (D / 4); q += 256) {
+        const int r = q / (D / 4), c = q % (D / 4);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (u0 + r < n_users_blk) v = *reinterpret_cast<const f32x4*>(U + (size_t)users[u0 + r] * D + 4 * c);
+        *reinterpret_cast<f32x4*>(&su[r][4 * c]) = v;
+    }
+    __syncthreads();
+    const int r = tid >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + (tid & 15) + 16 * q;
+        if (u0 + r >= n_users_blk || j >= n_items) continue;
+        const int item = items ? items[j] : j;
+        const float* v = I + (size_t)item * D;
+        float acc[2] = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < D / 8; ++c) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(v + 8 * c), b = *reinterpret_cast<const f32x4*>(v + 8 * c + 4);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                acc[c & 1] = fmaf(su[r][8 * c + s2], a[s2], acc[c & 1]);
+                acc[c & 1] = fmaf(su[r][8 * c + 4 + s2], b[s2], acc[c & 1]);
+            }
+        }
+        float sc = acc[0] + acc[1];
+        if (head == PDA_HEAD_POP) sc = (sc > 0.0f ? sc + 1.0f : __expf(sc)) * pop[j];
+        out[(size_t)(u0 + r) * n_items + j] = sc;
+    }
+}
+}  // namespace
+
+extern "C" int pda_score_dense_f32(const float* U, const float* I, const float* pop, const int32_t* users, int n_users_blk, const int32_t* items,
+                                   int n_items, int d, int head, float* out, void* stream) {
+    if (!U || !I || !users || !out || n_users_blk <= 0 || n_items <= 0) return PDA_ERR_ARG;
+    if (head != PDA_HEAD_RAW && head != PDA_HEAD_POP) return PDA_ERR_ARG;
+    if (head == PDA_HEAD_POP && !pop) return PDA_ERR_ARG;
+    const dim3 grid((unsigned)((n_items + 63) / 64), (unsigned)((n_users_blk + 15) / 16));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (d) {
+        case 32: hipLaunchKernelGGL(score_dense_kernel<32>, grid, dim3(256), 0, s, U, I, pop, users, n_users_blk, items, n_items, head, out); break;
+        case 64: hipLaunchKernelGGL(score_dense_kernel<64>, grid, dim3(256), 0, s, U, I, pop, users, n_users_blk, items, n_items, head, out); break;
+        case 128: hipLaunchKernelGGL(score_dense_kernel<128>, grid, dim3(256), 0, s, U, I, pop, users, n_users_blk, items, n_items, head, out); break;
+        case 256: hipLaunchKernelGGL(score_dense_kernel<256>, grid, dim3(256), 0, s, U, I, pop, users, n_users_blk, items, n_items, head, out); break;
+        default: return PDA_ERR_UNSUPPORTED;
+    }
+    PDA_CHECK_LAUNCH();
+    return PDA_OK;
+}
+
 extern "C" int pda_abi_version(void) { return PDA_ABI_VERSION; }
 
 extern "C" const char* pda_error_string(int code) {

@@ -1,21 +1,23 @@
 // The funnel (round 5): exact top-K for sweeps that meet HUNDREDS of list insertions per user -- the raw head (MF/train_new_api.py:597-598,
-// the ranking the reference evaluates in every epoch, :1139-1141, and the only one of --train normal, :1160-1165) and any head in natural
-// item order -- on the huge geometry's machine mapping.  Included by pda_score_topk_v4.hip behind pda_v5_sweep.h.
+// the ranking the reference evaluates in every epoch, :1139-1141, and the only one of --train normal, :1160-1165) -- on the huge geometry's
+// machine mapping.  Compiled in pda_score_funnel.hip (which holds the schedule, the workspace layout and the host entry points).
 //
 // What bound generation 4's many-candidates geometry: a running exact list takes K ln(n / n0) true insertions per user
 // (359 measured at config 3), each an exact rescoring that gathers a 512-byte item row -- 46 GB per launch against 0.4 GB algorithmic,
 // matrix pipe 24 % busy.  The funnel keeps everything approximate until the end:
-//   * sweep7_kernel (loop: pda_v7_emit_loop_asm.h) scores a PART of the catalogue against FIXED per-user thresholds and writes, for every
-//     (user, quarter of a half-tile) whose best bound s~ + ct beats the threshold, the lane's eight bounds to the lane's own list: no list
-//     maintenance, no gather, no exit from the loop;
-//   * select7_kernel turns the entries into the user's candidate pool {ub >= Tk}, Tk = the K-th largest LOWER bound seen so far (valid by
-//     construction: K items reach it), and into the threshold of the next part: the r-th largest lower bound, r < K chosen so that the
-//     threshold stays below the final K-th value with probability 1 - 1e-4 (the parts grow geometrically: 256, 768, 2 304, ... items);
-//   * resolve7_kernel rescores the final pool (~K + the pairs inside the bound's band) exactly -- the fp32 chain of the oracle --, masks the
-//     train items, sorts and writes the K keys.  A user whose final Tk fell below a threshold that was used (the estimate was too bold), or
-//     whose lists overflowed, is swept again against Tk itself (exact by construction), and as a last resort by generation 4's exact lists.
-// Every returned score is an fp32 score of the oracle's chain; the bf16 products decide only what is looked at, under the same rigorous
-// bound as everywhere (pda_score_topk_v3.hip).
+//   * sweep7_kernel (loops: pda_v7_emit_loop_asm.h, fp16 operands) scores a PART of the catalogue against FIXED per-user thresholds and writes,
+//     for every (user, quarter of a half-tile) whose best bound s~ + ct beats the threshold, the lane's eight bounds to the lane's own list: no
+//     list maintenance, no gather, no exit from the loop.  The first launch (Loop7M) writes nothing: it keeps maxima, maxthr7_kernel turns them
+//     into the first thresholds;
+//   * expand7_kernel turns a launch's entries into the row's pool {ub >= the thresholds used so far} (train items masked), threshold7_kernel
+//     finds the threshold of the next part -- the r-th largest LOWER bound, r < K chosen so that the threshold stays below the row's final
+//     K-th value with probability 1 - g_fail_p (1e-6 per row and launch; the parts grow by 4, then by 2) -- and, after the last part,
+//     tk = the K-th largest lower bound (valid by construction: K items reach it);
+//   * resolve7_kernel rescores the final pool {ub >= tk} exactly -- the fp32 chain of the oracle --, sorts and writes the K keys.  A row whose
+//     bets were lost (fewer than K pairs of the final pool reach a threshold that was used) or whose lists overflowed is served inside the
+//     same call by generation 4's exact lists, seeded with the row's tk (pda_score_funnel.hip: fail list, fallback sweep, fail_merge7_kernel).
+// Every returned score is an fp32 score of the oracle's chain; the fp16 products decide only what is looked at, under a rigorous bound formed
+// from the ACTUAL rounding residuals (see sweep7_kernel).
 #pragma once
 #include "pda_v7_emit_loop_asm.h"
 
@@ -81,7 +83,7 @@ __global__ void __launch_bounds__(256, 1) sweep7_kernel(Args7 g) {
         const int rb = utile * UT + row0 + 16 * u + j;
         const float nu_r = rb < n_rows ? g.unorm[rb] : 0.f, ue_r = rb < n_rows ? g.uerr[rb] : 0.f;
         ea = fmaxf(ea, ue_r + nu_r * 6.103515625e-5f);
-        eb = fmaxf(eb, nu_r * 1.00390625f);
+        eb = fmaxf(eb, nu_r + ue_r);             // ||u~|| <= ||u|| + ||u - u~||: rigorous for any rounding (fp16 subnormals included; round 5 used 1.0039 ||u||)
         thr[u] = rb < n_rows ? fminf(fmaxf(g.thr[rb], -1.0e30f), 1.0e30f) : 1.0e30f;
     }
 #pragma unroll
@@ -288,7 +290,7 @@ __global__ void __launch_bounds__(256) expand7_kernel(Sel7 g) {
     const uint32_t t_old_o = pda_ordf(g.r.tmax[rbs] + 0.0f);                   // the (un-lowered) source of thr_used: -inf in the first launch
     const bool first = g.first_launch != 0;
     const float eu = g.e.eu_wave[2 * (utile * 4 + w)], eu2 = g.e.eu_wave[2 * (utile * 4 + w) + 1];      // what the launch formed ct with
-    const float ua = (g.e.uerr[rbs] + g.e.unorm[rbs] * 6.103515625e-5f) * 1.001f, ub2 = g.e.unorm[rbs] * 1.00390625f * 1.001f;   // the ROW's own A, B
+    const float ua = (g.e.uerr[rbs] + g.e.unorm[rbs] * 6.103515625e-5f) * 1.001f, ub2 = (g.e.unorm[rbs] + g.e.uerr[rbs]) * 1.001f;   // the ROW's own A, B
     const bool hist_on = g.hist_indptr != nullptr;
     long long hb = 0, he = 0;
     if (hist_on && row_ok) {

@@ -693,6 +693,9 @@ def funnel_order(I_shard: torch.Tensor) -> torch.Tensor:
     return o
 
 
+FUNNEL_WORKSPACE_BUDGET = 24 << 30      # PDA_FUNNEL_WORKSPACE_BUDGET (include/pda_hip.h)
+
+
 def funnel_applies(d: int, K: int, nu: int, nloc: int, head: int, prune, hist: Optional[HistoryCSR]) -> bool:
     """Does score_topk_keys serve this call with the funnel?  (PDA_SCORE_FUNNEL=0 | 1 forces it off / on wherever it can run.)"""
     can = head == HEAD_RAW and d in (64, 128, 256) and K <= TOPK_K_V4 and 4096 <= nloc <= (1 << 26) and prune is not True \
@@ -703,7 +706,8 @@ def funnel_applies(d: int, K: int, nu: int, nloc: int, head: int, prune, hist: O
     if forced == "1":
         return True
     return nu >= FUNNEL_MIN_USERS and nloc >= FUNNEL_MIN_ITEMS and (nloc >= FUNNEL_SMALL_ITEMS or nu <= FUNNEL_SMALL_MAX_USERS) \
-        and not os.environ.get("PDA_SCORE_KERNEL") and not os.environ.get("PDA_SCORE_LISTS")
+        and not os.environ.get("PDA_SCORE_KERNEL") and not os.environ.get("PDA_SCORE_LISTS") \
+        and _lib.load().pda_score_topk7_workspace_bytes(nu, nloc, d) <= FUNNEL_WORKSPACE_BUDGET     # (~27 KB per user: pda_score_topk_plan's rule)
 
 
 def score_topk_funnel(U, I_shard, users, K=50, hist: Optional[HistoryCSR] = None, item_offset=0, stats: Optional[dict] = None) -> torch.Tensor:
@@ -720,7 +724,7 @@ def score_topk_funnel(U, I_shard, users, K=50, hist: Optional[HistoryCSR] = None
     out = torch.empty((1, nu, K), dtype=torch.int64, device=U.device)
     nbytes = lib.pda_score_topk7_workspace_bytes(nu, nloc, d)
     if nbytes == 0:
-        raise ValueError("the funnel: embed dim 64 / 128")
+        raise ValueError("the funnel: embed dim 64 / 128 / 256")
     ws = torch.empty(nbytes, dtype=torch.uint8, device=U.device)
     fn = lib.pda_score_topk7_bf16 if bf else lib.pda_score_topk7_f32
     check(fn(ptr(U), ptr(I_shard), ptr(prep), ptr(users), nu, item_offset, nloc, d, ptr(hist.indptr) if hist else None,
@@ -979,6 +983,22 @@ def apply_user_grads(U, users, g, lr: float):
     check(lib.pda_apply_user_grads_f32(ptr(U), ptr(users), ptr(g), n, d, g.stride(0), float(lr), stream_ptr()),
           "pda_apply_user_grads_f32")
     mark_modified(U)
+
+
+def score_dense(U, I, users, head: int, pop=None, items=None) -> torch.Tensor:
+    """pda_score_dense_f32: the ratings matrix float32 [len(users), n_items] (batch_ratings / condition_ratings of the reference), every entry
+    the exact fmaf chain of the top-K kernels.  items: int32 row ids of I or None (all rows); pop: float32 per returned column."""
+    U, I = _need(U, torch.float32, "U"), _need(I, torch.float32, "I")
+    users = _need(users, torch.int32, "users")
+    items = _need(items, torch.int32, "items", optional=True)
+    pop = _need(pop, torch.float32, "pop", optional=True)
+    n = I.shape[0] if items is None else items.numel()
+    if pop is not None and pop.numel() != n:
+        raise ValueError("pop holds one value per returned column")
+    out = torch.empty((users.numel(), n), dtype=torch.float32, device=U.device)
+    check(_lib.load().pda_score_dense_f32(ptr(U), ptr(I), ptr(pop), ptr(users), users.numel(), ptr(items), n, U.shape[1], int(head), ptr(out), stream_ptr()),
+          "pda_score_dense_f32")
+    return out
 
 
 def adam_lr_t(lr: float, t: int, beta1=ADAM_BETA1, beta2=ADAM_BETA2) -> float:

@@ -203,19 +203,22 @@ class DatasetApi_Model:
         return ops.recommend_topk(self.Recommender.score_tables()[0], I, users, K, head, pop_t, hist)
 
     def testing(self, sess, batch_users, items, model_type, pos_pop=None):
-        """Dense scores f32 [B, len(items)] (:642-669).  Compatibility surface for the NeuRec evaluators (which the
-        reference imports and never calls); NOT on the hot path and deliberately plain torch."""
-        self.Recommender.sync_optimizer()
-        U = self.Recommender.weights["user_embedding"]
-        users = torch.as_tensor(np.asarray(batch_users, dtype=np.int64), device=self.device)
-        I, _ = self._tables(items)
-        R = U.index_select(0, users) @ I.float().t()
-        if model_type == "main_branch":
-            return R.cpu().numpy()
+        """Dense scores f32 [B, len(items)] (:642-669): batch_ratings / condition_ratings as the NeuRec evaluators' protocol fetches them (the
+        reference imports that protocol and never calls it).  pda_score_dense_f32: every entry is the exact fmaf chain of the top-K kernels, so
+        these scores equal the values do_recommendation ranks by, bit for bit (bf16 tables: widened first, as their scores are defined)."""
+        if model_type not in ("main_branch", "condition"):
+            raise NotImplementedError("error -- not implement this type testing method...")      # :664
+        U, I = self.Recommender.score_tables()
+        users = torch.as_tensor(np.asarray(batch_users, dtype=np.int32), device=self.device)
+        it = np.asarray(items, dtype=np.int64).reshape(-1)
+        whole = it.size == I.shape[0] and bool((it == np.arange(it.size)).all())
+        it_t = None if whole else torch.as_tensor(it.astype(np.int32), device=self.device)
+        if U.dtype != torch.float32:
+            U, I = U.float(), I.float()
+        pop = None
         if model_type == "condition":
             pop = torch.as_tensor(np.asarray(pos_pop, dtype=np.float32).reshape(-1), device=self.device)
-            return ((torch.nn.functional.elu(R) + 1.0) * pop.unsqueeze(0)).cpu().numpy()
-        raise NotImplementedError("error -- not implement this type testing method...")      # :664
+        return ops.score_dense(U, I, users, ops.HEAD_POP if model_type == "condition" else ops.HEAD_RAW, pop, it_t).cpu().numpy()
 
     def switch_to_testing_or_reinit(self, sess=None, feed_dict=None):
         return None

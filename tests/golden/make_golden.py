@@ -12,7 +12,9 @@ code produced for them.
   topk_ref.npz     util/cython/include/arg_topk.h:arg_top_k_2d and evaluator/backend/cpp evaluate.h:
                    cpp_evaluate_matrix (compiled into oracle/_ref) on tie-free score matrices
   flags.json       argparse namespace of MF/parse.py with no arguments (flag names and defaults)
-  popularity_heads.npz   the numpy expressions of MF/train_new_api.py:954-959,988-990 evaluated literally
+  popularity_heads.npz   NOT a reference run: the numpy expressions of MF/train_new_api.py:954-959,988-990 TRANSCRIBED by the builder
+                         (that file imports TensorFlow and cannot be imported here).  It pins our host code against a second writing
+                         of the same three lines, nothing more; every other fixture above is an output of the reference's own code.
 """
 import importlib.util
 import json

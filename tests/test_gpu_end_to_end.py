@@ -230,3 +230,45 @@ def test_exact_sgd_through_the_trainer_takes_the_planned_step(dev, toy, tmp_path
         res.append((rec.weights["user_embedding"].clone(), rec.weights["item_embedding"].clone()))
     np.testing.assert_allclose(res[0][0].cpu().numpy(), res[1][0].cpu().numpy(), atol=2e-6)
     np.testing.assert_allclose(res[0][1].cpu().numpy(), res[1][1].cpu().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("train", ["s_condition", "normal"])
+def test_testing_and_predict_return_the_scores_the_recommender_ranks_by(dev, toy, tmp_path, train):
+    """DatasetApi_Model.testing / predict (MF/train_new_api.py:642-696: batch_ratings / condition_ratings as a matrix, the NeuRec evaluators'
+    protocol) through pda_score_dense_f32: float32 [B, len(items)], equal to the oracle's scores to 1e-5, and -- the same fmaf chain --
+    BIT FOR BIT the values do_recommendation's top-K lists carry for the same pairs; a subset / permutation of the items gathers columns."""
+    from pda_amd import ops, train_new_api as t
+    t.configure(_argv(toy, str(tmp_path) + "/", train))
+    args, data = t.args, t.data
+    model = t.DatasetApi_Model(args, {"n_users": data.n_users, "n_items": data.n_items}, 256, None, dev)
+    sess = t.Session(model)
+    model.set_sess(sess)
+    rng = np.random.default_rng(5)
+    users = rng.permutation(data.n_users)[:37].tolist()
+    items = list(range(data.n_items))
+    pop = (rng.uniform(0, 1, data.n_items) ** 0.22).astype(np.float32)
+    U = model.Recommender.weights["user_embedding"].cpu().numpy().astype(np.float64)
+    I = model.Recommender.weights["item_embedding"].cpu().numpy().astype(np.float64)
+    R = U[users] @ I.T
+    raw = model.testing(sess, users, items, "main_branch")
+    assert raw.dtype == np.float32 and raw.shape == (37, data.n_items)
+    np.testing.assert_allclose(raw, R, atol=1e-5, rtol=1e-5)
+    cond = model.testing(sess, users, items, "condition", pos_pop=pop)
+    np.testing.assert_allclose(cond, np.where(R > 0, R + 1.0, np.exp(R)) * pop[None, :], atol=1e-5, rtol=1e-5)
+    sub = rng.permutation(data.n_items)[:50].tolist()
+    np.testing.assert_array_equal(model.testing(sess, users, sub, "main_branch"), raw[:, sub])
+    np.testing.assert_array_equal(model.testing(sess, users, sub, "condition", pos_pop=pop[sub]), cond[:, sub])
+    # the lists of the recommender: same pairs, same bits
+    ut = torch.as_tensor(np.asarray(users, dtype=np.int32), device=dev)
+    Ut, It = model.Recommender.score_tables()
+    for head, mat, p in ((ops.HEAD_RAW, raw, None), (ops.HEAD_POP, cond, torch.as_tensor(pop, device=dev))):
+        idx, val = ops.recommend_topk(Ut, It, ut, 50, head, p, None)
+        idx, val = idx.cpu().numpy(), val.cpu().numpy()
+        np.testing.assert_array_equal(val, np.take_along_axis(mat, idx.astype(np.int64), axis=1))
+    # predict(): the NeuRec protocol on top of it (:683-696)
+    model.set_testing_way("o", None)
+    np.testing.assert_array_equal(model.predict(users, None), raw)
+    model.set_testing_way("condition", pop)
+    np.testing.assert_array_equal(model.predict(users, sub), cond[:, sub])
+    with pytest.raises(NotImplementedError):
+        model.testing(sess, users, items, "nonsense")

@@ -96,13 +96,15 @@ def test_config4_eight_item_shards_at_full_size_on_one_gpu(tmp_path):
     step, replicated hot items, the all-to-all of the partial lists) with the real kernels at full size -- eight processes on the ONE GPU of the
     test box over gloo (RCCL needs eight devices: tests/test_gpu_rccl.py, the driver's scaling run).  The union of the ranks' lists of a step
     equals the one-rank lists row for row, for the dense headline pass and for the early-terminating pass."""
-    env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PDA_BENCH_DUMP=str(tmp_path))
+    env = dict(os.environ, PDA_BENCH_ONE_GPU="1", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PDA_BENCH_DUMP=str(tmp_path),
+               PDA_BENCH_WATCHDOG="800")         # (a hang ends in every thread's stack on stderr instead of a silent timeout)
     common = ["--workload", "c3", "--steps", "2", "--warmup", "1", "--no-train", "--no-cpu-baseline", "--no-per-config", "--eval-block", "262144"]
     one = _run([sys.executable, "bench.py"] + common, env)
     eight = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
                   "--master-port", "29541", "bench.py", "--gpus", "8"] + common, env)
     lay = eight["config"]["layout"]
-    assert lay == {"user_groups": 1, "item_shards": 8, "users_per_rank_and_step": 262144, "items_per_rank": 25000}, lay
+    assert lay["user_groups"] == 1 and lay["item_shards"] == 8 and lay["users_per_rank_and_step"] == 262144, lay
+    assert 25000 <= lay["items_per_rank"] <= 25088, lay          # (rank 0's shard: 200 000 / 8, cut at a multiple of 64 items)
     assert "replicated hot rows" in eight["config"]["item_shard_path"] and one["config"]["layout"]["item_shards"] == 1
     for name in ("topk_dense", "topk"):
         a = torch.load(os.path.join(tmp_path, "%s_w1_r0.pt" % name))
