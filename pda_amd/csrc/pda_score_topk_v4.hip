@@ -2225,9 +2225,11 @@ __global__ void __launch_bounds__(256) seed_pick_kernel(const float* __restrict_
 int pda_v4_run_score4_dev(const void* U, const void* I_shard, bool bf16, const void* prep, const float* pop_shard, const int32_t* users, int n_users_blk,
                           const int* n_users_dev, int item_offset, int n_items_local, int d, const int64_t* hist_indptr, const int32_t* hist_indices,
                           int hist_row_mode, int K, int head, int early_stop, int n_splits, const float* seed, uint64_t* out_keys, void* workspace, hipStream_t s) {
-    // seed: a lower bound of every row's final K-th value (the funnel's tk), or NULL
+    // seed: a lower bound of every row's final K-th value (the funnel's tk: K unmasked items reach it), or NULL.  With a seed the sweep runs from EMPTY
+    // lists (phase 4): the exact warm-up would cost its ~100 us per 128-user workgroup to collect what the seed already prunes to ~K pairs per row
+    // (round 6: configs 1 / 2, where one row of 50 000 goes through here in every call).
     return run_score4(U, I_shard, bf16, prep, pop_shard, users, n_users_blk, item_offset, n_items_local, d, hist_indptr, hist_indices, hist_row_mode, K, head,
-                      early_stop, n_splits, out_keys, workspace, s, 3, seed, 0, n_users_dev);
+                      early_stop, n_splits, out_keys, workspace, s, seed != nullptr ? 4 : 3, seed, 0, n_users_dev);
 }
 
 extern "C" int pda_topk_seed_bounds(const uint64_t* keys, int n_splits, int n_users_blk, int K, int m, float* bounds, void* stream) {
