@@ -21,6 +21,7 @@ int g_maxima = 1;              // the first launch keeps maxima only (rank-8 thr
 int g_first_mult = 2;          // the first emitting launch behind a maxima launch over m tiles: tiles [0, g_first_mult x m)
 int g_late_den = 6;            // from 1 / g_late_den of the catalogue on the parts grow by g_late_growth_x10 / 10 instead of g_growth
 int g_late_growth_x10 = 20;
+bool g_tuned = false;          // pda_debug_funnel_tune(2) was called: the globals above rule whatever the item splits
 constexpr int kFallbackSplits = 8;
 
 struct Stage7 {
@@ -47,8 +48,14 @@ int rank_for7(int K, double m, double n, double p) {
         if (gamma_cdf7(r, x) <= p) return r;
     return K;
 }
-std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
+std::vector<Stage7> schedule7(int n_tiles, int n_items, int K, int n_splits = 1) {
     std::vector<Stage7> st;
+    // What a launch writes per list is ~ rank x (growth - 1) / (4 quarters x S item splits): a block that fills the chip with item splits (few users:
+    // the reference's 2 048-user blocks run 32 splits, configs 1 / 2 five) has room for parts that grow by 8, then by 4 -- one or two launches and
+    // selections less where every launch is fixed cost (round 6, tools/funnel_small_tune.sh: 2 048 users x 200 000 items 0.91 -> 0.75 ms, config 1
+    // 1.64 -> 1.48, config 2 1.56 -> 1.49).  One split (262 144 users) keeps growth 4 / 2: there the longer parts overflow the lists.
+    const bool wide = n_splits >= 4 && !g_tuned;
+    const int growth = wide ? 8 : g_growth, first_mult = wide ? 4 : g_first_mult, late_growth_x10 = wide ? 40 : g_late_growth_x10;
     int lo = 0, hi = std::min(n_tiles, std::max(1, g_first_tiles));
     if (g_maxima) {
         // the maxima launch: as many tiles as rank 8 carries (P(Gamma(8) < K m / n) <= p), at least two; the first emitting launch starts over at tile 0
@@ -57,7 +64,7 @@ std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
         if (m2 * 3 / 2 <= n_tiles / 8 && gamma_cdf7(8, (double)K * (m2 * 3 / 2) * 64.0 / n_items) <= g_fail_p) m2 = m2 * 3 / 2;
         if (gamma_cdf7(8, (double)K * m2 * 64.0 / n_items) <= g_fail_p && K >= 8) {
             st.push_back(Stage7{0, m2, 8, 1});
-            hi = std::min(n_tiles, m2 * std::max(1, g_first_mult));          // (rank 8 is a coarse estimate: the first emitting launch stays short)
+            hi = std::min(n_tiles, m2 * std::max(1, first_mult));            // (rank 8 is a coarse estimate: the first emitting launch stays short)
         }
     }
     for (;;) {
@@ -70,7 +77,7 @@ std::vector<Stage7> schedule7(int n_tiles, int n_items, int K) {
         lo = hi;
         // the parts grow by g_growth, and by 2 from a sixth of the catalogue on: what a launch writes per list is ~ rank x (growth - 1) + the
         // pairs inside the bound's band, and the lists of the last, longest launches are the ones that fill
-        const int gr10 = (long long)hi * g_late_den >= n_tiles ? std::max(11, g_late_growth_x10) : 10 * std::max(2, g_growth);
+        const int gr10 = (long long)hi * g_late_den >= n_tiles ? std::max(11, late_growth_x10) : 10 * std::max(2, growth);
         hi = (int)std::min<long long>((long long)n_tiles, ((long long)hi * gr10 + 9) / 10);
     }
     return st;
@@ -202,7 +209,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
             reinterpret_cast<float*>(wsb + W.mrun), nullptr, reinterpret_cast<const int*>(pb + L.hdr)};
     Sel7 q{e, R, reinterpret_cast<const u32x4*>(pb + L.pinfo), users, hist_indptr, hist_indices, bloom, hist_row_mode, item_offset, n_items_local, K, 0, 0, U, I_shard, out_keys,
            reinterpret_cast<int*>(wsb + W.fail_list), fail_count};
-    const std::vector<Stage7> stages = schedule7(L.n_tiles, n_items_local, K);
+    const std::vector<Stage7> stages = schedule7(L.n_tiles, n_items_local, K, W.n_splits);
     for (const Stage7& st : stages) {
         e.tile_lo = st.lo;
         e.tile_hi = st.hi;
@@ -290,6 +297,7 @@ extern "C" int pda_score_topk7_bf16(const uint16_t* U, const uint16_t* I_shard, 
 }
 // measurements only: failure probability target, growth factor, list capacity, first tiles (0 / negative: keep)
 extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int first_tiles) {
+    g_tuned = true;
     if (fail_p > 0.0) g_fail_p = fail_p;
     if (growth >= 2) g_growth = growth;
     if (cap_e > 0) g_cap_e = cap_e;
@@ -297,6 +305,7 @@ extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int f
     return PDA_OK;
 }
 extern "C" int pda_debug_funnel_tune2(int first_mult, int late_den, int late_growth_x10) {
+    g_tuned = true;
     if (first_mult > 0) g_first_mult = first_mult;
     if (late_den > 0) g_late_den = late_den;
     if (late_growth_x10 > 10) g_late_growth_x10 = late_growth_x10;
@@ -315,8 +324,12 @@ extern "C" int pda_debug_funnel_layout(int n_users_blk, int n_items_local, int d
     return (w.n_splits << 16) | w.cap_e;
 }
 // the launches of a funnel: out[3 i .. 3 i + 2] = (first tile, end tile, rank of the next threshold); returns their number
-extern "C" int pda_debug_funnel_schedule(int n_items_local, int K, int* out, int max_stages) {
-    const std::vector<Stage7> st = schedule7((n_items_local + 63) / 64, n_items_local, K);
+extern "C" int pda_debug_funnel_schedule_for(int n_users_blk, int n_items_local, int d, int K, int* out, int max_stages);
+extern "C" int pda_debug_funnel_schedule(int n_items_local, int K, int* out, int max_stages) { return pda_debug_funnel_schedule_for(0, n_items_local, 0, K, out, max_stages); }
+// ... of a block of n_users_blk users at embed dim d (the item splits decide how fast the parts grow); n_users_blk = 0: one item split
+extern "C" int pda_debug_funnel_schedule_for(int n_users_blk, int n_items_local, int d, int K, int* out, int max_stages) {
+    const int S = n_users_blk > 0 ? ws7_layout(n_users_blk, n_items_local, d).n_splits : 1;
+    const std::vector<Stage7> st = schedule7((n_items_local + 63) / 64, n_items_local, K, S);
     for (size_t i = 0; i < st.size() && (int)i < max_stages; ++i) {
         out[3 * i] = st[i].lo;
         out[3 * i + 1] = st[i].hi;

@@ -22,7 +22,7 @@ if os.environ.get("FUNNEL_TUNE2"):
     a = [int(x) for x in os.environ["FUNNEL_TUNE2"].split(",")]
     L.pda_debug_funnel_tune2(a[0], a[1], a[2])
 out = (C.c_int * 96)()
-ns = L.pda_debug_funnel_schedule(W.n_items, 50, out, 32)
+ns = L.pda_debug_funnel_schedule_for(Bu, W.n_items, W.d, 50, out, 32)
 print("schedule", [(out[3 * i], out[3 * i + 1], out[3 * i + 2]) for i in range(ns)])
 st = {}
 for _ in range(3):          # (the workspace of a call is allocated per call: the allocator's blocks exist after two)
