@@ -1,0 +1,79 @@
+#!/usr/bin/env python
+"""EVERY row of the bench's operating point against the bit-exact oracle (round 6).
+
+tests/test_gpu_full_size.py checks 256 users of each 262 144-user block against oracle/pda_oracle.c (c_oracle.score_topk, the fmaf chain of the
+kernels) and the other 261 888 rows through "every kernel generation returns identical keys".  This tool removes the indirection once per
+round: the library's own plan (no PDA_* variable) on a whole block, both heads, and the oracle on ALL its rows on the host cores (OpenMP;
+config 3: ~4 minutes per head on the box's 16 cores).  Raw head: values and lists bit-exact.  Popularity head: values to 1e-5 and every list
+disagreement a near-tie inside that tolerance (hardware v_exp_f32 against libm's expf in the last ulp), counted.
+
+usage: python tools/full_oracle_check.py [workload=c3] [users=262144] [first user=200000]      (test infrastructure: imports oracle/)"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import c_oracle                    # noqa: E402
+from pda_amd import ops, synthetic             # noqa: E402
+
+wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 200000
+TOL = 1e-5
+dev = torch.device("cuda", 0)
+W = synthetic.make_workload(wl, dev, table_dtype=torch.bfloat16 if wl.startswith("c5") else torch.float32)
+n = min(n, W.n_users - first)
+users = torch.arange(first, first + n, dtype=torch.int32, device=dev)
+hist = ops.HistoryCSR(W.hist_indptr, W.hist_indices, by_user=True)
+Iw = W.I.float().cpu().numpy()
+pop = W.pop_last.cpu().numpy()
+print("%s: %d users (ids %d ..) x %d items, d = %d, tables %s" % (wl, n, first, W.n_items, W.d, str(W.U.dtype).split(".")[-1]), flush=True)
+CH = 8192
+for head, name in ((ops.HEAD_RAW, "raw head (main_branch)"), (ops.HEAD_POP, "popularity head (condition)")):
+    st = {}
+    t0 = time.time()
+    keys = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, head, W.pop_last if head else None, hist, stats=st), want="keys")
+    torch.cuda.synchronize()
+    ident = ops.kernel_identity(st["kernel_id"][0]) if "kernel_id" in st else {}
+    gi, gv = ops.unpack_keys(keys)
+    t_gpu = time.time() - t0
+    bad_val = bad_rows = near = 0
+    worst = 0.0
+    t0 = time.time()
+    for s in range(0, n, CH):
+        e = min(n, s + CH)
+        ub = users[s:e].long()
+        lo, hi = W.hist_indptr[ub].cpu().numpy(), W.hist_indptr[ub + 1].cpu().numpy()
+        # the block's history rows, gathered on the device (one contiguous range: the users are consecutive ids)
+        seg = W.hist_indices[int(lo[0]):int(hi[-1])].cpu().numpy()
+        bip = np.concatenate([[0], np.cumsum(hi - lo)]).astype(np.int64)
+        Uw = W.U[ub].float().cpu().numpy()
+        ridx, rval = c_oracle.score_topk(Uw, Iw, np.arange(e - s, dtype=np.int32), 50, 1 if head else 0, pop if head else None, bip, seg, order=1)
+        a_i, a_v = gi[s:e], gv[s:e]
+        if head == 0:
+            bad_val += int((a_v != rval).sum())
+            bad_rows += int((a_i != ridx).any(axis=1).sum())
+        else:
+            d = np.abs(a_v - rval) / np.maximum(1.0, np.abs(rval))
+            worst = max(worst, float(d.max()))
+            bad_val += int((d > TOL).sum())
+            rows = np.flatnonzero((a_i != ridx).any(axis=1))
+            if rows.size:
+                _, _, sc = c_oracle.score_topk(Uw[rows], Iw, np.arange(rows.size, dtype=np.int32), 50, 1, pop, None, None, order=1, want_scores=True)   # (unmasked scores of those rows)
+                for q, r in enumerate(rows):
+                    for k in np.flatnonzero(a_i[r] != ridx[r]):
+                        x, y = a_i[r, k], ridx[r, k]
+                        if abs(sc[q, x] - sc[q, y]) <= TOL * max(1.0, abs(sc[q, y])):
+                            near += 1
+                        else:
+                            bad_rows += 1
+        if (s // CH) % 8 == 0:
+            print("  %s: %d / %d rows checked, %.0f s" % (name, e, n, time.time() - t0), flush=True)
+    print("%s: kernel %s; %d rows x 50: values differing %d (worst relative %.2e), rows with a wrong list %d, near-tie swaps inside 1e-5 %d; oracle %.0f s on the host, library %.3f s"
+          % (name, ident, n, bad_val, worst, bad_rows, near, time.time() - t0, t_gpu), flush=True)
+    assert bad_val == 0 and bad_rows == 0, name
+print("ok: every row equals the oracle")
