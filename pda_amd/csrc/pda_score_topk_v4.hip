@@ -373,55 +373,68 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
     return changed;
 }
 
-// Train items among the warm positions of a 128-user tile -> bit masks [128][2 kWarmTiles] in LDS: a wave walks the histories of
-// its 32 rows, 64 entries of a row per step and four rows in flight (two dependent loads per entry: the id, its visiting position).
+// Train items among the warm positions of a 128-user tile -> bit masks [128][2 kWarmTiles] in LDS.  A wave walks the histories of its 32 rows as ONE
+// flat list of (row, entry) pairs, 64 x 8 of them per round with all eight id loads and then all eight position loads of a lane in flight (two
+// dependent loads per train item); a row's length no longer decides the number of dependent rounds.  Measured (round 6, tools/warm_ablate_small.sh and
+// two load ablations): the walk is 70 - 80 of the warm-up's ~190 us at config 2 (150 train items per user) -- ~40 the id loads, ~16 the position
+// gathers, the rest index arithmetic -- in THIS form as in the four-rows-at-a-time form of rounds 2 - 5: the rewrite bought nothing measurable there
+// (0.197 vs 0.186 - 0.200 ms lease to lease) and is kept for its bounded worst case (a single 800-item row used to cost 13 dependent pairs).
 __device__ __forceinline__ void warm_hist_walk(const Args4& g, unsigned* hmask, int utile, int split, int nwarm, int wave, int lane) {
-        long long hb_l = 0, he_l = 0;
-        {
-            const int rb = utile * kUserTile + wave * 32 + (lane & 31);
-            if (rb < g.n_users_blk) {
-                const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)g.users[rb] : (int64_t)rb;
-                hb_l = g.hist_indptr[hr];
-                he_l = g.hist_indptr[hr + 1];
+    constexpr int UN = 8;
+    long long hb_l = 0;
+    int len_l = 0;
+    {
+        const int rb = utile * kUserTile + wave * 32 + (lane & 31);
+        if (lane < 32 && rb < g.n_users_blk) {
+            const int64_t hr = g.hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)g.users[rb] : (int64_t)rb;
+            hb_l = g.hist_indptr[hr];
+            len_l = (int)min((long long)0x3FFFFFF, g.hist_indptr[hr + 1] - hb_l);          // (a row of more than 2^26 train items cannot exist: n_items <= 2^26)
+        }
+    }
+    // exclusive prefix of the rows' lengths over lanes 0 .. 31 (lanes 32 .. 63 hold the total)
+    int inc = len_l;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if ((lane & 31) >= o) inc += v;
+    }
+    const int total = __shfl(inc, 31, 64);
+    const int pre_l = lane < 32 ? inc - len_l : total;
+    const int warm_end = 64 * nwarm * g.n_splits;       // visiting positions behind the last warm tile of any split
+    for (int base = 0; base < total; base += 64 * UN) {
+        int row[UN], loc[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int f = base + q * 64 + lane;
+            // the row of flat entry f: the last lane r < 32 with pre[r] <= f (rows without entries are skipped by construction)
+            int r = 0;
+#pragma unroll
+            for (int st = 16; st >= 1; st >>= 1) {
+                const int pm = __shfl(pre_l, r + st, 64);
+                if (pm <= f) r += st;
+            }
+            const int pr = __shfl(pre_l, r, 64);
+            const long long hbr = __shfl(hb_l, r, 64);
+            row[q] = r;
+            loc[q] = f < total ? g.hist_indices[hbr + (f - pr)] - g.item_offset : -1;
+        }
+        int pp[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const bool in = loc[q] >= 0 && loc[q] < g.n_items_local;
+            pp[q] = in ? (g.pos_of ? g.pos_of[loc[q]] : loc[q]) : -1;
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            if (pp[q] >= 0 && pp[q] < warm_end) {        // (the cheap test first: the integer division below is ~80 instructions, and ~99 % of the train items fail here)
+                const int T = pp[q] >> 6;
+                if (T % g.n_splits == split) {
+                    const int qq = (T - split) / g.n_splits;
+                    if (qq < nwarm) atomicOr(&hmask[(wave * 32 + row[q]) * (2 * kWarmTiles) + 2 * qq + ((pp[q] & 63) >> 5)], 1u << (pp[q] & 31));
+                }
             }
         }
-        auto mark = [&](int r, int loc) __attribute__((always_inline)) {
-            const int pp = g.pos_of ? g.pos_of[loc] : loc;
-            const int T = pp >> 6;
-            if (T % g.n_splits != split) return;
-            const int q = (T - split) / g.n_splits;
-            if (q < nwarm) atomicOr(&hmask[r * (2 * kWarmTiles) + 2 * q + ((pp & 63) >> 5)], 1u << (pp & 31));
-        };
-        for (int r0 = 0; r0 < 32; r0 += 4) {
-            long long hb[4], he[4];
-            int loc[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                hb[u] = __shfl(hb_l, r0 + u, 64);
-                he[u] = __shfl(he_l, r0 + u, 64);
-                loc[u] = hb[u] + lane < he[u] ? g.hist_indices[hb[u] + lane] - g.item_offset : -1;
-            }
-            int pp[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const bool in = loc[u] >= 0 && loc[u] < g.n_items_local;
-                pp[u] = in ? (g.pos_of ? g.pos_of[loc[u]] : loc[u]) : -1;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (pp[u] >= 0) {
-                    const int T = pp[u] >> 6;
-                    if (T % g.n_splits == split) {
-                        const int q = (T - split) / g.n_splits;
-                        if (q < nwarm) atomicOr(&hmask[(wave * 32 + r0 + u) * (2 * kWarmTiles) + 2 * q + ((pp[u] & 63) >> 5)], 1u << (pp[u] & 31));
-                    }
-                }
-                for (long long e = hb[u] + 64 + lane; e < he[u]; e += 64) {          // rows with more than 64 train items
-                    const int l2 = g.hist_indices[e] - g.item_offset;
-                    if (l2 >= 0 && l2 < g.n_items_local) mark(wave * 32 + r0 + u, l2);
-                }
-            }
-        }
+    }
 }
 
 // The same as a kernel of its own (grid and workgroup = warm4_kernel's): at eight waves per SIMD the two dependent, mostly missing
