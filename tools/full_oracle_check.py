@@ -41,6 +41,15 @@ for head, name in ((ops.HEAD_RAW, "raw head (main_branch)"), (ops.HEAD_POP, "pop
     ident = ops.kernel_identity(st["kernel_id"][0]) if "kernel_id" in st else {}
     gi, gv = ops.unpack_keys(keys)
     t_gpu = time.time() - t0
+    if head:
+        # the popularity head's OTHER sweep mode: dense in visiting order -- bench.py's headline (the huge geometry at this block size); its keys must be
+        # the early-terminating default's, which the loop below holds against the oracle row by row
+        st2 = {}
+        dense = ops.topk_merge(ops.score_topk_keys(W.U, W.I, users, 50, head, W.pop_last, hist, prune="order", stats=st2), want="keys")
+        ident2 = ops.kernel_identity(st2["kernel_id"][0]) if "kernel_id" in st2 else {}
+        same = bool(torch.equal(dense, keys))
+        print("  popularity head, dense sweep in visiting order: kernel %s; keys identical to the early-terminating default's on all %d rows: %s" % (ident2, n, same), flush=True)
+        assert same and ident2.get("geometry") == "huge", ident2
     bad_val = bad_rows = near = 0
     worst = 0.0
     t0 = time.time()
