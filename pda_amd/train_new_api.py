@@ -422,13 +422,18 @@ def main(argv=None):
         torch.save(rec.state_dict(), save_ckpt_dir + name)
 
     for epoch in range(args.epoch):
-        acc = torch.zeros(3, dtype=torch.float64, device=device)
         model.switch_to_training_or_reinitsampler(sess)
+        rec.start_loss_rows(n_batch + 1)                # losses stay on the device, a row per step: one reduction and one sync per epoch
+        extra = torch.zeros(3, dtype=torch.float64, device=device)
         try:
             while True:
-                acc += sess.run_async(fetches)          # losses stay on the device: one sync per epoch, not per step
+                before = rec._loss_row_i
+                row = sess.run_async(fetches)
+                if rec._loss_row_i == before:           # (a generator longer than n_batch + 1 steps: the step fell back to the ring's rows)
+                    extra += row
         except OutOfRangeError:
             pass
+        acc = rec.finish_loss_rows() + extra
         loss, mf_loss, reg_loss = (acc / n_batch).tolist()
         if np.isnan(loss):
             print("ERROR: loss is nan.")
