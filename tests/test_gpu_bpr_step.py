@@ -1053,9 +1053,11 @@ def test_two_launch_adam_step_equals_the_step_plus_seven_stream_sweep(dev, d, po
         # may differ between two launches: equal to rounding of that order
         once_u = torch.bincount(users.long(), minlength=nU) <= 1
         once_i = torch.bincount(torch.cat([pos, neg]).long(), minlength=nI) <= 1
+        # (repeated rows: a gradient element that is a cancellation residual of ~1e-10 moves x by lr_t m / (sqrt(v) + eps) ~ 3e-5 |g| / 1e-8 in the first steps --
+        # Adam amplifies the order of the atomic sums; TF's own scatter-add has the same freedom.  1e-6 flaked once in eight runs of the GPU suite.)
         for x, y, once in ((Ua, Ub, once_u), (sa[0], sb[0], once_u), (sa[1], sb[1], once_u), (Ia, Ib, once_i), (sa[3], sb[3], once_i), (sa[4], sb[4], once_i)):
             assert torch.equal(x[once], y[once])
-            torch.testing.assert_close(x, y, atol=1e-6, rtol=1e-5)
+            torch.testing.assert_close(x, y, atol=2e-5, rtol=1e-5)
         assert float(sb[2].abs().max()) == 0.0 and float(sb[5].abs().max()) == 0.0
         torch.testing.assert_close(la, lb, atol=1e-6, rtol=1e-5)
         # keep the two paths in step so that rounding differences of the atomic order do not compound
