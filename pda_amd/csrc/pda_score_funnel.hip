@@ -217,7 +217,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
             const int rc = launch_sweep7<D, BF, UPW, true>(e, s);
             if (rc != PDA_OK) return rc;
             q.e = e;
-            hipLaunchKernelGGL((maxthr7_kernel<D>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, q);
+            hipLaunchKernelGGL((maxthr7_kernel<D>), dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, q);
             PDA_CHECK_LAUNCH();
             continue;
         }

@@ -179,33 +179,49 @@ __device__ __forceinline__ float lowered7(float tq) {     // strictly below tq (
 // launch's m items.  T = the smallest over the four quarters of the quarter's SECOND largest lower bound: eight distinct items reach it, two per
 // quarter, and the items of the whole catalogue that reach it number at least (n / m) x Gamma(8) (four independent Gamma(2) classes): the bet of
 // rank_for7 with rank 8.  Lower bounds: a maximum is s~ + ct of its half-tile; minus twice the wave's largest ct (which half-tile is not kept).
-// One thread per row; the splits' maxima of a quarter are merged first.
+// Four lanes per row (a quarter each); the splits' maxima of a quarter are merged first.
 template <int D>
 __global__ void __launch_bounds__(256) maxthr7_kernel(Sel7 g) {
+    // Four lanes per row, one per quarter (round 6; one thread per row walked 12 S dependent-free but serially issued loads: 63 us for a 2 048-user
+    // block with its 32 item splits -- eight workgroups on the whole chip); the splits four at a time, their loads in flight together.
     constexpr int UPW = D == 256 ? 128 : 256, UT = 4 * UPW, NU = UPW / 16, MR = (2 * NU + 1) * 64;
     const int n_rows = g.e.n_users_dev != nullptr ? min(g.e.n_users_blk, *g.e.n_users_dev) : g.e.n_users_blk;
-    const int rb = blockIdx.x * 256 + threadIdx.x;
-    if (rb >= n_rows) return;
+    const int rb = blockIdx.x * 64 + (threadIdx.x >> 2), hh = threadIdx.x & 3;
+    const bool ok = rb < n_rows;
+    const int rbs = ok ? rb : 0;
     const int S = g.e.n_splits;
-    const int utile = rb / UT, w = (rb % UT) / UPW, u = (rb % UPW) >> 4, j = rb & 15;
-    float t = INFINITY;
-    for (int hh = 0; hh < 4; ++hh) {
-        float b1 = -INFINITY, b2 = -INFINITY;                    // the quarter's two largest lower bounds over the splits
-        for (int sp = 0; sp < S; ++sp) {
+    const int utile = rbs / UT, w = (rbs % UT) / UPW, u = (rbs % UPW) >> 4, j = rbs & 15;
+    float b1 = -INFINITY, b2 = -INFINITY;                        // the quarter's two largest lower bounds over the splits
+    auto take = [&](float m, float ctm) __attribute__((always_inline)) {
+        const float lb = m == -INFINITY ? -INFINITY : (m - ctm) - ctm - (fabsf(m) + ctm) * 4.8e-7f;
+        const float lo = fminf(b1, lb);
+        b1 = fmaxf(b1, lb);
+        b2 = fmaxf(b2, lo);
+    };
+    for (int sp0 = 0; sp0 < S; sp0 += 4) {
+        float ctm[4], m0[4], m1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int sp = min(sp0 + q, S - 1);
             const float* mr = g.e.mrun + (((size_t)utile * S + sp) * 4 + w) * MR;
-            const float ctm = mr[2 * NU * 64 + j + 16 * hh];
-            for (int k = 0; k < 2; ++k) {
-                const float m = mr[(k * NU + u) * 64 + j + 16 * hh];
-                const float lb = m == -INFINITY ? -INFINITY : (m - ctm) - ctm - (fabsf(m) + ctm) * 4.8e-7f;
-                const float lo = fminf(b1, lb);
-                b1 = fmaxf(b1, lb);
-                b2 = fmaxf(b2, lo);
-            }
+            ctm[q] = mr[2 * NU * 64 + j + 16 * hh];
+            m0[q] = mr[u * 64 + j + 16 * hh];
+            m1[q] = mr[(NU + u) * 64 + j + 16 * hh];
         }
-        t = fminf(t, b2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (sp0 + q < S) {                                   // (same order as one thread per row took them: split by split, k = 0 then 1)
+                take(m0[q], ctm[q]);
+                take(m1[q], ctm[q]);
+            }
     }
-    g.r.thr[rb] = lowered7(t);
-    g.r.tmax[rb] = t;
+    float t = b2;                                                // the smallest over the row's four quarters (lanes 4 r .. 4 r + 3)
+    t = fminf(t, __shfl_xor(t, 1, 64));
+    t = fminf(t, __shfl_xor(t, 2, 64));
+    if (ok && hh == 0) {
+        g.r.thr[rb] = lowered7(t);
+        g.r.tmax[rb] = t;
+    }
 }
 
 // The selection between two launches, in two kernels (one wave per row doing both was latency-bound: ~15 dependent round trips per row at five
