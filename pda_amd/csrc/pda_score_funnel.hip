@@ -253,7 +253,7 @@ int run_funnel_t(const void* U, const void* I_shard, const void* prep, const int
     const int rc = pda_v4_run_score4_dev(U, I_shard, BF, prep, nullptr, users2, n, n_dev2, item_offset, n_items_local, D, hist_indptr, hist_indices, hist_row_mode, K,
                                          PDA_HEAD_RAW, PDA_SWEEP_MANY_CANDIDATES, kFallbackSplits, seed2, fb_keys, wsb + W.fb_ws, s);
     if (rc != PDA_OK) return rc;
-    hipLaunchKernelGGL(fail_merge7_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, fb_keys, kFallbackSplits, n, K, q.fail_list, fail_count, by_row, out_keys, reinterpret_cast<unsigned*>(workspace));
+    hipLaunchKernelGGL(fail_merge7_kernel, dim3((unsigned)std::min((n + 3) / 4, 1024)), dim3(256), 0, s, fb_keys, kFallbackSplits, n, K, q.fail_list, fail_count, by_row, out_keys, reinterpret_cast<unsigned*>(workspace));
     PDA_CHECK_LAUNCH();
     return PDA_OK;
 }

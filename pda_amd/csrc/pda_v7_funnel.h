@@ -251,13 +251,23 @@ __global__ void __launch_bounds__(256) hist_bloom7_kernel(const int32_t* __restr
     if (u < n_users_blk) {
         const int64_t hr = hist_row_mode == PDA_HIST_BY_USER_ID ? (int64_t)users[u] : (int64_t)u;
         const int64_t b = indptr[hr], e = indptr[hr + 1];
-        for (int64_t i = b + sub; i < e; i += 8) {
-            const int loc = indices[i] - item_offset;
-            if (loc < 0 || loc >= n_items_local) continue;
-            const unsigned pos = (unsigned)pos_of[loc];
-            const unsigned h1 = bloom7_h1(pos), h2 = bloom7_h2(pos);
-            atomicOr(&w[r * 32 + (h1 >> 5)], 1u << (h1 & 31u));
-            atomicOr(&w[r * 32 + (h2 >> 5)], 1u << (h2 & 31u));
+        for (int64_t i0 = b + sub; i0 < e; i0 += 8 * 4) {          // (four ids, then four positions of a lane in flight: two dependent loads per train item)
+            int loc[4];
+            unsigned pos[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                loc[q] = i0 + 8 * q < e ? indices[i0 + 8 * q] - item_offset : -1;
+                if (loc[q] >= n_items_local) loc[q] = -1;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pos[q] = loc[q] >= 0 ? (unsigned)pos_of[loc[q]] : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (loc[q] >= 0) {
+                    const unsigned h1 = bloom7_h1(pos[q]), h2 = bloom7_h2(pos[q]);
+                    atomicOr(&w[r * 32 + (h1 >> 5)], 1u << (h1 & 31u));
+                    atomicOr(&w[r * 32 + (h2 >> 5)], 1u << (h2 & 31u));
+                }
         }
     }
     __syncthreads();
@@ -794,9 +804,11 @@ __global__ void __launch_bounds__(256) fail_users7_kernel(const int32_t* __restr
 // one wave per failed row: the best K of its S sorted partial lists (K rounds of "the largest head"), written to the row it came from
 __global__ void __launch_bounds__(256) fail_merge7_kernel(const uint64_t* __restrict__ keys, int S, int n, int K, const int* __restrict__ fail_list,
                                                           const int* __restrict__ fail_count, int by_row, uint64_t* __restrict__ out_keys, unsigned* __restrict__ stats) {
-    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) stats[6] = (unsigned)*fail_count;      // workspace + 24: rows served by the exact fallback
-    if (i >= min(n, *fail_count)) return;
+    const int nf = min(n, *fail_count);
+    // (a bounded grid striding over the failed rows -- a handful as a rule; one workgroup per four ROWS OF THE BLOCK was 12 500 workgroups that left at once: 26 us at config 2)
+    for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < nf; i += gridDim.x * 4) {
     int cur = 0;                                                                  // lane s < S: the head of list s
     uint64_t* orow = out_keys + (size_t)fail_list[i] * K;
     const size_t krow = by_row ? (size_t)fail_list[i] : (size_t)i;                // (by_row: the fallback's rows kept their places)
@@ -819,6 +831,7 @@ __global__ void __launch_bounds__(256) fail_merge7_kernel(const uint64_t* __rest
         }
         if (h == best) ++cur;                                                     // (keys are distinct: one lane advances)
         if (lane == 0) orow[k] = best;
+    }
     }
 }
 
