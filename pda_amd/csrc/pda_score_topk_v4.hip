@@ -380,7 +380,10 @@ __device__ __forceinline__ bool append_keys(bool p, int lrow, float tt, uint64_t
 // gathers, the rest index arithmetic -- in THIS form as in the four-rows-at-a-time form of rounds 2 - 5: the rewrite bought nothing measurable there
 // (0.197 vs 0.186 - 0.200 ms lease to lease) and is kept for its bounded worst case (a single 800-item row used to cost 13 dependent pairs).
 __device__ __forceinline__ void warm_hist_walk(const Args4& g, unsigned* hmask, int utile, int split, int nwarm, int wave, int lane) {
-    constexpr int UN = 8;
+#ifndef PDA_W4_WALK_UN
+#define PDA_W4_WALK_UN 8
+#endif
+    constexpr int UN = PDA_W4_WALK_UN;
     long long hb_l = 0;
     int len_l = 0;
     {

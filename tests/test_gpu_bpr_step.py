@@ -1092,3 +1092,43 @@ def test_tagged_adam_sweep_equals_the_seven_stream_sweep_on_given_gradients(dev)
         ops.adam_dense_sweep4(b[0], b[1], b[2], gUb, tu, b[3], b[4], b[5], gIb, ti, t, lr_t, cache_policy=1 + (t & 1))
         for x, y in zip(a + [gUa, gIa], b + [gUb, gIb]):
             assert torch.equal(x, y)
+
+
+def test_a_c_caller_runs_the_reference_train_step_with_ctypes_alone(dev):
+    """INTEGRATION.md section 2, `adam_step`: pda_adam_step_f32 bound with ctypes only (no pda_amd.ops), argument for argument as the stub there -- the same
+    tables, moments, tags and loss words as ops.adam_step on a batch without repeated rows (bit for bit), over two steps."""
+    import ctypes as C
+    from pda_amd import _lib, ops
+    lib = C.CDLL(_lib.LIB_PATH)
+    lib.pda_adam_step_f32.restype = C.c_int
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    nU, nI, d, B, regs, lr = 5000, 3000, 64, 1024, 1e-2, 1e-3
+    U0, I0 = torch.randn(nU, d, generator=g, device=dev) * 0.1, torch.randn(nI, d, generator=g, device=dev) * 0.1
+    z = torch.zeros_like
+    def fresh():
+        U, I = U0.clone(), I0.clone()
+        return U, I, [z(U), z(U), z(U), z(I), z(I), z(I)], ops.adam_row_tags(nU, nI, dev)
+    Ua, Ia, sa, ta = fresh()
+    Ub, Ib, sb, tb = fresh()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for t in (1, 2):
+        users = torch.randperm(nU, generator=g, device=dev)[:B].to(torch.int32)
+        items = torch.randperm(nI, generator=g, device=dev)[:2 * B].to(torch.int32)
+        pos, neg = items[:B].contiguous(), items[B:].contiguous()
+        pp, pn = torch.rand(B, generator=g, device=dev), torch.rand(B, generator=g, device=dev)
+        la, lb = torch.zeros(3, device=dev), torch.zeros(3, device=dev)
+        lr_t = lr * (1 - 0.999 ** t) ** 0.5 / (1 - 0.9 ** t)
+        rc = lib.pda_adam_step_f32(p(Ua), p(sa[0]), p(sa[1]), p(sa[2]), p(ta[0]), C.c_size_t(nU), p(Ia), p(sa[3]), p(sa[4]), p(sa[5]), p(ta[1]), C.c_size_t(nI),
+                                   p(users), p(pos), p(neg), p(pp), p(pn), B, d, C.c_float(regs), C.c_float(B), t, C.c_float(lr_t), C.c_float(0.9), C.c_float(0.999),
+                                   C.c_float(1e-8), 0x100 | 0x200, 0, p(la), stream)
+        assert rc == 0
+        ops.adam_step(Ub, sb[0], sb[1], sb[2], tb[0], Ib, sb[3], sb[4], sb[5], tb[1], users, pos, neg, pp, pn, regs=regs, reg_div=B, step=t, lr_t=lr_t,
+                      users_distinct=True, loss_acc=lb)
+        torch.cuda.synchronize()
+        for x, y in zip([Ua, Ia] + sa + list(ta), [Ub, Ib] + sb + list(tb)):
+            assert torch.equal(x, y)
+        torch.testing.assert_close(la, lb, atol=1e-6, rtol=1e-6)
+    assert lib.pda_adam_step_f32(None, p(sa[0]), p(sa[1]), p(sa[2]), p(ta[0]), C.c_size_t(nU), p(Ia), p(sa[3]), p(sa[4]), p(sa[5]), p(ta[1]), C.c_size_t(nI),
+                                 p(users), p(pos), p(neg), None, None, B, d, C.c_float(regs), C.c_float(B), 3, C.c_float(lr), C.c_float(0.9), C.c_float(0.999),
+                                 C.c_float(1e-8), 0, 0, None, stream) == -1          # PDA_ERR_ARG, nothing launched
