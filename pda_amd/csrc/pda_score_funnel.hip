@@ -366,7 +366,7 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
     // the raw head on blocks of one 1 024-user tile and more: the funnel -- unless its workspace (~27 KB per user: lists 12 KB, pools 7 KB, the
     // fallback's keys 4 KB ...; 7 GB at 262 144 users, stepping up where more item splits are taken) would pass PDA_FUNNEL_WORKSPACE_BUDGET: such
     // a block stays with generation 4 (same keys); callers with larger blocks cut them (pda_amd.ops.score_topk_keys: <= 262 144 users per call)
-    const bool funnel = head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 16384 && (uint64_t)n_items_local <= (1ull << 26) &&
+    const bool funnel = head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 4096 && (uint64_t)n_items_local <= (1ull << 26) &&
                         n_users_blk >= 1024 && (n_items_local >= 20000 || n_users_blk <= 16384) && !early &&
                         (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID || (hist_row_mode == PDA_HIST_BY_BLOCK_ROW && n_users_blk <= 16384)) &&
                         pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d) <= PDA_FUNNEL_WORKSPACE_BUDGET;
@@ -378,7 +378,9 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
     } else if (funnel) {
         // (tools/funnel_crossover.py: from ONE 1 024-user tile on the funnel beats generation 4's many-candidates geometry on catalogues of 65 536 items and
         // more -- 2 048 users x 200 000 items 0.88 vs 1.85 ms --, and on smaller ones too (config 2, 50 000 users x 20 000 items: 1.73 vs 2.13 ms; config 1: 1.58 vs
-        // 2.30) except the very smallest with many users (16 384 items x 65 536 users: 2.1 vs 1.9))
+        // 2.30) except the very smallest with many users (16 384 items x 65 536 users: 2.1 vs 1.9).  Round 6 (the selection kernels no longer latency-bound on few
+        // users; CROSS_SMALL=1 tools/funnel_crossover.py): from 4 096 items on -- the funnel's own minimum -- up to 16 384 users: 8 192 items x 4 096 users 0.32 - 0.34 vs
+        // 0.43 - 0.55 ms, 4 096 x 16 384 0.56 - 0.58 vs 0.69 - 0.90; 65 536 users on catalogues below 20 000 items stay with generation 4 (1.4 - 1.7 vs 0.95 - 1.5))
         p.path = PDA_PATH_FUNNEL;                                // pda_score_topk7_*
         p.n_splits = 1;                                          // (ONE list per user comes back: the item splits are merged inside)
         p.order = PDA_ORDER_RANDOM;
