@@ -23,6 +23,10 @@ int g_late_den = 6;            // from 1 / g_late_den of the catalogue on the pa
 int g_late_growth_x10 = 20;
 bool g_tuned = false;          // pda_debug_funnel_tune(2) was called: the globals above rule whatever the item splits
 constexpr int kFallbackSplits = 8;
+// (a tune call that restores every default hands the schedule back to the library: the parts that grow by 8 / 4 under item splits)
+static void funnel_tuned_or_default() {
+    g_tuned = !(g_fail_p == 1e-6 && g_growth == 4 && g_cap_e == 64 && g_first_tiles == 4 && g_first_mult == 2 && g_late_den == 6 && g_late_growth_x10 == 20);
+}
 
 struct Stage7 {
     int lo, hi;                // global 64-item tiles [lo, hi)
@@ -302,6 +306,7 @@ extern "C" int pda_debug_funnel_tune(double fail_p, int growth, int cap_e, int f
     if (growth >= 2) g_growth = growth;
     if (cap_e > 0) g_cap_e = cap_e;
     if (first_tiles > 0) g_first_tiles = first_tiles;
+    funnel_tuned_or_default();
     return PDA_OK;
 }
 extern "C" int pda_debug_funnel_tune2(int first_mult, int late_den, int late_growth_x10) {
@@ -309,6 +314,7 @@ extern "C" int pda_debug_funnel_tune2(int first_mult, int late_den, int late_gro
     if (first_mult > 0) g_first_mult = first_mult;
     if (late_den > 0) g_late_den = late_den;
     if (late_growth_x10 > 10) g_late_growth_x10 = late_growth_x10;
+    funnel_tuned_or_default();
     return PDA_OK;
 }
 // measurements / tests only: the first launch in maxima mode (1, the default) or as an emitting launch against -inf (0)
@@ -363,11 +369,12 @@ extern "C" int pda_score_topk_plan(int n_users_blk, int n_items_local, int d, in
         sweep_mode = head == PDA_HEAD_POP ? PDA_SWEEP_MODE_EARLY_STOP : ((d == 64 || d == 128) ? PDA_SWEEP_MODE_VISITING_ORDER : PDA_SWEEP_MODE_NATURAL);
     p.sweep_mode = sweep_mode;
     const bool early = sweep_mode == PDA_SWEEP_MODE_EARLY_STOP, ordered = sweep_mode != PDA_SWEEP_MODE_NATURAL;
-    // the raw head on blocks of one 1 024-user tile and more: the funnel -- unless its workspace (~27 KB per user: lists 12 KB, pools 7 KB, the
+    // the raw head on catalogues of 4 096 items and more: the funnel, whatever the number of users (round 6: a block of 64 .. 1 000 users fills ONE 1 024-user tile partly and still
+    // runs 0.25 - 0.38 ms against generation 4's 2.0 - 3.2 ms at 200 000 items, 0.20 - 0.33 against 0.48 - 1.0 at 20 000: CROSS_FEW=1 tools/funnel_crossover.py) -- unless its workspace (~27 KB per user: lists 12 KB, pools 7 KB, the
     // fallback's keys 4 KB ...; 7 GB at 262 144 users, stepping up where more item splits are taken) would pass PDA_FUNNEL_WORKSPACE_BUDGET: such
     // a block stays with generation 4 (same keys); callers with larger blocks cut them (pda_amd.ops.score_topk_keys: <= 262 144 users per call)
     const bool funnel = head == PDA_HEAD_RAW && dv && K <= 54 && n_items_local >= 4096 && (uint64_t)n_items_local <= (1ull << 26) &&
-                        n_users_blk >= 1024 && (n_items_local >= 20000 || n_users_blk <= 16384) && !early &&
+                        n_users_blk >= 1 && (n_items_local >= 20000 || n_users_blk <= 16384) && !early &&
                         (hist_row_mode < 0 || hist_row_mode == PDA_HIST_BY_USER_ID || (hist_row_mode == PDA_HIST_BY_BLOCK_ROW && n_users_blk <= 16384)) &&
                         pda_score_topk7_workspace_bytes(n_users_blk, n_items_local, d) <= PDA_FUNNEL_WORKSPACE_BUDGET;
     if (!dv || K > PDA_TOPK_CAP - 4) {

@@ -674,7 +674,7 @@ def score_topk_keys(U, I_shard, users, K=50, head=HEAD_RAW, pop_shard=None, hist
 # ---- the funnel (pda_score_topk7_*): the raw head on large user blocks ------------------------------------------------------------
 # Measured (config 3, same box): 262 144 users 22.3 vs 29.7 ms for generation 4's many-candidates geometry, 65 536 users 6.4 vs 7.3 ms; config 2 (50 000 users
 # x 20 000 items, d = 64) 3.3 vs 2.1 ms -- a funnel is ~25 launches whose per-row work does not shrink with the catalogue.
-FUNNEL_MIN_USERS = 1024          # one 1 024-user tile (tools/funnel_crossover.py: 2 048 users x 200 000 items 0.88 vs 1.85 ms for generation 4)
+FUNNEL_MIN_USERS = 1             # (round 6; 1 024 before: a partly filled 1 024-user tile still wins -- 256 users x 200 000 items 0.27 - 0.32 vs 2.0 - 2.2 ms for generation 4)
 FUNNEL_MIN_ITEMS = 4096           # (round 6: the funnel's own minimum; 8 192 items x 4 096 users 0.32 vs 0.43 ms for generation 4)
 FUNNEL_BLOCK_ROW_MAX_USERS = 16384        # a mask by BLOCK ROW (the reference's per-block COO triple): the exact fallback sweeps the whole block again if a row fails
 FUNNEL_SMALL_ITEMS, FUNNEL_SMALL_MAX_USERS = 20000, 16384     # catalogues below 20 000 items: up to 16 384 users (16 384 items x 65 536 users: 2.1 vs 1.9 ms for generation 4)

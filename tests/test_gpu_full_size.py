@@ -152,7 +152,9 @@ def test_full_size_c3(dev, monkeypatch):
     assert torch.equal(k20r, raw[None][:20000])
     k2r, _ = run(ops, W, hist, huge[:2048].contiguous(), RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})        # (the reference's own block size: 32 item splits)
     assert torch.equal(k2r, raw[None][:2048])
-    k1r, _ = run(ops, W, hist, huge[:1000].contiguous(), RAW, None, {"generation": 4, "geometry": "many", "head": 0})          # (below one 1 024-user tile: generation 4)
+    k1r, _ = run(ops, W, hist, huge[:1000].contiguous(), RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})        # (a partly filled 1 024-user tile: the funnel too since round 6)
+    k64r, _ = run(ops, W, hist, huge[:64].contiguous(), RAW, None, {"generation": 4, "geometry": "funnel", "head": 0})
+    assert torch.equal(k64r, raw[None][:64])
     assert torch.equal(k1r, raw[None][:1000])
 
     # ---- every other geometry forced on the same 262 144-user block: identical keys

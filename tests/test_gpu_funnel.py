@@ -341,3 +341,34 @@ def test_filter_bound_worst_case_rounding(dev, monkeypatch, path):
     np.testing.assert_array_equal(idx[:64], ridx[:64])
     if head == 0:
         np.testing.assert_array_equal(val[:64], rval[:64])
+
+
+@pytest.mark.parametrize("d,nI,nu", [(64, 5000, 1), (64, 5000, 7), (128, 5000, 64), (128, 30000, 500), (64, 30000, 1000), (256, 9000, 130)])
+def test_blocks_of_few_users_take_the_funnel_unforced(dev, monkeypatch, d, nI, nu):
+    """Round 6: the library's plan sends the raw head through the funnel from 4 096 items on whatever the number of users (a block below one 1 024-user tile
+    fills it partly: 0.25 - 0.38 ms against generation 4's 2 - 3 ms at 200 000 items).  No PDA_* variable set: the identity word says funnel, the lists equal
+    the oracle's bit for bit and generation 4's (forced) key for key."""
+    from pda_amd import ops
+    rng = np.random.default_rng(7 + d + nu)
+    nU = 3000
+    U, I = make(rng, nU, nI, d)
+    users = rng.permutation(nU)[:nu].astype(np.int32)
+    rows = [rng.choice(nI, rng.integers(0, 60), replace=False) for _ in range(nU)]
+    ip, ix = csr(rows)
+    Ut, It, ut = torch.from_numpy(U).to(dev), torch.from_numpy(I).to(dev), torch.from_numpy(users).to(dev)
+    hist = ops.HistoryCSR(torch.from_numpy(ip).to(dev), torch.from_numpy(ix).to(dev), by_user=True)
+    st = {}
+    keys = ops.topk_merge(ops.score_topk_keys(Ut, It, ut, 50, ops.HEAD_RAW, None, hist, stats=st), want="keys")
+    ident = ops.kernel_identity(st["kernel_id"][0])
+    assert ident["geometry"] == "funnel" and int(st["error"][0]) == 0, ident
+    gi, gv = ops.unpack_keys(keys)
+    bip, bix = csr([rows[u] for u in users])
+    ridx, rval = c_oracle.score_topk(U[users], I, np.arange(nu, dtype=np.int32), 50, 0, None, bip, bix, order=1)
+    np.testing.assert_array_equal(gv, rval)
+    np.testing.assert_array_equal(gi, ridx)
+    monkeypatch.setenv("PDA_SCORE_FUNNEL", "0")
+    st4 = {}
+    k4 = ops.topk_merge(ops.score_topk_keys(Ut, It, ut, 50, ops.HEAD_RAW, None, hist, stats=st4), want="keys")
+    if "kernel_id" in st4:                                        # (d = 256: generation 3 serves the forced-off call and writes no identity word)
+        assert ops.kernel_identity(st4["kernel_id"][0]).get("geometry") != "funnel"
+    assert torch.equal(k4, keys)

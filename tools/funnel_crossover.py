@@ -20,9 +20,9 @@ def timeit(f, n=4):
     return e0.elapsed_time(e1) / n
 
 
-for nI in ((4096, 8192, 16384, 32768) if os.environ.get("CROSS_SMALL") else (16384, 32768, 65536, 200000)):
+for nI in ((4096, 8192, 16384, 32768) if os.environ.get("CROSS_SMALL") else ((20000, 200000) if os.environ.get("CROSS_FEW") else (16384, 32768, 65536, 200000))):
     I = torch.randn(nI, d, device=dev, generator=g) * 0.1
-    for nu in (1024, 2048, 4096, 16384, 65536):
+    for nu in ((64, 128, 256, 512, 1000) if os.environ.get("CROSS_FEW") else (1024, 2048, 4096, 16384, 65536)):
         U = torch.randn(nu, d, device=dev, generator=g) * 0.1
         users = torch.arange(nu, dtype=torch.int32, device=dev)
         cnt = torch.full((nu,), 50, dtype=torch.int64, device=dev)
